@@ -1,0 +1,42 @@
+"""pytest configuration: markers and shared fixtures.
+
+`-m "not gpu"` runs here (no GPU): oracle vs golden vectors, oracle vs the
+compiled reference (when oracle/_ref exists), host logic, C-ABI symbol checks.
+`-m gpu` runs on an MI355X: parity of the HIP engine against the oracle.
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "slow: takes more than a few seconds on CPU")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from oracle.pyoracle import Oracle, build
+
+    build(ref=True)
+    return Oracle("orc")
+
+
+@pytest.fixture(scope="session")
+def ref():
+    from oracle.pyoracle import Oracle, build, have_ref
+
+    build(ref=True)
+    if not have_ref():
+        pytest.skip("oracle/_ref/libhehub_ref.so not built (no /root/reference here)")
+    return Oracle("ref")
+
+
+def pytest_collection_modifyitems(config, items):
+    # "slow" is informational only; everything not marked gpu runs on CPU
+    pass

@@ -1,0 +1,44 @@
+"""Parameter sets shared by tests, fixtures and bench.
+
+Prime values are DATA taken from the reference's table
+(src/fhe/common/primelists.cpp: 40-bit row :85-86, 50-bit row :131) and from
+its tests (tests/ntt_t.cpp:21-23,94-96, tests/mod_arith_t.cpp:8,36,
+tests/bgv_t.cpp:28).
+"""
+
+# first primes of the 50-bit row; create_params draws them in this order
+P50 = [1125899904679937, 1125899903827969, 1125899903500289, 1125899903107073]
+# first primes of the 40-bit row
+P40 = [1099510054913, 1099507695617, 1099506515969, 1099504549889, 1099503894529,
+       1099503370241, 1099502714881, 1099502518273, 1099501731841, 1099500814337]
+
+# moduli exercised by the reference's NTT tests
+NTT_TEST_Q = [65537, 260898817, 35184358850561, 36028796997599233, 576460752272228353]
+# moduli of tests/mod_arith_t.cpp "batched barrett"
+BARRETT_TEST_Q = [65537, 33333333, 777777777777777, 1234567890111111111]
+MULMOD_TEST_Q = 1234567890111111111
+
+# C1: bench/ntt_bm.cpp:9
+C1_Q = 576460752272228353
+C1_LOGN = 12
+
+# C2: N=16384, first four 50-bit primes, batch 1024
+C2_LOGN = 14
+C2_MODULI = P50[:4]
+C2_BATCH = 1024
+
+# C3/C4: ckks::create_params(32768, {50, 40 x 9}, 50, 2^40): p (additional) is
+# drawn first from the 50-bit row, then q0 from the same row, then nine 40-bit
+C3_LOGN = 15
+C3_P = P50[0]
+C3_Q = [P50[1]] + P40[:9]
+C3_MODULI_EXT = C3_Q + [C3_P]
+C3_BATCH = 256
+
+# C5: create_params(8192, {40 x 7}): q0..q5 then p
+C5_LOGN = 13
+C5_Q = P40[:6]
+C5_P = P40[6]
+C5_MODULI_EXT = C5_Q + [C5_P]
+C5_T = 65537
+C5_BATCH = 4096
