@@ -1,0 +1,89 @@
+"""ctypes binding of include/hehub_amd.h.
+
+The library is the product; this module only loads it and declares signatures.
+It raises loudly when the shared library is missing -- there is no CPU or
+PyTorch fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libhehub_amd.so")
+
+u64 = C.c_uint64
+szt = C.c_size_t
+P = C.c_void_p
+INT = C.c_int
+
+HP_OK, HP_EINVAL, HP_EUNSUPPORTED, HP_EHIP, HP_ENOMEM, HP_ELOGIC = range(6)
+
+# name -> (restype, argtypes); mirrors include/hehub_amd.h one to one
+SIGNATURES = {
+    "hp_ctx_create": (INT, [INT, C.POINTER(P)]),
+    "hp_ctx_destroy": (None, [P]),
+    "hp_last_error": (C.c_char_p, [P]),
+    "hp_version": (C.c_char_p, []),
+    "hp_ctx_set_stream": (INT, [P, P]),
+    "hp_ctx_reset_stream": (INT, [P]),
+    "hp_ctx_get_stream": (P, [P]),
+    "hp_sync": (INT, [P]),
+    "hp_dev_alloc": (INT, [P, szt, C.POINTER(P)]),
+    "hp_dev_free": (INT, [P, P]),
+    "hp_memcpy_h2d": (INT, [P, P, P, szt]),
+    "hp_memcpy_d2h": (INT, [P, P, P, szt]),
+    "hp_ctx_set_force_generic": (INT, [P, INT]),
+    "hp_ntt_negacyclic_inplace_lazy": (INT, [P, szt, u64, P]),
+    "hp_intt_negacyclic_inplace_lazy": (INT, [P, szt, u64, P]),
+    "hp_cache_ntt_factors_strict": (INT, [P, szt, P, szt]),
+    "hp_batched_barrett_lazy": (INT, [P, u64, szt, P]),
+    "hp_batched_barrett": (INT, [P, u64, szt, P]),
+    "hp_batched_reduce_strict": (INT, [P, u64, szt, P]),
+    "hp_batched_mul_mod_hybrid_lazy": (INT, [P, u64, szt, P, P, P]),
+    "hp_batched_mul_mod_barrett_lazy": (INT, [P, u64, szt, P, P, P]),
+    "hp_batched_montgomery_128_lazy": (INT, [P, u64, szt, P, P]),
+    "hp_dev_ntt": (INT, [P, szt, szt, P, szt, P]),
+    "hp_dev_intt": (INT, [P, szt, szt, P, szt, P, INT]),
+    "hp_dev_poly_add": (INT, [P, szt, szt, P, szt, P, P, P]),
+    "hp_dev_poly_sub": (INT, [P, szt, szt, P, szt, P, P, P]),
+    "hp_dev_poly_mul": (INT, [P, szt, szt, P, szt, P, P, P]),
+    "hp_dev_poly_scalar_mul": (INT, [P, szt, szt, P, szt, P, P, P]),
+    "hp_dev_poly_reduce_strict": (INT, [P, szt, szt, P, szt, P]),
+    "hp_dev_poly_involution": (INT, [P, szt, szt, szt, P, P]),
+    "hp_dev_poly_cycle": (INT, [P, szt, szt, szt, szt, P, P]),
+    "hp_dev_mult_low_level": (INT, [P, szt, szt, P, szt, P, P, P]),
+    "hp_dev_ext_prod_montgomery": (INT, [P, szt, szt, P, szt, P, P, P]),
+    "hp_dev_ckks_rescale": (INT, [P, szt, szt, P, szt, P, P]),
+    "hp_dev_bgv_mod_switch": (INT, [P, szt, szt, P, u64, szt, P, P]),
+    "hp_dev_ckks_relinearize": (INT, [P, szt, szt, P, szt, P, P, P]),
+    "hp_dev_bgv_relinearize": (INT, [P, szt, szt, P, u64, szt, P, P, P]),
+    "hp_dev_ckks_mult_relin_rescale": (INT, [P, szt, szt, P, szt, P, P, P, P]),
+    "hp_dev_bgv_mult_relin_modswitch": (INT, [P, szt, szt, P, u64, szt, P, P, P, P]),
+    "hp_prof_begin": (INT, [P, C.c_char_p]),
+    "hp_prof_end": (INT, [P, C.POINTER(szt), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+class EngineMissing(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libhehub_amd.so (build it first with `python -m hehub_amd.build`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineMissing(
+            f"{LIB_PATH} is missing: the HIP engine has not been built "
+            "(python -m hehub_amd.build). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = ABI drift; let it propagate
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,341 @@
+// hp_elem.hip -- coefficient-wise CDNA4 kernels (HBM-streaming, 16-byte accesses).
+//
+// Bound: HBM.  Algorithmic bytes per limb of n words: binary op 24n, unary 16n
+// (SURVEY.md section 8d).  One workgroup streams one 2048-word chunk of one
+// limb with 16-byte loads/stores; the limb's constants are wave-uniform and
+// come from scalar loads of the plan entry.
+#include "hp_kernels.h"
+
+#define ELEM_THREADS 256
+#define ELEM_CHUNK 2048u   // words per workgroup = 256 threads x 4 x 16 B
+
+struct alignas(16) U2 {
+    u64 x, y;
+};
+
+static inline void elem_grid(u32 n, u32 rows, u32 &chunks, dim3 &grid) {
+    chunks = (n + ELEM_CHUNK - 1) / ELEM_CHUNK;
+    grid = dim3(chunks * rows, 1, 1);
+}
+
+// ---- binary: rns.cpp:58-87 (add), :89-118 (sub), :120-140 (mul) ----------------
+template <int OP>
+__global__ void __launch_bounds__(ELEM_THREADS) k_poly_binary(const HpLimb *__restrict__ limbs, u32 L, u32 n,
+                                                             u32 chunks, const u64 *__restrict__ a,
+                                                             const u64 *__restrict__ b, u64 *__restrict__ out) {
+    const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    const HpLimb m = limbs[row % L];
+    const size_t base = (size_t)row * n;
+    const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
+    for (u32 i = chunk * ELEM_CHUNK + threadIdx.x * 2; i < end; i += ELEM_THREADS * 2) {
+        if (i + 1 < end) {
+            U2 va = *reinterpret_cast<const U2 *>(a + base + i);
+            U2 vb = *reinterpret_cast<const U2 *>(b + base + i);
+            U2 r;
+            if (OP == HP_ADD) { r.x = hp_add_lazy(va.x, vb.x, m.two_q); r.y = hp_add_lazy(va.y, vb.y, m.two_q); }
+            if (OP == HP_SUB) { r.x = hp_sub_lazy(va.x, vb.x, m.two_q); r.y = hp_sub_lazy(va.y, vb.y, m.two_q); }
+            if (OP == HP_MUL) { r.x = hp_mul_hybrid_lazy(va.x, vb.x, m); r.y = hp_mul_hybrid_lazy(va.y, vb.y, m); }
+            *reinterpret_cast<U2 *>(out + base + i) = r;
+        } else {
+            u64 va = a[base + i], vb = b[base + i], r = 0;
+            if (OP == HP_ADD) r = hp_add_lazy(va, vb, m.two_q);
+            if (OP == HP_SUB) r = hp_sub_lazy(va, vb, m.two_q);
+            if (OP == HP_MUL) r = hp_mul_hybrid_lazy(va, vb, m);
+            out[base + i] = r;
+        }
+    }
+}
+
+hipError_t hp_launch_poly_binary(int op, const HpLimb *limbs, u32 L, u32 n, u32 rows, const u64 *a,
+                                 const u64 *b, u64 *out, hipStream_t stream) {
+    u32 chunks; dim3 grid;
+    elem_grid(n, rows, chunks, grid);
+    if (op == HP_ADD) k_poly_binary<HP_ADD><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, n, chunks, a, b, out);
+    else if (op == HP_SUB) k_poly_binary<HP_SUB><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, n, chunks, a, b, out);
+    else k_poly_binary<HP_MUL><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, n, chunks, a, b, out);
+    return hipGetLastError();
+}
+
+// ---- unary: rns.cpp:142-171 (scalar multiply), mod_arith.h:65-72 (strict) --------
+template <int STRICT>
+__global__ void __launch_bounds__(ELEM_THREADS) k_poly_unary(const HpLimb *__restrict__ limbs, HpScalars sc, u32 L,
+                                                            u32 n, u32 chunks, const u64 *__restrict__ a,
+                                                            u64 *__restrict__ out) {
+    const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    const u32 k = row % L;
+    const u64 q = limbs[k].q;
+    const u64 s = sc.s[k], sh = sc.sh[k];
+    const size_t base = (size_t)row * n;
+    const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
+    for (u32 i = chunk * ELEM_CHUNK + threadIdx.x * 2; i < end; i += ELEM_THREADS * 2) {
+        if (i + 1 < end) {
+            U2 v = *reinterpret_cast<const U2 *>(a + base + i);
+            if (STRICT) { v.x = hp_strict(v.x, q); v.y = hp_strict(v.y, q); }
+            else { v.x = hp_harvey_lazy(v.x, s, sh, q); v.y = hp_harvey_lazy(v.y, s, sh, q); }
+            *reinterpret_cast<U2 *>(out + base + i) = v;
+        } else {
+            u64 v = a[base + i];
+            out[base + i] = STRICT ? hp_strict(v, q) : hp_harvey_lazy(v, s, sh, q);
+        }
+    }
+}
+
+hipError_t hp_launch_poly_scalar_mul(const HpLimb *limbs, const HpScalars &sc, u32 L, u32 n, u32 rows,
+                                     const u64 *a, u64 *out, hipStream_t stream) {
+    u32 chunks; dim3 grid;
+    elem_grid(n, rows, chunks, grid);
+    k_poly_unary<0><<<grid, ELEM_THREADS, 0, stream>>>(limbs, sc, L, n, chunks, a, out);
+    return hipGetLastError();
+}
+
+hipError_t hp_launch_poly_strict(const HpLimb *limbs, u32 L, u32 n, u32 rows, u64 *x, hipStream_t stream) {
+    u32 chunks; dim3 grid;
+    elem_grid(n, rows, chunks, grid);
+    HpScalars sc = {};
+    k_poly_unary<1><<<grid, ELEM_THREADS, 0, stream>>>(limbs, sc, L, n, chunks, x, x);
+    return hipGetLastError();
+}
+
+// ---- gathers: permutation.cpp:28-75 -------------------------------------------------
+__global__ void __launch_bounds__(ELEM_THREADS) k_gather(const u32 *__restrict__ perm, u32 n, u32 chunks,
+                                                        const u64 *__restrict__ in, u64 *__restrict__ out) {
+    const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    const size_t base = (size_t)row * n;
+    const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
+    for (u32 i = chunk * ELEM_CHUNK + threadIdx.x; i < end; i += ELEM_THREADS) out[base + i] = in[base + perm[i]];
+}
+
+hipError_t hp_launch_gather(const u32 *perm, u32 n, u32 rows, const u64 *in, u64 *out, hipStream_t stream) {
+    u32 chunks; dim3 grid;
+    elem_grid(n, rows, chunks, grid);
+    k_gather<<<grid, ELEM_THREADS, 0, stream>>>(perm, n, chunks, in, out);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(ELEM_THREADS) k_reverse(u32 n, u32 chunks, const u64 *__restrict__ in,
+                                                         u64 *__restrict__ out) {
+    const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    const size_t base = (size_t)row * n;
+    const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
+    for (u32 i = chunk * ELEM_CHUNK + threadIdx.x; i < end; i += ELEM_THREADS) out[base + i] = in[base + (n - 1 - i)];
+}
+
+hipError_t hp_launch_reverse(u32 n, u32 rows, const u64 *in, u64 *out, hipStream_t stream) {
+    u32 chunks; dim3 grid;
+    elem_grid(n, rows, chunks, grid);
+    k_reverse<<<grid, ELEM_THREADS, 0, stream>>>(n, chunks, in, out);
+    return hipGetLastError();
+}
+
+// ---- single-vector kernels (drop-in mod_arith entry points) --------------------------
+template <int OP>
+__global__ void __launch_bounds__(ELEM_THREADS) k_vec(HpVecConsts c, size_t n, const u64 *__restrict__ a,
+                                                     const u64 *__restrict__ b, u64 *__restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * ELEM_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * ELEM_THREADS) {
+        u64 r = 0;
+        if (OP == HP_V_BARRETT_LAZY) r = hp_barrett_lazy(a[i], c.q, c.barrett_c);            // mod_arith.cpp:9-17
+        if (OP == HP_V_BARRETT) r = hp_strict(hp_barrett_lazy(a[i], c.q, c.barrett_c), c.q);   // mod_arith.h:18-25
+        if (OP == HP_V_STRICT) r = hp_strict(a[i], c.q);                                       // mod_arith.h:58-63
+        if (OP == HP_V_MUL_HYBRID) {                                                           // mod_arith.cpp:64-92
+            u64 lo, hi;
+            hp_mul128(a[i], b[i], lo, hi);
+            u64 t = hp_montgomery128_lazy(lo, hi, c.q, c.mqinv);
+            r = hp_harvey_lazy(t, c.r64, c.r64h, c.q);
+        }
+        if (OP == HP_V_MUL_BARRETT) {                                                          // mod_arith.cpp:94-111
+            u64 al, ah;
+            hp_mul128(a[i], b[i], al, ah);
+            // approx_quotient = ah*ch + ((ah*cl + al*ch) >> 64)   (the inner sum is a wrapping u128)
+            u64 p1l, p1h, p2l, p2h;
+            hp_mul128(ah, c.c128_lo, p1l, p1h);
+            hp_mul128(al, c.c128_hi, p2l, p2h);
+            u64 sl = p1l + p2l;
+            u64 sh = p1h + p2h + (sl < p1l ? 1ull : 0ull);
+            u64 qhat = ah * c.c128_hi + sh;
+            r = al - c.q * qhat;
+        }
+        if (OP == HP_V_MONTGOMERY128) r = hp_montgomery128_lazy(a[2 * i], a[2 * i + 1], c.q, c.mqinv);
+        out[i] = r;
+    }
+}
+
+hipError_t hp_launch_vec(int op, const HpVecConsts &c, size_t n, const u64 *a, const u64 *b, u64 *out,
+                         hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n + ELEM_THREADS - 1) / ELEM_THREADS;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    dim3 grid((unsigned)blocks);
+    switch (op) {
+    case HP_V_BARRETT_LAZY: k_vec<HP_V_BARRETT_LAZY><<<grid, ELEM_THREADS, 0, stream>>>(c, n, a, b, out); break;
+    case HP_V_BARRETT: k_vec<HP_V_BARRETT><<<grid, ELEM_THREADS, 0, stream>>>(c, n, a, b, out); break;
+    case HP_V_STRICT: k_vec<HP_V_STRICT><<<grid, ELEM_THREADS, 0, stream>>>(c, n, a, b, out); break;
+    case HP_V_MUL_HYBRID: k_vec<HP_V_MUL_HYBRID><<<grid, ELEM_THREADS, 0, stream>>>(c, n, a, b, out); break;
+    case HP_V_MUL_BARRETT: k_vec<HP_V_MUL_BARRETT><<<grid, ELEM_THREADS, 0, stream>>>(c, n, a, b, out); break;
+    case HP_V_MONTGOMERY128: k_vec<HP_V_MONTGOMERY128><<<grid, ELEM_THREADS, 0, stream>>>(c, n, a, b, out); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---- fused tensor product: ckks/arith.cpp:55-62 / bgv/arith.cpp:59-69 -------------------
+// d0 = a0*b0, d1 = (a0*b1) + (a1*b0), d2 = a1*b1.  Reads 4 limbs, writes 3: 56n bytes per limb index.
+__global__ void __launch_bounds__(ELEM_THREADS) k_tensor(const HpLimb *__restrict__ limbs, u32 L, u32 n, u32 chunks,
+                                                        const u64 *__restrict__ ct1, const u64 *__restrict__ ct2,
+                                                        u64 *__restrict__ quad) {
+    const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;   // row = p*L + k
+    const u32 p = row / L, k = row % L;
+    const HpLimb m = limbs[k];
+    const size_t poly = (size_t)L * n;
+    const u64 *a0 = ct1 + (size_t)p * 2 * poly + (size_t)k * n, *a1 = a0 + poly;
+    const u64 *b0 = ct2 + (size_t)p * 2 * poly + (size_t)k * n, *b1 = b0 + poly;
+    u64 *d0 = quad + (size_t)p * 3 * poly + (size_t)k * n, *d1 = d0 + poly, *d2 = d1 + poly;
+    const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
+    for (u32 i = chunk * ELEM_CHUNK + threadIdx.x * 2; i < end; i += ELEM_THREADS * 2) {
+        if (i + 1 < end) {
+            U2 va0 = *reinterpret_cast<const U2 *>(a0 + i), va1 = *reinterpret_cast<const U2 *>(a1 + i);
+            U2 vb0 = *reinterpret_cast<const U2 *>(b0 + i), vb1 = *reinterpret_cast<const U2 *>(b1 + i);
+            U2 r0, r1, r2;
+            r0.x = hp_mul_hybrid_lazy(va0.x, vb0.x, m);
+            r0.y = hp_mul_hybrid_lazy(va0.y, vb0.y, m);
+            r1.x = hp_add_lazy(hp_mul_hybrid_lazy(va0.x, vb1.x, m), hp_mul_hybrid_lazy(va1.x, vb0.x, m), m.two_q);
+            r1.y = hp_add_lazy(hp_mul_hybrid_lazy(va0.y, vb1.y, m), hp_mul_hybrid_lazy(va1.y, vb0.y, m), m.two_q);
+            r2.x = hp_mul_hybrid_lazy(va1.x, vb1.x, m);
+            r2.y = hp_mul_hybrid_lazy(va1.y, vb1.y, m);
+            *reinterpret_cast<U2 *>(d0 + i) = r0;
+            *reinterpret_cast<U2 *>(d1 + i) = r1;
+            *reinterpret_cast<U2 *>(d2 + i) = r2;
+        } else {
+            u64 x0 = a0[i], x1 = a1[i], y0 = b0[i], y1 = b1[i];
+            d0[i] = hp_mul_hybrid_lazy(x0, y0, m);
+            d1[i] = hp_add_lazy(hp_mul_hybrid_lazy(x0, y1, m), hp_mul_hybrid_lazy(x1, y0, m), m.two_q);
+            d2[i] = hp_mul_hybrid_lazy(x1, y1, m);
+        }
+    }
+}
+
+hipError_t hp_launch_tensor(const HpLimb *limbs, u32 L, u32 n, u32 P, const u64 *ct1, const u64 *ct2, u64 *quad,
+                            hipStream_t stream) {
+    u32 chunks; dim3 grid;
+    elem_grid(n, P * L, chunks, grid);
+    k_tensor<<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, n, chunks, ct1, ct2, quad);
+    return hipGetLastError();
+}
+
+// ---- key-switch inner product: rgsw.cpp:121-153 --------------------------------------------
+// out[p][half][k][i] = montgomery_128( sum_j D[p][j][k][i] * key[j][half][k][i] ), 128-bit accumulators
+// in registers, both halves from one pass over the digits.  Per (p, k, i): reads L digit words and 2L key
+// words (the key is shared by the whole batch and stays in L2 / Infinity Cache), writes 2 words.
+__global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner(const HpLimb *__restrict__ limbs, u32 L, u32 n, u32 chunks,
+                                                          const u64 *__restrict__ digits, const u64 *__restrict__ pt,
+                                                          u32 pt_pstride, const u64 *__restrict__ key,
+                                                          u64 *__restrict__ out) {
+    const u32 Le = L + 1;
+    const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;   // row = k*P' ... decoded below
+    // modulus-major numbering keeps one key column (2L limbs) hot per XCD slice
+    const u32 P = gridDim.x / (chunks * Le);
+    const u32 k = row / P, p = row % P;
+    const u64 q = limbs[k].q, mqinv = limbs[k].mqinv;
+    const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
+    for (u32 i = chunk * ELEM_CHUNK + threadIdx.x * 2; i < end; i += ELEM_THREADS * 2) {
+        const bool two = (i + 1 < end);
+        u64 a0l[2] = {0, 0}, a0h[2] = {0, 0}, a1l[2] = {0, 0}, a1h[2] = {0, 0};
+        for (u32 j = 0; j < L; j++) {
+            const u64 *d = (j == k) ? pt + ((size_t)p * pt_pstride + j) * n : digits + (((size_t)p * L + j) * Le + k) * n;
+            const u64 *g0 = key + (((size_t)j * 2 + 0) * Le + k) * n;
+            const u64 *g1 = key + (((size_t)j * 2 + 1) * Le + k) * n;
+            u64 dv[2], k0[2], k1[2];
+            if (two) {
+                U2 t = *reinterpret_cast<const U2 *>(d + i); dv[0] = t.x; dv[1] = t.y;
+                t = *reinterpret_cast<const U2 *>(g0 + i); k0[0] = t.x; k0[1] = t.y;
+                t = *reinterpret_cast<const U2 *>(g1 + i); k1[0] = t.x; k1[1] = t.y;
+            } else {
+                dv[0] = d[i]; k0[0] = g0[i]; k1[0] = g1[i]; dv[1] = k0[1] = k1[1] = 0;
+            }
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                u64 lo, hi;
+                hp_mul128(dv[e], k0[e], lo, hi);
+                a0l[e] += lo; a0h[e] += hi + (a0l[e] < lo ? 1ull : 0ull);
+                hp_mul128(dv[e], k1[e], lo, hi);
+                a1l[e] += lo; a1h[e] += hi + (a1l[e] < lo ? 1ull : 0ull);
+            }
+        }
+        u64 *o0 = out + (((size_t)p * 2 + 0) * Le + k) * n;
+        u64 *o1 = out + (((size_t)p * 2 + 1) * Le + k) * n;
+        u64 r00 = hp_montgomery128_lazy(a0l[0], a0h[0], q, mqinv), r10 = hp_montgomery128_lazy(a1l[0], a1h[0], q, mqinv);
+        if (two) {
+            U2 v0{r00, hp_montgomery128_lazy(a0l[1], a0h[1], q, mqinv)};
+            U2 v1{r10, hp_montgomery128_lazy(a1l[1], a1h[1], q, mqinv)};
+            *reinterpret_cast<U2 *>(o0 + i) = v0;
+            *reinterpret_cast<U2 *>(o1 + i) = v1;
+        } else {
+            o0[i] = r00; o1[i] = r10;
+        }
+    }
+}
+
+hipError_t hp_launch_ks_inner(const HpLimb *limbs, u32 L, u32 n, u32 P, const u64 *digits, const u64 *pt,
+                              u32 pt_pstride, const u64 *key, u64 *out, hipStream_t stream) {
+    u32 chunks; dim3 grid;
+    elem_grid(n, P * (L + 1), chunks, grid);
+    k_ks_inner<<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, n, chunks, digits, pt, pt_pstride, key, out);
+    return hipGetLastError();
+}
+
+// ---- drop-last-prime helpers: rescaling.cpp:54-74 / mod_switch.cpp:52-76 --------------------
+// rem[p2][k][i] = strict_barrett_{q_k}(c[i]) (+ q_k - r_k if c[i] >= q_last/2) (BGV: then * t)
+__global__ void __launch_bounds__(ELEM_THREADS) k_drop_rem(const HpLimb *__restrict__ limbs, HpDropConsts dc, u32 Lm1,
+                                                          u32 n, u32 chunks, const u64 *__restrict__ clast,
+                                                          u64 *__restrict__ rem) {
+    const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;   // row = p2*Lm1 + k
+    const u32 p2 = row / Lm1, k = row % Lm1;
+    const u64 q = limbs[k].q, bc = limbs[k].barrett_c;
+    const u64 bump = q - dc.r[k];
+    const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
+    for (u32 i = chunk * ELEM_CHUNK + threadIdx.x; i < end; i += ELEM_THREADS) {
+        const u64 c = clast[(size_t)p2 * n + i];
+        u64 v = hp_strict(hp_barrett_lazy(c, q, bc), q);
+        if (c >= dc.half_q_last) v += bump;
+        if (dc.bgv) v = hp_harvey_lazy(v, dc.t[k], dc.t_h[k], q);
+        rem[(size_t)row * n + i] = v;
+    }
+}
+
+hipError_t hp_launch_drop_rem(const HpLimb *limbs, const HpDropConsts &dc, u32 Lm1, u32 n, u32 P2, const u64 *clast,
+                              u64 *rem, hipStream_t stream) {
+    u32 chunks; dim3 grid;
+    elem_grid(n, P2 * Lm1, chunks, grid);
+    k_drop_rem<<<grid, ELEM_THREADS, 0, stream>>>(limbs, dc, Lm1, n, chunks, clast, rem);
+    return hipGetLastError();
+}
+
+// out = ((x - rem) * inv) [* (q_last mod t)] [+ addend]     (rns.cpp:89-118, :155-171, :58-87)
+__global__ void __launch_bounds__(ELEM_THREADS) k_drop_fin(const HpLimb *__restrict__ limbs, HpDropConsts dc, u32 L,
+                                                          u32 n, u32 chunks, const u64 *__restrict__ x,
+                                                          const u64 *__restrict__ rem, const u64 *__restrict__ addend,
+                                                          u32 add_poly_stride, u32 add_ct_stride, u64 *__restrict__ out) {
+    const u32 Lm1 = L - 1;
+    const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;   // row = p2*Lm1 + k
+    const u32 p2 = row / Lm1, k = row % Lm1;
+    const u64 q = limbs[k].q, two_q = limbs[k].two_q;
+    const u64 *xs = x + ((size_t)p2 * L + k) * n;
+    const u64 *as = addend ? addend + ((size_t)(p2 >> 1) * add_ct_stride + (size_t)(p2 & 1) * add_poly_stride + k) * n : nullptr;
+    const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
+    for (u32 i = chunk * ELEM_CHUNK + threadIdx.x; i < end; i += ELEM_THREADS) {
+        u64 v = hp_sub_lazy(xs[i], rem[(size_t)row * n + i], two_q);
+        v = hp_harvey_lazy(v, dc.inv[k], dc.inv_h[k], q);
+        if (dc.bgv) v = hp_harvey_lazy(v, dc.qlt[k], dc.qlt_h[k], q);
+        if (as) v = hp_add_lazy(v, as[i], two_q);
+        out[(size_t)row * n + i] = v;
+    }
+}
+
+hipError_t hp_launch_drop_fin(const HpLimb *limbs, const HpDropConsts &dc, u32 L, u32 n, u32 P2, const u64 *x,
+                              const u64 *rem, const u64 *addend, u32 add_poly_stride, u32 add_ct_stride, u64 *out,
+                              hipStream_t stream) {
+    u32 chunks; dim3 grid;
+    elem_grid(n, P2 * (L - 1), chunks, grid);
+    k_drop_fin<<<grid, ELEM_THREADS, 0, stream>>>(limbs, dc, L, n, chunks, x, rem, addend, add_poly_stride,
+                                                  add_ct_stride, out);
+    return hipGetLastError();
+}

@@ -1,0 +1,796 @@
+// hp_engine.cpp -- the C ABI of include/hehub_amd.h: engine context, table / plan caches,
+// argument checks that mirror hehub's exceptions, and the composition of the HIP kernels into
+// hehub's key-switch / rescale / mult pipelines.
+//
+// There is NO CPU fallback in this file: every entry point launches HIP kernels or fails.
+#include "../../include/hehub_amd.h"
+
+#include "hp_kernels.h"
+#include "hp_tables.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace {
+
+struct DevTables {
+    u64x2 *fwd_ref = nullptr, *inv_ref = nullptr, *fwd_k = nullptr, *inv_k = nullptr;
+};
+
+struct Plan {
+    HpLimb *d_limbs = nullptr;
+    std::vector<hp::ModConsts> consts;
+};
+
+struct ProfEvent {
+    hipEvent_t a, b;
+};
+
+} // namespace
+
+struct hp_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string err;
+    bool force_generic = false;
+    std::map<std::pair<u64, size_t>, DevTables> tables;          // (q, logn)
+    std::map<std::pair<size_t, std::vector<u64>>, Plan> plans;   // (logn, moduli); logn == 0: no transforms needed
+    std::map<std::pair<size_t, size_t>, u32 *> perms;            // (logn, step) -> gather map
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    // profiling
+    std::string prof_family;
+    bool prof_on = false;
+    std::vector<ProfEvent> prof_events;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                    \
+            return HP_EHIP;                                                                     \
+        }                                                                                       \
+    } while (0)
+
+int fail(hp_ctx *ctx, int code, const std::string &msg) {
+    ctx->err = msg;
+    return code;
+}
+
+struct Guard {
+    hp_ctx *ctx;
+    std::unique_lock<std::mutex> lk;
+    explicit Guard(hp_ctx *c) : ctx(c), lk(c->mu) { (void)hipSetDevice(c->device); }
+};
+
+int upload(hp_ctx *ctx, const void *host, size_t bytes, void **dptr) {
+    HIP_TRY(ctx, hipMalloc(dptr, bytes));
+    HIP_TRY(ctx, hipMemcpy(*dptr, host, bytes, hipMemcpyHostToDevice));
+    return HP_OK;
+}
+
+// twiddle tables of one (modulus, logn), built on first use (the reference fills global maps
+// lazily in the same way, ntt.cpp:117-143)
+int get_tables(hp_ctx *ctx, u64 q, size_t logn, DevTables &out) {
+    auto key = std::make_pair(q, logn);
+    auto it = ctx->tables.find(key);
+    if (it != ctx->tables.end()) {
+        out = it->second;
+        return HP_OK;
+    }
+    std::string why = hp::check_ntt_modulus(q, logn);
+    if (!why.empty()) return fail(ctx, HP_EINVAL, why);
+    std::vector<hp::Pair> fwd, inv, fk, ik;
+    hp::build_fwd_ref(q, logn, fwd);
+    hp::build_inv_ref(q, logn, inv);
+    DevTables t;
+    int rc;
+    if ((rc = upload(ctx, fwd.data(), fwd.size() * sizeof(hp::Pair), (void **)&t.fwd_ref))) return rc;
+    if ((rc = upload(ctx, inv.data(), inv.size() * sizeof(hp::Pair), (void **)&t.inv_ref))) return rc;
+    if (logn >= 11 && logn <= 15) {
+        hp::build_fwd_fast(fwd, logn, fk);
+        hp::build_inv_fast(inv, logn, ik);
+        if ((rc = upload(ctx, fk.data(), fk.size() * sizeof(hp::Pair), (void **)&t.fwd_k))) return rc;
+        if ((rc = upload(ctx, ik.data(), ik.size() * sizeof(hp::Pair), (void **)&t.inv_k))) return rc;
+    }
+    ctx->tables[key] = t;
+    out = t;
+    return HP_OK;
+}
+
+// device array of per-limb constants for a modulus chain; with_ntt == false skips the twiddles
+int get_plan(hp_ctx *ctx, size_t logn, const uint64_t *moduli, size_t count, bool with_ntt, const Plan **out) {
+    if (count == 0 || count > HP_MAX_LIMBS) return fail(ctx, HP_EINVAL, "unsupported number of RNS components");
+    std::vector<u64> mv(moduli, moduli + count);
+    for (u64 q : mv)
+        if (q < 2) return fail(ctx, HP_EINVAL, "modulus must be >= 2");
+    auto key = std::make_pair(with_ntt ? logn : (size_t)0, mv);
+    auto it = ctx->plans.find(key);
+    if (it != ctx->plans.end()) {
+        *out = &it->second;
+        return HP_OK;
+    }
+    Plan plan;
+    std::vector<HpLimb> limbs(count);
+    for (size_t k = 0; k < count; k++) {
+        hp::ModConsts c = hp::make_consts(mv[k]);
+        plan.consts.push_back(c);
+        HpLimb &l = limbs[k];
+        memset(&l, 0, sizeof(l));
+        l.q = c.q; l.two_q = c.two_q; l.neg_q = c.neg_q; l.mqinv = c.mqinv; l.r64 = c.r64; l.r64h = c.r64h;
+        l.barrett_c = c.barrett_c; l.k = c.k; l.fix = c.fix;
+        if (with_ntt) {
+            DevTables t;
+            int rc = get_tables(ctx, mv[k], logn, t);
+            if (rc) return rc;
+            l.fwd_ref = t.fwd_ref; l.inv_ref = t.inv_ref; l.fwd_k = t.fwd_k; l.inv_k = t.inv_k;
+        }
+    }
+    int rc = upload(ctx, limbs.data(), limbs.size() * sizeof(HpLimb), (void **)&plan.d_limbs);
+    if (rc) return rc;
+    auto ins = ctx->plans.emplace(key, std::move(plan));
+    *out = &ins.first->second;
+    return HP_OK;
+}
+
+// grow-only workspace; stream order makes reuse across calls safe
+int ws_reserve(hp_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return HP_OK;
+    if (ctx->ws) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    hipError_t e = hipMalloc(&ctx->ws, bytes);
+    if (e != hipSuccess) {
+        ctx->err = std::string("workspace hipMalloc: ") + hipGetErrorString(e);
+        return HP_ENOMEM;
+    }
+    ctx->ws_bytes = bytes;
+    return HP_OK;
+}
+
+struct Carver {
+    char *base;
+    size_t off = 0;
+    explicit Carver(void *b) : base((char *)b) {}
+    u64 *take(size_t words) {
+        u64 *p = (u64 *)(base + off);
+        off += (words * 8 + 255) & ~(size_t)255;
+        return p;
+    }
+};
+inline size_t padded(size_t words) { return (words * 8 + 255) & ~(size_t)255; }
+
+// ---- profiling brackets ---------------------------------------------------------
+hipEvent_t get_event(hp_ctx *ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {
+    hp_ctx *ctx;
+    bool on;
+    ProfEvent ev;
+    ProfScope(hp_ctx *c, const char *family) : ctx(c) {
+        on = c->prof_on && c->prof_family == family;
+        if (on) {
+            ev.a = get_event(c);
+            ev.b = get_event(c);
+            (void)hipEventRecord(ev.a, c->stream);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            (void)hipEventRecord(ev.b, ctx->stream);
+            ctx->prof_events.push_back(ev);
+        }
+    }
+};
+
+// ---- kernel-launch wrappers --------------------------------------------------------
+int run_ntt(hp_ctx *ctx, const HpNttJob &job) {
+    if (job.W == 0) return HP_OK;
+    hipError_t e;
+    {
+        ProfScope ps(ctx, job.inverse ? "intt" : "ntt");
+        if (!ctx->force_generic && job.logn >= 11 && job.logn <= 15) e = hp_launch_ntt_fast(job, ctx->stream);
+        else e = hp_launch_ntt_generic(job, ctx->stream);
+    }
+    if (e != hipSuccess) return fail(ctx, HP_EHIP, std::string("transform launch: ") + hipGetErrorString(e));
+    return HP_OK;
+}
+
+int chk(hp_ctx *ctx, hipError_t e, const char *what) {
+    if (e != hipSuccess) return fail(ctx, HP_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+    return HP_OK;
+}
+
+HpNttJob batch_job(const Plan *plan, size_t logn, size_t L, size_t P, const u64 *src, u64 *dst, size_t src_ps,
+                   size_t dst_ps, int inverse, int strict) {
+    HpNttJob j;
+    memset(&j, 0, sizeof(j));
+    j.limbs = plan->d_limbs; j.src = src; j.dst = dst; j.logn = (u32)logn; j.L = (u32)L; j.P = (u32)P;
+    j.src_pstride = (u32)src_ps; j.dst_pstride = (u32)dst_ps; j.W = (u32)(L * P); j.mode = HP_NTT_BATCH;
+    j.inverse = inverse; j.strict = strict;
+    return j;
+}
+
+bool logn_ok(size_t logn) { return logn >= 1 && logn <= 15; }
+
+// rgsw.cpp:57-156 on a batch.  pt rows: polynomial p at pt + p*pt_pstride limbs.
+// workspace: coef [P][L][N], digits [P][L][L+1][N]
+size_t ext_prod_ws_words(size_t n, size_t L, size_t P) { return padded(P * L * n) / 8 + padded(P * L * (L + 1) * n) / 8; }
+
+int ext_prod(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P, const u64 *pt, size_t pt_pstride,
+             const u64 *key, u64 *out, Carver &cv) {
+    const size_t n = (size_t)1 << logn;
+    u64 *coef = cv.take(P * L * n);
+    u64 *digits = cv.take(P * L * (L + 1) * n);
+    int rc;
+    // (i) c = strict(INTT(pt))                                    rgsw.cpp:103-105
+    if ((rc = run_ntt(ctx, batch_job(plan, logn, L, P, pt, coef, pt_pstride, L, 1, 1)))) return rc;
+    // (ii) D[j][k] = NTT_{q_k}(c[j]), k != j                       rgsw.cpp:108-119
+    HpNttJob sj;
+    memset(&sj, 0, sizeof(sj));
+    sj.limbs = plan->d_limbs; sj.src = coef; sj.dst = digits; sj.logn = (u32)logn; sj.L = (u32)L; sj.P = (u32)P;
+    sj.W = (u32)((L + 1) * P * L); sj.mode = HP_NTT_SPREAD;
+    if ((rc = run_ntt(ctx, sj))) return rc;
+    // (iii) u128 inner product + Montgomery                         rgsw.cpp:121-153
+    {
+        ProfScope ps(ctx, "ks_inner");
+        rc = chk(ctx, hp_launch_ks_inner(plan->d_limbs, (u32)L, (u32)n, (u32)P, digits, pt, (u32)pt_pstride, key, out,
+                                         ctx->stream), "ks_inner");
+    }
+    return rc;
+}
+
+// rescaling.cpp:46-75 / mod_switch.cpp:45-77 on P2 polynomials of L limbs (x rows: poly p2 at x + p2*L limbs)
+size_t drop_ws_words(size_t n, size_t L, size_t P2) { return padded(P2 * n) / 8 + padded(P2 * (L - 1) * n) / 8; }
+
+int drop_last(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, bool bgv, u64 t, const u64 *x,
+              const u64 *addend, size_t add_poly_stride, size_t add_ct_stride, u64 *out, Carver &cv) {
+    const size_t n = (size_t)1 << logn;
+    const u64 q_last = plan->consts[L - 1].q;
+    HpDropConsts dc;
+    memset(&dc, 0, sizeof(dc));
+    dc.q_last = q_last;
+    dc.half_q_last = q_last / 2;
+    dc.bgv = bgv ? 1 : 0;
+    for (size_t k = 0; k + 1 < L; k++) {
+        const u64 q = plan->consts[k].q;
+        dc.r[k] = q_last % q;
+        const u64 inv = hp::inverse_mod_prime(q_last, q) % q;
+        dc.inv[k] = inv;
+        dc.inv_h[k] = hp::harvey_quotient(inv, q);
+        if (bgv) {
+            dc.t[k] = t % q;
+            dc.t_h[k] = hp::harvey_quotient(dc.t[k], q);
+            dc.qlt[k] = (q_last % t) % q;
+            dc.qlt_h[k] = hp::harvey_quotient(dc.qlt[k], q);
+        }
+    }
+    u64 *clast = cv.take(P2 * n);
+    u64 *rem = cv.take(P2 * (L - 1) * n);
+    // c = strict(INTT_{q_last}(x[last]))  (BGV: times t^-1 before the strict reduction)
+    // a one-limb batch whose rows are the last limbs of the P2 polynomials
+    HpNttJob lj;
+    memset(&lj, 0, sizeof(lj));
+    lj.limbs = plan->d_limbs + (L - 1); lj.src = x + (L - 1) * n; lj.dst = clast; lj.logn = (u32)logn; lj.L = 1;
+    lj.P = (u32)P2; lj.src_pstride = (u32)L; lj.dst_pstride = 1; lj.W = (u32)P2; lj.mode = HP_NTT_BATCH;
+    lj.inverse = 1; lj.strict = 1;
+    if (bgv) {
+        const u64 s = hp::inverse_mod_prime(t, q_last) % q_last;
+        lj.post_scalar = s;
+        lj.post_scalar_h = hp::harvey_quotient(s, q_last);
+        lj.use_post_scalar = 1;
+    }
+    int rc;
+    if ((rc = run_ntt(ctx, lj))) return rc;
+    {
+        ProfScope ps(ctx, "drop_rem");
+        if ((rc = chk(ctx, hp_launch_drop_rem(plan->d_limbs, dc, (u32)(L - 1), (u32)n, (u32)P2, clast, rem, ctx->stream),
+                      "drop_rem")))
+            return rc;
+    }
+    if (getenv("HP_DEBUG_DROP")) {
+        (void)hipStreamSynchronize(ctx->stream);
+        std::vector<u64> h(P2 * n), r(P2 * (L - 1) * n);
+        (void)hipMemcpy(h.data(), clast, h.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(r.data(), rem, r.size() * 8, hipMemcpyDeviceToHost);
+        for (size_t p = 0; p < P2; p++)
+            fprintf(stderr, "[drop] clast[%zu] = %llu %llu | rem[%zu][0] = %llu %llu\n", p, (unsigned long long)h[p * n],
+                    (unsigned long long)h[p * n + 1], p, (unsigned long long)r[p * (L - 1) * n],
+                    (unsigned long long)r[p * (L - 1) * n + 1]);
+    }
+    if ((rc = run_ntt(ctx, batch_job(plan, logn, L - 1, P2, rem, rem, L - 1, L - 1, 0, 0)))) return rc;
+    {
+        ProfScope ps(ctx, "drop_fin");
+        rc = chk(ctx, hp_launch_drop_fin(plan->d_limbs, dc, (u32)L, (u32)n, (u32)P2, x, rem, addend, (u32)add_poly_stride,
+                                         (u32)add_ct_stride, out, ctx->stream), "drop_fin");
+    }
+    return rc;
+}
+
+int check_ext_args(hp_ctx *ctx, size_t logn, size_t L, size_t batch) {
+    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (L < 1 || L + 1 > HP_MAX_LIMBS) return fail(ctx, HP_EINVAL, "Invalid component number in RGSW ciphertext.");
+    if (batch == 0) return fail(ctx, HP_EINVAL, "empty batch");
+    return HP_OK;
+}
+
+int host_vec(hp_ctx *ctx, int op, uint64_t q, size_t n, const uint64_t *a, const uint64_t *b, uint64_t *out,
+             size_t a_words_per_elem) {
+    if (q < 2) return fail(ctx, HP_EINVAL, "modulus must be >= 2");
+    if (n == 0) return HP_OK;
+    if ((op == HP_V_MUL_HYBRID || op == HP_V_MONTGOMERY128) && (q & 1) == 0)
+        return fail(ctx, HP_EINVAL, "Montgomery reduction needs an odd modulus");
+    hp::ModConsts mc = hp::make_consts(q);
+    HpVecConsts c;
+    c.q = q; c.mqinv = mc.mqinv; c.r64 = mc.r64; c.r64h = mc.r64h; c.barrett_c = mc.barrett_c;
+    hp::u128 c128 = (~(hp::u128)0) / q;
+    c.c128_hi = (u64)(c128 >> 64);
+    c.c128_lo = (u64)c128;
+    const size_t abytes = n * 8 * a_words_per_elem, obytes = n * 8;
+    int rc = ws_reserve(ctx, padded(abytes / 8) + 2 * padded(n));
+    if (rc) return rc;
+    Carver cv(ctx->ws);
+    u64 *da = cv.take(abytes / 8), *db = cv.take(n), *dout = cv.take(n);
+    HIP_TRY(ctx, hipMemcpyAsync(da, a, abytes, hipMemcpyHostToDevice, ctx->stream));
+    if (b) HIP_TRY(ctx, hipMemcpyAsync(db, b, obytes, hipMemcpyHostToDevice, ctx->stream));
+    {
+        ProfScope ps(ctx, "vec");
+        if ((rc = chk(ctx, hp_launch_vec(op, c, n, da, db, dout, ctx->stream), "vec kernel"))) return rc;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(out, dout, obytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HP_OK;
+}
+
+int host_transform(hp_ctx *ctx, size_t logn, uint64_t q, uint64_t *x, int inverse) {
+    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    const Plan *plan;
+    int rc = get_plan(ctx, logn, &q, 1, true, &plan);
+    if (rc) return rc;
+    const size_t n = (size_t)1 << logn;
+    if ((rc = ws_reserve(ctx, padded(n)))) return rc;
+    u64 *d = (u64 *)ctx->ws;
+    HIP_TRY(ctx, hipMemcpyAsync(d, x, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = run_ntt(ctx, batch_job(plan, logn, 1, 1, d, d, 1, 1, inverse, 0)))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(x, d, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HP_OK;
+}
+
+} // namespace
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+extern "C" {
+
+const char *hp_version(void) { return "hehub_amd 0.1 (gfx950)"; }
+
+int hp_ctx_create(int device, hp_ctx **out) {
+    if (!out) return HP_EINVAL;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return HP_EHIP;
+    if (hipSetDevice(device) != hipSuccess) return HP_EHIP;
+    hp_ctx *c = new hp_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return HP_EHIP;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return HP_OK;
+}
+
+void hp_ctx_destroy(hp_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto &kv : ctx->tables) {
+        (void)hipFree(kv.second.fwd_ref); (void)hipFree(kv.second.inv_ref);
+        (void)hipFree(kv.second.fwd_k); (void)hipFree(kv.second.inv_k);
+    }
+    for (auto &kv : ctx->plans) (void)hipFree(kv.second.d_limbs);
+    for (auto &kv : ctx->perms) (void)hipFree(kv.second);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char *hp_last_error(hp_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int hp_ctx_set_stream(hp_ctx *ctx, void *s) {
+    Guard g(ctx);
+    ctx->stream = (hipStream_t)s;   // NULL is the HIP default (null) stream, e.g. torch's default stream
+    return HP_OK;
+}
+int hp_ctx_reset_stream(hp_ctx *ctx) {
+    Guard g(ctx);
+    ctx->stream = ctx->own_stream;
+    return HP_OK;
+}
+void *hp_ctx_get_stream(hp_ctx *ctx) { return (void *)ctx->stream; }
+
+int hp_sync(hp_ctx *ctx) {
+    Guard g(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HP_OK;
+}
+
+int hp_dev_alloc(hp_ctx *ctx, size_t bytes, void **dptr) {
+    Guard g(ctx);
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e != hipSuccess) return fail(ctx, HP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return HP_OK;
+}
+int hp_dev_free(hp_ctx *ctx, void *dptr) {
+    Guard g(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(dptr));
+    return HP_OK;
+}
+int hp_memcpy_h2d(hp_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    Guard g(ctx);
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HP_OK;
+}
+int hp_memcpy_d2h(hp_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    Guard g(ctx);
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HP_OK;
+}
+int hp_ctx_set_force_generic(hp_ctx *ctx, int on) {
+    Guard g(ctx);
+    ctx->force_generic = on != 0;
+    return HP_OK;
+}
+
+// ---- drop-in, host pointers -----------------------------------------------------------
+int hp_ntt_negacyclic_inplace_lazy(hp_ctx *ctx, size_t logn, uint64_t q, uint64_t *x) {
+    Guard g(ctx);
+    return host_transform(ctx, logn, q, x, 0);
+}
+int hp_intt_negacyclic_inplace_lazy(hp_ctx *ctx, size_t logn, uint64_t q, uint64_t *x) {
+    Guard g(ctx);
+    return host_transform(ctx, logn, q, x, 1);
+}
+int hp_cache_ntt_factors_strict(hp_ctx *ctx, size_t logn, const uint64_t *moduli, size_t count) {
+    Guard g(ctx);
+    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    for (size_t i = 0; i < count; i++) {
+        DevTables t;
+        int rc = get_tables(ctx, moduli[i], logn, t);
+        if (rc) return rc;
+    }
+    return HP_OK;
+}
+int hp_batched_barrett_lazy(hp_ctx *ctx, uint64_t q, size_t n, uint64_t *v) {
+    Guard g(ctx);
+    return host_vec(ctx, HP_V_BARRETT_LAZY, q, n, v, nullptr, v, 1);
+}
+int hp_batched_barrett(hp_ctx *ctx, uint64_t q, size_t n, uint64_t *v) {
+    Guard g(ctx);
+    return host_vec(ctx, HP_V_BARRETT, q, n, v, nullptr, v, 1);
+}
+int hp_batched_reduce_strict(hp_ctx *ctx, uint64_t q, size_t n, uint64_t *v) {
+    Guard g(ctx);
+    return host_vec(ctx, HP_V_STRICT, q, n, v, nullptr, v, 1);
+}
+int hp_batched_mul_mod_hybrid_lazy(hp_ctx *ctx, uint64_t q, size_t n, const uint64_t *a, const uint64_t *b,
+                                   uint64_t *out) {
+    Guard g(ctx);
+    return host_vec(ctx, HP_V_MUL_HYBRID, q, n, a, b, out, 1);
+}
+int hp_batched_mul_mod_barrett_lazy(hp_ctx *ctx, uint64_t q, size_t n, const uint64_t *a, const uint64_t *b,
+                                    uint64_t *out) {
+    Guard g(ctx);
+    return host_vec(ctx, HP_V_MUL_BARRETT, q, n, a, b, out, 1);
+}
+int hp_batched_montgomery_128_lazy(hp_ctx *ctx, uint64_t q, size_t n, const uint64_t *in128, uint64_t *out) {
+    Guard g(ctx);
+    return host_vec(ctx, HP_V_MONTGOMERY128, q, n, in128, nullptr, out, 2);
+}
+
+// ---- device-resident batches ---------------------------------------------------------------
+int hp_dev_ntt(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *d_x) {
+    Guard g(ctx);
+    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (batch == 0) return HP_OK;
+    const Plan *plan;
+    int rc = get_plan(ctx, logn, moduli, L, true, &plan);
+    if (rc) return rc;
+    return run_ntt(ctx, batch_job(plan, logn, L, batch, d_x, d_x, L, L, 0, 0));
+}
+
+int hp_dev_intt(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *d_x, int strict) {
+    Guard g(ctx);
+    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (batch == 0) return HP_OK;
+    const Plan *plan;
+    int rc = get_plan(ctx, logn, moduli, L, true, &plan);
+    if (rc) return rc;
+    return run_ntt(ctx, batch_job(plan, logn, L, batch, d_x, d_x, L, L, 1, strict));
+}
+
+static int dev_binary(hp_ctx *ctx, int op, size_t n, size_t L, const uint64_t *moduli, size_t batch,
+                      const uint64_t *a, const uint64_t *b, uint64_t *out) {
+    Guard g(ctx);
+    if (n == 0 || (n & (n - 1))) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (batch == 0) return HP_OK;
+    const Plan *plan;
+    int rc = get_plan(ctx, 0, moduli, L, false, &plan);
+    if (rc) return rc;
+    if (op == HP_MUL)
+        for (auto &c : plan->consts)
+            if ((c.q & 1) == 0) return fail(ctx, HP_EINVAL, "Montgomery reduction needs an odd modulus");
+    ProfScope ps(ctx, "elem");
+    return chk(ctx, hp_launch_poly_binary(op, plan->d_limbs, (u32)L, (u32)n, (u32)(batch * L), a, b, out, ctx->stream),
+               "poly_binary");
+}
+int hp_dev_poly_add(hp_ctx *ctx, size_t n, size_t L, const uint64_t *m, size_t batch, const uint64_t *a,
+                    const uint64_t *b, uint64_t *out) { return dev_binary(ctx, HP_ADD, n, L, m, batch, a, b, out); }
+int hp_dev_poly_sub(hp_ctx *ctx, size_t n, size_t L, const uint64_t *m, size_t batch, const uint64_t *a,
+                    const uint64_t *b, uint64_t *out) { return dev_binary(ctx, HP_SUB, n, L, m, batch, a, b, out); }
+int hp_dev_poly_mul(hp_ctx *ctx, size_t n, size_t L, const uint64_t *m, size_t batch, const uint64_t *a,
+                    const uint64_t *b, uint64_t *out) { return dev_binary(ctx, HP_MUL, n, L, m, batch, a, b, out); }
+
+int hp_dev_poly_scalar_mul(hp_ctx *ctx, size_t n, size_t L, const uint64_t *moduli, size_t batch,
+                           const uint64_t *rns_scalar, const uint64_t *a, uint64_t *out) {
+    Guard g(ctx);
+    if (n == 0 || (n & (n - 1))) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (batch == 0) return HP_OK;
+    const Plan *plan;
+    int rc = get_plan(ctx, 0, moduli, L, false, &plan);
+    if (rc) return rc;
+    HpScalars sc;
+    memset(&sc, 0, sizeof(sc));
+    for (size_t k = 0; k < L; k++) {
+        sc.s[k] = rns_scalar[k] % moduli[k];                 // rns.cpp:145,163
+        sc.sh[k] = hp::harvey_quotient(sc.s[k], moduli[k]);  // rns.cpp:146,164
+    }
+    ProfScope ps(ctx, "elem");
+    return chk(ctx, hp_launch_poly_scalar_mul(plan->d_limbs, sc, (u32)L, (u32)n, (u32)(batch * L), a, out, ctx->stream),
+               "poly_scalar_mul");
+}
+
+int hp_dev_poly_reduce_strict(hp_ctx *ctx, size_t n, size_t L, const uint64_t *moduli, size_t batch, uint64_t *x) {
+    Guard g(ctx);
+    if (n == 0 || (n & (n - 1))) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (batch == 0) return HP_OK;
+    const Plan *plan;
+    int rc = get_plan(ctx, 0, moduli, L, false, &plan);
+    if (rc) return rc;
+    ProfScope ps(ctx, "elem");
+    return chk(ctx, hp_launch_poly_strict(plan->d_limbs, (u32)L, (u32)n, (u32)(batch * L), x, ctx->stream), "poly_strict");
+}
+
+int hp_dev_poly_involution(hp_ctx *ctx, size_t logn, size_t L, size_t batch, const uint64_t *in, uint64_t *out) {
+    Guard g(ctx);
+    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (batch == 0) return HP_OK;
+    if (in == out) return fail(ctx, HP_EINVAL, "involution cannot run in place");
+    ProfScope ps(ctx, "elem");
+    return chk(ctx, hp_launch_reverse((u32)1 << logn, (u32)(batch * L), in, out, ctx->stream), "involution");
+}
+
+int hp_dev_poly_cycle(hp_ctx *ctx, size_t logn, size_t L, size_t batch, size_t step, const uint64_t *in,
+                      uint64_t *out) {
+    Guard g(ctx);
+    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (batch == 0) return HP_OK;
+    if (in == out) return fail(ctx, HP_EINVAL, "cycle cannot run in place");
+    if (step >= ((size_t)1 << 17)) return fail(ctx, HP_EINVAL, "rotation step out of range");
+    const size_t n = (size_t)1 << logn;
+    auto key = std::make_pair(logn, step);
+    auto it = ctx->perms.find(key);
+    if (it == ctx->perms.end()) {
+        // permutation.cpp:39-53 turned into a gather map: out[to] = in[perm[to]]
+        std::vector<u32> perm(n);
+        for (size_t i = 0; i < n; i++) perm[i] = (u32)i;
+        const u32 mask = (u32)((1u << (logn + 1)) - 1);
+        u32 factor = 1;
+        for (size_t s = 0; s < step; s++) factor *= 3u;
+        factor &= mask;
+        u32 pw = 1;
+        for (size_t i = 0; i < n / 2; i++, pw *= 3u) {
+            const u32 old_idx = pw & mask;
+            const u32 from = hp::bit_rev((old_idx - 1) / 2, (int)logn);
+            const u32 to = hp::bit_rev((((old_idx * factor) & mask) - 1) / 2, (int)logn);
+            perm[to] = from;
+            perm[n - 1 - to] = (u32)(n - 1 - from);
+        }
+        u32 *d = nullptr;
+        int rc = upload(ctx, perm.data(), n * sizeof(u32), (void **)&d);
+        if (rc) return rc;
+        it = ctx->perms.emplace(key, d).first;
+    }
+    ProfScope ps(ctx, "elem");
+    return chk(ctx, hp_launch_gather(it->second, (u32)n, (u32)(batch * L), in, out, ctx->stream), "cycle");
+}
+
+int hp_dev_mult_low_level(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch,
+                          const uint64_t *ct1, const uint64_t *ct2, uint64_t *quad) {
+    Guard g(ctx);
+    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (batch == 0) return HP_OK;
+    const Plan *plan;
+    int rc = get_plan(ctx, 0, moduli, L, false, &plan);
+    if (rc) return rc;
+    ProfScope ps(ctx, "tensor");
+    return chk(ctx, hp_launch_tensor(plan->d_limbs, (u32)L, (u32)1 << logn, (u32)batch, ct1, ct2, quad, ctx->stream),
+               "tensor");
+}
+
+int hp_dev_ext_prod_montgomery(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch,
+                               const uint64_t *pt, const uint64_t *key, uint64_t *out) {
+    Guard g(ctx);
+    int rc = check_ext_args(ctx, logn, L, batch);
+    if (rc) return rc;
+    const Plan *plan;
+    if ((rc = get_plan(ctx, logn, moduli_ext, L + 1, true, &plan))) return rc;
+    const size_t n = (size_t)1 << logn;
+    if ((rc = ws_reserve(ctx, ext_prod_ws_words(n, L, batch) * 8))) return rc;
+    Carver cv(ctx->ws);
+    return ext_prod(ctx, plan, logn, L, batch, pt, L, key, out, cv);
+}
+
+static int dev_drop(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, bool bgv, uint64_t t, size_t batch,
+                    const uint64_t *ct, uint64_t *out) {
+    Guard g(ctx);
+    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (L < 2) return fail(ctx, HP_EINVAL, "Unable to drop the only one prime.");
+    if (bgv && t == 0) return fail(ctx, HP_EINVAL, "plain modulus must be positive");
+    if (batch == 0) return HP_OK;
+    const Plan *plan;
+    int rc = get_plan(ctx, logn, moduli, L, true, &plan);
+    if (rc) return rc;
+    const size_t n = (size_t)1 << logn;
+    if ((rc = ws_reserve(ctx, drop_ws_words(n, L, 2 * batch) * 8))) return rc;
+    Carver cv(ctx->ws);
+    return drop_last(ctx, plan, logn, L, 2 * batch, bgv, t, ct, nullptr, 0, 0, out, cv);
+}
+int hp_dev_ckks_rescale(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, const uint64_t *ct,
+                        uint64_t *out) { return dev_drop(ctx, logn, L, moduli, false, 0, batch, ct, out); }
+int hp_dev_bgv_mod_switch(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, uint64_t t, size_t batch,
+                          const uint64_t *ct, uint64_t *out) { return dev_drop(ctx, logn, L, moduli, true, t, batch, ct, out); }
+
+// relinearize on a batch: ext_prod(quad[2]) -> drop p -> += quad[0], quad[1]
+static int relin_core(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P, bool bgv, u64 inner_t,
+                      const u64 *quad, const u64 *key, u64 *out, Carver &cv) {
+    const size_t n = (size_t)1 << logn;
+    u64 *ext = cv.take(P * 2 * (L + 1) * n);
+    int rc = ext_prod(ctx, plan, logn, L, P, quad + 2 * L * n, 3 * L, key, ext, cv);
+    if (rc) return rc;
+    return drop_last(ctx, plan, logn, L + 1, 2 * P, bgv, inner_t, ext, quad, L, 3 * L, out, cv);
+}
+static size_t relin_ws_words(size_t n, size_t L, size_t P) {
+    return padded(P * 2 * (L + 1) * n) / 8 + ext_prod_ws_words(n, L, P) + drop_ws_words(n, L + 1, 2 * P);
+}
+
+static int dev_relin(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, bool bgv, u64 inner_t,
+                     size_t batch, const uint64_t *quad, const uint64_t *key, uint64_t *out) {
+    Guard g(ctx);
+    int rc = check_ext_args(ctx, logn, L, batch);
+    if (rc) return rc;
+    if (bgv && inner_t == 0) return fail(ctx, HP_EINVAL, "plain modulus must be positive");
+    const Plan *plan;
+    if ((rc = get_plan(ctx, logn, moduli_ext, L + 1, true, &plan))) return rc;
+    const size_t n = (size_t)1 << logn;
+    if ((rc = ws_reserve(ctx, relin_ws_words(n, L, batch) * 8))) return rc;
+    Carver cv(ctx->ws);
+    return relin_core(ctx, plan, logn, L, batch, bgv, inner_t, quad, key, out, cv);
+}
+int hp_dev_ckks_relinearize(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch,
+                            const uint64_t *quad, const uint64_t *key, uint64_t *out) {
+    return dev_relin(ctx, logn, L, moduli_ext, false, 0, batch, quad, key, out);
+}
+int hp_dev_bgv_relinearize(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, uint64_t inner_t,
+                           size_t batch, const uint64_t *quad, const uint64_t *key, uint64_t *out) {
+    return dev_relin(ctx, logn, L, moduli_ext, true, inner_t, batch, quad, key, out);
+}
+
+// mult_low_level + relinearize + drop q_last, processed in sub-batches so the working set
+// (dominated by the L(L+1) digit limbs per ciphertext) stays small
+static int dev_mult(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, bool bgv, u64 t, size_t batch,
+                    const uint64_t *ct1, const uint64_t *ct2, const uint64_t *key, uint64_t *out) {
+    Guard g(ctx);
+    int rc = check_ext_args(ctx, logn, L, batch);
+    if (rc) return rc;
+    if (L < 2) return fail(ctx, HP_EINVAL, "Unable to drop the only one prime.");
+    if (bgv && t == 0) return fail(ctx, HP_EINVAL, "plain modulus must be positive");
+    const Plan *plan;
+    if ((rc = get_plan(ctx, logn, moduli_ext, L + 1, true, &plan))) return rc;
+    const size_t n = (size_t)1 << logn;
+    size_t chunk = batch;
+    if (const char *e = getenv("HP_MULT_CHUNK")) {
+        size_t c = (size_t)atol(e);
+        if (c > 0 && c < chunk) chunk = c;
+    }
+    const size_t ws_words = padded(chunk * 3 * L * n) / 8 + padded(chunk * 2 * L * n) / 8 + relin_ws_words(n, L, chunk) +
+                            drop_ws_words(n, L, 2 * chunk);
+    if ((rc = ws_reserve(ctx, ws_words * 8))) return rc;
+    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const size_t P = (batch - b0 < chunk) ? batch - b0 : chunk;
+        Carver cv(ctx->ws);
+        u64 *quad = cv.take(P * 3 * L * n);
+        u64 *lin = cv.take(P * 2 * L * n);
+        {
+            ProfScope ps(ctx, "tensor");
+            if ((rc = chk(ctx, hp_launch_tensor(plan->d_limbs, (u32)L, (u32)n, (u32)P, ct1 + b0 * 2 * L * n,
+                                                ct2 + b0 * 2 * L * n, quad, ctx->stream), "tensor")))
+                return rc;
+        }
+        // the reference's bgv::relinearize runs its inner mod switch with plain_modulus == 1 (bgv.h:32)
+        if ((rc = relin_core(ctx, plan, logn, L, P, bgv, 1, quad, key, lin, cv))) return rc;
+        if ((rc = drop_last(ctx, plan, logn, L, 2 * P, bgv, t, lin, nullptr, 0, 0, out + b0 * 2 * (L - 1) * n, cv)))
+            return rc;
+    }
+    return HP_OK;
+}
+int hp_dev_ckks_mult_relin_rescale(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch,
+                                   const uint64_t *ct1, const uint64_t *ct2, const uint64_t *key, uint64_t *out) {
+    return dev_mult(ctx, logn, L, moduli_ext, false, 0, batch, ct1, ct2, key, out);
+}
+int hp_dev_bgv_mult_relin_modswitch(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, uint64_t t,
+                                    size_t batch, const uint64_t *ct1, const uint64_t *ct2, const uint64_t *key,
+                                    uint64_t *out) {
+    return dev_mult(ctx, logn, L, moduli_ext, true, t, batch, ct1, ct2, key, out);
+}
+
+// ---- profiling ------------------------------------------------------------------------------
+int hp_prof_begin(hp_ctx *ctx, const char *family) {
+    Guard g(ctx);
+    for (auto &ev : ctx->prof_events) { ctx->event_pool.push_back(ev.a); ctx->event_pool.push_back(ev.b); }
+    ctx->prof_events.clear();
+    ctx->prof_family = family ? family : "";
+    ctx->prof_on = true;
+    return HP_OK;
+}
+int hp_prof_end(hp_ctx *ctx, size_t *launches, double *total_ms) {
+    Guard g(ctx);
+    ctx->prof_on = false;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double total = 0;
+    for (auto &ev : ctx->prof_events) {
+        float ms = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev.a, ev.b));
+        total += ms;
+        ctx->event_pool.push_back(ev.a);
+        ctx->event_pool.push_back(ev.b);
+    }
+    if (launches) *launches = ctx->prof_events.size();
+    if (total_ms) *total_ms = total;
+    ctx->prof_events.clear();
+    return HP_OK;
+}
+
+} // extern "C"

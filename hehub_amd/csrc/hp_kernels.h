@@ -1,0 +1,97 @@
+// hp_kernels.h -- host-callable launchers of the HIP kernels (one per kernel family).
+// Every launcher enqueues on `stream` and returns the hipError_t of the launch.
+#pragma once
+#include "hp_device.h"
+
+#define HP_MAX_LIMBS 32
+
+// ---- transform jobs -----------------------------------------------------------
+// A transform launch processes W independent limb transforms ("work items").
+// Items are numbered modulus-major so that neighbouring items share a twiddle
+// table; hp_xcd_remap() then gives each XCD a contiguous slice of them.
+enum HpNttMode : int {
+    HP_NTT_BATCH = 0,   // rows [P][L][N]: item w = k*P + p         -> src/dst row p*L + k, limb k
+    HP_NTT_SPREAD = 1,  // digit spread (rgsw.cpp:108-119): item w = k*(P*L) + p*L + j, k in [0,L]:
+                        //   src = coef row p*L + j, dst = digit row (p*L + j)*(L+1) + k, limb k; k == j is skipped
+    HP_NTT_LAST = 2,    // last-limb inverse for rescale: item w = p: src row p*L + (L-1), dst row p, limb L-1
+};
+
+struct HpNttJob {
+    const HpLimb *limbs;  // plan (device)
+    const u64 *src;
+    u64 *dst;
+    u32 logn;
+    u32 L;          // limbs per polynomial
+    u32 P;          // polynomials
+    u32 src_pstride;  // HP_NTT_BATCH / HP_NTT_LAST: rows (limbs) between consecutive polynomials of src
+    u32 dst_pstride;  // HP_NTT_BATCH: same for dst
+    u32 W;          // work items
+    int mode;
+    int inverse;
+    int strict;     // inverse only: reduce_strict epilogue (ntt.h:88-92)
+    // inverse only: multiply by a per-launch scalar (s, s') with the Harvey
+    // multiplication BEFORE the strict reduction (mod_switch.cpp:49-50); s_h == 0 and s == 0 -> off
+    u64 post_scalar, post_scalar_h;
+    int use_post_scalar;
+};
+
+hipError_t hp_launch_ntt_generic(const HpNttJob &job, hipStream_t stream);
+// fast path: logn in [11,15]; returns hipErrorNotSupported otherwise
+hipError_t hp_launch_ntt_fast(const HpNttJob &job, hipStream_t stream);
+
+// ---- coefficient-wise kernels on [rows][n], limb of a row = row % L ---------------
+enum HpBinOp : int { HP_ADD = 0, HP_SUB = 1, HP_MUL = 2 };
+hipError_t hp_launch_poly_binary(int op, const HpLimb *limbs, u32 L, u32 n, u32 rows, const u64 *a,
+                                 const u64 *b, u64 *out, hipStream_t stream);
+struct HpScalars {
+    u64 s[HP_MAX_LIMBS];
+    u64 sh[HP_MAX_LIMBS];
+};
+hipError_t hp_launch_poly_scalar_mul(const HpLimb *limbs, const HpScalars &sc, u32 L, u32 n, u32 rows,
+                                     const u64 *a, u64 *out, hipStream_t stream);
+hipError_t hp_launch_poly_strict(const HpLimb *limbs, u32 L, u32 n, u32 rows, u64 *x, hipStream_t stream);
+hipError_t hp_launch_gather(const u32 *perm, u32 n, u32 rows, const u64 *in, u64 *out, hipStream_t stream);
+hipError_t hp_launch_reverse(u32 n, u32 rows, const u64 *in, u64 *out, hipStream_t stream);
+
+// single-vector kernels behind the drop-in mod_arith entry points
+enum HpVecOp : int {
+    HP_V_BARRETT_LAZY = 0,
+    HP_V_BARRETT = 1,
+    HP_V_STRICT = 2,
+    HP_V_MUL_HYBRID = 3,
+    HP_V_MUL_BARRETT = 4,
+    HP_V_MONTGOMERY128 = 5
+};
+struct HpVecConsts {
+    u64 q, mqinv, r64, r64h, barrett_c, c128_hi, c128_lo;
+};
+hipError_t hp_launch_vec(int op, const HpVecConsts &c, size_t n, const u64 *a, const u64 *b, u64 *out,
+                         hipStream_t stream);
+
+// ---- scheme-level kernels ---------------------------------------------------------
+// ckks/arith.cpp:55-62: ct1, ct2 [P][2][L][n] -> quad [P][3][L][n]
+hipError_t hp_launch_tensor(const HpLimb *limbs, u32 L, u32 n, u32 P, const u64 *ct1, const u64 *ct2,
+                            u64 *quad, hipStream_t stream);
+// rgsw.cpp:121-153: digits [P][L][L+1][n] (diagonal taken from pt [P][L][n]), key [L][2][L+1][n]
+//   -> out [P][2][L+1][n]
+hipError_t hp_launch_ks_inner(const HpLimb *limbs, u32 L, u32 n, u32 P, const u64 *digits, const u64 *pt,
+                              u32 pt_pstride, const u64 *key, u64 *out, hipStream_t stream);
+
+// drop-last-prime helpers (rescaling.cpp:46-75 / mod_switch.cpp:45-77)
+struct HpDropConsts {
+    u64 q_last, half_q_last;
+    u64 r[HP_MAX_LIMBS];       // q_last mod q_k
+    u64 inv[HP_MAX_LIMBS];     // q_last^{-1} mod q_k (already reduced mod q_k)
+    u64 inv_h[HP_MAX_LIMBS];
+    int bgv;
+    u64 t[HP_MAX_LIMBS], t_h[HP_MAX_LIMBS];          // plain_modulus mod q_k      (mod_switch.cpp:70)
+    u64 qlt[HP_MAX_LIMBS], qlt_h[HP_MAX_LIMBS];      // (q_last mod t) mod q_k     (mod_switch.cpp:76)
+};
+// clast [P2][n] (strict coefficients of the last limb) -> rem [P2][L-1][n]
+hipError_t hp_launch_drop_rem(const HpLimb *limbs, const HpDropConsts &dc, u32 Lm1, u32 n, u32 P2,
+                              const u64 *clast, u64 *rem, hipStream_t stream);
+// x [P2][L][n] (first L-1 limbs used), rem [P2][L-1][n] (NTT form), optional addend [P2][addL][n]
+//   -> out [P2][L-1][n]:  out = ((x - rem) * inv) [* qlt]  [+ addend]
+hipError_t hp_launch_drop_fin(const HpLimb *limbs, const HpDropConsts &dc, u32 L, u32 n, u32 P2, const u64 *x,
+                              const u64 *rem, const u64 *addend, u32 add_poly_stride, u32 add_ct_stride,
+                              u64 *out, hipStream_t stream);

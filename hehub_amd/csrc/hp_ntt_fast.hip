@@ -1,0 +1,333 @@
+// hp_ntt_fast.hip -- register-tiled negacyclic NTT / INTT for N = 2^11 .. 2^15 on gfx950.
+//
+// One workgroup transforms one RNS limb.  The limb is read from HBM once and written once
+// (algorithmic traffic 16*N bytes); everything in between happens in
+// registers and LDS:
+//
+//   * every thread keeps 32 coefficients (64 VGPRs) and runs up to five radix-2 stages on
+//     them per pass -- the butterflies are exactly the reference's lazy Harvey butterflies
+//     (ntt.cpp:160-166), only their schedule changes, so raw output words are identical;
+//   * N = 32 * T coefficients, T = N/32 threads; logN = a + 5 + 5 stages = three passes
+//     (A: top a bits, B: bits 9..5, C: bits 4..0 of the coefficient index; the inverse runs
+//     them in the opposite order, C' B' A');
+//   * between passes the workgroup transposes through LDS, 32 bits at a time (low words, then
+//     high words), so a whole limb needs only 4*N bytes of LDS: 128 KiB at N = 32768 (one
+//     workgroup of 16 waves per CU) and 64 KiB at N = 16384 (two workgroups per CU);
+//   * the exchange between the passes that work inside a 1024-coefficient block (B <-> C) and
+//     the transposition that makes the HBM stores/loads of the contiguous pass coalesced are
+//     wave-local: each wave owns 2048 consecutive coefficients there, so they need no
+//     s_barrier and waves drift apart, overlapping one wave's LDS traffic with another's
+//     integer multiplies.  Only the A <-> B exchange is workgroup-wide (3 barriers);
+//   * LDS word address of coefficient i is i ^ ((i >> 5) & 31): every ds_read_b32 /
+//     ds_write_b32 of every exchange hits 32 distinct banks per 32-lane group;
+//   * twiddles are (w, floor(w*2^64/q)) pairs read as one 16-byte load from per-modulus tables
+//     laid out [slot][class] (hp_tables.cpp) so a wavefront reads consecutive pairs; the
+//     tables are shared by the whole batch and live in L2 -- work items are numbered
+//     modulus-major and handed to XCDs in contiguous slices (hp_xcd_remap) to keep them there.
+//
+// The kernel is co-limited by HBM and by 32-bit integer multiplies (10 half-rate
+// v_mad_u64_u32 / v_mul_* per butterfly, tools/ubench_valu.hip); see DESIGN.md.
+#include "hp_kernels.h"
+#include "hp_ntt_job.h"
+
+namespace {
+
+template <int LOGN> struct Geo {
+    static constexpr int A = LOGN - 10;          // stages of pass A (1..5)
+    static constexpr int PB = 5 - A;             // passenger bits of pass A's register index
+    static constexpr int T = 1 << (LOGN - 5);    // threads per workgroup
+    static constexpr int N = 1 << LOGN;
+    static constexpr int MINW = (T >= 1024) ? 4 : 4;   // waves per SIMD wanted (<= 128 VGPRs)
+};
+
+HP_DEV u32 lo32(u64 v) { return (u32)v; }
+HP_DEV u32 hi32(u64 v) { return (u32)(v >> 32); }
+HP_DEV u64 mk64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+
+// ---- passes ---------------------------------------------------------------------------------
+// A pass runs up to five radix-2 stages on the 5-bit register index.  Its twiddles are numbered by
+// "slot" 0..30 in the order they are consumed:
+//   forward: stage on register bit b = 4 - floor(log2(slot+1)); the pairs (r, r | 1<<b) that use the
+//            slot are those with r >> (b+1) == slot + 1 - 2^(4-b)
+//   inverse: stage on register bit b = floor(log2(slot+1));      pairs with (r & (2^b - 1)) == slot + 1 - 2^b
+// Twiddle loads run TW_DEPTH slots ahead of their use through a small register ring; scheduling
+// barriers keep the compiler from hoisting all 31 loads (124 VGPRs) to the top of the pass, which
+// would push the kernel past the 128-VGPR budget of 4 waves per SIMD.
+#define TW_DEPTH 4
+
+constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
+
+template <bool FWD, int S0, int S1>
+HP_DEV void run_pass(u64 (&x)[32], const u64x2 *__restrict__ tbl, u32 ncls, u32 cls, u64 q, u64 two_q) {
+    u64x2 ring[TW_DEPTH];
+#pragma unroll
+    for (int s = S0; s < S0 + TW_DEPTH; ++s)
+        if (s < S1) ring[(s - S0) % TW_DEPTH] = tbl[(u32)s * ncls + cls];
+    int since = 0;
+#pragma unroll
+    for (int s = S0; s < S1; ++s) {
+        const u64x2 tw = ring[(s - S0) % TW_DEPTH];
+        if (s + TW_DEPTH < S1) ring[(s - S0) % TW_DEPTH] = tbl[(u32)(s + TW_DEPTH) * ncls + cls];
+        const int lg = ilog2c(s + 1);
+        const int b = FWD ? 4 - lg : lg;
+        const int idx = s + 1 - (1 << lg);
+#pragma unroll
+        for (int o = 0; o < (1 << (4 - lg)); ++o) {
+            // forward: idx = bits above b, o = bits below b; inverse: idx = bits below b, o = bits above b
+            const int r = FWD ? ((idx << (b + 1)) | o) : ((o << (b + 1)) | idx);
+            hp_butterfly(x[r], x[r | (1 << b)], tw.x, tw.y, q, two_q);
+        }
+        since += 1 << (4 - lg);
+        if (since >= 4) {
+            __builtin_amdgcn_sched_barrier(0);
+            since = 0;
+        }
+    }
+}
+
+// forward: stages on register bits BHI..BLO (descending)
+template <int BHI, int BLO>
+HP_DEV void fwd_pass(u64 (&x)[32], const u64x2 *__restrict__ tbl, u32 ncls, u32 cls, u64 q, u64 two_q) {
+    static_assert(BHI == 4, "forward passes start at register bit 4");
+    run_pass<true, 0, (1 << (5 - BLO)) - 1>(x, tbl, ncls, cls, q, two_q);
+}
+
+// inverse: stages on register bits BLO..BHI (ascending)
+template <int BLO, int BHI>
+HP_DEV void inv_pass(u64 (&x)[32], const u64x2 *__restrict__ tbl, u32 ncls, u32 cls, u64 q, u64 two_q) {
+    static_assert(BHI == 4, "inverse passes end at register bit 4");
+    run_pass<false, (1 << BLO) - 1, 31>(x, tbl, ncls, cls, q, two_q);
+}
+
+// ---- LDS word addresses of the four register layouts ------------------------------------------
+// (all already swizzled: addr(i) = i ^ ((i >> 5) & 31))
+//
+//   layout A ("strided"):   r = (kk << PB) | pp,  i = (kk << 10) | (tid << PB) | pp
+//   layout B ("blocked"):   r = m,                i = (blk << 10) | (m << 5) | j,  blk = tid >> 5, j = tid & 31
+//   layout C ("contiguous"): r,                   i = (tid << 5) | r
+//   layout S ("stream"):    r = s,                i = (wave << 11) | (s << 6) | lane   (coalesced HBM access)
+template <int LOGN> struct Addr {
+    using G = Geo<LOGN>;
+    u32 a_base;   // ((tid << PB) ^ h) with h = bits 9..5 of (tid << PB)
+    u32 b_base;   // (blk << 10) | j
+    u32 c_base;   // (tid << 5) | (tid & 31)
+    u32 s_base;   // (wave << 11) | (lane & 32) | ((lane & 31) ^ (lane >> 5))
+    HP_DEV void init(u32 tid) {
+        const u32 t = tid << G::PB;
+        a_base = t ^ ((t >> 5) & 31u);
+        b_base = ((tid >> 5) << 10) | (tid & 31u);
+        c_base = (tid << 5) | (tid & 31u);
+        const u32 lane = tid & 63u, wave = tid >> 6;
+        s_base = (wave << 11) | (lane & 32u) | ((lane & 31u) ^ (lane >> 5));
+    }
+};
+
+enum { LAY_A = 0, LAY_B = 1, LAY_C = 2, LAY_S = 3 };
+
+// Launder a thread-constant through an empty asm so the compiler treats it as a fresh value:
+// the 32 LDS addresses derived from it are then recomputed (one v_xor each) in every round of
+// an exchange instead of being kept live in 32 VGPRs across rounds.
+HP_DEV u32 opaque(u32 v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+template <int LOGN, int LAY> HP_DEV u32 lay_base(const Addr<LOGN> &ad) {
+    if (LAY == LAY_A) return ad.a_base;
+    if (LAY == LAY_B) return ad.b_base;
+    if (LAY == LAY_C) return ad.c_base;
+    return ad.s_base;
+}
+
+template <int LOGN, int LAY> HP_DEV u32 lay_addr(u32 base, int r) {
+    using G = Geo<LOGN>;
+    if (LAY == LAY_A) return (base ^ (u32)(r & ((1 << G::PB) - 1))) + (u32)((r >> G::PB) << 10);
+    if (LAY == LAY_B) return (base ^ (u32)r) + (u32)(r << 5);
+    if (LAY == LAY_C) return base ^ (u32)r;
+    return (base ^ (u32)((2 * r) & 31)) + (u32)(r << 6);
+}
+
+// Transpose the workgroup's coefficients from register layout FROM to layout TO through LDS, one
+// 32-bit half at a time.  WG: the exchange crosses waves (needs s_barrier); otherwise it is
+// confined to the wave's own 2048-word region and relies on in-order LDS execution per wave.
+template <int LOGN, int FROM, int TO, bool WG>
+HP_DEV void exchange(u64 (&x)[32], u32 *lds, const Addr<LOGN> &ad) {
+    u32 keep[32];
+    {
+        const u32 fb = opaque(lay_base<LOGN, FROM>(ad));
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            lds[lay_addr<LOGN, FROM>(fb, r)] = lo32(x[r]);
+            keep[r] = hi32(x[r]);
+        }
+    }
+    if (WG) __syncthreads();
+    u32 nlo[32];
+    {
+        const u32 tb = opaque(lay_base<LOGN, TO>(ad));
+#pragma unroll
+        for (int r = 0; r < 32; ++r) nlo[r] = lds[lay_addr<LOGN, TO>(tb, r)];
+    }
+    if (WG) __syncthreads();
+    {
+        const u32 fb = opaque(lay_base<LOGN, FROM>(ad));
+#pragma unroll
+        for (int r = 0; r < 32; ++r) lds[lay_addr<LOGN, FROM>(fb, r)] = keep[r];
+    }
+    if (WG) __syncthreads();
+    {
+        const u32 tb = opaque(lay_base<LOGN, TO>(ad));
+#pragma unroll
+        for (int r = 0; r < 32; ++r) x[r] = mk64(nlo[r], lds[lay_addr<LOGN, TO>(tb, r)]);
+    }
+}
+
+struct alignas(16) V2 {
+    u64 x, y;
+};
+
+// ---- forward kernel ----------------------------------------------------------------------------
+template <int LOGN>
+__global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd(HpNttJob job) {
+    using G = Geo<LOGN>;
+    __shared__ u32 lds[G::N];
+    const u32 w = hp_xcd_remap(blockIdx.x, job.W);
+    HpItem it;
+    if (!hp_decode_item(job, w, it)) return;
+    const HpLimb *lp = job.limbs + it.limb;
+    const u64 q = lp->q, two_q = lp->two_q;
+    const u32 tid = threadIdx.x;
+    Addr<LOGN> ad;
+    ad.init(tid);
+
+    u64 x[32];
+    // load, layout A: thread reads 2^PB consecutive coefficients at 2^A places 1024 apart
+    {
+        const u64 *s = it.src + ((size_t)tid << G::PB);
+#pragma unroll
+        for (int kk = 0; kk < (1 << G::A); ++kk) {
+            if (G::PB == 0) {
+                x[kk] = s[(size_t)kk << 10];
+            } else {
+#pragma unroll
+                for (int pp = 0; pp < (1 << G::PB); pp += 2) {
+                    const V2 v = *reinterpret_cast<const V2 *>(s + ((size_t)kk << 10) + pp);
+                    x[(kk << G::PB) | pp] = v.x;
+                    x[(kk << G::PB) | pp | 1] = v.y;
+                }
+            }
+        }
+    }
+    // pass A: global stages 1..A, wave-uniform twiddles seq[1 .. 2^A - 1]
+    fwd_pass<4, G::PB>(x, lp->fwd_ref + 1, 1u, 0u, q, two_q);
+    exchange<LOGN, LAY_A, LAY_B, true>(x, lds, ad);
+    // pass B: global stages A+1..A+5, twiddles depend on the 1024-block
+    fwd_pass<4, 0>(x, lp->fwd_k, 1u << G::A, tid >> 5, q, two_q);
+    exchange<LOGN, LAY_B, LAY_C, false>(x, lds, ad);
+    // pass C: global stages A+6..logN, per-thread twiddles
+    fwd_pass<4, 0>(x, lp->fwd_k + 31 * (1 << G::A), (u32)G::T, tid, q, two_q);
+    // final fold (ntt.cpp:171-175)
+    {
+        const u32 k = lp->k, fix = lp->fix;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) x[r] = hp_shift_fold(x[r], q, k, fix);
+    }
+    exchange<LOGN, LAY_C, LAY_S, false>(x, lds, ad);
+    // store, layout S: a wave writes 64 consecutive words per instruction
+    {
+        u64 *d = it.dst + (((size_t)(tid >> 6)) << 11) + (tid & 63u);
+#pragma unroll
+        for (int s = 0; s < 32; ++s) d[(size_t)s << 6] = x[s];
+    }
+}
+
+// ---- inverse kernel ----------------------------------------------------------------------------
+template <int LOGN, bool STRICT, bool PSCAL>
+__global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_inv(HpNttJob job) {
+    using G = Geo<LOGN>;
+    __shared__ u32 lds[G::N];
+    const u32 w = hp_xcd_remap(blockIdx.x, job.W);
+    HpItem it;
+    if (!hp_decode_item(job, w, it)) return;
+    const HpLimb *lp = job.limbs + it.limb;
+    const u64 q = lp->q, two_q = lp->two_q;
+    const u32 tid = threadIdx.x;
+    Addr<LOGN> ad;
+    ad.init(tid);
+
+    u64 x[32];
+    {
+        const u64 *s = it.src + (((size_t)(tid >> 6)) << 11) + (tid & 63u);
+#pragma unroll
+        for (int r = 0; r < 32; ++r) x[r] = s[(size_t)r << 6];
+    }
+    exchange<LOGN, LAY_S, LAY_C, false>(x, lds, ad);
+    // pass A': levels 0..4 (pairs 1,2,4,8,16 apart), wave-uniform twiddles
+    inv_pass<0, 4>(x, lp->inv_k, 1u, 0u, q, two_q);
+    exchange<LOGN, LAY_C, LAY_B, false>(x, lds, ad);
+    // pass B': levels 5..9, twiddles depend on j = tid & 31
+    inv_pass<0, 4>(x, lp->inv_k + 31, 32u, tid & 31u, q, two_q);
+    exchange<LOGN, LAY_B, LAY_A, true>(x, lds, ad);
+    // pass C': levels 10..logN-1, per-thread twiddles
+    inv_pass<G::PB, 4>(x, lp->inv_k + 31 + 31 * 32, (u32)G::T, tid, q, two_q);
+    // fold, multiply by psi^-i * N^-1 (ntt.cpp:214-222), optional scalar + strict reduction, store (layout A)
+    {
+        const u32 k = lp->k, fix = lp->fix;
+        const u64x2 *sc = lp->inv_ref + G::N + ((size_t)tid << G::PB);
+        u64 *d = it.dst + ((size_t)tid << G::PB);
+        const u64 psc = job.post_scalar, psh = job.post_scalar_h;
+#pragma unroll
+        for (int r0 = 0; r0 < 32; r0 += 4) {
+            u64x2 f[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = r0 + e, kk = r >> G::PB, pp = r & ((1 << G::PB) - 1);
+                f[e] = sc[((size_t)kk << 10) + pp];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = r0 + e;
+                u64 v = hp_harvey_lazy(hp_shift_fold(x[r], q, k, fix), f[e].x, f[e].y, q);
+                if (PSCAL) v = hp_harvey_lazy(v, psc, psh, q);
+                if (STRICT) v = hp_strict(v, q);
+                x[r] = v;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int kk = 0; kk < (1 << G::A); ++kk) {
+            if (G::PB == 0) {
+                d[(size_t)kk << 10] = x[kk];
+            } else {
+#pragma unroll
+                for (int pp = 0; pp < (1 << G::PB); pp += 2) {
+                    V2 v{x[(kk << G::PB) | pp], x[(kk << G::PB) | pp | 1]};
+                    *reinterpret_cast<V2 *>(d + ((size_t)kk << 10) + pp) = v;
+                }
+            }
+        }
+    }
+}
+
+template <int LOGN> hipError_t launch(const HpNttJob &job, hipStream_t stream) {
+    if (!job.inverse) k_ntt_fwd<LOGN><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
+    else if (job.use_post_scalar && job.strict) k_ntt_inv<LOGN, true, true><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
+    else if (job.use_post_scalar) return hipErrorNotSupported;
+    else if (job.strict) k_ntt_inv<LOGN, true, false><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
+    else k_ntt_inv<LOGN, false, false><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
+    return hipGetLastError();
+}
+
+} // namespace
+
+hipError_t hp_launch_ntt_fast(const HpNttJob &job, hipStream_t stream) {
+    if (job.W == 0) return hipSuccess;
+    switch (job.logn) {
+    case 11: return launch<11>(job, stream);
+    case 12: return launch<12>(job, stream);
+    case 13: return launch<13>(job, stream);
+    case 14: return launch<14>(job, stream);
+    case 15: return launch<15>(job, stream);
+    default: return hipErrorNotSupported;
+    }
+}

@@ -1,0 +1,266 @@
+"""Python front-end of the C ABI for tests and benchmarks.
+
+PyTorch is plumbing here: it owns device buffers (int64 tensors holding the raw
+u64 words) and the current HIP stream, and provides torch.distributed for
+multi-GPU runs.  Every operation is a call into libhehub_amd.so; nothing is
+computed by torch or numpy.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+
+from . import capi
+
+
+class HpError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[hp_status {code}] {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class InvalidArgument(HpError, ValueError):
+    """The reference throws std::invalid_argument for the same input."""
+
+
+def _u64arr(v: Sequence[int]):
+    return (capi.u64 * len(v))(*[int(x) for x in v])
+
+
+class Engine:
+    """One engine context on one GPU (include/hehub_amd.h: hp_ctx)."""
+
+    def __init__(self, device: int = 0, use_torch_stream: bool = True):
+        import torch  # noqa: F401  (loads the HIP runtime the library binds to)
+
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise capi.EngineMissing("no HIP device visible: the engine needs an MI355X (no CPU fallback)")
+        self.lib = capi.load()
+        self.device = device
+        torch.cuda.set_device(device)
+        h = capi.P()
+        rc = self.lib.hp_ctx_create(device, C.byref(h))
+        if rc != capi.HP_OK:
+            raise HpError(rc, "hp_ctx_create failed")
+        self.h = h
+        if use_torch_stream:
+            self.use_stream(torch.cuda.current_stream(device))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hp_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers -----------------------------------------------------------
+    def _chk(self, rc: int):
+        if rc == capi.HP_OK:
+            return
+        msg = self.lib.hp_last_error(self.h).decode()
+        if rc == capi.HP_EINVAL:
+            raise InvalidArgument(rc, msg)
+        raise HpError(rc, msg)
+
+    def use_stream(self, stream):
+        self._chk(self.lib.hp_ctx_set_stream(self.h, C.c_void_p(stream.cuda_stream)))
+
+    def sync(self):
+        self._chk(self.lib.hp_sync(self.h))
+
+    def force_generic(self, on: bool):
+        self._chk(self.lib.hp_ctx_set_force_generic(self.h, int(on)))
+
+    def to_device(self, a: np.ndarray):
+        assert a.dtype == np.uint64
+        return self.torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(f"cuda:{self.device}")
+
+    @staticmethod
+    def to_host(t) -> np.ndarray:
+        return t.detach().cpu().numpy().view(np.uint64)
+
+    def empty(self, *shape):
+        return self.torch.empty(*shape, dtype=self.torch.int64, device=f"cuda:{self.device}")
+
+    @staticmethod
+    def _ptr(t):
+        assert t.is_contiguous() and t.element_size() == 8
+        return C.c_void_p(t.data_ptr())
+
+    # -- profiling ---------------------------------------------------------
+    def prof_begin(self, family: str):
+        self._chk(self.lib.hp_prof_begin(self.h, family.encode()))
+
+    def prof_end(self):
+        n = capi.szt(0)
+        ms = C.c_double(0)
+        self._chk(self.lib.hp_prof_end(self.h, C.byref(n), C.byref(ms)))
+        return int(n.value), float(ms.value)
+
+    # -- drop-in host calls (numpy in, numpy out) ----------------------------
+    def host_ntt(self, logn: int, q: int, x: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x.copy())
+        self._chk(self.lib.hp_ntt_negacyclic_inplace_lazy(self.h, logn, q, x.ctypes.data_as(capi.P)))
+        return x
+
+    def host_intt(self, logn: int, q: int, x: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x.copy())
+        self._chk(self.lib.hp_intt_negacyclic_inplace_lazy(self.h, logn, q, x.ctypes.data_as(capi.P)))
+        return x
+
+    def cache_ntt_factors_strict(self, logn: int, moduli):
+        self._chk(self.lib.hp_cache_ntt_factors_strict(self.h, logn, _u64arr(moduli), len(moduli)))
+
+    def _host_inplace(self, fn, q, v):
+        v = np.ascontiguousarray(v.copy())
+        self._chk(fn(self.h, q, v.size, v.ctypes.data_as(capi.P)))
+        return v
+
+    def host_barrett_lazy(self, q, v):
+        return self._host_inplace(self.lib.hp_batched_barrett_lazy, q, v)
+
+    def host_barrett(self, q, v):
+        return self._host_inplace(self.lib.hp_batched_barrett, q, v)
+
+    def host_reduce_strict(self, q, v):
+        return self._host_inplace(self.lib.hp_batched_reduce_strict, q, v)
+
+    def host_mul_hybrid_lazy(self, q, a, b):
+        out = np.empty_like(a)
+        self._chk(self.lib.hp_batched_mul_mod_hybrid_lazy(self.h, q, a.size, a.ctypes.data_as(capi.P),
+                                                          b.ctypes.data_as(capi.P), out.ctypes.data_as(capi.P)))
+        return out
+
+    def host_mul_barrett_lazy(self, q, a, b):
+        out = np.empty_like(a)
+        self._chk(self.lib.hp_batched_mul_mod_barrett_lazy(self.h, q, a.size, a.ctypes.data_as(capi.P),
+                                                           b.ctypes.data_as(capi.P), out.ctypes.data_as(capi.P)))
+        return out
+
+    def host_montgomery_128_lazy(self, q, in128):
+        in128 = np.ascontiguousarray(in128)
+        out = np.empty(in128.shape[0], dtype=np.uint64)
+        self._chk(self.lib.hp_batched_montgomery_128_lazy(self.h, q, out.size, in128.ctypes.data_as(capi.P),
+                                                          out.ctypes.data_as(capi.P)))
+        return out
+
+    # -- device batches: tensors [batch, L, N] of int64 (raw u64 words) --------
+    def ntt_(self, moduli, x):
+        B, L, n = x.shape
+        self._chk(self.lib.hp_dev_ntt(self.h, n.bit_length() - 1, L, _u64arr(moduli), B, self._ptr(x)))
+        return x
+
+    def intt_(self, moduli, x, strict: bool = False):
+        B, L, n = x.shape
+        self._chk(self.lib.hp_dev_intt(self.h, n.bit_length() - 1, L, _u64arr(moduli), B, self._ptr(x), int(strict)))
+        return x
+
+    def _binary(self, fn, moduli, a, b, out=None):
+        B, L, n = a.shape
+        out = self.empty(a.shape) if out is None else out
+        self._chk(fn(self.h, n, L, _u64arr(moduli), B, self._ptr(a), self._ptr(b), self._ptr(out)))
+        return out
+
+    def poly_add(self, moduli, a, b, out=None):
+        return self._binary(self.lib.hp_dev_poly_add, moduli, a, b, out)
+
+    def poly_sub(self, moduli, a, b, out=None):
+        return self._binary(self.lib.hp_dev_poly_sub, moduli, a, b, out)
+
+    def poly_mul(self, moduli, a, b, out=None):
+        return self._binary(self.lib.hp_dev_poly_mul, moduli, a, b, out)
+
+    def poly_scalar_mul(self, moduli, a, scalars, out=None):
+        B, L, n = a.shape
+        if isinstance(scalars, int):
+            scalars = [scalars] * L
+        if len(scalars) != L:
+            raise InvalidArgument(capi.HP_EINVAL, "Numbers of RNS component mismatch.")
+        out = self.empty(a.shape) if out is None else out
+        self._chk(self.lib.hp_dev_poly_scalar_mul(self.h, n, L, _u64arr(moduli), B, _u64arr(scalars), self._ptr(a),
+                                                  self._ptr(out)))
+        return out
+
+    def poly_reduce_strict_(self, moduli, x):
+        B, L, n = x.shape
+        self._chk(self.lib.hp_dev_poly_reduce_strict(self.h, n, L, _u64arr(moduli), B, self._ptr(x)))
+        return x
+
+    def poly_involution(self, a):
+        B, L, n = a.shape
+        out = self.empty(a.shape)
+        self._chk(self.lib.hp_dev_poly_involution(self.h, n.bit_length() - 1, L, B, self._ptr(a), self._ptr(out)))
+        return out
+
+    def poly_cycle(self, a, step: int):
+        B, L, n = a.shape
+        out = self.empty(a.shape)
+        self._chk(self.lib.hp_dev_poly_cycle(self.h, n.bit_length() - 1, L, B, step, self._ptr(a), self._ptr(out)))
+        return out
+
+    # -- scheme level: ciphertext batches [batch, 2|3, L, N] -------------------
+    def mult_low_level(self, moduli, ct1, ct2):
+        B, two, L, n = ct1.shape
+        out = self.empty((B, 3, L, n))
+        self._chk(self.lib.hp_dev_mult_low_level(self.h, n.bit_length() - 1, L, _u64arr(moduli), B, self._ptr(ct1),
+                                                 self._ptr(ct2), self._ptr(out)))
+        return out
+
+    def ext_prod(self, moduli_ext, pt, key):
+        B, L, n = pt.shape
+        out = self.empty((B, 2, L + 1, n))
+        self._chk(self.lib.hp_dev_ext_prod_montgomery(self.h, n.bit_length() - 1, L, _u64arr(moduli_ext), B,
+                                                      self._ptr(pt), self._ptr(key), self._ptr(out)))
+        return out
+
+    def ckks_rescale(self, moduli, ct):
+        B, two, L, n = ct.shape
+        out = self.empty((B, 2, max(L - 1, 1), n))
+        self._chk(self.lib.hp_dev_ckks_rescale(self.h, n.bit_length() - 1, L, _u64arr(moduli), B, self._ptr(ct),
+                                               self._ptr(out)))
+        return out
+
+    def bgv_mod_switch(self, moduli, t, ct):
+        B, two, L, n = ct.shape
+        out = self.empty((B, 2, max(L - 1, 1), n))
+        self._chk(self.lib.hp_dev_bgv_mod_switch(self.h, n.bit_length() - 1, L, _u64arr(moduli), t, B, self._ptr(ct),
+                                                 self._ptr(out)))
+        return out
+
+    def ckks_relinearize(self, moduli_ext, quad, key):
+        B, three, L, n = quad.shape
+        out = self.empty((B, 2, L, n))
+        self._chk(self.lib.hp_dev_ckks_relinearize(self.h, n.bit_length() - 1, L, _u64arr(moduli_ext), B,
+                                                   self._ptr(quad), self._ptr(key), self._ptr(out)))
+        return out
+
+    def bgv_relinearize(self, moduli_ext, quad, key, inner_t: int = 1):
+        B, three, L, n = quad.shape
+        out = self.empty((B, 2, L, n))
+        self._chk(self.lib.hp_dev_bgv_relinearize(self.h, n.bit_length() - 1, L, _u64arr(moduli_ext), inner_t, B,
+                                                  self._ptr(quad), self._ptr(key), self._ptr(out)))
+        return out
+
+    def ckks_mult(self, moduli_ext, ct1, ct2, key, out=None):
+        B, two, L, n = ct1.shape
+        out = self.empty((B, 2, L - 1, n)) if out is None else out
+        self._chk(self.lib.hp_dev_ckks_mult_relin_rescale(self.h, n.bit_length() - 1, L, _u64arr(moduli_ext), B,
+                                                          self._ptr(ct1), self._ptr(ct2), self._ptr(key),
+                                                          self._ptr(out)))
+        return out
+
+    def bgv_mult(self, moduli_ext, t, ct1, ct2, key, out=None):
+        B, two, L, n = ct1.shape
+        out = self.empty((B, 2, L - 1, n)) if out is None else out
+        self._chk(self.lib.hp_dev_bgv_mult_relin_modswitch(self.h, n.bit_length() - 1, L, _u64arr(moduli_ext), t, B,
+                                                           self._ptr(ct1), self._ptr(ct2), self._ptr(key),
+                                                           self._ptr(out)))
+        return out

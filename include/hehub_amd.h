@@ -1,0 +1,165 @@
+/*
+ * hehub_amd.h -- C ABI of the MI355X-native RNS ring-arithmetic engine.
+ *
+ * This is the drop-in boundary for primihub/hehub's data-parallel hot path
+ * (negacyclic NTT/INTT, coefficient-wise modular arithmetic, key-switch inner
+ * product, rescale / mod-switch).  hehub has no FFI layer of its own: its seam
+ * is the set of free functions in namespace hehub declared in
+ *   src/fhe/common/ntt.h, mod_arith.h, rns.h, src/fhe/primitives/rgsw.h,
+ *   src/fhe/ckks/ckks.h, src/fhe/bgv/bgv.h .
+ * Each entry point below names the reference declaration (file:line, relative
+ * to the hehub source tree) it stands in for.  The C++ shim a hehub maintainer
+ * links instead of hehub's own .cpp files is hehub_amd/host/ (see
+ * INTEGRATION.md).
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, integers.  No torch / STL types.
+ *   - every function returns an hp_status; nothing throws across the ABI.
+ *     hp_last_error(ctx) gives the message for the last failure on that ctx.
+ *   - one hp_ctx per GPU; calls on one ctx are serialised by an internal
+ *     mutex; different ctxs are independent.
+ *   - "host" entry points take caller-owned host pointers, are synchronous and
+ *     retain nothing.  "dev" entry points take device pointers (hipMalloc'd by
+ *     the caller, by hp_dev_alloc, or by any other allocator in the process,
+ *     e.g. a torch tensor's data_ptr()), enqueue on the ctx stream and return
+ *     without synchronising.
+ *   - all words are uint64_t, little-endian, in the reference's lazy
+ *     (redundant) representation; outputs are bit-identical to the
+ *     reference's for identical inputs.
+ *
+ * Device layouts (row-major):
+ *   polynomial batch   u64[batch][L][N]
+ *   ciphertext batch   u64[batch][2][L][N]     (quadratic: [batch][3][L][N])
+ *   key-switch key     u64[L][2][L+1][N]       rgsw[j][half][k], Montgomery form
+ *                                               (keys.cpp:8-36, rgsw.cpp:33-55)
+ */
+#ifndef HEHUB_AMD_H
+#define HEHUB_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hp_ctx hp_ctx;
+
+typedef enum {
+    HP_OK = 0,
+    HP_EINVAL = 1,       /* reference would throw std::invalid_argument */
+    HP_EUNSUPPORTED = 2, /* reference throws "under development" / not built */
+    HP_EHIP = 3,         /* HIP runtime failure */
+    HP_ENOMEM = 4,
+    HP_ELOGIC = 5
+} hp_status;
+
+/* ---- engine ------------------------------------------------------------ */
+int hp_ctx_create(int device, hp_ctx **out);
+void hp_ctx_destroy(hp_ctx *ctx);
+const char *hp_last_error(hp_ctx *ctx);
+const char *hp_version(void);
+/* enqueue on an existing hipStream_t (e.g. torch's current stream); NULL = the HIP default stream.
+ * A fresh ctx uses a private non-blocking stream; hp_ctx_reset_stream goes back to it. */
+int hp_ctx_set_stream(hp_ctx *ctx, void *hip_stream);
+int hp_ctx_reset_stream(hp_ctx *ctx);
+void *hp_ctx_get_stream(hp_ctx *ctx);
+int hp_sync(hp_ctx *ctx);
+int hp_dev_alloc(hp_ctx *ctx, size_t bytes, void **dptr);
+int hp_dev_free(hp_ctx *ctx, void *dptr);
+int hp_memcpy_h2d(hp_ctx *ctx, void *dst, const void *src, size_t bytes);
+int hp_memcpy_d2h(hp_ctx *ctx, void *dst, const void *src, size_t bytes);
+/* force the simple one-stage-at-a-time transform kernels (debug / cross-check) */
+int hp_ctx_set_force_generic(hp_ctx *ctx, int on);
+/* timing of the last profiled launch group: see hp_prof_* below */
+
+/* ---- drop-in, host pointers (one call = one reference call) -------------- */
+/* ntt.h:33   void ntt_negacyclic_inplace_lazy(size_t log_dimension, u64 modulus, u64 coeffs[]) */
+int hp_ntt_negacyclic_inplace_lazy(hp_ctx *ctx, size_t log_dimension, uint64_t modulus, uint64_t *coeffs);
+/* ntt.h:64   void intt_negacyclic_inplace_lazy(size_t log_dimension, u64 modulus, u64 values[]) */
+int hp_intt_negacyclic_inplace_lazy(hp_ctx *ctx, size_t log_dimension, uint64_t modulus, uint64_t *values);
+/* ntt.h:102  void cache_ntt_factors_strict(u64 log_dimension, const std::vector<u64>&) */
+int hp_cache_ntt_factors_strict(hp_ctx *ctx, size_t log_dimension, const uint64_t *moduli, size_t count);
+/* mod_arith.h:16   batched_barrett_lazy(modulus, vec_len, vec) */
+int hp_batched_barrett_lazy(hp_ctx *ctx, uint64_t modulus, size_t vec_len, uint64_t *vec);
+/* mod_arith.h:18   batched_barrett */
+int hp_batched_barrett(hp_ctx *ctx, uint64_t modulus, size_t vec_len, uint64_t *vec);
+/* mod_arith.h:58   batched_reduce_strict */
+int hp_batched_reduce_strict(hp_ctx *ctx, uint64_t modulus, size_t vec_len, uint64_t *vec);
+/* mod_arith.h:27   batched_mul_mod_hybrid_lazy(modulus, vec_len, in1, in2, out) */
+int hp_batched_mul_mod_hybrid_lazy(hp_ctx *ctx, uint64_t modulus, size_t vec_len, const uint64_t *in1,
+                                   const uint64_t *in2, uint64_t *out);
+/* mod_arith.h:41   batched_mul_mod_barrett_lazy */
+int hp_batched_mul_mod_barrett_lazy(hp_ctx *ctx, uint64_t modulus, size_t vec_len, const uint64_t *in1,
+                                    const uint64_t *in2, uint64_t *out);
+/* mod_arith.h:55   batched_montgomery_128_lazy(modulus, len, const u128 in[], u64 out[]); in = {lo,hi} pairs */
+int hp_batched_montgomery_128_lazy(hp_ctx *ctx, uint64_t modulus, size_t len, const uint64_t *in128,
+                                   uint64_t *out);
+
+/* ---- device-resident batches (throughput path) --------------------------- */
+/* ntt.h:41-51 / :72-82 applied to every polynomial of a batch u64[batch][L][N], in place.
+ * strict != 0 on the inverse also applies reduce_strict (ntt.h:88-92). */
+int hp_dev_ntt(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *d_x);
+int hp_dev_intt(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *d_x,
+                int strict);
+/* rns.cpp:58-87 / :89-118 / :120-140 / :142-171 on u64[batch][L][N].  d_self may alias d_out. */
+int hp_dev_poly_add(hp_ctx *ctx, size_t n, size_t L, const uint64_t *moduli, size_t batch,
+                    const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out);
+int hp_dev_poly_sub(hp_ctx *ctx, size_t n, size_t L, const uint64_t *moduli, size_t batch,
+                    const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out);
+int hp_dev_poly_mul(hp_ctx *ctx, size_t n, size_t L, const uint64_t *moduli, size_t batch,
+                    const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out);
+/* per-limb scalars (operator*=(vector<u64>)); pass the same value L times for operator*=(u64) */
+int hp_dev_poly_scalar_mul(hp_ctx *ctx, size_t n, size_t L, const uint64_t *moduli, size_t batch,
+                           const uint64_t *rns_scalar, const uint64_t *d_a, uint64_t *d_out);
+/* mod_arith.h:65-72 */
+int hp_dev_poly_reduce_strict(hp_ctx *ctx, size_t n, size_t L, const uint64_t *moduli, size_t batch,
+                              uint64_t *d_x);
+/* permutation.cpp:59-75 / :28-57 (NTT-form gathers) */
+int hp_dev_poly_involution(hp_ctx *ctx, size_t logn, size_t L, size_t batch, const uint64_t *d_in,
+                           uint64_t *d_out);
+int hp_dev_poly_cycle(hp_ctx *ctx, size_t logn, size_t L, size_t batch, size_t step, const uint64_t *d_in,
+                      uint64_t *d_out);
+
+/* ckks/arith.cpp:55-62, bgv/arith.cpp:59-69: ct1, ct2 u64[batch][2][L][N] -> u64[batch][3][L][N] */
+int hp_dev_mult_low_level(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch,
+                          const uint64_t *d_ct1, const uint64_t *d_ct2, uint64_t *d_quad);
+/* rgsw.h:51  RlweCt ext_prod_montgomery(const RlwePt&, const RgswCt&):
+ * pt u64[batch][L][N] (NTT form), key u64[L][2][L+1][N] -> out u64[batch][2][L+1][N].
+ * moduli_ext = q_0..q_{L-1}, p. */
+int hp_dev_ext_prod_montgomery(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch,
+                               const uint64_t *d_pt, const uint64_t *d_key, uint64_t *d_out);
+/* ckks.h:313 rescale_inplace(ct, 1) -> rescaling.cpp:14-78: ct u64[batch][2][L][N] -> u64[batch][2][L-1][N] */
+int hp_dev_ckks_rescale(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch,
+                        const uint64_t *d_ct, uint64_t *d_out);
+/* bgv.h:167 mod_switch_inplace(ct, 1) -> mod_switch.cpp:13-78 */
+int hp_dev_bgv_mod_switch(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, uint64_t plain_modulus,
+                          size_t batch, const uint64_t *d_ct, uint64_t *d_out);
+/* ckks.h relinearize (ckks/arith.cpp:64-73): quad u64[batch][3][L][N] -> u64[batch][2][L][N] */
+int hp_dev_ckks_relinearize(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch,
+                            const uint64_t *d_quad, const uint64_t *d_key, uint64_t *d_out);
+/* bgv.h:159 relinearize (bgv/arith.cpp:71-79).  inner_plain_modulus = 1 reproduces the reference. */
+int hp_dev_bgv_relinearize(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext,
+                           uint64_t inner_plain_modulus, size_t batch, const uint64_t *d_quad,
+                           const uint64_t *d_key, uint64_t *d_out);
+/* ckks.h:270 mult(ct1, ct2, relin_key) followed by ckks.h:313 rescale_inplace:
+ * ct1, ct2 u64[batch][2][L][N] -> out u64[batch][2][L-1][N] */
+int hp_dev_ckks_mult_relin_rescale(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext,
+                                   size_t batch, const uint64_t *d_ct1, const uint64_t *d_ct2,
+                                   const uint64_t *d_key, uint64_t *d_out);
+/* bgv::mult_low_level + bgv::relinearize + bgv::mod_switch_inplace (bgv.h:150-167) */
+int hp_dev_bgv_mult_relin_modswitch(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext,
+                                    uint64_t plain_modulus, size_t batch, const uint64_t *d_ct1,
+                                    const uint64_t *d_ct2, const uint64_t *d_key, uint64_t *d_out);
+
+/* ---- in-library kernel timing (HIP events on the ctx stream) -------------- */
+/* Between hp_prof_begin and hp_prof_end every kernel launch of the named
+ * family is bracketed by hipEvents on the stream it is launched on.
+ * hp_prof_end synchronises and returns launches and total milliseconds. */
+int hp_prof_begin(hp_ctx *ctx, const char *kernel_family);
+int hp_prof_end(hp_ctx *ctx, size_t *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

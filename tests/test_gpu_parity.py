@@ -1,0 +1,176 @@
+"""GPU parity: every C-ABI entry point of the HIP engine against the oracle on identical seeded
+inputs, bit-exact on raw lazy u64 words (Level B of SURVEY.md section 8).  Run with -m gpu."""
+import numpy as np
+import pytest
+
+import params as P
+from oracle.pyoracle import SplitMix
+
+pytestmark = pytest.mark.gpu
+U = np.uint64
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from hehub_amd.engine import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def eq(a, b):
+    return a.shape == b.shape and bool((a == b).all())
+
+
+# ---- drop-in host entry points (mirror tests/mod_arith_t.cpp, tests/ntt_t.cpp) ----------------
+@pytest.mark.parametrize("q", P.BARRETT_TEST_Q + [P.P40[0], P.P50[0], P.C1_Q])
+def test_host_mod_arith(eng, orc, q):
+    for n in (1, 7, 4096, 100003):
+        a = SplitMix(11 + n).words(n, 0)
+        b = SplitMix(12 + n).words(n, 0)
+        assert eq(eng.host_barrett_lazy(q, a), orc.batched_barrett_lazy(q, a))
+        assert eq(eng.host_barrett(q, a), orc.batched_barrett(q, a))
+        assert eq(eng.host_reduce_strict(q, a), orc.batched_reduce_strict(q, a))
+        assert eq(eng.host_mul_barrett_lazy(q, a % U(q), b % U(q)), orc.mul_barrett_lazy(q, a % U(q), b % U(q)))
+        if q % 2:
+            for aa, bb in ((a % U(2 * q), b % U(2 * q)), (a, b)):
+                assert eq(eng.host_mul_hybrid_lazy(q, aa, bb), orc.mul_hybrid_lazy(q, aa, bb))
+            in128 = np.stack([a, b % U(q)], axis=1)
+            assert eq(eng.host_montgomery_128_lazy(q, in128), orc.montgomery_128_lazy(q, in128))
+    assert eng.host_barrett(q, np.zeros(0, dtype=U)).size == 0
+
+
+@pytest.mark.parametrize("logn", [1, 2, 4, 7, 10, 11, 12, 13, 14, 15])
+@pytest.mark.parametrize("q", P.NTT_TEST_Q + [P.P50[0], P.P40[0]])
+def test_host_ntt_round_trip(eng, orc, logn, q):
+    from hehub_amd.engine import InvalidArgument
+
+    n = 1 << logn
+    if (q - 1) % (2 * n):
+        with pytest.raises(InvalidArgument, match="2N doesn't divide"):
+            eng.host_ntt(logn, q, np.zeros(n, dtype=U))
+        return
+    rng = SplitMix(100 + logn)
+    for x in (rng.words(n, q), rng.words(n, 2 * q), np.zeros(n, dtype=U), np.full(n, q - 1, dtype=U)):
+        y = eng.host_ntt(logn, q, x)
+        assert eq(y, orc.ntt(logn, q, x))
+        z = eng.host_intt(logn, q, y)
+        assert eq(z, orc.intt(logn, q, y))
+        assert eq(orc.batched_reduce_strict(q, z), x % U(q))
+    # delta and X (tests/ntt_t.cpp "one", "just x")
+    d = np.zeros(n, dtype=U); d[0] = 1
+    assert (eng.host_ntt(logn, q, d) % U(q) == 1).all()
+
+
+def test_host_ntt_rejects_60_bit(eng):
+    from hehub_amd.engine import InvalidArgument
+
+    with pytest.raises(InvalidArgument, match="bit size > 59"):
+        eng.host_ntt(4, 1152921504606844417, np.zeros(16, dtype=U))
+
+
+@pytest.mark.parametrize("logn", [11, 12, 13, 14, 15])
+def test_tiled_kernels_match_simple_kernels(eng, orc, logn):
+    """the register/LDS-tiled transforms against the one-stage-at-a-time kernels on the GPU itself"""
+    q = P.P50[0]
+    x = SplitMix(7).words(1 << logn, 2 * q)
+    eng.force_generic(True)
+    yg, zg = eng.host_ntt(logn, q, x), eng.host_intt(logn, q, x)
+    eng.force_generic(False)
+    assert eq(eng.host_ntt(logn, q, x), yg) and eq(eng.host_intt(logn, q, x), zg)
+    assert eq(yg, orc.ntt(logn, q, x))
+
+
+# ---- device batches ---------------------------------------------------------------------------
+BATCH_CASES = [(3, [17179672577, 17179410433, 17176854529], 5), (10, P.P40[:4], 3), (12, P.P40[:3], 9),
+               (13, P.C5_Q, 4), (14, P.C2_MODULI, 6), (15, P.C3_Q[:3], 5)]
+
+
+@pytest.mark.parametrize("logn,moduli,B", BATCH_CASES)
+def test_dev_batch_ops(eng, orc, logn, moduli, B):
+    n, L = 1 << logn, len(moduli)
+    rng = SplitMix(logn * 31 + B)
+    two_q = [2 * m for m in moduli]
+    a = rng.poly((B, L, n), two_q)
+    b = rng.poly((B, L, n), two_q)
+    da, db = eng.to_device(a), eng.to_device(b)
+    exp = lambda f: np.stack([f(i) for i in range(B)])
+    assert eq(eng.to_host(eng.poly_add(moduli, da, db)), exp(lambda i: orc.poly_add(moduli, a[i], b[i])))
+    assert eq(eng.to_host(eng.poly_sub(moduli, da, db)), exp(lambda i: orc.poly_sub(moduli, a[i], b[i])))
+    assert eq(eng.to_host(eng.poly_mul(moduli, da, db)), exp(lambda i: orc.poly_mul(moduli, a[i], b[i])))
+    sc = [int(w) for w in rng.words(L, 0)]
+    assert eq(eng.to_host(eng.poly_scalar_mul(moduli, da, sc)), exp(lambda i: orc.poly_rns_scalar_mul(moduli, a[i], sc)))
+    assert eq(eng.to_host(eng.poly_scalar_mul(moduli, da, 2**63 + 5)), exp(lambda i: orc.poly_scalar_mul(moduli, a[i], 2**63 + 5)))
+    assert eq(eng.to_host(eng.poly_involution(da)), exp(lambda i: orc.poly_involution(a[i])))
+    for step in (1, 3, n // 4 + 1):
+        assert eq(eng.to_host(eng.poly_cycle(da, step)), exp(lambda i: orc.poly_cycle(a[i], step)))
+    y = eng.to_host(eng.ntt_(moduli, da.clone()))
+    assert eq(y, exp(lambda i: orc.poly_ntt(moduli, a[i])))
+    z = eng.to_host(eng.intt_(moduli, eng.to_device(y)))
+    assert eq(z, exp(lambda i: orc.poly_intt(moduli, y[i])))
+    zs = eng.to_host(eng.intt_(moduli, eng.to_device(y), strict=True))
+    assert eq(zs, exp(lambda i: orc.poly_reduce_strict(moduli, orc.poly_intt(moduli, y[i]))))
+    assert eq(zs, a % np.array(moduli, dtype=U)[None, :, None])
+    assert eq(eng.to_host(eng.poly_reduce_strict_(moduli, da.clone())), exp(lambda i: orc.poly_reduce_strict(moduli, a[i])))
+
+
+SCHEME_CASES = [
+    (3, [1099510054913, 1073479681, 1072496641, 1099507695617], 4),     # tests/ckks_t.cpp shape {40,30,30}+40, N=8
+    (7, [P.P40[0], P.P40[1], P.P50[0]], 3),
+    (11, P.P40[:3] + [P.P50[0]], 2),
+    (12, [P.P50[1]] + P.P40[:4] + [P.P50[0]], 3),
+    (P.C5_LOGN, P.C5_MODULI_EXT, 2),
+]
+
+
+@pytest.mark.parametrize("logn,mext,B", SCHEME_CASES)
+def test_dev_scheme_level(eng, orc, logn, mext, B):
+    n, L = 1 << logn, len(mext) - 1
+    q = mext[:L]
+    rng = SplitMix(1000 + logn)
+    ct1 = rng.poly((B, 2, L, n), q)
+    ct2 = rng.poly((B, 2, L, n), q)
+    key = rng.poly((L, 2, L + 1, n), mext)
+    d1, d2, dk = eng.to_device(ct1), eng.to_device(ct2), eng.to_device(key)
+    exp = lambda f: np.stack([f(i) for i in range(B)])
+    quad = eng.mult_low_level(q, d1, d2)
+    quad_h = eng.to_host(quad)
+    assert eq(quad_h, exp(lambda i: orc.mult_low_level(q, ct1[i], ct2[i])))
+    pt = quad[:, 2].contiguous()
+    ext = eng.ext_prod(mext, pt, dk)
+    ext_h = eng.to_host(ext)
+    assert eq(ext_h, exp(lambda i: orc.ext_prod(mext, quad_h[i, 2], key)))
+    assert eq(eng.to_host(eng.ckks_rescale(mext, ext)), exp(lambda i: orc.ckks_rescale(mext, ext_h[i])))
+    assert eq(eng.to_host(eng.ckks_rescale(q, d1)), exp(lambda i: orc.ckks_rescale(q, ct1[i])))
+    for t in (65537, 2, 1):
+        assert eq(eng.to_host(eng.bgv_mod_switch(q, t, d2)), exp(lambda i: orc.bgv_mod_drop(q, t, ct2[i])))
+    assert eq(eng.to_host(eng.ckks_relinearize(mext, quad, dk)), exp(lambda i: orc.ckks_relinearize(mext, quad_h[i], key)))
+    assert eq(eng.to_host(eng.bgv_relinearize(mext, quad, dk)), exp(lambda i: orc.bgv_relinearize(mext, quad_h[i], key)))
+    assert eq(eng.to_host(eng.ckks_mult(mext, d1, d2, dk)), exp(lambda i: orc.ckks_mult(mext, ct1[i], ct2[i], key)))
+    assert eq(eng.to_host(eng.bgv_mult(mext, P.C5_T, d1, d2, dk)), exp(lambda i: orc.bgv_mult(mext, P.C5_T, ct1[i], ct2[i], key)))
+
+
+def test_c3_shape_ckks_mult(eng, orc):
+    """BASELINE config 3 shape (N=32768, L=10), two ciphertext pairs, raw words vs the oracle."""
+    logn, mext = P.C3_LOGN, P.C3_MODULI_EXT
+    n, L, B = 1 << logn, 10, 2
+    rng = SplitMix(3)
+    ct1 = rng.poly((B, 2, L, n), mext[:L])
+    ct2 = rng.poly((B, 2, L, n), mext[:L])
+    key = rng.poly((L, 2, L + 1, n), mext)
+    out = eng.to_host(eng.ckks_mult(mext, eng.to_device(ct1), eng.to_device(ct2), eng.to_device(key)))
+    for i in range(B):
+        assert eq(out[i], orc.ckks_mult(mext, ct1[i], ct2[i], key))
+
+
+def test_error_behaviour(eng):
+    from hehub_amd.engine import InvalidArgument
+
+    x = eng.empty((1, 1, 8))
+    with pytest.raises(InvalidArgument, match="Unable to drop the only one prime"):
+        eng.ckks_rescale([P.P40[0]], eng.empty((1, 2, 1, 8)))
+    with pytest.raises(InvalidArgument, match="2N doesn't divide"):
+        eng.ntt_([12289], eng.empty((1, 1, 1 << 15)))
+    with pytest.raises(InvalidArgument):
+        eng.poly_scalar_mul([65537], x, [1, 2])
