@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the MI355X ring-arithmetic engine.
+
+    python bench.py --gpus 1 --steps K --warmup W [--workload ckks|ntt|bgv] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic ciphertexts that is already
+resident in HBM:
+
+  ckks (default, BASELINE config 3/4): ckks::mult + relinearize + rescale_inplace on `batch`
+        ciphertext pairs, N = 32768, L = 10 moduli {50,40x9} bits + 50-bit special prime
+  ntt  (BASELINE config 2): forward negacyclic NTT of 1024 polynomials x 4 limbs, N = 16384
+  bgv  (BASELINE config 5 shape): bgv mult + relinearize + mod_switch, N = 8192, L = 6
+
+One process per GPU; ciphertext batches are sharded across ranks with no data-path collective
+(SURVEY.md section 8e), so per-GPU work is fixed: weak scaling.  Rank 0 prints ONE JSON line.
+
+The oracle / compiled reference is used only for the `cpu_baseline` leg (rank 0, N = 1).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="ckks", choices=["ckks", "ntt", "bgv"])
+    ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (0 = BASELINE config value)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")
+    return ap.parse_args()
+
+
+def rand_words(torch, shape, moduli, device, seed):
+    """uniform words in [0, q_k) per limb (limb axis = -2), generated on the device"""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = torch.empty(shape, dtype=torch.int64, device=device)
+    for k, q in enumerate(moduli):
+        out.select(-2, k).copy_(torch.randint(0, int(q), out.select(-2, k).shape, generator=g, device=device,
+                                              dtype=torch.int64))
+    return out
+
+
+def cpu_baseline(workload, P, budget_s):
+    """Time the CPU path on this host: the compiled reference when oracle/_ref travelled with the
+    snapshot ("reference"), else the C restatement ("port").  Single thread, bounded sample."""
+    import numpy as np
+    from oracle.pyoracle import Oracle, SplitMix, have_ref, build
+
+    build(ref=False)
+    kind = "reference" if have_ref() else "port"
+    lib = Oracle("ref" if kind == "reference" else "orc")
+    rng = SplitMix(3)
+    if workload == "ntt":
+        logn, q = P.C2_LOGN, P.C2_MODULI[0]
+        x = rng.words(1 << logn, q)
+        if kind == "reference":
+            per = lib.time_ntt(logn, q, 0, 200, x)
+            iters = max(200, int(budget_s / max(per, 1e-6)))
+            per = lib.time_ntt(logn, q, 0, iters, x)
+        else:
+            lib.ntt(logn, q, x)
+            iters, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < budget_s:
+                lib.ntt(logn, q, x); iters += 1
+            per = (time.perf_counter() - t0) / iters
+        return {"value": 1.0 / per, "unit": "limb-NTT/s", "cores": 1, "kind": kind,
+                "sample": f"{iters} forward NTTs of one limb, N={1 << logn}, q={q}, single thread, tables warm"}
+    if workload == "ckks":
+        logn, mext, t = P.C3_LOGN, P.C3_MODULI_EXT, 0
+    else:
+        logn, mext, t = P.C5_LOGN, P.C5_MODULI_EXT, P.C5_T
+    n, L = 1 << logn, len(mext) - 1
+    ct1 = rng.poly((2, L, n), mext[:L]); ct2 = rng.poly((2, L, n), mext[:L])
+    key = rng.poly((L, 2, L + 1, n), mext)
+    if kind == "reference":
+        f = (lambda it: lib.time_ckks_mult(mext, ct1, ct2, key, it)) if workload == "ckks" else \
+            (lambda it: lib.time_bgv_mult(mext, t, ct1, ct2, key, it))
+        per = f(2)
+        iters = max(2, int(budget_s / max(per, 1e-6)))
+        per = f(iters)
+    else:
+        f = (lambda: lib.ckks_mult(mext, ct1, ct2, key)) if workload == "ckks" else \
+            (lambda: lib.bgv_mult(mext, t, ct1, ct2, key))
+        f()
+        iters, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            f(); iters += 1
+        per = (time.perf_counter() - t0) / iters
+    name = "ckks::mult+relinearize+rescale_inplace" if workload == "ckks" else "bgv mult+relinearize+mod_switch"
+    return {"value": 1.0 / per, "unit": "hom-mult/s", "cores": 1, "kind": kind,
+            "sample": f"{iters} x {name} on one ciphertext pair, N={n}, L={L}, single thread, tables warm"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import params as P
+    from hehub_amd.engine import Engine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    eng = Engine(local)
+
+    wl = args.workload
+    if wl == "ntt":
+        logn, moduli = P.C2_LOGN, P.C2_MODULI
+        B = args.batch or P.C2_BATCH
+        n, L = 1 << logn, len(moduli)
+        x = rand_words(torch, (B, L, n), moduli, dev, 2 + rank)
+        units_per_step = B * L
+        step = lambda: eng.ntt_(moduli, x)
+        family = "ntt"
+        alg_bytes_per_step = 16.0 * n * B * L
+        launches_per_step = 1
+        metric, unit = "limb_ntt_per_s", "limb-NTT/s"
+        cfg = {"workload": f"C2: batched forward negacyclic NTT, N={n}, {L} RNS limbs (50-bit), batch={B} polynomials per GPU",
+               "N": n, "limbs": L, "batch_per_gpu": B}
+    else:
+        if wl == "ckks":
+            logn, mext, t, B0 = P.C3_LOGN, P.C3_MODULI_EXT, 0, P.C3_BATCH
+        else:
+            logn, mext, t, B0 = P.C5_LOGN, P.C5_MODULI_EXT, P.C5_T, 512
+        B = args.batch or B0
+        n, L = 1 << logn, len(mext) - 1
+        ct1 = rand_words(torch, (B, 2, L, n), mext[:L], dev, 3 + rank)
+        ct2 = rand_words(torch, (B, 2, L, n), mext[:L], dev, 1003 + rank)
+        key = rand_words(torch, (L, 2, L + 1, n), mext, dev, 7)
+        out = eng.empty((B, 2, L - 1, n))
+        units_per_step = B
+        if wl == "ckks":
+            step = lambda: eng.ckks_mult(mext, ct1, ct2, key, out=out)
+            metric, unit = "ckks_hom_mult_per_s", "hom-mult/s"
+            name = "C3: ckks::mult + relinearize + rescale_inplace"
+        else:
+            step = lambda: eng.bgv_mult(mext, t, ct1, ct2, key, out=out)
+            metric, unit = "bgv_hom_mult_per_s", "hom-mult/s"
+            name = "C5 shape: bgv mult_low_level + relinearize + mod_switch_inplace"
+        family = "ntt"
+        fwd_per_ct = L * L + 4 * L - 2          # forward limb transforms per hom-mult
+        alg_bytes_per_step = 16.0 * n * fwd_per_ct * B
+        launches_per_step = None
+        cfg = {"workload": f"{name}, N={n}, L={L} moduli + special prime, batch={B} ciphertext pairs per GPU",
+               "N": n, "L": L, "batch_per_gpu": B, "sub_batch": int(os.environ.get("HP_MULT_CHUNK", "0")) or B,
+               "A_step_bytes_per_op": (5 * L * L + 36 * L) * 8 * n}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    eng.prof_begin(family)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    launches, kern_ms = eng.prof_end()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    barrier()
+
+    value = units_per_step * world * args.steps / elapsed
+    res = {
+        "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic", "config": cfg,
+    }
+    # roofline of the dominant kernel family (forward NTT), from HIP events recorded by the library on the
+    # launch stream around every launch of that family inside the timed region (rank-local)
+    if launches:
+        bytes_per_launch = alg_bytes_per_step * args.steps / launches
+        avg_s = kern_ms * 1e-3 / launches
+        achieved = bytes_per_launch / avg_s / 1e9
+        res["roofline"] = {"bound": "hbm", "kernel": "k_ntt_fwd (register/LDS-tiled forward NTT)",
+                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": None, "launches": launches, "avg_launch_ms": kern_ms / launches,
+                           "algorithmic_bytes_per_launch": bytes_per_launch,
+                           "share_of_step_time": kern_ms * 1e-3 / elapsed}
+    if wl != "ntt":
+        a_step = (5 * L * L + 36 * L) * 8 * n
+        res["pipeline_roofline"] = {"A_step_GBps": value / world * a_step / 1e9,
+                                    "frac_of_hbm_peak": value / world * a_step / 1e9 / HBM_PEAK_GBS}
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(wl, P, args.cpu_seconds)
+            except Exception as e:  # the checker is optional infrastructure; the GPU number stands on its own
+                res["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
