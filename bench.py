@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="ckks", choices=["ckks", "ntt", "bgv"])
+    ap.add_argument("--workload", default="ckks", choices=["ckks", "ntt", "ntt15", "intt", "intt15", "bgv"])
     ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (0 = BASELINE config value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")
@@ -65,21 +65,23 @@ def cpu_baseline(workload, P, budget_s):
     kind = "reference" if have_ref() else "port"
     lib = Oracle("ref" if kind == "reference" else "orc")
     rng = SplitMix(3)
-    if workload == "ntt":
-        logn, q = P.C2_LOGN, P.C2_MODULI[0]
+    if "ntt" in workload:
+        logn, q = (P.C3_LOGN, P.C3_P) if workload.endswith("15") else (P.C2_LOGN, P.C2_MODULI[0])
+        inv = int(workload.startswith("intt"))
         x = rng.words(1 << logn, q)
         if kind == "reference":
-            per = lib.time_ntt(logn, q, 0, 200, x)
+            per = lib.time_ntt(logn, q, inv, 200, x)
             iters = max(200, int(budget_s / max(per, 1e-6)))
-            per = lib.time_ntt(logn, q, 0, iters, x)
+            per = lib.time_ntt(logn, q, inv, iters, x)
         else:
-            lib.ntt(logn, q, x)
+            f = lib.intt if inv else lib.ntt
+            f(logn, q, x)
             iters, t0 = 0, time.perf_counter()
             while time.perf_counter() - t0 < budget_s:
-                lib.ntt(logn, q, x); iters += 1
+                f(logn, q, x); iters += 1
             per = (time.perf_counter() - t0) / iters
         return {"value": 1.0 / per, "unit": "limb-NTT/s", "cores": 1, "kind": kind,
-                "sample": f"{iters} forward NTTs of one limb, N={1 << logn}, q={q}, single thread, tables warm"}
+                "sample": f"{iters} {'inverse' if inv else 'forward'} NTTs of one limb, N={1 << logn}, q={q}, single thread, tables warm"}
     if workload == "ckks":
         logn, mext, t = P.C3_LOGN, P.C3_MODULI_EXT, 0
     else:
@@ -126,18 +128,23 @@ def main():
     eng = Engine(local)
 
     wl = args.workload
-    if wl == "ntt":
-        logn, moduli = P.C2_LOGN, P.C2_MODULI
-        B = args.batch or P.C2_BATCH
+    if wl in ("ntt", "ntt15", "intt", "intt15"):
+        inverse = wl.startswith("intt")
+        if wl.endswith("15"):   # the transform shape inside the C3 pipeline: N=32768, 10 moduli + special prime
+            logn, moduli = P.C3_LOGN, P.C3_MODULI_EXT
+            B = args.batch or 256
+        else:
+            logn, moduli = P.C2_LOGN, P.C2_MODULI
+            B = args.batch or P.C2_BATCH
         n, L = 1 << logn, len(moduli)
         x = rand_words(torch, (B, L, n), moduli, dev, 2 + rank)
         units_per_step = B * L
-        step = lambda: eng.ntt_(moduli, x)
-        family = "ntt"
+        step = (lambda: eng.intt_(moduli, x)) if inverse else (lambda: eng.ntt_(moduli, x))
+        family = "intt" if inverse else "ntt"
         alg_bytes_per_step = 16.0 * n * B * L
         launches_per_step = 1
         metric, unit = "limb_ntt_per_s", "limb-NTT/s"
-        cfg = {"workload": f"C2: batched forward negacyclic NTT, N={n}, {L} RNS limbs (50-bit), batch={B} polynomials per GPU",
+        cfg = {"workload": f"{'C2' if logn == 14 else 'C3-shape'}: batched {'inverse' if inverse else 'forward'} negacyclic NTT, N={n}, {L} RNS limbs, batch={B} polynomials per GPU",
                "N": n, "limbs": L, "batch_per_gpu": B}
     else:
         if wl == "ckks":
@@ -201,12 +208,12 @@ def main():
         bytes_per_launch = alg_bytes_per_step * args.steps / launches
         avg_s = kern_ms * 1e-3 / launches
         achieved = bytes_per_launch / avg_s / 1e9
-        res["roofline"] = {"bound": "hbm", "kernel": "k_ntt_fwd (register/LDS-tiled forward NTT)",
+        res["roofline"] = {"bound": "hbm", "kernel": "k_ntt_inv (register/LDS-tiled inverse NTT)" if family == "intt" else "k_ntt_fwd (register/LDS-tiled forward NTT)",
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": None, "launches": launches, "avg_launch_ms": kern_ms / launches,
                            "algorithmic_bytes_per_launch": bytes_per_launch,
                            "share_of_step_time": kern_ms * 1e-3 / elapsed}
-    if wl != "ntt":
+    if wl in ("ckks", "bgv"):
         a_step = (5 * L * L + 36 * L) * 8 * n
         res["pipeline_roofline"] = {"A_step_GBps": value / world * a_step / 1e9,
                                     "frac_of_hbm_peak": value / world * a_step / 1e9 / HBM_PEAK_GBS}
