@@ -111,19 +111,16 @@ def cpu_baseline(workload, P, budget_s):
 def main():
     args = parse()
     import torch
-    import torch.distributed as dist
 
     import params as P
     from hehub_amd.engine import Engine
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    from hehub_amd import dist as hd
+
+    world, rank, local = hd.env_world()
     torch.cuda.set_device(local)
+    hd.init("nccl", device=torch.device(f"cuda:{local}"))   # "nccl" is RCCL on ROCm; rendezvous + timing fences only
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = f"cuda:{local}"
     eng = Engine(local)
 
@@ -174,14 +171,9 @@ def main():
                "N": n, "L": L, "batch_per_gpu": B, "sub_batch": int(os.environ.get("HP_MULT_CHUNK", "0")) or B,
                "A_step_bytes_per_op": (5 * L * L + 36 * L) * 8 * n}
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
-    barrier()
+    hd.barrier()                       # dist.barrier() + torch.cuda.synchronize()
     eng.prof_begin(family)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -189,12 +181,8 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     launches, kern_ms = eng.prof_end()
-    elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    barrier()
+    elapsed = hd.max_over_ranks(t1 - t0, device=dev)
+    hd.barrier()
 
     value = units_per_step * world * args.steps / elapsed
     res = {
@@ -224,8 +212,7 @@ def main():
             except Exception as e:  # the checker is optional infrastructure; the GPU number stands on its own
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res))
-    if world > 1:
-        dist.destroy_process_group()
+    hd.finalize()
     eng.close()
 
 

@@ -59,3 +59,20 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose=True))
+
+
+HOST_LIB = os.path.join(LIBDIR, "libhehub_amd_host.so")
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    """The hehub-compatible C++ host layer (hehub_amd/host) over the C ABI; plain g++, no HIP needed."""
+    build_lib(force=False, verbose=verbose)
+    src = os.path.join(HERE, "host", "hehub.cpp")
+    deps = [src, os.path.join(HERE, "host", "hehub.hpp"), os.path.join(os.path.dirname(HERE), "include", "hehub_amd.h")]
+    if force or _stale(HOST_LIB, deps):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", src, "-o", HOST_LIB, f"-L{LIBDIR}", "-lhehub_amd",
+               "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    return HOST_LIB

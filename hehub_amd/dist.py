@@ -1,0 +1,64 @@
+"""Multi-GPU plumbing for the batch-sharded mode.
+
+Ciphertexts are independent units: a node-level batch is cut into contiguous slices, one per rank
+(one process per GPU), with NO collective on the data path -- keys and twiddle tables are read-only
+and replicated.  torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" on CPU for tests) is only
+used to rendezvous, to fence the timed region and to take the max elapsed time over ranks.
+"""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+
+def env_world() -> Tuple[int, int, int]:
+    return (int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous slice [lo, hi) of `total` units owned by `rank`; sizes differ by at most one."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def init(backend: str, device=None):
+    import torch.distributed as dist
+
+    world, rank, _ = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kwargs = {"device_id": device} if (device is not None and backend == "nccl") else {}
+        dist.init_process_group(backend, **kwargs)
+    return world, rank
+
+
+def barrier(sync_device: bool = True):
+    import torch
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+    if sync_device and torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+def max_over_ranks(seconds: float, device="cpu") -> float:
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def finalize():
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()

@@ -1,0 +1,211 @@
+// hehub.hpp -- C++ host layer that mirrors primihub/hehub's public interface for the ring-arithmetic
+// hot path and forwards every operation to the HIP engine through the C ABI (include/hehub_amd.h).
+//
+// Same names, argument meaning and error behaviour as the reference headers it stands in for
+// (citations are relative to the hehub source tree):
+//   RnsIntVec / RnsPolynomial and operators     src/fhe/common/rns.h:15-280, rns.cpp:58-171
+//   ntt / intt / reduce_strict / batched_*       src/fhe/common/ntt.h:33-102, mod_arith.h:16-78
+//   cycle / involution                           src/fhe/common/permutation.h:90-92
+//   RlweCt, add/sub/mult_plain_core              src/fhe/primitives/rlwe.h:27,98-134
+//   RgswCt, RlweKsk, ext_prod_montgomery         src/fhe/primitives/rgsw.h:20,51, keys.h:19-32
+//   ckks::{add,sub,mult_low_level,relinearize,mult,rescale_inplace}   src/fhe/ckks/ckks.h:73-313
+//   bgv::{add,sub,mult_low_level,relinearize,mod_switch_inplace}      src/fhe/bgv/bgv.h:24-167
+//
+// What is NOT here (out of scope): encoders, samplers, key generation, BigInt,
+// rns_base_transform.  A hehub build keeps its own files for those and links this layer for the rest
+// (INTEGRATION.md).
+//
+// This is the per-call drop-in path: every call moves its operands over PCIe.  Throughput code uses
+// the device-resident batch entry points of the C ABI directly.
+#pragma once
+
+#include <array>
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <vector>
+
+struct hp_ctx;
+
+namespace hehub {
+
+using u64 = uint64_t;
+using u128 = unsigned __int128;
+
+namespace amd {
+/// The process-wide engine (device 0 unless HEHUB_AMD_DEVICE is set); created on first use, like the
+/// reference's lazily filled global caches (ntt.cpp:107-143).  Throws std::runtime_error when no GPU
+/// or no engine library is available -- there is no CPU fallback.
+hp_ctx *engine();
+} // namespace amd
+
+class RnsIntVec {
+public:
+    struct Params {
+        size_t dimension = 0;
+        size_t component_count;
+        std::vector<u64> moduli;
+    };
+    using ComponentData = std::vector<u64>;
+
+    RnsIntVec() {}
+    RnsIntVec(const size_t dimension, const size_t components, const std::vector<u64> &moduli);
+    RnsIntVec(const Params &params);
+
+    inline bool operator==(const RnsIntVec &o) const {
+        return log_dimension_ == o.log_dimension_ && dimension_ == o.dimension_ && moduli_ == o.moduli_ &&
+               components_ == o.components_;
+    }
+    inline Params params() const { return Params{dimension_, components_.size(), moduli_}; }
+    inline size_t component_count() const { return components_.size(); }
+    inline size_t log_dimension() const { return log_dimension_; }
+    inline size_t dimension() const { return dimension_; }
+    inline std::vector<ComponentData> &components() { return components_; }
+    inline const std::vector<ComponentData> &components() const { return components_; }
+    inline auto begin() { return components_.begin(); }
+    inline auto begin() const { return components_.cbegin(); }
+    inline auto end() { return components_.end(); }
+    inline auto end() const { return components_.cend(); }
+    inline auto last() { return components_.end() - 1; }
+    inline auto last() const { return components_.cend() - 1; }
+    inline u64 modulus_at(int i) const { return moduli_[i]; }
+    inline const std::vector<u64> &modulus_vec() const { return moduli_; }
+    inline ComponentData &operator[](int i) { return components_[i]; }
+    inline const ComponentData &operator[](int i) const { return components_[i]; }
+
+    void add_components(const std::vector<u64> &new_moduli, size_t adding = 1);
+    void remove_components(size_t removing = 1);
+
+private:
+    size_t log_dimension_ = 0;
+    size_t dimension_ = 0;
+    std::vector<ComponentData> components_;
+    std::vector<u64> moduli_;
+};
+
+class RnsPolynomial : public RnsIntVec {
+public:
+    using RnsIntVec::RnsIntVec;
+    enum class RepForm { coeff, value };
+    RnsPolynomial() {}
+    RnsPolynomial(RnsIntVec &&v) : RnsIntVec(v) {}
+    RepForm rep_form = RepForm::coeff;
+};
+using RnsPolyParams = RnsPolynomial::Params;
+using PolyRepForm = RnsPolynomial::RepForm;
+
+// ---- rns.h operators ---------------------------------------------------------------------------
+const RnsIntVec &operator+=(RnsIntVec &self, const RnsIntVec &b);
+const RnsIntVec &operator-=(RnsIntVec &self, const RnsIntVec &b);
+RnsIntVec operator*(const RnsIntVec &a, const RnsIntVec &b);
+const RnsIntVec &operator*=(RnsIntVec &self, const u64 small_scalar);
+const RnsIntVec &operator*=(RnsIntVec &self, const std::vector<u64> &rns_scalar);
+inline RnsIntVec operator+(const RnsIntVec &a, const RnsIntVec &b) { auto r(a); r += b; return r; }
+inline RnsIntVec operator-(const RnsIntVec &a, const RnsIntVec &b) { auto r(a); r -= b; return r; }
+
+const RnsPolynomial &operator+=(RnsPolynomial &self, const RnsPolynomial &b);
+const RnsPolynomial &operator-=(RnsPolynomial &self, const RnsPolynomial &b);
+RnsPolynomial operator*(const RnsPolynomial &a, const RnsPolynomial &b);
+inline RnsPolynomial operator+(const RnsPolynomial &a, const RnsPolynomial &b) { auto r(a); r += b; return r; }
+inline RnsPolynomial operator-(const RnsPolynomial &a, const RnsPolynomial &b) { auto r(a); r -= b; return r; }
+inline const RnsPolynomial &operator*=(RnsPolynomial &self, const RnsPolynomial &b) { auto t(self); return self = t * b; }
+const RnsPolynomial &operator*=(RnsPolynomial &self, const u64 small_scalar);
+const RnsPolynomial &operator*=(RnsPolynomial &self, const std::vector<u64> &rns_scalar);
+inline RnsPolynomial operator*(const RnsPolynomial &p, const std::vector<u64> &s) { auto c(p); c *= s; return c; }
+
+// ---- mod_arith.h ---------------------------------------------------------------------------------
+void batched_barrett_lazy(const u64 modulus, const size_t vec_len, u64 vec[]);
+void batched_barrett(const u64 modulus, const size_t vec_len, u64 vec[]);
+void batched_mul_mod_hybrid_lazy(const u64 modulus, const size_t vec_len, const u64 in_vec1[], const u64 in_vec2[],
+                                 u64 out_vec[]);
+void batched_mul_mod_hybrid(const u64 modulus, const size_t vec_len, const u64 in_vec1[], const u64 in_vec2[],
+                            u64 out_vec[]);
+void batched_mul_mod_barrett_lazy(const u64 modulus, const size_t vec_len, const u64 in_vec1[], const u64 in_vec2[],
+                                  u64 out_vec[]);
+void batched_mul_mod_barrett(const u64 modulus, const size_t vec_len, const u64 in_vec1[], const u64 in_vec2[],
+                             u64 out_vec[]);
+void batched_montgomery_128_lazy(const u64 modulus, const size_t len, const u128 in[], u64 out[]);
+void batched_reduce_strict(const u64 modulus, const size_t vec_len, u64 vec[]);
+void reduce_strict(RnsPolynomial &rns_poly);
+/// scalar helper kept on the host exactly as in the reference (mod_arith.h:74-78)
+inline u64 mul_mod_harvey_lazy(const u64 modulus, const u64 in1, const u64 in2, const u64 in2_harvey) {
+    u64 approx_quotient = (u128)in1 * in2_harvey >> 64;
+    return (u128)in1 * in2 - (u128)approx_quotient * modulus;
+}
+u64 inverse_mod_prime(const u64 elem, const u64 prime);
+
+// ---- ntt.h ------------------------------------------------------------------------------------------
+void ntt_negacyclic_inplace_lazy(const size_t log_dimension, const u64 modulus, u64 coeffs[]);
+void ntt_negacyclic_inplace_lazy(RnsPolynomial &rns_poly);
+void intt_negacyclic_inplace_lazy(const size_t log_dimension, const u64 modulus, u64 values[]);
+void intt_negacyclic_inplace_lazy(RnsPolynomial &rns_poly);
+void intt_negacyclic_inplace(RnsPolynomial &rns_poly);
+void cache_ntt_factors_strict(const u64 log_dimension, const std::vector<u64> &moduli);
+
+// ---- permutation.h -------------------------------------------------------------------------------------
+RnsPolynomial cycle(const RnsPolynomial &poly_ntt, const size_t step);
+RnsPolynomial involution(const RnsPolynomial &poly_ntt);
+
+// ---- rlwe.h / rgsw.h / keys.h ---------------------------------------------------------------------------
+using RlwePt = RnsPolynomial;
+using RlweCt = std::array<RnsPolynomial, 2>;
+RlweCt add(const RlweCt &ct1, const RlweCt &ct2);
+RlweCt sub(const RlweCt &ct1, const RlweCt &ct2);
+RlweCt add_plain_core(const RlweCt &ct, const RlwePt &pt);
+RlweCt sub_plain_core(const RlweCt &ct, const RlwePt &pt);
+RlweCt mult_plain_core(const RlweCt &ct, const RlwePt &pt);
+
+using RgswCt = std::vector<RlweCt>;
+struct RlweKsk : public RgswCt {
+    using RgswCt::RgswCt;
+    RlweKsk() {}
+    RlweKsk(RgswCt &&rgsw) : RgswCt(std::move(rgsw)) {}
+};
+RlweCt ext_prod_montgomery(const RlwePt &pt, const RgswCt &rgsw);
+
+// ---- ckks.h -----------------------------------------------------------------------------------------------
+namespace ckks {
+struct CkksCt : public RlweCt {
+    using RlweCt::RlweCt;
+    CkksCt() {}
+    CkksCt(RlweCt &&other) : RlweCt(std::move(other)) {}
+    double scaling_factor = 1.0;
+};
+struct CkksQuadraticCt : public std::array<RnsPolynomial, 3> {
+    double scaling_factor = 1.0;
+};
+CkksCt add(const CkksCt &ct1, const CkksCt &ct2);
+CkksCt sub(const CkksCt &ct1, const CkksCt &ct2);
+CkksQuadraticCt mult_low_level(const CkksCt &ct1, const CkksCt &ct2);
+CkksCt relinearize(const CkksQuadraticCt &ct, const RlweKsk &relin_key);
+inline CkksCt mult(const CkksCt &ct1, const CkksCt &ct2, const RlweKsk &relin_key) {
+    auto ct_prod = mult_low_level(ct1, ct2);
+    return relinearize(ct_prod, relin_key);
+}
+CkksCt conjugate(const CkksCt &ct, const RlweKsk &conj_key);
+CkksCt rotate(const CkksCt &ct, const RlweKsk &rot_key, const size_t step);
+void rescale_inplace(CkksCt &ct, size_t dropping_primes = 1);
+} // namespace ckks
+
+// ---- bgv.h --------------------------------------------------------------------------------------------------
+namespace bgv {
+struct BgvCt : public RlweCt {
+    using RlweCt::RlweCt;
+    BgvCt() {}
+    BgvCt(RlweCt &&other) : RlweCt(std::move(other)) {}
+    u64 plain_modulus = 1;
+};
+struct BgvQuadraticCt : public std::array<RnsPolynomial, 3> {
+    u64 plain_modulus = 1;
+};
+BgvCt add(const BgvCt &ct1, const BgvCt &ct2);
+BgvCt sub(const BgvCt &ct1, const BgvCt &ct2);
+BgvQuadraticCt mult_low_level(const BgvCt &ct1, const BgvCt &ct2);
+BgvCt relinearize(const BgvQuadraticCt &ct, const RlweKsk &relin_key);
+void mod_switch_inplace(BgvCt &ct, size_t dropping_primes = 1);
+} // namespace bgv
+
+using CkksCt = ckks::CkksCt;
+using BgvCt = bgv::BgvCt;
+
+} // namespace hehub

@@ -1,0 +1,273 @@
+// host_api_test.cpp -- the reference's own unit tests for this path, restated against the
+// hehub-compatible host layer (hehub_amd/host/hehub.hpp) which runs everything on the GPU.
+// Mirrors: tests/mod_arith_t.cpp:6-78, tests/ntt_t.cpp:18-181, tests/common_t.cpp:39-61,
+// tests/ckks_t.cpp:136-175 (exact rescale rounding), plus raw-word comparisons of the scheme-level
+// calls against the oracle (test infrastructure) and the reference's error behaviour.
+// Built and run by tests/test_host_api.py (compile-only without a GPU).
+#include "hehub.hpp"
+
+#include "../../oracle/hehub_oracle.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace hehub;
+
+static int g_fail = 0, g_checks = 0;
+#define REQUIRE(c)                                                              \
+    do {                                                                        \
+        g_checks++;                                                             \
+        if (!(c)) { g_fail++; std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); } \
+    } while (0)
+#define REQUIRE_THROWS_AS(expr, T)                                              \
+    do {                                                                        \
+        g_checks++;                                                             \
+        bool ok__ = false;                                                      \
+        try { expr; } catch (const T &) { ok__ = true; } catch (...) {}         \
+        if (!ok__) { g_fail++; std::printf("FAIL %s:%d: expected throw: %s\n", __FILE__, __LINE__, #expr); } \
+    } while (0)
+
+static u64 pow_mod(u64 q, u64 b, u64 e) {
+    u64 r = 1;
+    b %= q;
+    while (e) {
+        if (e & 1) r = (u128)r * b % q;
+        b = (u128)b * b % q;
+        e >>= 1;
+    }
+    return r;
+}
+static u64 bit_rev(u64 x, int bits) {
+    u64 r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+static u64 g_state = 88172645463325252ull;
+static u64 rnd() {   // xorshift64: any deterministic stream will do
+    g_state ^= g_state << 13; g_state ^= g_state >> 7; g_state ^= g_state << 17;
+    return g_state;
+}
+
+static void test_batched_barrett() {   // tests/mod_arith_t.cpp:6-32
+    const size_t LEN = 1024;
+    for (u64 q : {65537ull, 33333333ull, 777777777777777ull, 1234567890111111111ull}) {
+        std::vector<u64> v(LEN), c;
+        v[0] = 42;
+        for (size_t i = 1; i < LEN; i++) v[i] = v[i - 1] * 6364136223846793005ull + 1442695040888963407ull;
+        c = v;
+        batched_barrett_lazy(q, LEN, v.data());
+        for (size_t i = 0; i < LEN; i++) { REQUIRE(v[i] < 2 * q); REQUIRE(v[i] % q == c[i] % q); }
+    }
+}
+
+static void test_batched_mul_mod() {   // tests/mod_arith_t.cpp:34-59
+    const size_t LEN = 1000;
+    const u64 q = 1234567890111111111ull;
+    std::vector<u64> f(LEN), g(LEN), h1(LEN), h2(LEN);
+    f[0] = 1234; g[0] = 5678;
+    for (size_t i = 1; i < LEN; i++) { f[i] = (f[i - 1] * 31 + 7) % q; g[i] = (g[i - 1] * 29 + 11) % q; }
+    batched_mul_mod_hybrid(q, LEN, f.data(), g.data(), h1.data());
+    batched_mul_mod_barrett(q, LEN, f.data(), g.data(), h2.data());
+    for (size_t i = 0; i < LEN; i += 7) {
+        REQUIRE(h1[i] == (u64)((u128)f[i] * g[i] % q));
+        REQUIRE(h2[i] == (u64)((u128)f[i] * g[i] % q));
+    }
+}
+
+static void test_montgomery() {   // tests/mod_arith_t.cpp:61-78
+    const size_t LEN = 1000;
+    const u64 q = 1099510054913ull;
+    std::vector<u128> in(LEN);
+    std::vector<u64> out(LEN);
+    for (auto &x : in) x = ((u128)(rnd() % q) << 64) | rnd();
+    batched_montgomery_128_lazy(q, LEN, in.data(), out.data());
+    const u128 r = ((u128)1 << 64) % q;
+    for (size_t i = 0; i < LEN; i++) { REQUIRE(out[i] < 2 * q); REQUIRE((u64)((u128)(out[i] % q) * r % q) == (u64)(in[i] % q)); }
+}
+
+static void test_ntt() {   // tests/ntt_t.cpp:18-181
+    for (size_t LOGN : {4, 7, 11, 13, 14, 15}) {
+        for (u64 Q : {65537ull, 260898817ull, 35184358850561ull, 36028796997599233ull, 576460752272228353ull}) {
+            const size_t N = (size_t)1 << LOGN;
+            if ((Q - 1) % (2 * N)) {
+                std::vector<u64> z(N, 0);
+                REQUIRE_THROWS_AS(ntt_negacyclic_inplace_lazy(LOGN, Q, z.data()), std::invalid_argument);
+                continue;
+            }
+            std::vector<u64> poly(N, 0);
+            poly[0] = 1;   // "one"
+            ntt_negacyclic_inplace_lazy(LOGN, Q, poly.data());
+            bool ok = true;
+            for (auto v : poly) ok = ok && v < 2 * Q && v % Q == 1;
+            REQUIRE(ok);
+            std::fill(poly.begin(), poly.end(), 0);
+            poly[1] = 1;   // "just x": ntt(X)[i] = psi^(2*bitrev(i)+1)
+            ntt_negacyclic_inplace_lazy(LOGN, Q, poly.data());
+            u64 g = 2;
+            while (pow_mod(Q, g, (Q - 1) / 2) != Q - 1) g++;
+            const u64 psi = pow_mod(Q, g, (Q - 1) / (2 * N));
+            for (size_t i = 0; i < N; i = i * 13 + 1) REQUIRE(poly[i] % Q == pow_mod(Q, psi, 2 * bit_rev(i, (int)LOGN) + 1));
+            std::vector<u64> orig(N);   // round trip on random data
+            for (auto &c : orig) c = rnd() % Q;
+            poly = orig;
+            ntt_negacyclic_inplace_lazy(LOGN, Q, poly.data());
+            intt_negacyclic_inplace_lazy(LOGN, Q, poly.data());
+            ok = true;
+            for (size_t i = 0; i < N; i++) { ok = ok && poly[i] < 2 * Q; poly[i] -= (poly[i] >= Q) ? Q : 0; ok = ok && poly[i] == orig[i]; }
+            REQUIRE(ok);
+        }
+    }
+    // RnsPolynomial overload + rep_form bookkeeping
+    RnsPolynomial p(4096, 3, std::vector<u64>{1099510054913ull, 1099507695617ull, 1099506515969ull});
+    for (auto &c : p) for (auto &w : c) w = rnd() % 1099506515969ull;
+    auto q(p);
+    ntt_negacyclic_inplace_lazy(q);
+    REQUIRE(q.rep_form == PolyRepForm::value);
+    intt_negacyclic_inplace(q);
+    REQUIRE(q.rep_form == PolyRepForm::coeff);
+    REQUIRE((const RnsIntVec &)q == (const RnsIntVec &)p);
+    std::vector<u64> z(16, 0);
+    REQUIRE_THROWS_AS(ntt_negacyclic_inplace_lazy(4, 1234567890111111111ull, z.data()), std::invalid_argument);
+}
+
+static void test_rns_polynomial() {   // tests/common_t.cpp:39-61
+    RnsPolynomial r1(4096, 3, std::vector<u64>{3, 5, 7});
+    RnsPolyParams params{4096, 3, std::vector<u64>{3, 5, 7}};
+    RnsPolynomial r2(params);
+    REQUIRE(r1.component_count() == 3 && r2.dimension() == 4096 && r2.log_dimension() == 12);
+    r2.add_components({11});
+    REQUIRE(r2.component_count() == 4 && r2.modulus_at(3) == 11);
+    r2.remove_components(2);
+    REQUIRE(r2.component_count() == 2 && r2.modulus_vec().size() == 2);
+    REQUIRE_THROWS_AS(RnsPolynomial(4095, 3, std::vector<u64>{3, 5, 7}), std::invalid_argument);
+    REQUIRE_THROWS_AS(RnsPolynomial(4096, 4, std::vector<u64>{3, 5, 7}), std::invalid_argument);
+    RnsPolynomial a(8, 1, std::vector<u64>{65537}), b(8, 1, std::vector<u64>{65537});
+    b.rep_form = PolyRepForm::value;
+    REQUIRE_THROWS_AS(a += b, std::invalid_argument);
+    REQUIRE_THROWS_AS(a * b, std::invalid_argument);
+    RnsPolynomial c(8, 1, std::vector<u64>{12289});
+    REQUIRE_THROWS_AS((RnsIntVec &)a += (const RnsIntVec &)c, std::invalid_argument);
+}
+
+// CRT-compose three residues (moduli < 2^35) into a u128
+static u128 compose3(const u64 r[3], const u64 q[3]) {
+    u128 x = r[0];
+    u64 inv01 = pow_mod(q[1], q[0] % q[1], q[1] - 2);
+    u64 t1 = (u64)((u128)((r[1] + q[1] - (u64)(x % q[1])) % q[1]) * inv01 % q[1]);
+    x += (u128)q[0] * t1;
+    u128 q01 = (u128)q[0] * q[1];
+    u64 inv2 = pow_mod(q[2], (u64)(q01 % q[2]), q[2] - 2);
+    u64 t2 = (u64)((u128)((r[2] + q[2] - (u64)(x % q[2])) % q[2]) * inv2 % q[2]);
+    return x + q01 * t2;
+}
+
+static void test_ckks_rescaling() {   // tests/ckks_t.cpp:136-175
+    const size_t N = 8;
+    const u64 q[3] = {17179672577ull, 17179410433ull, 17176854529ull};   // create_params(8, {34,34,34})
+    std::vector<u64> moduli(q, q + 3);
+    ckks::CkksCt ct;
+    ct.scaling_factor = std::pow(2.0, 80);
+    u128 composed[2][N];
+    for (int h = 0; h < 2; h++) {
+        ct[h] = RnsPolynomial(N, 3, moduli);
+        for (size_t k = 0; k < 3; k++) for (auto &w : ct[h][(int)k]) w = rnd() % q[k];
+        for (size_t i = 0; i < N; i++) { u64 r[3] = {ct[h][0][i], ct[h][1][i], ct[h][2][i]}; composed[h][i] = compose3(r, q); }
+        ntt_negacyclic_inplace_lazy(ct[h]);
+    }
+    ckks::rescale_inplace(ct);
+    REQUIRE(ct[0].component_count() == 2 && ct[1].component_count() == 2);
+    REQUIRE(std::abs(ct.scaling_factor - std::pow(2.0, 80) / q[2]) < std::pow(2.0, -60) * std::pow(2.0, 46));
+    for (int h = 0; h < 2; h++) {
+        intt_negacyclic_inplace_lazy(ct[h]);
+        reduce_strict(ct[h]);
+        for (size_t i = 0; i < N; i++) {
+            u128 expect = (composed[h][i] + q[2] / 2) / q[2];
+            REQUIRE(ct[h][0][i] == (u64)(expect % q[0]));
+            REQUIRE(ct[h][1][i] == (u64)(expect % q[1]));
+        }
+    }
+    REQUIRE_THROWS_AS(ckks::rescale_inplace(ct, 0), std::invalid_argument);
+    bool threw_cstr = false;
+    try { ckks::rescale_inplace(ct, 2); } catch (const char *) { threw_cstr = true; }
+    REQUIRE(threw_cstr);
+    ckks::CkksCt one;
+    one[0] = RnsPolynomial(N, 1, moduli); one[1] = RnsPolynomial(N, 1, moduli);
+    REQUIRE_THROWS_AS(ckks::rescale_inplace(one), std::invalid_argument);
+}
+
+static void flatten(const RnsPolynomial &p, std::vector<u64> &out) {
+    for (auto &c : p) out.insert(out.end(), c.begin(), c.end());
+}
+
+static void test_scheme_level_vs_oracle() {   // raw lazy words of ckks::mult+rescale and bgv mult+mod switch
+    const size_t logn = 10, N = 1 << logn, L = 3;
+    std::vector<u64> mext{1099510054913ull, 1099507695617ull, 1099506515969ull, 1125899904679937ull};
+    std::vector<u64> q(mext.begin(), mext.begin() + L);
+    ckks::CkksCt a, b;
+    bgv::BgvCt ba, bb;
+    for (int h = 0; h < 2; h++) {
+        a[h] = RnsPolynomial(N, L, q); b[h] = RnsPolynomial(N, L, q);
+        for (size_t k = 0; k < L; k++) { for (auto &w : a[h][(int)k]) w = rnd() % q[k]; for (auto &w : b[h][(int)k]) w = rnd() % q[k]; }
+        a[h].rep_form = b[h].rep_form = PolyRepForm::value;
+        ba[h] = a[h]; bb[h] = b[h];
+    }
+    ba.plain_modulus = bb.plain_modulus = 65537;
+    RlweKsk key(L);
+    for (auto &s : key) for (auto &p : s) {
+        p = RnsPolynomial(N, L + 1, mext);
+        for (size_t k = 0; k <= L; k++) for (auto &w : p[(int)k]) w = rnd() % mext[k];
+        p.rep_form = PolyRepForm::value;
+    }
+    std::vector<u64> f1, f2, fk;
+    for (int h = 0; h < 2; h++) { flatten(a[h], f1); flatten(b[h], f2); }
+    for (auto &s : key) for (auto &p : s) flatten(p, fk);
+
+    auto r = ckks::mult(a, b, key);
+    ckks::rescale_inplace(r);
+    std::vector<u64> got, exp(2 * (L - 1) * N);
+    for (int h = 0; h < 2; h++) flatten(r[h], got);
+    REQUIRE(orc_ckks_mult_relin_rescale(logn, L, mext.data(), f1.data(), f2.data(), fk.data(), exp.data()) == 0);
+    REQUIRE(got == exp);
+
+    auto br = bgv::relinearize(bgv::mult_low_level(ba, bb), key);
+    bgv::mod_switch_inplace(br);
+    got.clear();
+    for (int h = 0; h < 2; h++) flatten(br[h], got);
+    REQUIRE(orc_bgv_mult_relin_modswitch(logn, L, mext.data(), 65537, f1.data(), f2.data(), fk.data(), exp.data()) == 0);
+    REQUIRE(got == exp);
+    REQUIRE(br.plain_modulus == 65537);
+
+    // rotation / conjugation compose the same kernels with an NTT-domain gather (ckks/arith.cpp:75-93)
+    auto rot = ckks::rotate(a, key, 3);
+    std::vector<u64> cyc(2 * L * N), ext(2 * (L + 1) * N), low(2 * L * N);
+    orc_poly_cycle(logn, L, 3, f1.data(), cyc.data());
+    orc_poly_cycle(logn, L, 3, f1.data() + L * N, cyc.data() + L * N);
+    REQUIRE(orc_ext_prod_montgomery(logn, L, mext.data(), cyc.data() + L * N, fk.data(), ext.data()) == 0);
+    REQUIRE(orc_ckks_rescale_by_one_prime(logn, L + 1, mext.data(), ext.data(), low.data()) == 0);
+    orc_poly_add_inplace(N, L, mext.data(), low.data(), cyc.data());
+    got.clear();
+    for (int h = 0; h < 2; h++) flatten(rot[h], got);
+    REQUIRE(got == low);
+
+    RlweKsk bad(L - 1);
+    REQUIRE_THROWS_AS(ext_prod_montgomery(a[0], RlweKsk()), std::invalid_argument);
+    bb.plain_modulus = 257;
+    REQUIRE_THROWS_AS(bgv::mult_low_level(ba, bb), std::invalid_argument);
+    b.scaling_factor = 3.0;
+    REQUIRE_THROWS_AS(ckks::add(a, b), std::invalid_argument);
+}
+
+int main() {
+    test_batched_barrett();
+    test_batched_mul_mod();
+    test_montgomery();
+    test_ntt();
+    test_rns_polynomial();
+    test_ckks_rescaling();
+    test_scheme_level_vs_oracle();
+    std::printf("%s: %d checks, %d failures\n", g_fail ? "FAILED" : "All tests passed", g_checks, g_fail);
+    return g_fail ? 1 : 0;
+}

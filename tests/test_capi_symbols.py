@@ -1,0 +1,58 @@
+"""The C-ABI library loads and exports every symbol include/hehub_amd.h declares (no compute calls:
+this runs without a GPU), and the ctypes table in hehub_amd/capi.py matches the header."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "hehub_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from hehub_amd.build import build_lib
+
+    lib = ctypes.CDLL(build_lib())
+    names = header_functions()
+    assert len(names) >= 40
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert lib.hp_version is not None
+    lib.hp_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.hp_version()
+
+
+def test_ctypes_table_matches_header():
+    from hehub_amd import capi
+
+    assert sorted(capi.SIGNATURES) == header_functions()
+    capi.load()
+
+
+def test_engine_fails_loudly_without_gpu():
+    import pytest
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from hehub_amd import capi
+    from hehub_amd.engine import Engine
+
+    with pytest.raises(capi.EngineMissing):
+        Engine(0)
+
+
+def test_product_never_touches_the_oracle():
+    """hehub_amd/ must not import, link or execute anything under oracle/."""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "hehub_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"hehub_oracle|pyoracle|oracle/|from oracle|import oracle|orc_[a-z]", text):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
