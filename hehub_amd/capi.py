@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libhehub_amd.so")
+# HEHUB_AMD_LIB selects another build of the SAME engine (kernel-tuning experiments); never a fallback
+LIB_PATH = os.environ.get("HEHUB_AMD_LIB") or os.path.join(HERE, "lib", "libhehub_amd.so")
 
 u64 = C.c_uint64
 szt = C.c_size_t

@@ -52,6 +52,49 @@ HP_DEV void hp_butterfly(u64 &lo, u64 &hi, u64 w, u64 wh, u64 q, u64 two_q) {
     lo = lo + t;
 }
 
+// The same product, hand-scheduled for gfx950 (17 VALU instructions per butterfly instead of the
+// compiler's 23).  nq = 2^64 - q is wave-uniform (SGPRs), so x*w - qhat*q becomes the wrapping sum
+// x*w + qhat*nq and both low products chain through v_mad_u64_u32 accumulators:
+//   qhat = floor(x*wh / 2^64), exactly:   A = x1*p0 + hi32(x0*p0)
+//                                          B = x0*p1 + A           (carry c from the mad's carry-out)
+//                                          qhat = x1*p1 + {B.hi, c}
+//   t.lo64 = (x0*w0 + q0*n0) + 2^32 * lo32(x0*w1 + x1*w0 + q0*n1 + q1*n0)
+// The asm statements only ever name whole registers; halves are split in C (free sub-register
+// references).  Hazards inside the strings: the v_addc_co reading the carry sits two instructions
+// after the v_mad_u64_u32 that writes vcc (the spacing the compiler itself uses on gfx950).
+HP_DEV u64 hp_harvey_lazy_nq(u64 x, u64 w, u64 wh, u32 n0, u32 n1) {
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32), p0 = (u32)wh, p1 = (u32)(wh >> 32);
+    const u32 w0 = (u32)w, w1 = (u32)(w >> 32);
+    const u64 A = (u64)x1 * p0 + (u64)__umulhi(x0, p0);
+    u64 B, G, E, sd;
+    u32 c;
+    asm("v_mad_u64_u32 %0, vcc, %5, %6, %7\n\t"
+        "v_mad_u64_u32 %1, %4, %5, %8, 0\n\t"
+        "v_mad_u64_u32 %2, %4, %5, %9, 0\n\t"
+        "v_addc_co_u32_e64 %3, vcc, 0, 0, vcc\n\t"
+        "v_mad_u64_u32 %2, %4, %10, %8, %2"
+        : "=&v"(B), "=&v"(G), "=&v"(E), "=&v"(c), "=&s"(sd)
+        : "v"(x0), "v"(p1), "v"(A), "v"(w0), "v"(w1), "v"(x1)
+        : "vcc");
+    const u64 U = ((u64)c << 32) | (B >> 32);
+    const u64 Q = (u64)x1 * p1 + U;
+    const u32 q0 = (u32)Q, q1 = (u32)(Q >> 32);
+    asm("v_mad_u64_u32 %0, %2, %3, %6, %0\n\t"
+        "v_mad_u64_u32 %1, %2, %3, %5, %1\n\t"
+        "v_mad_u64_u32 %0, %2, %4, %5, %0"
+        : "+v"(E), "+v"(G), "=&s"(sd)
+        : "v"(q0), "v"(q1), "s"(n0), "s"(n1));
+    u32 th;
+    asm("v_add_u32 %0, %1, %2" : "=v"(th) : "v"((u32)(G >> 32)), "v"((u32)E));
+    return ((u64)th << 32) | (u32)G;
+}
+
+HP_DEV void hp_butterfly_nq(u64 &lo, u64 &hi, u64 w, u64 wh, u64 two_q, u32 n0, u32 n1) {
+    const u64 t = hp_harvey_lazy_nq(hi, w, wh, n0, n1);
+    hi = lo + two_q - t;
+    lo = lo + t;
+}
+
 // ntt.cpp:171-175
 HP_DEV u64 hp_shift_fold(u64 x, u64 q, u32 k, u32 fix) { return x - ((x >> k) - (u64)fix) * q; }
 

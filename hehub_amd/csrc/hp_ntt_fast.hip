@@ -30,6 +30,8 @@
 #include "hp_kernels.h"
 #include "hp_ntt_job.h"
 
+#include <cstdlib>
+
 namespace {
 
 template <int LOGN> struct Geo {
@@ -53,21 +55,40 @@ HP_DEV u64 mk64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 // Twiddle loads run TW_DEPTH slots ahead of their use through a small register ring; scheduling
 // barriers keep the compiler from hoisting all 31 loads (124 VGPRs) to the top of the pass, which
 // would push the kernel past the 128-VGPR budget of 4 waves per SIMD.
+#ifndef TW_DEPTH
 #define TW_DEPTH 4
+#endif
+
+typedef u64 __attribute__((ext_vector_type(2))) u64v2;
+typedef const u64v2 __attribute__((address_space(1))) * gptr_u64x2;
+HP_DEV u64x2 gload(gptr_u64x2 p, size_t i) {   // one global_load_dwordx4
+    const u64v2 v = p[i];
+    return u64x2{v.x, v.y};
+}
 
 constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
 
 template <bool FWD, int S0, int S1>
-HP_DEV void run_pass(u64 (&x)[32], const u64x2 *__restrict__ tbl, u32 ncls, u32 cls, u64 q, u64 two_q) {
+HP_DEV void run_pass(u64 (&x)[32], const u64x2 *__restrict__ tbl_generic, u32 ncls, u32 cls, u64 nq, u64 two_q) {
+    // The table pointer comes out of a struct in memory, so the compiler only knows it as a generic
+    // (flat) pointer; flat loads bump both vmcnt and lgkmcnt and force full s_waitcnt 0 waits, which
+    // would serialise the twiddle prefetch ring behind L2 latency.  Tell it the truth: global memory.
+    const gptr_u64x2 tbl = (gptr_u64x2)tbl_generic;
+#ifdef HP_ABLATE_PASS   // tuning experiment only (wrong results): no butterflies
+    return;
+#endif
+#ifdef HP_ABLATE_TW     // tuning experiment only (wrong results): one twiddle for the whole pass
+    ncls = 0; cls = 0;
+#endif
     u64x2 ring[TW_DEPTH];
 #pragma unroll
     for (int s = S0; s < S0 + TW_DEPTH; ++s)
-        if (s < S1) ring[(s - S0) % TW_DEPTH] = tbl[(u32)s * ncls + cls];
+        if (s < S1) ring[(s - S0) % TW_DEPTH] = gload(tbl, (u32)s * ncls + cls);
     int since = 0;
 #pragma unroll
     for (int s = S0; s < S1; ++s) {
         const u64x2 tw = ring[(s - S0) % TW_DEPTH];
-        if (s + TW_DEPTH < S1) ring[(s - S0) % TW_DEPTH] = tbl[(u32)(s + TW_DEPTH) * ncls + cls];
+        if (s + TW_DEPTH < S1) ring[(s - S0) % TW_DEPTH] = gload(tbl, (u32)(s + TW_DEPTH) * ncls + cls);
         const int lg = ilog2c(s + 1);
         const int b = FWD ? 4 - lg : lg;
         const int idx = s + 1 - (1 << lg);
@@ -75,7 +96,7 @@ HP_DEV void run_pass(u64 (&x)[32], const u64x2 *__restrict__ tbl, u32 ncls, u32 
         for (int o = 0; o < (1 << (4 - lg)); ++o) {
             // forward: idx = bits above b, o = bits below b; inverse: idx = bits below b, o = bits above b
             const int r = FWD ? ((idx << (b + 1)) | o) : ((o << (b + 1)) | idx);
-            hp_butterfly(x[r], x[r | (1 << b)], tw.x, tw.y, q, two_q);
+            hp_butterfly_nq(x[r], x[r | (1 << b)], tw.x, tw.y, two_q, (u32)nq, (u32)(nq >> 32));
         }
         since += 1 << (4 - lg);
         if (since >= 4) {
@@ -87,16 +108,16 @@ HP_DEV void run_pass(u64 (&x)[32], const u64x2 *__restrict__ tbl, u32 ncls, u32 
 
 // forward: stages on register bits BHI..BLO (descending)
 template <int BHI, int BLO>
-HP_DEV void fwd_pass(u64 (&x)[32], const u64x2 *__restrict__ tbl, u32 ncls, u32 cls, u64 q, u64 two_q) {
+HP_DEV void fwd_pass(u64 (&x)[32], const u64x2 *__restrict__ tbl, u32 ncls, u32 cls, u64 nq, u64 two_q) {
     static_assert(BHI == 4, "forward passes start at register bit 4");
-    run_pass<true, 0, (1 << (5 - BLO)) - 1>(x, tbl, ncls, cls, q, two_q);
+    run_pass<true, 0, (1 << (5 - BLO)) - 1>(x, tbl, ncls, cls, nq, two_q);
 }
 
 // inverse: stages on register bits BLO..BHI (ascending)
 template <int BLO, int BHI>
-HP_DEV void inv_pass(u64 (&x)[32], const u64x2 *__restrict__ tbl, u32 ncls, u32 cls, u64 q, u64 two_q) {
+HP_DEV void inv_pass(u64 (&x)[32], const u64x2 *__restrict__ tbl, u32 ncls, u32 cls, u64 nq, u64 two_q) {
     static_assert(BHI == 4, "inverse passes end at register bit 4");
-    run_pass<false, (1 << BLO) - 1, 31>(x, tbl, ncls, cls, q, two_q);
+    run_pass<false, (1 << BLO) - 1, 31>(x, tbl, ncls, cls, nq, two_q);
 }
 
 // ---- LDS word addresses of the four register layouts ------------------------------------------
@@ -105,20 +126,21 @@ HP_DEV void inv_pass(u64 (&x)[32], const u64x2 *__restrict__ tbl, u32 ncls, u32 
 //   layout A ("strided"):   r = (kk << PB) | pp,  i = (kk << 10) | (tid << PB) | pp
 //   layout B ("blocked"):   r = m,                i = (blk << 10) | (m << 5) | j,  blk = tid >> 5, j = tid & 31
 //   layout C ("contiguous"): r,                   i = (tid << 5) | r
-//   layout S ("stream"):    r = s,                i = (wave << 11) | (s << 6) | lane   (coalesced HBM access)
+//   layout S ("stream"):    r = (s << 1) | e,     i = (wave << 11) | (s << 7) | (lane << 1) | e
+//                           (a lane moves 16 contiguous bytes, a wave 1 KiB per HBM instruction)
 template <int LOGN> struct Addr {
     using G = Geo<LOGN>;
     u32 a_base;   // ((tid << PB) ^ h) with h = bits 9..5 of (tid << PB)
     u32 b_base;   // (blk << 10) | j
     u32 c_base;   // (tid << 5) | (tid & 31)
-    u32 s_base;   // (wave << 11) | (lane & 32) | ((lane & 31) ^ (lane >> 5))
+    u32 s_base;   // (wave << 11) | ((lane >> 4) << 5) | (((lane & 15) << 1) ^ (lane >> 4))
     HP_DEV void init(u32 tid) {
         const u32 t = tid << G::PB;
         a_base = t ^ ((t >> 5) & 31u);
         b_base = ((tid >> 5) << 10) | (tid & 31u);
         c_base = (tid << 5) | (tid & 31u);
         const u32 lane = tid & 63u, wave = tid >> 6;
-        s_base = (wave << 11) | (lane & 32u) | ((lane & 31u) ^ (lane >> 5));
+        s_base = (wave << 11) | ((lane >> 4) << 5) | (((lane & 15u) << 1) ^ (lane >> 4));
     }
 };
 
@@ -144,7 +166,7 @@ template <int LOGN, int LAY> HP_DEV u32 lay_addr(u32 base, int r) {
     if (LAY == LAY_A) return (base ^ (u32)(r & ((1 << G::PB) - 1))) + (u32)((r >> G::PB) << 10);
     if (LAY == LAY_B) return (base ^ (u32)r) + (u32)(r << 5);
     if (LAY == LAY_C) return base ^ (u32)r;
-    return (base ^ (u32)((2 * r) & 31)) + (u32)(r << 6);
+    return (base ^ (u32)((r & 1) | (((r >> 1) & 7) << 2))) + (u32)((r >> 1) << 7);
 }
 
 // Transpose the workgroup's coefficients from register layout FROM to layout TO through LDS, one
@@ -152,6 +174,9 @@ template <int LOGN, int LAY> HP_DEV u32 lay_addr(u32 base, int r) {
 // confined to the wave's own 2048-word region and relies on in-order LDS execution per wave.
 template <int LOGN, int FROM, int TO, bool WG>
 HP_DEV void exchange(u64 (&x)[32], u32 *lds, const Addr<LOGN> &ad) {
+#ifdef HP_ABLATE_EXCH   // tuning experiment only (wrong results): no LDS transposition
+    return;
+#endif
     u32 keep[32];
     {
         const u32 fb = opaque(lay_base<LOGN, FROM>(ad));
@@ -186,6 +211,36 @@ struct alignas(16) V2 {
     u64 x, y;
 };
 
+HP_DEV void stagger_start(const HpNttJob &job) {
+    if (blockIdx.x < job.stagger_first && job.stagger_phases > 1) {
+        const u32 phase = (blockIdx.x >> 3) % job.stagger_phases;
+        const u64 until = __builtin_amdgcn_s_memtime() + (u64)phase * job.stagger_ticks;
+        while (__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+// value held by the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2], no LDS involved
+HP_DEV u64 from_pair_lane(u64 v) {
+    const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0xB1, 0xF, 0xF, true);
+    const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0xB1, 0xF, 0xF, true);
+    return ((u64)hi << 32) | lo;
+}
+
+// Phase tracing for kernel tuning (variant builds only, -DHP_TRACE): shader-clock stamps of wave 0
+// of every 16th workgroup at the phase boundaries, read back with hp_debug_trace().
+#ifdef HP_TRACE
+#define HP_TRACE_SLOTS 12
+__device__ u64 g_trace[4096 * HP_TRACE_SLOTS];
+#define TRACE_DECL u64 tr__[HP_TRACE_SLOTS]; int tri__ = 0;
+#define TRACE_MARK() do { __builtin_amdgcn_sched_barrier(0); tr__[tri__++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TRACE_FLUSH() do { if ((threadIdx.x == 0 || threadIdx.x == blockDim.x - 64) && (blockIdx.x & 15) == 0 && (blockIdx.x >> 4) < 2048) { \
+        for (int i__ = 0; i__ < HP_TRACE_SLOTS; i__++) g_trace[((blockIdx.x >> 4) * 2 + (threadIdx.x != 0)) * HP_TRACE_SLOTS + i__] = i__ < tri__ ? tr__[i__] : 0; } } while (0)
+#else
+#define TRACE_DECL
+#define TRACE_MARK() do { } while (0)
+#define TRACE_FLUSH() do { } while (0)
+#endif
+
 // ---- forward kernel ----------------------------------------------------------------------------
 template <int LOGN>
 __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd(HpNttJob job) {
@@ -194,20 +249,37 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd(HpNtt
     const u32 w = hp_xcd_remap(blockIdx.x, job.W);
     HpItem it;
     if (!hp_decode_item(job, w, it)) return;
+    stagger_start(job);
     const HpLimb *lp = job.limbs + it.limb;
-    const u64 q = lp->q, two_q = lp->two_q;
+    const u64 q = lp->q, two_q = lp->two_q, nq = lp->neg_q;
     const u32 tid = threadIdx.x;
     Addr<LOGN> ad;
     ad.init(tid);
 
+    TRACE_DECL
+    TRACE_MARK();
     u64 x[32];
     // load, layout A: thread reads 2^PB consecutive coefficients at 2^A places 1024 apart
     {
         const u64 *s = it.src + ((size_t)tid << G::PB);
+        if (G::PB == 0) {
+            // N = 32768: a thread owns one column (tid) of 32 rows 1024 apart.  Two neighbouring lanes
+            // fetch 16 bytes (both their columns) of alternate rows and trade halves with one DPP swap,
+            // so every HBM instruction still moves 16 bytes per lane.
+            const bool odd = (tid & 1u) != 0;
+            const u64 *sp = it.src + (tid & ~1u);
 #pragma unroll
-        for (int kk = 0; kk < (1 << G::A); ++kk) {
+            for (int p = 0; p < 16; ++p) {
+                const V2 v = *reinterpret_cast<const V2 *>(sp + ((size_t)(2 * p + (odd ? 1 : 0)) << 10));
+                const u64 keep = odd ? v.y : v.x, send = odd ? v.x : v.y;
+                const u64 recv = from_pair_lane(send);
+                x[2 * p] = odd ? recv : keep;
+                x[2 * p + 1] = odd ? keep : recv;
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < (G::PB == 0 ? 0 : (1 << G::A)); ++kk) {
             if (G::PB == 0) {
-                x[kk] = s[(size_t)kk << 10];
             } else {
 #pragma unroll
                 for (int pp = 0; pp < (1 << G::PB); pp += 2) {
@@ -218,27 +290,43 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd(HpNtt
             }
         }
     }
+#ifdef HP_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    TRACE_MARK();   // 1: coefficients have arrived
     // pass A: global stages 1..A, wave-uniform twiddles seq[1 .. 2^A - 1]
-    fwd_pass<4, G::PB>(x, lp->fwd_ref + 1, 1u, 0u, q, two_q);
+    fwd_pass<4, G::PB>(x, lp->fwd_ref + 1, 1u, 0u, nq, two_q);
+    TRACE_MARK();   // 2
     exchange<LOGN, LAY_A, LAY_B, true>(x, lds, ad);
+    TRACE_MARK();   // 3
     // pass B: global stages A+1..A+5, twiddles depend on the 1024-block
-    fwd_pass<4, 0>(x, lp->fwd_k, 1u << G::A, tid >> 5, q, two_q);
+    fwd_pass<4, 0>(x, lp->fwd_k, 1u << G::A, tid >> 5, nq, two_q);
+    TRACE_MARK();   // 4
     exchange<LOGN, LAY_B, LAY_C, false>(x, lds, ad);
+    TRACE_MARK();   // 5
     // pass C: global stages A+6..logN, per-thread twiddles
-    fwd_pass<4, 0>(x, lp->fwd_k + 31 * (1 << G::A), (u32)G::T, tid, q, two_q);
+    fwd_pass<4, 0>(x, lp->fwd_k + 31 * (1 << G::A), (u32)G::T, tid, nq, two_q);
+    TRACE_MARK();   // 6
     // final fold (ntt.cpp:171-175)
     {
         const u32 k = lp->k, fix = lp->fix;
 #pragma unroll
         for (int r = 0; r < 32; ++r) x[r] = hp_shift_fold(x[r], q, k, fix);
     }
+    TRACE_MARK();   // 7: fold done
     exchange<LOGN, LAY_C, LAY_S, false>(x, lds, ad);
-    // store, layout S: a wave writes 64 consecutive words per instruction
+    TRACE_MARK();   // 8
+    // store, layout S: 16 bytes per lane, a wave writes 1 KiB of consecutive words per instruction
     {
-        u64 *d = it.dst + (((size_t)(tid >> 6)) << 11) + (tid & 63u);
+        u64 *d = it.dst + (((size_t)(tid >> 6)) << 11) + ((tid & 63u) << 1);
 #pragma unroll
-        for (int s = 0; s < 32; ++s) d[(size_t)s << 6] = x[s];
+        for (int s = 0; s < 16; ++s) {
+            V2 v{x[2 * s], x[2 * s + 1]};
+            *reinterpret_cast<V2 *>(d + ((size_t)s << 7)) = v;
+        }
     }
+    TRACE_MARK();   // 9: stores issued
+    TRACE_FLUSH();
 }
 
 // ---- inverse kernel ----------------------------------------------------------------------------
@@ -249,31 +337,36 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_inv(HpNtt
     const u32 w = hp_xcd_remap(blockIdx.x, job.W);
     HpItem it;
     if (!hp_decode_item(job, w, it)) return;
+    stagger_start(job);
     const HpLimb *lp = job.limbs + it.limb;
-    const u64 q = lp->q, two_q = lp->two_q;
+    const u64 q = lp->q, two_q = lp->two_q, nq = lp->neg_q;
     const u32 tid = threadIdx.x;
     Addr<LOGN> ad;
     ad.init(tid);
 
     u64 x[32];
     {
-        const u64 *s = it.src + (((size_t)(tid >> 6)) << 11) + (tid & 63u);
+        const u64 *s = it.src + (((size_t)(tid >> 6)) << 11) + ((tid & 63u) << 1);
 #pragma unroll
-        for (int r = 0; r < 32; ++r) x[r] = s[(size_t)r << 6];
+        for (int r = 0; r < 16; ++r) {
+            const V2 v = *reinterpret_cast<const V2 *>(s + ((size_t)r << 7));
+            x[2 * r] = v.x;
+            x[2 * r + 1] = v.y;
+        }
     }
     exchange<LOGN, LAY_S, LAY_C, false>(x, lds, ad);
     // pass A': levels 0..4 (pairs 1,2,4,8,16 apart), wave-uniform twiddles
-    inv_pass<0, 4>(x, lp->inv_k, 1u, 0u, q, two_q);
+    inv_pass<0, 4>(x, lp->inv_k, 1u, 0u, nq, two_q);
     exchange<LOGN, LAY_C, LAY_B, false>(x, lds, ad);
     // pass B': levels 5..9, twiddles depend on j = tid & 31
-    inv_pass<0, 4>(x, lp->inv_k + 31, 32u, tid & 31u, q, two_q);
+    inv_pass<0, 4>(x, lp->inv_k + 31, 32u, tid & 31u, nq, two_q);
     exchange<LOGN, LAY_B, LAY_A, true>(x, lds, ad);
     // pass C': levels 10..logN-1, per-thread twiddles
-    inv_pass<G::PB, 4>(x, lp->inv_k + 31 + 31 * 32, (u32)G::T, tid, q, two_q);
+    inv_pass<G::PB, 4>(x, lp->inv_k + 31 + 31 * 32, (u32)G::T, tid, nq, two_q);
     // fold, multiply by psi^-i * N^-1 (ntt.cpp:214-222), optional scalar + strict reduction, store (layout A)
     {
         const u32 k = lp->k, fix = lp->fix;
-        const u64x2 *sc = lp->inv_ref + G::N + ((size_t)tid << G::PB);
+        const gptr_u64x2 sc = (gptr_u64x2)(lp->inv_ref + G::N + ((size_t)tid << G::PB));
         u64 *d = it.dst + ((size_t)tid << G::PB);
         const u64 psc = job.post_scalar, psh = job.post_scalar_h;
 #pragma unroll
@@ -282,7 +375,7 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_inv(HpNtt
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = r0 + e, kk = r >> G::PB, pp = r & ((1 << G::PB) - 1);
-                f[e] = sc[((size_t)kk << 10) + pp];
+                f[e] = gload(sc, ((size_t)kk << 10) + pp);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -294,10 +387,21 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_inv(HpNtt
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (G::PB == 0) {   // mirror of the forward load: lane pairs assemble 16-byte stores
+            const bool odd = (tid & 1u) != 0;
+            u64 *dp = it.dst + (tid & ~1u);
 #pragma unroll
-        for (int kk = 0; kk < (1 << G::A); ++kk) {
+            for (int p = 0; p < 16; ++p) {
+                const u64 recv = from_pair_lane(odd ? x[2 * p] : x[2 * p + 1]);
+                V2 v;
+                v.x = odd ? recv : x[2 * p];
+                v.y = odd ? x[2 * p + 1] : recv;
+                *reinterpret_cast<V2 *>(dp + ((size_t)(2 * p + (odd ? 1 : 0)) << 10)) = v;
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < (G::PB == 0 ? 0 : (1 << G::A)); ++kk) {
             if (G::PB == 0) {
-                d[(size_t)kk << 10] = x[kk];
             } else {
 #pragma unroll
                 for (int pp = 0; pp < (1 << G::PB); pp += 2) {
@@ -309,7 +413,25 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_inv(HpNtt
     }
 }
 
-template <int LOGN> hipError_t launch(const HpNttJob &job, hipStream_t stream) {
+template <int LOGN> hipError_t launch(const HpNttJob &job_in, hipStream_t stream) {
+    HpNttJob job = job_in;
+    {
+        // first dispatch wave = CUs x resident workgroups per CU (LDS- and VGPR-limited)
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+            else cus = 256;
+        }
+        const u32 per_cu = (u32)(1024 / Geo<LOGN>::T);
+        static const char *e_ph = getenv("HP_STAGGER_PHASES"), *e_tk = getenv("HP_STAGGER_TICKS");
+        const u32 phases = e_ph ? (u32)atoi(e_ph) : 8u;
+        const u32 ticks = e_tk ? (u32)atoi(e_tk) : (u32)(10000u >> (15 - LOGN));
+        job.stagger_first = (job.W > 2u * cus * per_cu) ? cus * per_cu : 0u;   // only worth it for long launches
+        job.stagger_phases = phases;
+        job.stagger_ticks = ticks;
+    }
     if (!job.inverse) k_ntt_fwd<LOGN><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
     else if (job.use_post_scalar && job.strict) k_ntt_inv<LOGN, true, true><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
     else if (job.use_post_scalar) return hipErrorNotSupported;
@@ -319,6 +441,12 @@ template <int LOGN> hipError_t launch(const HpNttJob &job, hipStream_t stream) {
 }
 
 } // namespace
+
+#ifdef HP_TRACE
+extern "C" int hp_debug_trace(u64 *out, size_t words) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), words * sizeof(u64));
+}
+#endif
 
 hipError_t hp_launch_ntt_fast(const HpNttJob &job, hipStream_t stream) {
     if (job.W == 0) return hipSuccess;
