@@ -61,63 +61,110 @@ HP_DEV u64 mk64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 
 typedef u64 __attribute__((ext_vector_type(2))) u64v2;
 typedef const u64v2 __attribute__((address_space(1))) * gptr_u64x2;
+typedef const u64v2 __attribute__((address_space(3))) * lptr_u64x2;
 HP_DEV u64x2 gload(gptr_u64x2 p, size_t i) {   // one global_load_dwordx4
     const u64v2 v = p[i];
     return u64x2{v.x, v.y};
 }
 
+// Where a pass finds its (w, w') pairs.
+//  GTab: a per-modulus table in global memory.  The table pointer comes out of a struct in memory, so the
+//        compiler only knows it as a generic (flat) pointer; flat loads bump both vmcnt and lgkmcnt and force
+//        full s_waitcnt 0 waits, which would serialise the prefetch ring behind L2 latency -- so it is cast to
+//        the global address space and the loads become counted global_load_dwordx4.
+//  LTab: a copy of the pass table staged in LDS by the workgroup (the per-1024-block tables of the middle
+//        pass: 31 * 2^A pairs forward, 31 * 32 pairs inverse).  Each entry is needed by exactly one half-wave,
+//        so from global memory every read would be an L1 miss; from LDS it is a broadcast ds_read_b128.
+struct GTab {
+    static constexpr int depth = TW_DEPTH;   // slots of L2 latency to cover
+    gptr_u64x2 p;
+    HP_DEV explicit GTab(const u64x2 *generic) : p((gptr_u64x2)generic) {}
+    HP_DEV u64x2 operator()(u32 i) const { const u64v2 v = p[i]; return u64x2{v.x, v.y}; }
+};
+struct LTab {
+    static constexpr int depth = 2;          // LDS latency is short
+    lptr_u64x2 p;
+    HP_DEV explicit LTab(const u64v2 *shared) : p((lptr_u64x2)shared) {}
+    HP_DEV u64x2 operator()(u32 i) const { const u64v2 v = p[i]; return u64x2{v.x, v.y}; }
+};
+
 constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
 
-template <bool FWD, int S0, int S1>
-HP_DEV void run_pass(u64 (&x)[32], const u64x2 *__restrict__ tbl_generic, u32 ncls, u32 cls, u64 nq, u64 two_q) {
-    // The table pointer comes out of a struct in memory, so the compiler only knows it as a generic
-    // (flat) pointer; flat loads bump both vmcnt and lgkmcnt and force full s_waitcnt 0 waits, which
-    // would serialise the twiddle prefetch ring behind L2 latency.  Tell it the truth: global memory.
-    const gptr_u64x2 tbl = (gptr_u64x2)tbl_generic;
+// register index of the o-th butterfly of slot s (compile-time): forward idx = bits above b, o = bits below b;
+// inverse the other way round
+template <bool FWD> constexpr int slot_reg(int s, int o) {
+    const int lg = ilog2c(s + 1), b = FWD ? 4 - lg : lg, idx = s + 1 - (1 << lg);
+    return FWD ? ((idx << (b + 1)) | o) : ((o << (b + 1)) | idx);
+}
+template <bool FWD> constexpr int slot_bit(int s) { return 1 << (FWD ? 4 - ilog2c(s + 1) : ilog2c(s + 1)); }
+
+// One slot (or, in the last stage of a pass where every butterfly has its own twiddle, two slots) of a pass;
+// recursion over the slot number keeps every register index a compile-time constant.
+template <bool FWD, int S, int S0, int S1, int D, class Tab>
+HP_DEV void pass_slots(u64 (&x)[32], u64x2 (&ring)[D], const Tab &tbl, u32 ncls, u32 cls, u64 two_q, u32 n0, u32 n1) {
+    if constexpr (S < S1) {
+        constexpr int cnt = 1 << (4 - ilog2c(S + 1));   // butterflies that use this slot's twiddle
+        constexpr int bit = slot_bit<FWD>(S);
+        const u64x2 tw = ring[(S - S0) % D];
+        if constexpr (S + D < S1) ring[(S - S0) % D] = tbl((u32)(S + D) * ncls + cls);
+        if constexpr (cnt >= 2) {
+#pragma unroll
+            for (int o = 0; o < cnt; o += 2) {
+                const int ra = slot_reg<FWD>(S, o), rb = slot_reg<FWD>(S, o + 1);
+#ifdef HP_SINGLE_BFLY   // tuning experiment: one butterfly at a time
+                hp_butterfly_nq(x[ra], x[ra | bit], tw.x, tw.y, two_q, n0, n1);
+                hp_butterfly_nq(x[rb], x[rb | bit], tw.x, tw.y, two_q, n0, n1);
+#else
+                hp_butterfly2_nq(x[ra], x[ra | bit], x[rb], x[rb | bit], tw.x, tw.y, tw.x, tw.y, two_q, n0, n1);
+#endif
+                if (o & 2) __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (cnt == 2) { if constexpr (S & 1) __builtin_amdgcn_sched_barrier(0); }
+            pass_slots<FWD, S + 1, S0, S1, D>(x, ring, tbl, ncls, cls, two_q, n0, n1);
+        } else {
+            static_assert(S + 1 < S1, "single-butterfly slots come in pairs");
+            const u64x2 tw2 = ring[(S + 1 - S0) % D];
+            if constexpr (S + 1 + D < S1) ring[(S + 1 - S0) % D] = tbl((u32)(S + 1 + D) * ncls + cls);
+            constexpr int ra = slot_reg<FWD>(S, 0), rb = slot_reg<FWD>(S + 1, 0);
+#ifdef HP_SINGLE_BFLY
+            hp_butterfly_nq(x[ra], x[ra | bit], tw.x, tw.y, two_q, n0, n1);
+            hp_butterfly_nq(x[rb], x[rb | bit], tw2.x, tw2.y, two_q, n0, n1);
+#else
+            hp_butterfly2_nq(x[ra], x[ra | bit], x[rb], x[rb | bit], tw.x, tw.y, tw2.x, tw2.y, two_q, n0, n1);
+#endif
+            if constexpr (((S - 15) & 2) != 0) __builtin_amdgcn_sched_barrier(0);
+            pass_slots<FWD, S + 2, S0, S1, D>(x, ring, tbl, ncls, cls, two_q, n0, n1);
+        }
+    }
+}
+
+template <bool FWD, int S0, int S1, int D, class Tab>
+HP_DEV void run_pass(u64 (&x)[32], const Tab tbl, u32 ncls, u32 cls, u64 nq, u64 two_q) {
 #ifdef HP_ABLATE_PASS   // tuning experiment only (wrong results): no butterflies
     return;
 #endif
 #ifdef HP_ABLATE_TW     // tuning experiment only (wrong results): one twiddle for the whole pass
     ncls = 0; cls = 0;
 #endif
-    u64x2 ring[TW_DEPTH];
+    u64x2 ring[D];
 #pragma unroll
-    for (int s = S0; s < S0 + TW_DEPTH; ++s)
-        if (s < S1) ring[(s - S0) % TW_DEPTH] = gload(tbl, (u32)s * ncls + cls);
-    int since = 0;
-#pragma unroll
-    for (int s = S0; s < S1; ++s) {
-        const u64x2 tw = ring[(s - S0) % TW_DEPTH];
-        if (s + TW_DEPTH < S1) ring[(s - S0) % TW_DEPTH] = gload(tbl, (u32)(s + TW_DEPTH) * ncls + cls);
-        const int lg = ilog2c(s + 1);
-        const int b = FWD ? 4 - lg : lg;
-        const int idx = s + 1 - (1 << lg);
-#pragma unroll
-        for (int o = 0; o < (1 << (4 - lg)); ++o) {
-            // forward: idx = bits above b, o = bits below b; inverse: idx = bits below b, o = bits above b
-            const int r = FWD ? ((idx << (b + 1)) | o) : ((o << (b + 1)) | idx);
-            hp_butterfly_nq(x[r], x[r | (1 << b)], tw.x, tw.y, two_q, (u32)nq, (u32)(nq >> 32));
-        }
-        since += 1 << (4 - lg);
-        if (since >= 4) {
-            __builtin_amdgcn_sched_barrier(0);
-            since = 0;
-        }
-    }
+    for (int s = S0; s < S0 + D; ++s)
+        if (s < S1) ring[(s - S0) % D] = tbl((u32)s * ncls + cls);
+    pass_slots<FWD, S0, S0, S1, D>(x, ring, tbl, ncls, cls, two_q, (u32)nq, (u32)(nq >> 32));
 }
 
 // forward: stages on register bits BHI..BLO (descending)
-template <int BHI, int BLO>
-HP_DEV void fwd_pass(u64 (&x)[32], const u64x2 *__restrict__ tbl, u32 ncls, u32 cls, u64 nq, u64 two_q) {
+template <int BHI, int BLO, class Tab>
+HP_DEV void fwd_pass(u64 (&x)[32], const Tab tbl, u32 ncls, u32 cls, u64 nq, u64 two_q) {
     static_assert(BHI == 4, "forward passes start at register bit 4");
-    run_pass<true, 0, (1 << (5 - BLO)) - 1>(x, tbl, ncls, cls, nq, two_q);
+    run_pass<true, 0, (1 << (5 - BLO)) - 1, Tab::depth>(x, tbl, ncls, cls, nq, two_q);
 }
 
 // inverse: stages on register bits BLO..BHI (ascending)
-template <int BLO, int BHI>
-HP_DEV void inv_pass(u64 (&x)[32], const u64x2 *__restrict__ tbl, u32 ncls, u32 cls, u64 nq, u64 two_q) {
+template <int BLO, int BHI, class Tab>
+HP_DEV void inv_pass(u64 (&x)[32], const Tab tbl, u32 ncls, u32 cls, u64 nq, u64 two_q) {
     static_assert(BHI == 4, "inverse passes end at register bit 4");
-    run_pass<false, (1 << BLO) - 1, 31>(x, tbl, ncls, cls, nq, two_q);
+    run_pass<false, (1 << BLO) - 1, 31, Tab::depth>(x, tbl, ncls, cls, nq, two_q);
 }
 
 // ---- LDS word addresses of the four register layouts ------------------------------------------
@@ -246,6 +293,7 @@ template <int LOGN>
 __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd(HpNttJob job) {
     using G = Geo<LOGN>;
     __shared__ u32 lds[G::N];
+    __shared__ u64v2 lds_tw[31 * (1 << G::A)];
     const u32 w = hp_xcd_remap(blockIdx.x, job.W);
     HpItem it;
     if (!hp_decode_item(job, w, it)) return;
@@ -255,6 +303,10 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd(HpNtt
     const u32 tid = threadIdx.x;
     Addr<LOGN> ad;
     ad.init(tid);
+    // stage the middle pass's twiddles (one pair per thread): the load is issued first, the LDS write after
+    // the coefficient loads are in flight; it becomes visible through the barriers of the A->B exchange
+    u64v2 stg = {0, 0};
+    if (tid < 31u * (1u << G::A)) stg = ((gptr_u64x2)lp->fwd_k)[tid];
 
     TRACE_DECL
     TRACE_MARK();
@@ -290,22 +342,29 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd(HpNtt
             }
         }
     }
+    if (tid < 31u * (1u << G::A)) lds_tw[tid] = stg;
 #ifdef HP_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     TRACE_MARK();   // 1: coefficients have arrived
     // pass A: global stages 1..A, wave-uniform twiddles seq[1 .. 2^A - 1]
-    fwd_pass<4, G::PB>(x, lp->fwd_ref + 1, 1u, 0u, nq, two_q);
+    fwd_pass<4, G::PB>(x, GTab(lp->fwd_ref + 1), 1u, 0u, nq, two_q);
     TRACE_MARK();   // 2
     exchange<LOGN, LAY_A, LAY_B, true>(x, lds, ad);
     TRACE_MARK();   // 3
     // pass B: global stages A+1..A+5, twiddles depend on the 1024-block
-    fwd_pass<4, 0>(x, lp->fwd_k, 1u << G::A, tid >> 5, nq, two_q);
+#if defined(HP_EXP_B_CLS0)      // tuning experiment (wrong results): every half-wave reads block 0's twiddles
+    fwd_pass<4, 0>(x, LTab(lds_tw), 1u << G::A, 0u, nq, two_q);
+#elif defined(HP_EXP_B_GLOBAL)  // tuning experiment: middle-pass twiddles straight from global memory
+    fwd_pass<4, 0>(x, GTab(lp->fwd_k), 1u << G::A, tid >> 5, nq, two_q);
+#else
+    fwd_pass<4, 0>(x, LTab(lds_tw), 1u << G::A, tid >> 5, nq, two_q);
+#endif
     TRACE_MARK();   // 4
     exchange<LOGN, LAY_B, LAY_C, false>(x, lds, ad);
     TRACE_MARK();   // 5
     // pass C: global stages A+6..logN, per-thread twiddles
-    fwd_pass<4, 0>(x, lp->fwd_k + 31 * (1 << G::A), (u32)G::T, tid, nq, two_q);
+    fwd_pass<4, 0>(x, GTab(lp->fwd_k + 31 * (1 << G::A)), (u32)G::T, tid, nq, two_q);
     TRACE_MARK();   // 6
     // final fold (ntt.cpp:171-175)
     {
@@ -334,6 +393,7 @@ template <int LOGN, bool STRICT, bool PSCAL>
 __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_inv(HpNttJob job) {
     using G = Geo<LOGN>;
     __shared__ u32 lds[G::N];
+    __shared__ u64v2 lds_tw[31 * 32];
     const u32 w = hp_xcd_remap(blockIdx.x, job.W);
     HpItem it;
     if (!hp_decode_item(job, w, it)) return;
@@ -343,6 +403,14 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_inv(HpNtt
     const u32 tid = threadIdx.x;
     Addr<LOGN> ad;
     ad.init(tid);
+    // stage the middle pass's twiddles (31 x 32 pairs; a few per thread when T < 992)
+    constexpr int NSTG = (31 * 32 + G::T - 1) / G::T;
+    u64v2 stg[NSTG];
+#pragma unroll
+    for (int i = 0; i < NSTG; ++i) {
+        const u32 e = tid + (u32)i * G::T;
+        stg[i] = (e < 31u * 32u) ? ((gptr_u64x2)(lp->inv_k + 31))[e] : u64v2{0, 0};
+    }
 
     u64 x[32];
     {
@@ -354,15 +422,21 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_inv(HpNtt
             x[2 * r + 1] = v.y;
         }
     }
+#pragma unroll
+    for (int i = 0; i < NSTG; ++i) {
+        const u32 e = tid + (u32)i * G::T;
+        if (e < 31u * 32u) lds_tw[e] = stg[i];
+    }
+    __syncthreads();   // the staged twiddles are read by other waves in pass B' (the exchanges before it are wave-local)
     exchange<LOGN, LAY_S, LAY_C, false>(x, lds, ad);
     // pass A': levels 0..4 (pairs 1,2,4,8,16 apart), wave-uniform twiddles
-    inv_pass<0, 4>(x, lp->inv_k, 1u, 0u, nq, two_q);
+    inv_pass<0, 4>(x, GTab(lp->inv_k), 1u, 0u, nq, two_q);
     exchange<LOGN, LAY_C, LAY_B, false>(x, lds, ad);
     // pass B': levels 5..9, twiddles depend on j = tid & 31
-    inv_pass<0, 4>(x, lp->inv_k + 31, 32u, tid & 31u, nq, two_q);
+    inv_pass<0, 4>(x, LTab(lds_tw), 32u, tid & 31u, nq, two_q);
     exchange<LOGN, LAY_B, LAY_A, true>(x, lds, ad);
     // pass C': levels 10..logN-1, per-thread twiddles
-    inv_pass<G::PB, 4>(x, lp->inv_k + 31 + 31 * 32, (u32)G::T, tid, nq, two_q);
+    inv_pass<G::PB, 4>(x, GTab(lp->inv_k + 31 + 31 * 32), (u32)G::T, tid, nq, two_q);
     // fold, multiply by psi^-i * N^-1 (ntt.cpp:214-222), optional scalar + strict reduction, store (layout A)
     {
         const u32 k = lp->k, fix = lp->fix;
@@ -426,7 +500,7 @@ template <int LOGN> hipError_t launch(const HpNttJob &job_in, hipStream_t stream
         }
         const u32 per_cu = (u32)(1024 / Geo<LOGN>::T);
         static const char *e_ph = getenv("HP_STAGGER_PHASES"), *e_tk = getenv("HP_STAGGER_TICKS");
-        const u32 phases = e_ph ? (u32)atoi(e_ph) : 8u;
+        const u32 phases = e_ph ? (u32)atoi(e_ph) : 1u;   // off by default: measured no gain (profiles/)
         const u32 ticks = e_tk ? (u32)atoi(e_tk) : (u32)(10000u >> (15 - LOGN));
         job.stagger_first = (job.W > 2u * cus * per_cu) ? cus * per_cu : 0u;   // only worth it for long launches
         job.stagger_phases = phases;
