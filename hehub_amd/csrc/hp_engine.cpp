@@ -232,7 +232,7 @@ HpNttJob batch_job(const Plan *plan, size_t logn, size_t L, size_t P, const u64 
     HpNttJob j;
     memset(&j, 0, sizeof(j));
     j.limbs = plan->d_limbs; j.src = src; j.dst = dst; j.logn = (u32)logn; j.L = (u32)L; j.P = (u32)P;
-    j.src_pstride = (u32)src_ps; j.dst_pstride = (u32)dst_ps; j.W = (u32)(L * P); j.mode = HP_NTT_BATCH;
+    j.src_pstride = (u32)src_ps; j.dst_pstride = (u32)dst_ps; j.src_kstride = 1; j.W = (u32)(L * P); j.mode = HP_NTT_BATCH;
     j.inverse = inverse; j.strict = strict;
     return j;
 }
@@ -298,7 +298,7 @@ int drop_last(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, b
     HpNttJob lj;
     memset(&lj, 0, sizeof(lj));
     lj.limbs = plan->d_limbs + (L - 1); lj.src = x + (L - 1) * n; lj.dst = clast; lj.logn = (u32)logn; lj.L = 1;
-    lj.P = (u32)P2; lj.src_pstride = (u32)L; lj.dst_pstride = 1; lj.W = (u32)P2; lj.mode = HP_NTT_BATCH;
+    lj.P = (u32)P2; lj.src_pstride = (u32)L; lj.dst_pstride = 1; lj.src_kstride = 1; lj.W = (u32)P2; lj.mode = HP_NTT_BATCH;
     lj.inverse = 1; lj.strict = 1;
     if (bgv) {
         const u64 s = hp::inverse_mod_prime(t, q_last) % q_last;
@@ -308,21 +308,22 @@ int drop_last(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, b
     }
     int rc;
     if ((rc = run_ntt(ctx, lj))) return rc;
+    // tiled sizes: Barrett + centring fused into the remainder NTT's loads, (x - rem)*inv [+ addend] into its stores
+    if (!ctx->force_generic && logn >= 11 && logn <= 15 && !getenv("HP_NO_FUSED_DROP")) {
+        HpNttJob fj = batch_job(plan, logn, L - 1, P2, clast, nullptr, 1, 0, 0, 0);
+        fj.src_kstride = 0;
+        HpDropArgs da;
+        memset(&da, 0, sizeof(da));
+        da.dc = dc; da.x = x; da.L = (u32)L; da.addend = addend; da.add_poly_stride = (u32)add_poly_stride;
+        da.add_ct_stride = (u32)add_ct_stride; da.out = out;
+        ProfScope ps(ctx, "ntt");
+        return chk(ctx, hp_launch_ntt_fast_drop(fj, da, ctx->stream), "fused drop NTT");
+    }
     {
         ProfScope ps(ctx, "drop_rem");
         if ((rc = chk(ctx, hp_launch_drop_rem(plan->d_limbs, dc, (u32)(L - 1), (u32)n, (u32)P2, clast, rem, ctx->stream),
                       "drop_rem")))
             return rc;
-    }
-    if (getenv("HP_DEBUG_DROP")) {
-        (void)hipStreamSynchronize(ctx->stream);
-        std::vector<u64> h(P2 * n), r(P2 * (L - 1) * n);
-        (void)hipMemcpy(h.data(), clast, h.size() * 8, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(r.data(), rem, r.size() * 8, hipMemcpyDeviceToHost);
-        for (size_t p = 0; p < P2; p++)
-            fprintf(stderr, "[drop] clast[%zu] = %llu %llu | rem[%zu][0] = %llu %llu\n", p, (unsigned long long)h[p * n],
-                    (unsigned long long)h[p * n + 1], p, (unsigned long long)r[p * (L - 1) * n],
-                    (unsigned long long)r[p * (L - 1) * n + 1]);
     }
     if ((rc = run_ntt(ctx, batch_job(plan, logn, L - 1, P2, rem, rem, L - 1, L - 1, 0, 0)))) return rc;
     {

@@ -13,7 +13,6 @@ enum HpNttMode : int {
     HP_NTT_BATCH = 0,   // rows [P][L][N]: item w = k*P + p         -> src/dst row p*L + k, limb k
     HP_NTT_SPREAD = 1,  // digit spread (rgsw.cpp:108-119): item w = k*(P*L) + p*L + j, k in [0,L]:
                         //   src = coef row p*L + j, dst = digit row (p*L + j)*(L+1) + k, limb k; k == j is skipped
-    HP_NTT_LAST = 2,    // last-limb inverse for rescale: item w = p: src row p*L + (L-1), dst row p, limb L-1
 };
 
 struct HpNttJob {
@@ -25,6 +24,7 @@ struct HpNttJob {
     u32 P;          // polynomials
     u32 src_pstride;  // HP_NTT_BATCH / HP_NTT_LAST: rows (limbs) between consecutive polynomials of src
     u32 dst_pstride;  // HP_NTT_BATCH: same for dst
+    u32 src_kstride;  // HP_NTT_BATCH: rows between consecutive limbs of src (1; 0 = every limb reads the same row)
     u32 W;          // work items
     int mode;
     int inverse;
@@ -92,6 +92,20 @@ struct HpDropConsts {
     u64 t[HP_MAX_LIMBS], t_h[HP_MAX_LIMBS];          // plain_modulus mod q_k      (mod_switch.cpp:70)
     u64 qlt[HP_MAX_LIMBS], qlt_h[HP_MAX_LIMBS];      // (q_last mod t) mod q_k     (mod_switch.cpp:76)
 };
+// Fused form for the tiled transform (rescaling.cpp:54-74 / mod_switch.cpp:52-76 in ONE launch): the forward
+// NTT of the remainder limbs reads the strict last-limb coefficients, applies Barrett + centring (+ *t) while
+// loading, and finishes with out = ((x - NTT(rem)) * inv) [* (q_last mod t)] [+ addend] while storing.
+struct HpDropArgs {
+    HpDropConsts dc;
+    const u64 *x;          // [P2][L][n]: polynomial p2 at x + p2*L*n, limb k at + k*n
+    u32 L;                 // limbs of x (the last one is being dropped)
+    const u64 *addend;     // optional [.][.][n]: row (p2>>1)*add_ct_stride + (p2&1)*add_poly_stride + k
+    u32 add_poly_stride, add_ct_stride;
+    u64 *out;              // [P2][L-1][n]
+};
+// job: HP_NTT_BATCH over L-1 limbs and P2 polynomials with src = clast [P2][n] (src_pstride 1, src_kstride 0)
+hipError_t hp_launch_ntt_fast_drop(const HpNttJob &job, const HpDropArgs &da, hipStream_t stream);
+
 // clast [P2][n] (strict coefficients of the last limb) -> rem [P2][L-1][n]
 hipError_t hp_launch_drop_rem(const HpLimb *limbs, const HpDropConsts &dc, u32 Lm1, u32 n, u32 P2,
                               const u64 *clast, u64 *rem, hipStream_t stream);

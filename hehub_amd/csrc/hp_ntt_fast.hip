@@ -289,8 +289,8 @@ __device__ u64 g_trace[4096 * HP_TRACE_SLOTS];
 #endif
 
 // ---- forward kernel ----------------------------------------------------------------------------
-template <int LOGN>
-__global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd(HpNttJob job) {
+template <int LOGN, bool DROP>
+HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
     using G = Geo<LOGN>;
     __shared__ u32 lds[G::N];
     __shared__ u64v2 lds_tw[31 * (1 << G::A)];
@@ -343,6 +343,22 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd(HpNtt
         }
     }
     if (tid < 31u * (1u << G::A)) lds_tw[tid] = stg;
+    if (DROP) {
+        // rescaling.cpp:54-69 / mod_switch.cpp:52-70 while the coefficients are still in flight order:
+        // rem = strict_barrett_{q_k}(c) (+ q_k - (q_last mod q_k) if c >= q_last/2) (BGV: * t)
+        const u32 k = it.limb;
+        const u64 bc = lp->barrett_c, bump = q - da->dc.r[k], half = da->dc.half_q_last;
+        const u64 tk = da->dc.t[k], tkh = da->dc.t_h[k];
+        const bool bgv = da->dc.bgv != 0;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const u64 c = x[r];
+            u64 v = hp_strict(hp_barrett_lazy(c, q, bc), q);
+            if (c >= half) v += bump;
+            if (bgv) v = hp_harvey_lazy_nq(v, tk, tkh, (u32)nq, (u32)(nq >> 32));
+            x[r] = v;
+        }
+    }
 #ifdef HP_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -376,16 +392,55 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd(HpNtt
     exchange<LOGN, LAY_C, LAY_S, false>(x, lds, ad);
     TRACE_MARK();   // 8
     // store, layout S: 16 bytes per lane, a wave writes 1 KiB of consecutive words per instruction
-    {
+    if (!DROP) {
         u64 *d = it.dst + (((size_t)(tid >> 6)) << 11) + ((tid & 63u) << 1);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             V2 v{x[2 * s], x[2 * s + 1]};
             *reinterpret_cast<V2 *>(d + ((size_t)s << 7)) = v;
         }
+    } else {
+        // rescaling.cpp:72-74 / mod_switch.cpp:72-76 (+ the += of relinearize, ckks/arith.cpp:70-71):
+        // out = ((x - NTT(rem)) * inv) [* (q_last mod t)] [+ addend], all in the lazy representation
+        const u32 k = it.limb, p2 = w % job.P;
+        const size_t off = (((size_t)(tid >> 6)) << 11) + ((tid & 63u) << 1);
+        const u64 *xs = da->x + ((size_t)p2 * da->L + k) * G::N + off;
+        const u64 *as = da->addend ? da->addend + ((size_t)(p2 >> 1) * da->add_ct_stride + (size_t)(p2 & 1) * da->add_poly_stride + k) * G::N + off : nullptr;
+        u64 *d = da->out + ((size_t)p2 * (da->L - 1) + k) * G::N + off;
+        const u64 inv = da->dc.inv[k], invh = da->dc.inv_h[k], ql = da->dc.qlt[k], qlh = da->dc.qlt_h[k];
+        const bool bgv = da->dc.bgv != 0;
+        const u32 n0 = (u32)nq, n1 = (u32)(nq >> 32);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const V2 xv = *reinterpret_cast<const V2 *>(xs + ((size_t)s << 7));
+            u64 v0 = hp_harvey_lazy_nq(hp_sub_lazy(xv.x, x[2 * s], two_q), inv, invh, n0, n1);
+            u64 v1 = hp_harvey_lazy_nq(hp_sub_lazy(xv.y, x[2 * s + 1], two_q), inv, invh, n0, n1);
+            if (bgv) {
+                v0 = hp_harvey_lazy_nq(v0, ql, qlh, n0, n1);
+                v1 = hp_harvey_lazy_nq(v1, ql, qlh, n0, n1);
+            }
+            if (as) {
+                const V2 av = *reinterpret_cast<const V2 *>(as + ((size_t)s << 7));
+                v0 = hp_add_lazy(v0, av.x, two_q);
+                v1 = hp_add_lazy(v1, av.y, two_q);
+            }
+            V2 v{v0, v1};
+            *reinterpret_cast<V2 *>(d + ((size_t)s << 7)) = v;
+        }
     }
     TRACE_MARK();   // 9: stores issued
     TRACE_FLUSH();
+}
+
+template <int LOGN>
+__global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd(HpNttJob job) {
+    ntt_fwd_body<LOGN, false>(job, nullptr);
+}
+
+// forward NTT with the drop-last-prime prologue/epilogue fused in (HpDropArgs in kernel-argument memory)
+template <int LOGN>
+__global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd_drop(HpNttJob job, HpDropArgs da) {
+    ntt_fwd_body<LOGN, true>(job, &da);
 }
 
 // ---- inverse kernel ----------------------------------------------------------------------------
@@ -521,6 +576,19 @@ extern "C" int hp_debug_trace(u64 *out, size_t words) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), words * sizeof(u64));
 }
 #endif
+
+hipError_t hp_launch_ntt_fast_drop(const HpNttJob &job, const HpDropArgs &da, hipStream_t stream) {
+    if (job.W == 0) return hipSuccess;
+    switch (job.logn) {
+    case 11: k_ntt_fwd_drop<11><<<job.W, Geo<11>::T, 0, stream>>>(job, da); break;
+    case 12: k_ntt_fwd_drop<12><<<job.W, Geo<12>::T, 0, stream>>>(job, da); break;
+    case 13: k_ntt_fwd_drop<13><<<job.W, Geo<13>::T, 0, stream>>>(job, da); break;
+    case 14: k_ntt_fwd_drop<14><<<job.W, Geo<14>::T, 0, stream>>>(job, da); break;
+    case 15: k_ntt_fwd_drop<15><<<job.W, Geo<15>::T, 0, stream>>>(job, da); break;
+    default: return hipErrorNotSupported;
+    }
+    return hipGetLastError();
+}
 
 hipError_t hp_launch_ntt_fast(const HpNttJob &job, hipStream_t stream) {
     if (job.W == 0) return hipSuccess;

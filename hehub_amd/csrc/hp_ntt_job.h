@@ -14,7 +14,7 @@ HP_DEV bool hp_decode_item(const HpNttJob &job, u32 w, HpItem &it) {
     const size_t n = (size_t)1 << job.logn;
     if (job.mode == HP_NTT_BATCH) {
         const u32 k = w / job.P, p = w % job.P;
-        it.src = job.src + ((size_t)p * job.src_pstride + k) * n;
+        it.src = job.src + ((size_t)p * job.src_pstride + (size_t)k * job.src_kstride) * n;
         it.dst = job.dst + ((size_t)p * job.dst_pstride + k) * n;
         it.limb = k;
         return true;
@@ -29,9 +29,5 @@ HP_DEV bool hp_decode_item(const HpNttJob &job, u32 w, HpItem &it) {
         it.limb = k;
         return true;
     }
-    // HP_NTT_LAST
-    it.src = job.src + ((size_t)w * job.src_pstride + (job.L - 1)) * n;
-    it.dst = job.dst + (size_t)w * n;
-    it.limb = job.L - 1;
-    return true;
+    return false;
 }
