@@ -81,6 +81,15 @@ struct GTab {
     HP_DEV explicit GTab(const u64x2 *generic) : p((gptr_u64x2)generic) {}
     HP_DEV u64x2 operator()(u32 i) const { const u64v2 v = p[i]; return u64x2{v.x, v.y}; }
 };
+// STab: wave-uniform entries of a global table (the first pass of a transform): constant address space, so the
+//       loads are scalar (s_load_dwordx4 through the scalar cache) and take no vector-memory slots.
+typedef const u64v2 __attribute__((address_space(4))) * cptr_u64x2;
+struct STab {
+    static constexpr int depth = 4;
+    cptr_u64x2 p;
+    HP_DEV explicit STab(const u64x2 *generic) : p((cptr_u64x2)generic) {}
+    HP_DEV u64x2 operator()(u32 i) const { const u64v2 v = p[i]; return u64x2{v.x, v.y}; }
+};
 struct LTab {
     static constexpr int depth = 2;          // LDS latency is short
     lptr_u64x2 p;
@@ -145,6 +154,12 @@ HP_DEV void run_pass(u64 (&x)[32], const Tab tbl, u32 ncls, u32 cls, u64 nq, u64
 #endif
 #ifdef HP_ABLATE_TW     // tuning experiment only (wrong results): one twiddle for the whole pass
     ncls = 0; cls = 0;
+#endif
+#ifdef HP_ABLATE_TW_GLOBAL   // tuning experiment only (wrong results): no per-thread global twiddle traffic
+    if (Tab::depth != 2 && ncls > 32) { ncls = 0; cls = 0; }
+#endif
+#ifdef HP_ABLATE_TW_LDS      // tuning experiment only (wrong results): no LDS twiddle reads
+    if (Tab::depth == 2) { ncls = 0; cls = 0; }
 #endif
     u64x2 ring[D];
 #pragma unroll
@@ -364,7 +379,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
 #endif
     TRACE_MARK();   // 1: coefficients have arrived
     // pass A: global stages 1..A, wave-uniform twiddles seq[1 .. 2^A - 1]
-    fwd_pass<4, G::PB>(x, GTab(lp->fwd_ref + 1), 1u, 0u, nq, two_q);
+    fwd_pass<4, G::PB>(x, STab(lp->fwd_ref + 1), 1u, 0u, nq, two_q);
     TRACE_MARK();   // 2
     exchange<LOGN, LAY_A, LAY_B, true>(x, lds, ad);
     TRACE_MARK();   // 3
@@ -485,7 +500,7 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_inv(HpNtt
     __syncthreads();   // the staged twiddles are read by other waves in pass B' (the exchanges before it are wave-local)
     exchange<LOGN, LAY_S, LAY_C, false>(x, lds, ad);
     // pass A': levels 0..4 (pairs 1,2,4,8,16 apart), wave-uniform twiddles
-    inv_pass<0, 4>(x, GTab(lp->inv_k), 1u, 0u, nq, two_q);
+    inv_pass<0, 4>(x, STab(lp->inv_k), 1u, 0u, nq, two_q);
     exchange<LOGN, LAY_C, LAY_B, false>(x, lds, ad);
     // pass B': levels 5..9, twiddles depend on j = tid & 31
     inv_pass<0, 4>(x, LTab(lds_tw), 32u, tid & 31u, nq, two_q);
