@@ -281,6 +281,27 @@ HP_DEV void stagger_start(const HpNttJob &job) {
     }
 }
 
+// Streaming accesses to coefficient data are marked non-temporal so that the once-read, once-written
+// limbs do not push the twiddle tables (re-read by every workgroup) out of L2: +3.5..5 % on every
+// transform shape (HP_TEMPORAL_DATA restores plain accesses for A/B runs).
+HP_DEV V2 ld_stream(const u64 *p) {
+#ifndef HP_TEMPORAL_DATA
+    typedef u64 __attribute__((ext_vector_type(2))) vv;
+    const vv v = __builtin_nontemporal_load(reinterpret_cast<const vv *>(p));
+    return V2{v.x, v.y};
+#else
+    return *reinterpret_cast<const V2 *>(p);
+#endif
+}
+HP_DEV void st_stream(u64 *p, const V2 &v) {
+#ifndef HP_TEMPORAL_DATA
+    typedef u64 __attribute__((ext_vector_type(2))) vv;
+    __builtin_nontemporal_store(vv{v.x, v.y}, reinterpret_cast<vv *>(p));
+#else
+    *reinterpret_cast<V2 *>(p) = v;
+#endif
+}
+
 // value held by the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2], no LDS involved
 HP_DEV u64 from_pair_lane(u64 v) {
     const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0xB1, 0xF, 0xF, true);
@@ -337,7 +358,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
             const u64 *sp = it.src + (tid & ~1u);
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
-                const V2 v = *reinterpret_cast<const V2 *>(sp + ((size_t)(2 * p + (odd ? 1 : 0)) << 10));
+                const V2 v = ld_stream(sp + ((size_t)(2 * p + (odd ? 1 : 0)) << 10));
                 const u64 keep = odd ? v.y : v.x, send = odd ? v.x : v.y;
                 const u64 recv = from_pair_lane(send);
                 x[2 * p] = odd ? recv : keep;
@@ -350,7 +371,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
             } else {
 #pragma unroll
                 for (int pp = 0; pp < (1 << G::PB); pp += 2) {
-                    const V2 v = *reinterpret_cast<const V2 *>(s + ((size_t)kk << 10) + pp);
+                    const V2 v = ld_stream(s + ((size_t)kk << 10) + pp);
                     x[(kk << G::PB) | pp] = v.x;
                     x[(kk << G::PB) | pp | 1] = v.y;
                 }
@@ -412,7 +433,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             V2 v{x[2 * s], x[2 * s + 1]};
-            *reinterpret_cast<V2 *>(d + ((size_t)s << 7)) = v;
+            st_stream(d + ((size_t)s << 7), v);
         }
     } else {
         // rescaling.cpp:72-74 / mod_switch.cpp:72-76 (+ the += of relinearize, ckks/arith.cpp:70-71):
@@ -427,7 +448,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
         const u32 n0 = (u32)nq, n1 = (u32)(nq >> 32);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const V2 xv = *reinterpret_cast<const V2 *>(xs + ((size_t)s << 7));
+            const V2 xv = ld_stream(xs + ((size_t)s << 7));
             u64 v0 = hp_harvey_lazy_nq(hp_sub_lazy(xv.x, x[2 * s], two_q), inv, invh, n0, n1);
             u64 v1 = hp_harvey_lazy_nq(hp_sub_lazy(xv.y, x[2 * s + 1], two_q), inv, invh, n0, n1);
             if (bgv) {
@@ -435,12 +456,12 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
                 v1 = hp_harvey_lazy_nq(v1, ql, qlh, n0, n1);
             }
             if (as) {
-                const V2 av = *reinterpret_cast<const V2 *>(as + ((size_t)s << 7));
+                const V2 av = ld_stream(as + ((size_t)s << 7));
                 v0 = hp_add_lazy(v0, av.x, two_q);
                 v1 = hp_add_lazy(v1, av.y, two_q);
             }
             V2 v{v0, v1};
-            *reinterpret_cast<V2 *>(d + ((size_t)s << 7)) = v;
+            st_stream(d + ((size_t)s << 7), v);
         }
     }
     TRACE_MARK();   // 9: stores issued
@@ -487,7 +508,7 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_inv(HpNtt
         const u64 *s = it.src + (((size_t)(tid >> 6)) << 11) + ((tid & 63u) << 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const V2 v = *reinterpret_cast<const V2 *>(s + ((size_t)r << 7));
+            const V2 v = ld_stream(s + ((size_t)r << 7));
             x[2 * r] = v.x;
             x[2 * r + 1] = v.y;
         }
@@ -540,7 +561,7 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_inv(HpNtt
                 V2 v;
                 v.x = odd ? recv : x[2 * p];
                 v.y = odd ? x[2 * p + 1] : recv;
-                *reinterpret_cast<V2 *>(dp + ((size_t)(2 * p + (odd ? 1 : 0)) << 10)) = v;
+                st_stream(dp + ((size_t)(2 * p + (odd ? 1 : 0)) << 10), v);
             }
         }
 #pragma unroll
@@ -550,7 +571,7 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_inv(HpNtt
 #pragma unroll
                 for (int pp = 0; pp < (1 << G::PB); pp += 2) {
                     V2 v{x[(kk << G::PB) | pp], x[(kk << G::PB) | pp | 1]};
-                    *reinterpret_cast<V2 *>(d + ((size_t)kk << 10) + pp) = v;
+                    st_stream(d + ((size_t)kk << 10) + pp, v);
                 }
             }
         }
