@@ -245,7 +245,11 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner(const HpLimb *__restr
             const u64 *g1 = key + (((size_t)j * 2 + 1) * Le + k) * n;
             u64 dv[2], k0[2], k1[2];
             if (two) {
-                U2 t = *reinterpret_cast<const U2 *>(d + i); dv[0] = t.x; dv[1] = t.y;
+                // digits are read exactly once: non-temporal, so they do not evict the key column from L2
+                typedef u64 __attribute__((ext_vector_type(2))) vv;
+                const vv dvv = __builtin_nontemporal_load(reinterpret_cast<const vv *>(d + i));
+                dv[0] = dvv.x; dv[1] = dvv.y;
+                U2 t;
                 t = *reinterpret_cast<const U2 *>(g0 + i); k0[0] = t.x; k0[1] = t.y;
                 t = *reinterpret_cast<const U2 *>(g1 + i); k1[0] = t.x; k1[1] = t.y;
             } else {

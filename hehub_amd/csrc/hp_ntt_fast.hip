@@ -84,8 +84,11 @@ struct GTab {
 // STab: wave-uniform entries of a global table (the first pass of a transform): constant address space, so the
 //       loads are scalar (s_load_dwordx4 through the scalar cache) and take no vector-memory slots.
 typedef const u64v2 __attribute__((address_space(4))) * cptr_u64x2;
+#ifndef STAB_DEPTH
+#define STAB_DEPTH 4
+#endif
 struct STab {
-    static constexpr int depth = 4;
+    static constexpr int depth = STAB_DEPTH;   // held in SGPRs; SMEM returns out of order, so every use waits for all of them
     cptr_u64x2 p;
     HP_DEV explicit STab(const u64x2 *generic) : p((cptr_u64x2)generic) {}
     HP_DEV u64x2 operator()(u32 i) const { const u64v2 v = p[i]; return u64x2{v.x, v.y}; }

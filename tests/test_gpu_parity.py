@@ -121,6 +121,7 @@ SCHEME_CASES = [
     (11, P.P40[:3] + [P.P50[0]], 2),
     (12, [P.P50[1]] + P.P40[:4] + [P.P50[0]], 3),
     (P.C5_LOGN, P.C5_MODULI_EXT, 2),
+    (14, P.P50[1:4] + [P.P50[0]], 2),     # C2 ring degree, fused drop-last-prime path
 ]
 
 
