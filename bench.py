@@ -201,6 +201,17 @@ def main():
                            "traffic": None, "launches": launches, "avg_launch_ms": kern_ms / launches,
                            "algorithmic_bytes_per_launch": bytes_per_launch,
                            "share_of_step_time": kern_ms * 1e-3 / elapsed}
+        # HBM traffic per launch from the committed PMC measurement of this kernel shape (rocprofv3 --pmc
+        # FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, tools/prof_pmc.sh); null when no measurement exists
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                tr = json.load(f).get(f"k_ntt_fwd_logn{logn}") if family == "ntt" else None
+            if tr:
+                limbs_per_launch = bytes_per_launch / (16.0 * n)
+                res["roofline"]["traffic"] = tr["bytes_per_limb"] * limbs_per_launch
+                res["roofline"]["traffic_source"] = "rocprofv3 PMC per-limb measurement x limbs per launch (profiles/r01_traffic.json)"
+        except (OSError, ValueError):
+            pass
     if wl in ("ckks", "bgv"):
         a_step = (5 * L * L + 36 * L) * 8 * n
         res["pipeline_roofline"] = {"A_step_GBps": value / world * a_step / 1e9,

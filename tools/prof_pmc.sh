@@ -12,3 +12,4 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_W
   rocprofv3 --pmc $SET --kernel-trace -d $R/gpurun_out/pmc_${TAG}_$i -o p -- python $R/bench.py "$@" --no-cpu-baseline > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1
 done
 python $R/tools/rocpd_summary.py $R/gpurun_out/pmc_${TAG}_*/p_results.db > $R/gpurun_out/pmc_${TAG}_summary.txt 2>&1
+rm -rf $R/gpurun_out/pmc_${TAG}_[0-9]* 
