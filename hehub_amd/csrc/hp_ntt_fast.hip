@@ -34,6 +34,14 @@
 
 namespace {
 
+// Cap the kernels' VGPR allocation below the 128 of "4 waves per SIMD" to leave room in the register file for
+// waves of other (HBM-bound, low-register) kernels running next to a transform workgroup on the same CU.
+#ifdef HP_NTT_NUM_VGPR
+#define HP_NTT_VGPR_ATTR __attribute__((amdgpu_num_vgpr(HP_NTT_NUM_VGPR)))
+#else
+#define HP_NTT_VGPR_ATTR
+#endif
+
 template <int LOGN> struct Geo {
     static constexpr int A = LOGN - 10;          // stages of pass A (1..5)
     static constexpr int PB = 5 - A;             // passenger bits of pass A's register index
@@ -472,19 +480,19 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
 }
 
 template <int LOGN>
-__global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd(HpNttJob job) {
+__global__ void HP_NTT_VGPR_ATTR __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd(HpNttJob job) {
     ntt_fwd_body<LOGN, false>(job, nullptr);
 }
 
 // forward NTT with the drop-last-prime prologue/epilogue fused in (HpDropArgs in kernel-argument memory)
 template <int LOGN>
-__global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd_drop(HpNttJob job, HpDropArgs da) {
+__global__ void HP_NTT_VGPR_ATTR __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd_drop(HpNttJob job, HpDropArgs da) {
     ntt_fwd_body<LOGN, true>(job, &da);
 }
 
 // ---- inverse kernel ----------------------------------------------------------------------------
 template <int LOGN, bool STRICT, bool PSCAL>
-__global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_inv(HpNttJob job) {
+__global__ void HP_NTT_VGPR_ATTR __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_inv(HpNttJob job) {
     using G = Geo<LOGN>;
     __shared__ u32 lds[G::N];
     __shared__ u64v2 lds_tw[31 * 32];
