@@ -59,6 +59,8 @@ SIGNATURES = {
     "hp_dev_bgv_mod_switch": (INT, [P, szt, szt, P, u64, szt, P, P]),
     "hp_dev_ckks_relinearize": (INT, [P, szt, szt, P, szt, P, P, P]),
     "hp_dev_bgv_relinearize": (INT, [P, szt, szt, P, u64, szt, P, P, P]),
+    "hp_dev_ckks_rotate": (INT, [P, szt, szt, P, szt, szt, P, P, P]),
+    "hp_dev_ckks_conjugate": (INT, [P, szt, szt, P, szt, P, P, P]),
     "hp_dev_ckks_mult_relin_rescale": (INT, [P, szt, szt, P, szt, P, P, P, P]),
     "hp_dev_bgv_mult_relin_modswitch": (INT, [P, szt, szt, P, u64, szt, P, P, P, P]),
     "hp_prof_begin": (INT, [P, C.c_char_p]),

@@ -317,13 +317,15 @@ hipError_t hp_launch_drop_rem(const HpLimb *limbs, const HpDropConsts &dc, u32 L
 __global__ void __launch_bounds__(ELEM_THREADS) k_drop_fin(const HpLimb *__restrict__ limbs, HpDropConsts dc, u32 L,
                                                           u32 n, u32 chunks, const u64 *__restrict__ x,
                                                           const u64 *__restrict__ rem, const u64 *__restrict__ addend,
-                                                          u32 add_poly_stride, u32 add_ct_stride, u64 *__restrict__ out) {
+                                                          u32 add_poly_stride, u32 add_ct_stride, u32 add_mask,
+                                                          u64 *__restrict__ out) {
     const u32 Lm1 = L - 1;
     const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;   // row = p2*Lm1 + k
     const u32 p2 = row / Lm1, k = row % Lm1;
     const u64 q = limbs[k].q, two_q = limbs[k].two_q;
     const u64 *xs = x + ((size_t)p2 * L + k) * n;
-    const u64 *as = addend ? addend + ((size_t)(p2 >> 1) * add_ct_stride + (size_t)(p2 & 1) * add_poly_stride + k) * n : nullptr;
+    const u64 *as = (addend && ((add_mask >> (p2 & 1)) & 1u))
+                        ? addend + ((size_t)(p2 >> 1) * add_ct_stride + (size_t)(p2 & 1) * add_poly_stride + k) * n : nullptr;
     const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
     for (u32 i = chunk * ELEM_CHUNK + threadIdx.x; i < end; i += ELEM_THREADS) {
         u64 v = hp_sub_lazy(xs[i], rem[(size_t)row * n + i], two_q);
@@ -335,11 +337,11 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_drop_fin(const HpLimb *__restr
 }
 
 hipError_t hp_launch_drop_fin(const HpLimb *limbs, const HpDropConsts &dc, u32 L, u32 n, u32 P2, const u64 *x,
-                              const u64 *rem, const u64 *addend, u32 add_poly_stride, u32 add_ct_stride, u64 *out,
-                              hipStream_t stream) {
+                              const u64 *rem, const u64 *addend, u32 add_poly_stride, u32 add_ct_stride, u32 add_mask,
+                              u64 *out, hipStream_t stream) {
     u32 chunks; dim3 grid;
     elem_grid(n, P2 * (L - 1), chunks, grid);
     k_drop_fin<<<grid, ELEM_THREADS, 0, stream>>>(limbs, dc, L, n, chunks, x, rem, addend, add_poly_stride,
-                                                  add_ct_stride, out);
+                                                  add_ct_stride, add_mask, out);
     return hipGetLastError();
 }

@@ -240,6 +240,35 @@ HpNttJob batch_job(const Plan *plan, size_t logn, size_t L, size_t P, const u64 
     return j;
 }
 
+// gather map of cycle(poly, step) (permutation.cpp:39-53): out[to] = in[perm[to]]; cached per (logn, step)
+int get_cycle_perm(hp_ctx *ctx, size_t logn, size_t step, const u32 **out) {
+    const size_t n = (size_t)1 << logn;
+    auto key = std::make_pair(logn, step);
+    auto it = ctx->perms.find(key);
+    if (it == ctx->perms.end()) {
+        std::vector<u32> perm(n);
+        for (size_t i = 0; i < n; i++) perm[i] = (u32)i;
+        const u32 mask = (u32)((1u << (logn + 1)) - 1);
+        u32 factor = 1;
+        for (size_t s = 0; s < step; s++) factor *= 3u;
+        factor &= mask;
+        u32 pw = 1;
+        for (size_t i = 0; i < n / 2; i++, pw *= 3u) {
+            const u32 old_idx = pw & mask;
+            const u32 from = hp::bit_rev((old_idx - 1) / 2, (int)logn);
+            const u32 to = hp::bit_rev((((old_idx * factor) & mask) - 1) / 2, (int)logn);
+            perm[to] = from;
+            perm[n - 1 - to] = (u32)(n - 1 - from);
+        }
+        u32 *d = nullptr;
+        int rc = upload(ctx, perm.data(), n * sizeof(u32), (void **)&d);
+        if (rc) return rc;
+        it = ctx->perms.emplace(key, d).first;
+    }
+    *out = it->second;
+    return HP_OK;
+}
+
 bool logn_ok(size_t logn) { return logn >= 1 && logn <= 15; }
 
 // rgsw.cpp:57-156 on a batch.  pt rows: polynomial p at pt + p*pt_pstride limbs.
@@ -273,7 +302,7 @@ int ext_prod(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P, con
 size_t drop_ws_words(size_t n, size_t L, size_t P2) { return padded(P2 * n) / 8 + padded(P2 * (L - 1) * n) / 8; }
 
 int drop_last(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, bool bgv, u64 t, const u64 *x,
-              const u64 *addend, size_t add_poly_stride, size_t add_ct_stride, u64 *out, Carver &cv) {
+              const u64 *addend, size_t add_poly_stride, size_t add_ct_stride, u32 add_mask, u64 *out, Carver &cv) {
     const size_t n = (size_t)1 << logn;
     const u64 q_last = plan->consts[L - 1].q;
     HpDropConsts dc;
@@ -318,7 +347,7 @@ int drop_last(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, b
         HpDropArgs da;
         memset(&da, 0, sizeof(da));
         da.dc = dc; da.x = x; da.L = (u32)L; da.addend = addend; da.add_poly_stride = (u32)add_poly_stride;
-        da.add_ct_stride = (u32)add_ct_stride; da.out = out;
+        da.add_ct_stride = (u32)add_ct_stride; da.add_mask = add_mask; da.out = out;
         ProfScope ps(ctx, "ntt");
         return chk(ctx, hp_launch_ntt_fast_drop(fj, da, ctx->stream), "fused drop NTT");
     }
@@ -332,7 +361,7 @@ int drop_last(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, b
     {
         ProfScope ps(ctx, "drop_fin");
         rc = chk(ctx, hp_launch_drop_fin(plan->d_limbs, dc, (u32)L, (u32)n, (u32)P2, x, rem, addend, (u32)add_poly_stride,
-                                         (u32)add_ct_stride, out, ctx->stream), "drop_fin");
+                                         (u32)add_ct_stride, add_mask, out, ctx->stream), "drop_fin");
     }
     return rc;
 }
@@ -619,31 +648,11 @@ int hp_dev_poly_cycle(hp_ctx *ctx, size_t logn, size_t L, size_t batch, size_t s
     if (in == out) return fail(ctx, HP_EINVAL, "cycle cannot run in place");
     if (step >= ((size_t)1 << 17)) return fail(ctx, HP_EINVAL, "rotation step out of range");
     const size_t n = (size_t)1 << logn;
-    auto key = std::make_pair(logn, step);
-    auto it = ctx->perms.find(key);
-    if (it == ctx->perms.end()) {
-        // permutation.cpp:39-53 turned into a gather map: out[to] = in[perm[to]]
-        std::vector<u32> perm(n);
-        for (size_t i = 0; i < n; i++) perm[i] = (u32)i;
-        const u32 mask = (u32)((1u << (logn + 1)) - 1);
-        u32 factor = 1;
-        for (size_t s = 0; s < step; s++) factor *= 3u;
-        factor &= mask;
-        u32 pw = 1;
-        for (size_t i = 0; i < n / 2; i++, pw *= 3u) {
-            const u32 old_idx = pw & mask;
-            const u32 from = hp::bit_rev((old_idx - 1) / 2, (int)logn);
-            const u32 to = hp::bit_rev((((old_idx * factor) & mask) - 1) / 2, (int)logn);
-            perm[to] = from;
-            perm[n - 1 - to] = (u32)(n - 1 - from);
-        }
-        u32 *d = nullptr;
-        int rc = upload(ctx, perm.data(), n * sizeof(u32), (void **)&d);
-        if (rc) return rc;
-        it = ctx->perms.emplace(key, d).first;
-    }
+    const u32 *perm;
+    int rc = get_cycle_perm(ctx, logn, step, &perm);
+    if (rc) return rc;
     ProfScope ps(ctx, "elem");
-    return chk(ctx, hp_launch_gather(it->second, (u32)n, (u32)(batch * L), in, out, ctx->stream), "cycle");
+    return chk(ctx, hp_launch_gather(perm, (u32)n, (u32)(batch * L), in, out, ctx->stream), "cycle");
 }
 
 int hp_dev_mult_low_level(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch,
@@ -685,7 +694,7 @@ static int dev_drop(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, 
     const size_t n = (size_t)1 << logn;
     if ((rc = ws_reserve(ctx, drop_ws_words(n, L, 2 * batch) * 8))) return rc;
     Carver cv(ctx->ws);
-    return drop_last(ctx, plan, logn, L, 2 * batch, bgv, t, ct, nullptr, 0, 0, out, cv);
+    return drop_last(ctx, plan, logn, L, 2 * batch, bgv, t, ct, nullptr, 0, 0, 0, out, cv);
 }
 int hp_dev_ckks_rescale(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, const uint64_t *ct,
                         uint64_t *out) { return dev_drop(ctx, logn, L, moduli, false, 0, batch, ct, out); }
@@ -699,7 +708,7 @@ static int relin_core(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size
     u64 *ext = cv.take(P * 2 * (L + 1) * n);
     int rc = ext_prod(ctx, plan, logn, L, P, quad + 2 * L * n, 3 * L, key, ext, cv);
     if (rc) return rc;
-    return drop_last(ctx, plan, logn, L + 1, 2 * P, bgv, inner_t, ext, quad, L, 3 * L, out, cv);
+    return drop_last(ctx, plan, logn, L + 1, 2 * P, bgv, inner_t, ext, quad, L, 3 * L, 3, out, cv);
 }
 static size_t relin_ws_words(size_t n, size_t L, size_t P) {
     return padded(P * 2 * (L + 1) * n) / 8 + ext_prod_ws_words(n, L, P) + drop_ws_words(n, L + 1, 2 * P);
@@ -725,6 +734,38 @@ int hp_dev_ckks_relinearize(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *
 int hp_dev_bgv_relinearize(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, uint64_t inner_t,
                            size_t batch, const uint64_t *quad, const uint64_t *key, uint64_t *out) {
     return dev_relin(ctx, logn, L, moduli_ext, true, inner_t, batch, quad, key, out);
+}
+
+// ckks/arith.cpp:75-93: rotate (cycle by `step`) or conjugate (involution) a batch and switch back to the
+// original key: moved = gather(ct); ext = ext_prod(moved[1], key); drop p; out[0] += moved[0]
+static int dev_ckks_automorphism(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch,
+                                 bool conj, size_t step, const uint64_t *ct, const uint64_t *key, uint64_t *out) {
+    Guard g(ctx);
+    int rc = check_ext_args(ctx, logn, L, batch);
+    if (rc) return rc;
+    if (!conj && step >= ((size_t)1 << 17)) return fail(ctx, HP_EINVAL, "rotation step out of range");
+    const Plan *plan;
+    if ((rc = get_plan(ctx, logn, moduli_ext, L + 1, true, &plan))) return rc;
+    const size_t n = (size_t)1 << logn;
+    const size_t words = padded(batch * 2 * L * n) / 8 + padded(batch * 2 * (L + 1) * n) / 8 + ext_prod_ws_words(n, L, batch) +
+                         drop_ws_words(n, L + 1, 2 * batch);
+    if ((rc = ws_reserve(ctx, words * 8))) return rc;
+    Carver cv(ctx->ws);
+    u64 *moved = cv.take(batch * 2 * L * n);
+    u64 *ext = cv.take(batch * 2 * (L + 1) * n);
+    {
+        ProfScope ps(ctx, "elem");
+        if (conj) {
+            rc = chk(ctx, hp_launch_reverse((u32)n, (u32)(batch * 2 * L), ct, moved, ctx->stream), "involution");
+        } else {
+            const u32 *perm;
+            if ((rc = get_cycle_perm(ctx, logn, step, &perm))) return rc;
+            rc = chk(ctx, hp_launch_gather(perm, (u32)n, (u32)(batch * 2 * L), ct, moved, ctx->stream), "cycle");
+        }
+    }
+    if (rc) return rc;
+    if ((rc = ext_prod(ctx, plan, logn, L, batch, moved + L * n, 2 * L, key, ext, cv))) return rc;
+    return drop_last(ctx, plan, logn, L + 1, 2 * batch, false, 0, ext, moved, L, 2 * L, 1, out, cv);
 }
 
 // mult_low_level + relinearize + drop q_last, processed in sub-batches so the working set
@@ -780,7 +821,7 @@ static int dev_mult(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_e
         }
         // the reference's bgv::relinearize runs its inner mod switch with plain_modulus == 1 (bgv.h:32)
         if (!rc) rc = relin_core(ctx, plan, logn, L, P, bgv, 1, quad, key, lin, cv);
-        if (!rc) rc = drop_last(ctx, plan, logn, L, 2 * P, bgv, t, lin, nullptr, 0, 0, out + b0 * 2 * (L - 1) * n, cv);
+        if (!rc) rc = drop_last(ctx, plan, logn, L, 2 * P, bgv, t, lin, nullptr, 0, 0, 0, out + b0 * 2 * (L - 1) * n, cv);
         if (rc) break;
     }
     ctx->stream = user;
@@ -791,6 +832,14 @@ static int dev_mult(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_e
         }
     }
     return rc;
+}
+int hp_dev_ckks_rotate(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch, size_t step,
+                       const uint64_t *ct, const uint64_t *rot_key, uint64_t *out) {
+    return dev_ckks_automorphism(ctx, logn, L, moduli_ext, batch, false, step, ct, rot_key, out);
+}
+int hp_dev_ckks_conjugate(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch,
+                          const uint64_t *ct, const uint64_t *conj_key, uint64_t *out) {
+    return dev_ckks_automorphism(ctx, logn, L, moduli_ext, batch, true, 0, ct, conj_key, out);
 }
 int hp_dev_ckks_mult_relin_rescale(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch,
                                    const uint64_t *ct1, const uint64_t *ct2, const uint64_t *key, uint64_t *out) {

@@ -101,6 +101,7 @@ struct HpDropArgs {
     u32 L;                 // limbs of x (the last one is being dropped)
     const u64 *addend;     // optional [.][.][n]: row (p2>>1)*add_ct_stride + (p2&1)*add_poly_stride + k
     u32 add_poly_stride, add_ct_stride;
+    u32 add_mask;          // bit h set: polynomial h of each ciphertext gets the addend (relinearize 3, rotate 1)
     u64 *out;              // [P2][L-1][n]
 };
 // job: HP_NTT_BATCH over L-1 limbs and P2 polynomials with src = clast [P2][n] (src_pstride 1, src_kstride 0)
@@ -113,4 +114,4 @@ hipError_t hp_launch_drop_rem(const HpLimb *limbs, const HpDropConsts &dc, u32 L
 //   -> out [P2][L-1][n]:  out = ((x - rem) * inv) [* qlt]  [+ addend]
 hipError_t hp_launch_drop_fin(const HpLimb *limbs, const HpDropConsts &dc, u32 L, u32 n, u32 P2, const u64 *x,
                               const u64 *rem, const u64 *addend, u32 add_poly_stride, u32 add_ct_stride,
-                              u64 *out, hipStream_t stream);
+                              u32 add_mask, u64 *out, hipStream_t stream);

@@ -459,7 +459,8 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
         const u32 k = it.limb, p2 = w % job.P;
         const size_t off = (((size_t)(tid >> 6)) << 11) + ((tid & 63u) << 1);
         const u64 *xs = da->x + ((size_t)p2 * da->L + k) * G::N + off;
-        const u64 *as = da->addend ? da->addend + ((size_t)(p2 >> 1) * da->add_ct_stride + (size_t)(p2 & 1) * da->add_poly_stride + k) * G::N + off : nullptr;
+        const u64 *as = (da->addend && ((da->add_mask >> (p2 & 1)) & 1u))
+                            ? da->addend + ((size_t)(p2 >> 1) * da->add_ct_stride + (size_t)(p2 & 1) * da->add_poly_stride + k) * G::N + off : nullptr;
         u64 *d = da->out + ((size_t)p2 * (da->L - 1) + k) * G::N + off;
         const u64 inv = da->dc.inv[k], invh = da->dc.inv_h[k], ql = da->dc.qlt[k], qlh = da->dc.qlt_h[k];
         const bool bgv = da->dc.bgv != 0;

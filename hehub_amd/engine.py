@@ -249,6 +249,20 @@ class Engine:
                                                   self._ptr(quad), self._ptr(key), self._ptr(out)))
         return out
 
+    def ckks_rotate(self, moduli_ext, ct, key, step: int):
+        B, two, L, n = ct.shape
+        out = self.empty((B, 2, L, n))
+        self._chk(self.lib.hp_dev_ckks_rotate(self.h, n.bit_length() - 1, L, _u64arr(moduli_ext), B, step, self._ptr(ct),
+                                              self._ptr(key), self._ptr(out)))
+        return out
+
+    def ckks_conjugate(self, moduli_ext, ct, key):
+        B, two, L, n = ct.shape
+        out = self.empty((B, 2, L, n))
+        self._chk(self.lib.hp_dev_ckks_conjugate(self.h, n.bit_length() - 1, L, _u64arr(moduli_ext), B, self._ptr(ct),
+                                                 self._ptr(key), self._ptr(out)))
+        return out
+
     def ckks_mult(self, moduli_ext, ct1, ct2, key, out=None):
         B, two, L, n = ct1.shape
         out = self.empty((B, 2, L - 1, n)) if out is None else out

@@ -452,21 +452,29 @@ void rescale_inplace(CkksCt &ct, size_t dropping_primes) {   // rescaling.cpp:80
     }
 }
 
-static CkksCt key_switched(const RlweCt &moved, const RlweKsk &key, double scale) {   // ckks/arith.cpp:75-93
-    CkksCt r = ext_prod_montgomery(moved[1], key);
-    rescale_inplace(r);
-    r.scaling_factor = scale;
-    r[0] += moved[0];
+// ckks/arith.cpp:75-93: automorphism, key switch, drop of the special prime and the add of moved[0] run as one
+// device call; the argument checks below are the ones the reference's composition performs, in its order.
+static CkksCt key_switched(const CkksCt &ct, const RlweKsk &key, bool conj, size_t step) {
+    for (int h = 0; h < 2; h++)
+        if (ct[h].rep_form != PolyRepForm::value) throw std::invalid_argument("poly_ntt is expected to be in NTT value form");
+    std::vector<u64> mext;
+    check_ext_prod(ct[1], key, mext);
+    const size_t n = ct[1].dimension(), L = ct[1].component_count(), logn = ct[1].log_dimension();
+    if (ct[0].dimension() != n || ct[0].component_count() != L) throw std::invalid_argument("Ill-formed ciphertext.");
+    DevBuf dct(2 * L * n), dk(L * 2 * (L + 1) * n), dout(2 * L * n);
+    for (int h = 0; h < 2; h++) put_poly(dct.p + (size_t)h * L * n, ct[h], L);
+    put_key(dk.p, key, L, n);
+    if (conj) check(hp_dev_ckks_conjugate(amd::engine(), logn, L, mext.data(), 1, dct.p, dk.p, dout.p));
+    else check(hp_dev_ckks_rotate(amd::engine(), logn, L, mext.data(), 1, step, dct.p, dk.p, dout.p));
+    std::vector<u64> q(mext.begin(), mext.begin() + L);
+    CkksCt r = make_ct(n, L, q, dout.p);
+    r.scaling_factor = ct.scaling_factor;
     return r;
 }
 
-CkksCt conjugate(const CkksCt &ct, const RlweKsk &conj_key) {
-    return key_switched(RlweCt{involution(ct[0]), involution(ct[1])}, conj_key, ct.scaling_factor);
-}
+CkksCt conjugate(const CkksCt &ct, const RlweKsk &conj_key) { return key_switched(ct, conj_key, true, 0); }
 
-CkksCt rotate(const CkksCt &ct, const RlweKsk &rot_key, const size_t step) {
-    return key_switched(RlweCt{cycle(ct[0], step), cycle(ct[1], step)}, rot_key, ct.scaling_factor);
-}
+CkksCt rotate(const CkksCt &ct, const RlweKsk &rot_key, const size_t step) { return key_switched(ct, rot_key, false, step); }
 
 } // namespace ckks
 

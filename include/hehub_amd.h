@@ -142,6 +142,12 @@ int hp_dev_ckks_relinearize(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *
 int hp_dev_bgv_relinearize(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext,
                            uint64_t inner_plain_modulus, size_t batch, const uint64_t *d_quad,
                            const uint64_t *d_key, uint64_t *d_out);
+/* ckks.h:284 rotate(ct, rot_key, step) / ckks.h:282 conjugate(ct, conj_key)  (ckks/arith.cpp:75-93):
+ * ct u64[batch][2][L][N], key u64[L][2][L+1][N] -> out u64[batch][2][L][N] */
+int hp_dev_ckks_rotate(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch, size_t step,
+                       const uint64_t *d_ct, const uint64_t *d_rot_key, uint64_t *d_out);
+int hp_dev_ckks_conjugate(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch,
+                          const uint64_t *d_ct, const uint64_t *d_conj_key, uint64_t *d_out);
 /* ckks.h:270 mult(ct1, ct2, relin_key) followed by ckks.h:313 rescale_inplace:
  * ct1, ct2 u64[batch][2][L][N] -> out u64[batch][2][L-1][N] */
 int hp_dev_ckks_mult_relin_rescale(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext,

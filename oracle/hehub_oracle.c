@@ -583,6 +583,32 @@ int orc_bgv_relinearize(size_t logn, size_t L, const u64 *moduli_ext, u64 inner_
     return relinearize_common(logn, L, moduli_ext, 1, inner_t, quad, key, out);
 }
 
+/* ckks/arith.cpp:75-93: moved = automorphism(ct); ct' = ext_prod(moved[1], key); drop p; ct'[0] += moved[0] */
+static int automorphism_switch(size_t logn, size_t L, const u64 *moduli_ext, int conj, size_t step, const u64 *ct,
+                               const u64 *key, u64 *out) {
+    const size_t n = (size_t)1 << logn;
+    u64 *moved = (u64 *)malloc(2 * L * n * sizeof(u64));
+    u64 *ext = (u64 *)malloc(2 * (L + 1) * n * sizeof(u64));
+    for (size_t h = 0; h < 2; h++) {
+        if (conj) orc_poly_involution(logn, L, ct + h * L * n, moved + h * L * n);
+        else orc_poly_cycle(logn, L, step, ct + h * L * n, moved + h * L * n);
+    }
+    int rc = orc_ext_prod_montgomery(logn, L, moduli_ext, moved + L * n, key, ext);
+    if (rc == 0) rc = orc_ckks_rescale_by_one_prime(logn, L + 1, moduli_ext, ext, out);
+    if (rc == 0) orc_poly_add_inplace(n, L, moduli_ext, out, moved);
+    free(ext);
+    free(moved);
+    return rc;
+}
+
+int orc_ckks_rotate(size_t logn, size_t L, const u64 *moduli_ext, size_t step, const u64 *ct, const u64 *key, u64 *out) {
+    return automorphism_switch(logn, L, moduli_ext, 0, step, ct, key, out);
+}
+
+int orc_ckks_conjugate(size_t logn, size_t L, const u64 *moduli_ext, const u64 *ct, const u64 *key, u64 *out) {
+    return automorphism_switch(logn, L, moduli_ext, 1, 0, ct, key, out);
+}
+
 /* ckks.h:270-274 followed by rescaling.cpp:80-90 */
 int orc_ckks_mult_relin_rescale(size_t logn, size_t L, const u64 *moduli_ext, const u64 *ct1,
                                 const u64 *ct2, const u64 *key, u64 *out) {

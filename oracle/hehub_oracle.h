@@ -117,6 +117,11 @@ int orc_ckks_relinearize(size_t logn, size_t L, const orc_u64 *moduli_ext,
 int orc_bgv_relinearize(size_t logn, size_t L, const orc_u64 *moduli_ext,
                         orc_u64 inner_plain_modulus, const orc_u64 *quad,
                         const orc_u64 *key, orc_u64 *out);
+/* ckks/arith.cpp:85-93 rotate(ct, rot_key, step) and :75-83 conjugate(ct, conj_key): ct u64[2][L][N] -> out u64[2][L][N] */
+int orc_ckks_rotate(size_t logn, size_t L, const orc_u64 *moduli_ext, size_t step, const orc_u64 *ct,
+                    const orc_u64 *key, orc_u64 *out);
+int orc_ckks_conjugate(size_t logn, size_t L, const orc_u64 *moduli_ext, const orc_u64 *ct, const orc_u64 *key,
+                       orc_u64 *out);
 /* mult_low_level + relinearize + rescale_inplace: out u64[2][L-1][N] */
 int orc_ckks_mult_relin_rescale(size_t logn, size_t L, const orc_u64 *moduli_ext,
                                 const orc_u64 *ct1, const orc_u64 *ct2,

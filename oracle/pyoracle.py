@@ -96,6 +96,8 @@ class Oracle:
         self._mll = f("mult_low_level", None, [szt, szt, P, P, P, P])
         self._crelin = f("ckks_relinearize", C.c_int, [szt, szt, P, P, P, P])
         self._brelin = f("bgv_relinearize", C.c_int, [szt, szt, P, u64, P, P, P])
+        self._crot = f("ckks_rotate", C.c_int, [szt, szt, P, szt, P, P, P])
+        self._cconj = f("ckks_conjugate", C.c_int, [szt, szt, P, P, P, P])
         self._cmult = f("ckks_mult_relin_rescale", C.c_int, [szt, szt, P, P, P, P, P])
         self._bmult = f("bgv_mult_relin_modswitch", C.c_int, [szt, szt, P, u64, P, P, P, P])
         if self.kind == "orc":
@@ -256,6 +258,22 @@ class Oracle:
         rc = self._brelin(n.bit_length() - 1, L, _p(_mods(moduli_ext)), inner_t, _p(quad), _p(key), _p(out))
         if rc != 0:
             raise ValueError(f"relin rc={rc}")
+        return out
+
+    def ckks_rotate(self, moduli_ext, ct, key, step):
+        _, L, n = ct.shape
+        out = np.empty((2, L, n), dtype=np.uint64)
+        rc = self._crot(n.bit_length() - 1, L, _p(_mods(moduli_ext)), step, _p(ct), _p(key), _p(out))
+        if rc != 0:
+            raise ValueError(f"rotate rc={rc}")
+        return out
+
+    def ckks_conjugate(self, moduli_ext, ct, key):
+        _, L, n = ct.shape
+        out = np.empty((2, L, n), dtype=np.uint64)
+        rc = self._cconj(n.bit_length() - 1, L, _p(_mods(moduli_ext)), _p(ct), _p(key), _p(out))
+        if rc != 0:
+            raise ValueError(f"conjugate rc={rc}")
         return out
 
     def ckks_mult(self, moduli_ext, ct1, ct2, key):

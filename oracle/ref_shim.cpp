@@ -251,6 +251,25 @@ int ref_ckks_mult_relin_rescale(size_t logn, size_t L, const u64 *moduli_ext, co
     });
 }
 
+static int ref_automorphism(size_t logn, size_t L, const u64 *moduli_ext, bool conj, size_t step, const u64 *ct,
+                            const u64 *key, u64 *out) {
+    const size_t n = (size_t)1 << logn;
+    return guarded([&] {
+        CkksCt a;
+        for (int h = 0; h < 2; h++) a[h] = load_poly(n, L, moduli_ext, ct + h * L * n, PolyRepForm::value);
+        auto ksk = load_key(n, L, moduli_ext, key);
+        CkksCt r = conj ? ckks::conjugate(a, ksk) : ckks::rotate(a, ksk, step);
+        store_poly(r[0], out);
+        store_poly(r[1], out + L * n);
+    });
+}
+int ref_ckks_rotate(size_t logn, size_t L, const u64 *moduli_ext, size_t step, const u64 *ct, const u64 *key, u64 *out) {
+    return ref_automorphism(logn, L, moduli_ext, false, step, ct, key, out);
+}
+int ref_ckks_conjugate(size_t logn, size_t L, const u64 *moduli_ext, const u64 *ct, const u64 *key, u64 *out) {
+    return ref_automorphism(logn, L, moduli_ext, true, 0, ct, key, out);
+}
+
 int ref_bgv_mult_relin_modswitch(size_t logn, size_t L, const u64 *moduli_ext, u64 t,
                                  const u64 *ct1, const u64 *ct2, const u64 *key, u64 *out) {
     const size_t n = (size_t)1 << logn;

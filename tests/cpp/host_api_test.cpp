@@ -251,6 +251,18 @@ static void test_scheme_level_vs_oracle() {   // raw lazy words of ckks::mult+re
     got.clear();
     for (int h = 0; h < 2; h++) flatten(rot[h], got);
     REQUIRE(got == low);
+    REQUIRE(orc_ckks_rotate(logn, L, mext.data(), 3, f1.data(), fk.data(), ext.data()) == 0);
+    REQUIRE(std::equal(got.begin(), got.end(), ext.begin()));
+    REQUIRE(rot.scaling_factor == a.scaling_factor);
+
+    auto cj = ckks::conjugate(b, key);
+    REQUIRE(orc_ckks_conjugate(logn, L, mext.data(), f2.data(), fk.data(), ext.data()) == 0);
+    got.clear();
+    for (int h = 0; h < 2; h++) flatten(cj[h], got);
+    REQUIRE(std::equal(got.begin(), got.end(), ext.begin()));
+    auto coeff = a;
+    coeff[1].rep_form = PolyRepForm::coeff;
+    REQUIRE_THROWS_AS(ckks::rotate(coeff, key, 1), std::invalid_argument);
 
     RlweKsk bad(L - 1);
     REQUIRE_THROWS_AS(ext_prod_montgomery(a[0], RlweKsk()), std::invalid_argument);

@@ -100,6 +100,8 @@ def run_cases(lib, big: bool = True) -> dict:
         out[f"bgv_mod_drop_t65537_{tag}"] = summary(lib.bgv_mod_drop(q, 65537, ct2))
         out[f"ckks_relinearize_{tag}"] = summary(lib.ckks_relinearize(mext, quad, key))
         out[f"bgv_relinearize_{tag}"] = summary(lib.bgv_relinearize(mext, quad, key))
+        out[f"ckks_rotate3_{tag}"] = summary(lib.ckks_rotate(mext, ct1, key, 3))
+        out[f"ckks_conjugate_{tag}"] = summary(lib.ckks_conjugate(mext, ct2, key))
         out[f"ckks_mult_{tag}"] = summary(lib.ckks_mult(mext, ct1, ct2, key))
         out[f"bgv_mult_{tag}"] = summary(lib.bgv_mult(mext, 65537, ct1, ct2, key))
     return out

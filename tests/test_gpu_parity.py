@@ -148,6 +148,9 @@ def test_dev_scheme_level(eng, orc, logn, mext, B):
         assert eq(eng.to_host(eng.bgv_mod_switch(q, t, d2)), exp(lambda i: orc.bgv_mod_drop(q, t, ct2[i])))
     assert eq(eng.to_host(eng.ckks_relinearize(mext, quad, dk)), exp(lambda i: orc.ckks_relinearize(mext, quad_h[i], key)))
     assert eq(eng.to_host(eng.bgv_relinearize(mext, quad, dk)), exp(lambda i: orc.bgv_relinearize(mext, quad_h[i], key)))
+    for step in (1, 3):
+        assert eq(eng.to_host(eng.ckks_rotate(mext, d1, dk, step)), exp(lambda i: orc.ckks_rotate(mext, ct1[i], key, step)))
+    assert eq(eng.to_host(eng.ckks_conjugate(mext, d2, dk)), exp(lambda i: orc.ckks_conjugate(mext, ct2[i], key)))
     assert eq(eng.to_host(eng.ckks_mult(mext, d1, d2, dk)), exp(lambda i: orc.ckks_mult(mext, ct1[i], ct2[i], key)))
     assert eq(eng.to_host(eng.bgv_mult(mext, P.C5_T, d1, d2, dk)), exp(lambda i: orc.bgv_mult(mext, P.C5_T, ct1[i], ct2[i], key)))
 

@@ -146,6 +146,9 @@ def test_key_switch_and_scheme_level(orc, ref, logn, mext):
     lin_o = orc.ckks_relinearize(mext, quad_o, key)
     assert (lin_o == ref.ckks_relinearize(mext, quad_o, key)).all()
     assert (orc.bgv_relinearize(mext, quad_o, key) == ref.bgv_relinearize(mext, quad_o, key)).all()
+    for step in (1, 2, 5):
+        assert (orc.ckks_rotate(mext, ct1, key, step) == ref.ckks_rotate(mext, ct1, key, step)).all()
+    assert (orc.ckks_conjugate(mext, ct2, key) == ref.ckks_conjugate(mext, ct2, key)).all()
     assert (orc.ckks_mult(mext, ct1, ct2, key) == ref.ckks_mult(mext, ct1, ct2, key)).all()
     assert (orc.bgv_mult(mext, 65537, ct1, ct2, key) == ref.bgv_mult(mext, 65537, ct1, ct2, key)).all()
 
