@@ -1,11 +1,37 @@
 // hehub.cpp -- implementation of the hehub-compatible host layer over the C ABI.  No arithmetic on
 // ring elements happens in this file: it validates arguments the way the reference does, stages host
 // limbs into contiguous device batches, calls the engine and copies the results back.
+//
+// Two ways to build it:
+//   default                      against hehub.hpp, our own mirror of the reference's types (hehub_amd/host);
+//   -DHEHUB_AMD_BIND_REFERENCE   against the reference's OWN headers (-I<hehub>/src): the file then defines
+//                                only the functions hehub defines out of line on the hot path (the ones listed in
+//                                SURVEY.md section 8a), with hehub's exact signatures, so linking it ahead of
+//                                hehub's ntt.cpp / mod_arith.cpp / rns.cpp / rgsw.cpp / rescaling.cpp /
+//                                mod_switch.cpp / arith.cpp / permutation.cpp moves that path to the GPU while
+//                                everything else (sampling, encoding, key generation, circuits, tests) stays
+//                                hehub's.  oracle/Makefile target `ref_tests` does exactly that with hehub's
+//                                own test suite.
+#ifdef HEHUB_AMD_BIND_REFERENCE
+#include "fhe/bgv/bgv.h"
+#include "fhe/ckks/ckks.h"
+#include "fhe/common/mod_arith.h"
+#include "fhe/common/ntt.h"
+#include "fhe/common/permutation.h"
+#include "fhe/common/rns.h"
+#include "fhe/primitives/keys.h"
+#include "fhe/primitives/rgsw.h"
+#include "fhe/primitives/rlwe.h"
+struct hp_ctx;
+namespace hehub { namespace amd { hp_ctx *engine(); } }
+#else
 #include "hehub.hpp"
+#endif
 
 #include "../../include/hehub_amd.h"
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <string>
@@ -30,7 +56,17 @@ hp_ctx *engine() {
 
 namespace {
 
+// number of engine calls made through this layer; printed at exit when HEHUB_AMD_VERBOSE is set, so a run of
+// somebody else's test-suite over this layer can show that the work really went to the device
+struct CallCounter {
+    unsigned long long n = 0;
+    ~CallCounter() {
+        if (std::getenv("HEHUB_AMD_VERBOSE")) std::fprintf(stderr, "hehub_amd: %llu engine calls (%s)\n", n, hp_version());
+    }
+} g_calls;
+
 void check(int rc) {
+    g_calls.n++;
     if (rc == HP_OK) return;
     std::string msg = hp_last_error(amd::engine());
     if (rc == HP_EINVAL) throw std::invalid_argument(msg);
@@ -204,6 +240,7 @@ void drop_last_prime(RlweCt &ct, bool bgv, u64 t) {
 // =====================================================================================================
 // rns.h / rns.cpp
 // =====================================================================================================
+#ifndef HEHUB_AMD_BIND_REFERENCE
 RnsIntVec::RnsIntVec(const size_t dimension, const size_t components, const std::vector<u64> &moduli)
     : log_dimension_((size_t)(std::log2((double)dimension) + 0.5)), dimension_(dimension), components_(components) {
     if (dimension_ != (size_t)1 << log_dimension_) throw std::invalid_argument("dimension should be a 2-power.");
@@ -228,6 +265,7 @@ void RnsIntVec::remove_components(size_t removing) {
     moduli_.erase(moduli_.end() - removing, moduli_.end());
     components_.erase(components_.end() - removing, components_.end());
 }
+#endif
 
 const RnsIntVec &operator+=(RnsIntVec &self, const RnsIntVec &b) {
     run_binary(Bin::add, self, b, self, check_addsub(self, b));
@@ -262,6 +300,7 @@ const RnsIntVec &operator*=(RnsIntVec &self, const std::vector<u64> &rns_scalar)
     return self;
 }
 
+#ifndef HEHUB_AMD_BIND_REFERENCE   // inline in the reference's rns.h:207-293
 const RnsPolynomial &operator+=(RnsPolynomial &self, const RnsPolynomial &b) {
     if (self.rep_form != b.rep_form) throw std::invalid_argument("Operands are in different representation form.");
     (RnsIntVec &)self += (const RnsIntVec &)b;
@@ -291,31 +330,39 @@ const RnsPolynomial &operator*=(RnsPolynomial &self, const std::vector<u64> &s) 
     (RnsIntVec &)self *= s;
     return self;
 }
+#endif
 
 // =====================================================================================================
 // mod_arith.h
 // =====================================================================================================
 void batched_barrett_lazy(const u64 q, const size_t n, u64 v[]) { check(hp_batched_barrett_lazy(amd::engine(), q, n, v)); }
+#ifndef HEHUB_AMD_BIND_REFERENCE   // inline in the reference's mod_arith.h:18-25,58-63
 void batched_barrett(const u64 q, const size_t n, u64 v[]) { check(hp_batched_barrett(amd::engine(), q, n, v)); }
 void batched_reduce_strict(const u64 q, const size_t n, u64 v[]) { check(hp_batched_reduce_strict(amd::engine(), q, n, v)); }
+#endif
 void batched_mul_mod_hybrid_lazy(const u64 q, const size_t n, const u64 a[], const u64 b[], u64 out[]) {
     check(hp_batched_mul_mod_hybrid_lazy(amd::engine(), q, n, a, b, out));
 }
+#ifndef HEHUB_AMD_BIND_REFERENCE
 void batched_mul_mod_hybrid(const u64 q, const size_t n, const u64 a[], const u64 b[], u64 out[]) {
     batched_mul_mod_hybrid_lazy(q, n, a, b, out);
     batched_reduce_strict(q, n, out);
 }
+#endif
 void batched_mul_mod_barrett_lazy(const u64 q, const size_t n, const u64 a[], const u64 b[], u64 out[]) {
     check(hp_batched_mul_mod_barrett_lazy(amd::engine(), q, n, a, b, out));
 }
+#ifndef HEHUB_AMD_BIND_REFERENCE
 void batched_mul_mod_barrett(const u64 q, const size_t n, const u64 a[], const u64 b[], u64 out[]) {
     batched_mul_mod_barrett_lazy(q, n, a, b, out);
     batched_reduce_strict(q, n, out);
 }
+#endif
 void batched_montgomery_128_lazy(const u64 q, const size_t len, const u128 in[], u64 out[]) {
     check(hp_batched_montgomery_128_lazy(amd::engine(), q, len, reinterpret_cast<const u64 *>(in), out));
 }
 
+#ifndef HEHUB_AMD_BIND_REFERENCE   // mod_arith.h:65-72 (inline) and mod_arith.cpp:136-149 stay the reference's
 void reduce_strict(RnsPolynomial &p) {
     const size_t n = p.dimension(), L = p.component_count();
     if (L == 0) return;
@@ -335,6 +382,7 @@ u64 inverse_mod_prime(const u64 elem, const u64 prime) {
     if (y0 < 0) y0 += prime;
     return (u64)y0;
 }
+#endif
 
 // =====================================================================================================
 // ntt.h
@@ -346,6 +394,7 @@ void intt_negacyclic_inplace_lazy(const size_t logn, const u64 q, u64 v[]) {
     check(hp_intt_negacyclic_inplace_lazy(amd::engine(), logn, q, v));
 }
 
+#ifndef HEHUB_AMD_BIND_REFERENCE   // ntt.h:41-92 (inline per-limb loops) stay the reference's
 static void poly_transform(RnsPolynomial &p, bool inverse, bool strict) {
     const size_t n = p.dimension(), L = p.component_count();
     if (L) {
@@ -360,6 +409,7 @@ static void poly_transform(RnsPolynomial &p, bool inverse, bool strict) {
 void ntt_negacyclic_inplace_lazy(RnsPolynomial &p) { poly_transform(p, false, false); }
 void intt_negacyclic_inplace_lazy(RnsPolynomial &p) { poly_transform(p, true, false); }
 void intt_negacyclic_inplace(RnsPolynomial &p) { poly_transform(p, true, true); }
+#endif
 
 void cache_ntt_factors_strict(const u64 logn, const std::vector<u64> &moduli) {
     check(hp_cache_ntt_factors_strict(amd::engine(), logn, moduli.data(), moduli.size()));
@@ -387,11 +437,13 @@ RnsPolynomial involution(const RnsPolynomial &p) { return gather(p, false, 0); }
 // =====================================================================================================
 // rlwe.h / rgsw.h
 // =====================================================================================================
+#ifndef HEHUB_AMD_BIND_REFERENCE   // rlwe.cpp:83-101: thin compositions of the operators above
 RlweCt add(const RlweCt &a, const RlweCt &b) { return RlweCt{a[0] + b[0], a[1] + b[1]}; }
 RlweCt sub(const RlweCt &a, const RlweCt &b) { return RlweCt{a[0] - b[0], a[1] - b[1]}; }
 RlweCt add_plain_core(const RlweCt &ct, const RlwePt &pt) { return RlweCt{ct[0] + pt, ct[1]}; }
 RlweCt sub_plain_core(const RlweCt &ct, const RlwePt &pt) { return RlweCt{ct[0] - pt, ct[1]}; }
 RlweCt mult_plain_core(const RlweCt &ct, const RlwePt &pt) { return RlweCt{ct[0] * pt, ct[1] * pt}; }
+#endif
 
 RlweCt ext_prod_montgomery(const RlwePt &pt, const RgswCt &rgsw) {
     std::vector<u64> mext;
@@ -409,6 +461,7 @@ RlweCt ext_prod_montgomery(const RlwePt &pt, const RgswCt &rgsw) {
 // =====================================================================================================
 namespace ckks {
 
+#ifndef HEHUB_AMD_BIND_REFERENCE   // ckks/arith.cpp:7-53 stay the reference's
 static void check_scaling_factor(double a, double b) {   // ckks/arith.cpp:7-13
     if (std::abs(a - b) > std::pow(2.0, -50)) throw std::invalid_argument("The scaling factors mismatch");
 }
@@ -426,6 +479,7 @@ CkksCt sub(const CkksCt &a, const CkksCt &b) {
     r.scaling_factor = a.scaling_factor;
     return r;
 }
+#endif
 
 CkksQuadraticCt mult_low_level(const CkksCt &a, const CkksCt &b) {
     auto q = mult_low_level_common<CkksQuadraticCt>(a, b);
@@ -483,6 +537,7 @@ CkksCt rotate(const CkksCt &ct, const RlweKsk &rot_key, const size_t step) { ret
 // =====================================================================================================
 namespace bgv {
 
+#ifndef HEHUB_AMD_BIND_REFERENCE   // bgv/arith.cpp:8-57 stay the reference's
 BgvCt add(const BgvCt &a, const BgvCt &b) {
     if (a.plain_modulus != b.plain_modulus) throw std::invalid_argument("Plain moduli mismatch.");
     BgvCt r = ::hehub::add((const RlweCt &)a, (const RlweCt &)b);
@@ -496,6 +551,7 @@ BgvCt sub(const BgvCt &a, const BgvCt &b) {
     r.plain_modulus = a.plain_modulus;
     return r;
 }
+#endif
 
 BgvQuadraticCt mult_low_level(const BgvCt &a, const BgvCt &b) {
     if (a.plain_modulus != b.plain_modulus) throw std::invalid_argument("Plain moduli mismatch.");

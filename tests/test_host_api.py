@@ -33,3 +33,20 @@ def test_host_layer_runs_reference_unit_tests():
     out = subprocess.run([build_binary()], capture_output=True, text=True, timeout=600)
     print(out.stdout[-3000:], out.stderr[-2000:])
     assert out.returncode == 0 and "All tests passed" in out.stdout
+
+
+REF_TESTS = os.path.join(ROOT, "oracle", "_ref", "ref_tests_amd")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_TESTS), reason="oracle/_ref/ref_tests_amd is only built where the reference tree exists (make -C oracle ref_tests)")
+def test_reference_test_suite_over_the_binding():
+    """hehub's own Catch2 suite (tests/*.cpp, 481 assertions), linked with hehub's own sampling / encoding /
+    key generation and with hehub_amd/host/hehub.cpp (-DHEHUB_AMD_BIND_REFERENCE) in place of hehub's hot-path
+    definitions.  The binary is prebuilt by oracle/Makefile; nothing is read from the reference tree here."""
+    env = dict(os.environ, HEHUB_AMD_VERBOSE="1")
+    out = subprocess.run([REF_TESTS], capture_output=True, text=True, timeout=900, env=env)
+    print(out.stdout[-3000:], out.stderr[-2000:])
+    assert out.returncode == 0 and "All tests passed" in out.stdout
+    calls = [int(l.split()[1]) for l in out.stderr.splitlines() if l.startswith("hehub_amd:") and "engine calls" in l]
+    assert calls and calls[0] > 1000, "the suite must actually have gone through the device engine"
