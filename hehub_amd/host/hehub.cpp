@@ -10,7 +10,7 @@
 //                                hehub's ntt.cpp / mod_arith.cpp / rns.cpp / rgsw.cpp / rescaling.cpp /
 //                                mod_switch.cpp / arith.cpp / permutation.cpp moves that path to the GPU while
 //                                everything else (sampling, encoding, key generation, circuits, tests) stays
-//                                hehub's.  oracle/Makefile target `ref_tests` does exactly that with hehub's
+//                                hehub's.  The `ref_tests` make target does exactly that with hehub's
 //                                own test suite.
 #ifdef HEHUB_AMD_BIND_REFERENCE
 #include "fhe/bgv/bgv.h"
