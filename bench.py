@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark of the MI355X ring-arithmetic engine.
 
-    python bench.py --gpus 1 --steps K --warmup W [--workload ckks|ntt|bgv] [--batch B]
+    python bench.py --gpus 1 --steps K --warmup W [--workload ckks|ntt|ntt15|intt|intt15|bgv|rotate] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one batch of synthetic ciphertexts that is already
@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="ckks", choices=["ckks", "ntt", "ntt15", "intt", "intt15", "bgv"])
+    ap.add_argument("--workload", default="ckks", choices=["ckks", "ntt", "ntt15", "intt", "intt15", "bgv", "rotate"])
     ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (0 = BASELINE config value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")
@@ -82,6 +82,18 @@ def cpu_baseline(workload, P, budget_s):
             per = (time.perf_counter() - t0) / iters
         return {"value": 1.0 / per, "unit": "limb-NTT/s", "cores": 1, "kind": kind,
                 "sample": f"{iters} {'inverse' if inv else 'forward'} NTTs of one limb, N={1 << logn}, q={q}, single thread, tables warm"}
+    if workload == "rotate":   # the reference's own benchmark workload (bench/benchmarks.cpp:21-37) at the C3 shape
+        logn, mext = P.C3_LOGN, P.C3_MODULI_EXT
+        n, L = 1 << logn, len(mext) - 1
+        ct = rng.poly((2, L, n), mext[:L])
+        key = rng.poly((L, 2, L + 1, n), mext)
+        lib.ckks_rotate(mext, ct, key, 1)
+        iters, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            lib.ckks_rotate(mext, ct, key, 1); iters += 1
+        per = (time.perf_counter() - t0) / iters
+        return {"value": 1.0 / per, "unit": "rotation/s", "cores": 1, "kind": kind,
+                "sample": f"{iters} x ckks::rotate(ct, key, 1) on one ciphertext, N={n}, L={L}, single thread, tables warm"}
     if workload == "ckks":
         logn, mext, t = P.C3_LOGN, P.C3_MODULI_EXT, 0
     else:
@@ -144,7 +156,7 @@ def main():
         cfg = {"workload": f"{'C2' if logn == 14 else 'C3-shape'}: batched {'inverse' if inverse else 'forward'} negacyclic NTT, N={n}, {L} RNS limbs, batch={B} polynomials per GPU",
                "N": n, "limbs": L, "batch_per_gpu": B}
     else:
-        if wl == "ckks":
+        if wl in ("ckks", "rotate"):
             logn, mext, t, B0 = P.C3_LOGN, P.C3_MODULI_EXT, 0, P.C3_BATCH
         else:
             logn, mext, t, B0 = P.C5_LOGN, P.C5_MODULI_EXT, P.C5_T, 512
@@ -155,7 +167,17 @@ def main():
         key = rand_words(torch, (L, 2, L + 1, n), mext, dev, 7)
         out = eng.empty((B, 2, L - 1, n))
         units_per_step = B
-        if wl == "ckks":
+        # compulsory bytes per op in limbs (S = 8N): SURVEY.md 8d for hom-mult; for a rotation the tensor product
+        # (7L) becomes the gather (4L), there is no second drop and only c0 gets the moved addend
+        a_limbs = 5 * L * L + 36 * L
+        fwd_per_ct = L * L + 4 * L - 2          # forward limb transforms per hom-mult (SURVEY.md 8d)
+        if wl == "rotate":
+            step = lambda: eng.ckks_rotate(mext, ct1, key, 1)
+            metric, unit = "ckks_rotation_per_s", "rotation/s"
+            name = "C3 shape: ckks::rotate (gather + key switch + drop of the special prime)"
+            a_limbs = 5 * L * L + 22 * L + 6
+            fwd_per_ct = L * L + L
+        elif wl == "ckks":
             step = lambda: eng.ckks_mult(mext, ct1, ct2, key, out=out)
             metric, unit = "ckks_hom_mult_per_s", "hom-mult/s"
             name = "C3: ckks::mult + relinearize + rescale_inplace"
@@ -164,12 +186,11 @@ def main():
             metric, unit = "bgv_hom_mult_per_s", "hom-mult/s"
             name = "C5 shape: bgv mult_low_level + relinearize + mod_switch_inplace"
         family = "ntt"
-        fwd_per_ct = L * L + 4 * L - 2          # forward limb transforms per hom-mult (SURVEY.md 8d)
         alg_bytes_per_step = 16.0 * n * fwd_per_ct * B
         launches_per_step = None
         cfg = {"workload": f"{name}, N={n}, L={L} moduli + special prime, batch={B} ciphertext pairs per GPU",
                "N": n, "L": L, "batch_per_gpu": B, "sub_batch": int(os.environ.get("HP_MULT_CHUNK", "0")) or B,
-               "A_step_bytes_per_op": (5 * L * L + 36 * L) * 8 * n}
+               "A_step_bytes_per_op": a_limbs * 8 * n}
 
     for _ in range(args.warmup):
         step()
@@ -212,10 +233,15 @@ def main():
                 res["roofline"]["traffic_source"] = "rocprofv3 PMC per-limb measurement x limbs per launch (profiles/r01_traffic.json)"
         except (OSError, ValueError):
             pass
-    if wl in ("ckks", "bgv"):
-        a_step = (5 * L * L + 36 * L) * 8 * n
+    if wl in ("ckks", "bgv", "rotate"):
+        a_step = a_limbs * 8 * n
         res["pipeline_roofline"] = {"A_step_GBps": value / world * a_step / 1e9,
                                     "frac_of_hbm_peak": value / world * a_step / 1e9 / HBM_PEAK_GBS}
+        if wl != "rotate":   # the two other yardsticks of SURVEY.md 8d: every primitive its own pass / I-O lower bound
+            a_prim = (6 * L * L + 67 * L) * 8 * n
+            a_min = (6 * L - 2) * 8 * n + 2 * L * (L + 1) * 8 * n / B
+            res["pipeline_roofline"].update({"A_prim_frac_of_hbm_peak": value / world * a_prim / 1e9 / HBM_PEAK_GBS,
+                                             "A_min_frac_of_hbm_peak": value / world * a_min / 1e9 / HBM_PEAK_GBS})
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
