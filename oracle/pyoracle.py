@@ -32,8 +32,8 @@ def build(ref: bool = True) -> None:
     if ref and os.path.isdir("/root/reference/src"):
         subprocess.run(["make", "-s", "-C", HERE, "ref"], check=True)
         if os.path.exists(os.path.join(HERE, "..", "hehub_amd", "lib", "libhehub_amd.so")):
-            # hehub's own test-suite over our binding (runs on a GPU box only)
-            subprocess.run(["make", "-s", "-j8", "-C", HERE, "ref_tests"], check=True)
+            # hehub's own test-suite / benchmark program and our end-to-end program over the binding (GPU box only)
+            subprocess.run(["make", "-s", "-j8", "-C", HERE, "ref_tests", "ref_e2e", "ref_bench"], check=True)
 
 
 def have_ref() -> bool:

@@ -50,3 +50,16 @@ def test_reference_test_suite_over_the_binding():
     assert out.returncode == 0 and "All tests passed" in out.stdout
     calls = [int(l.split()[1]) for l in out.stderr.splitlines() if l.startswith("hehub_amd:") and "engine calls" in l]
     assert calls and calls[0] > 1000, "the suite must actually have gone through the device engine"
+
+
+REF_E2E = os.path.join(ROOT, "oracle", "_ref", "ref_e2e_amd")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_E2E), reason="oracle/_ref/ref_e2e_amd is only built where the reference tree exists (make -C oracle ref_e2e)")
+def test_end_to_end_tolerance_at_baseline_shapes():
+    """tests/cpp/ref_e2e.cpp: hehub's own keygen / encode / encrypt / decrypt around the device hot path.  CKKS C3 shape
+    (N=32768, L=10): mult + relinearize + rescale max slot error <= 2^-24; BGV C5 shape: plaintext-level checks."""
+    out = subprocess.run([REF_E2E], capture_output=True, text=True, timeout=900)
+    print(out.stdout[-3000:], out.stderr[-2000:])
+    assert out.returncode == 0 and "All end-to-end checks passed" in out.stdout
