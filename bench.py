@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="ckks", choices=["ckks", "ntt", "ntt15", "intt", "intt15", "bgv", "rotate"])
+    ap.add_argument("--workload", default="ckks", choices=["ckks", "ntt", "ntt15", "intt", "intt15", "bgv", "rotate", "ckks-limb"])
     ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (0 = BASELINE config value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")
@@ -156,8 +156,8 @@ def main():
         cfg = {"workload": f"{'C2' if logn == 14 else 'C3-shape'}: batched {'inverse' if inverse else 'forward'} negacyclic NTT, N={n}, {L} RNS limbs, batch={B} polynomials per GPU",
                "N": n, "limbs": L, "batch_per_gpu": B}
     else:
-        if wl in ("ckks", "rotate"):
-            logn, mext, t, B0 = P.C3_LOGN, P.C3_MODULI_EXT, 0, P.C3_BATCH
+        if wl in ("ckks", "rotate", "ckks-limb"):
+            logn, mext, t, B0 = P.C3_LOGN, P.C3_MODULI_EXT, 0, (P.C3_BATCH if wl != "ckks-limb" else 8)
         else:
             logn, mext, t, B0 = P.C5_LOGN, P.C5_MODULI_EXT, P.C5_T, 512
         B = args.batch or B0
@@ -171,7 +171,22 @@ def main():
         # (7L) becomes the gather (4L), there is no second drop and only c0 gets the moved addend
         a_limbs = 5 * L * L + 36 * L
         fwd_per_ct = L * L + 4 * L - 2          # forward limb transforms per hom-mult
-        if wl == "rotate":
+        scaling = "weak"
+        if wl == "ckks-limb":
+            # latency mode (hehub_amd/sharded.py): the SAME small batch on every rank, cut by output modulus, with
+            # the all-gather of the key-switch digits over RCCL; total work is fixed as N grows -> strong scaling
+            from hehub_amd.sharded import Comm, ShardedMult
+
+            comm, sm = Comm(), ShardedMult(eng, mext, world)
+            ct1 = rand_words(torch, (B, 2, L, n), mext[:L], dev, 3)
+            ct2 = rand_words(torch, (B, 2, L, n), mext[:L], dev, 1003)
+            bufs = sm.buffers(B, n)
+            step = lambda: sm.run(comm, ct1, ct2, key, bufs)
+            metric, unit = "ckks_hom_mult_per_s", "hom-mult/s"
+            name = "C3 shape, limb-sharded latency mode: ckks::mult + relinearize + rescale_inplace"
+            scaling = "strong"
+            units_per_step = B / world   # `value` multiplies by world below: the batch is shared, not replicated work
+        elif wl == "rotate":
             step = lambda: eng.ckks_rotate(mext, ct1, key, 1)
             metric, unit = "ckks_rotation_per_s", "rotation/s"
             name = "C3 shape: ckks::rotate (gather + key switch + drop of the special prime)"
@@ -208,7 +223,7 @@ def main():
     value = units_per_step * world * args.steps / elapsed
     res = {
         "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling if wl == "ckks-limb" else "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic", "config": cfg,
     }
     # roofline of the dominant kernel family (forward NTT), from HIP events recorded by the library on the
@@ -233,11 +248,11 @@ def main():
                 res["roofline"]["traffic_source"] = "rocprofv3 PMC per-limb measurement x limbs per launch (profiles/r01_traffic.json)"
         except (OSError, ValueError):
             pass
-    if wl in ("ckks", "bgv", "rotate"):
+    if wl in ("ckks", "bgv", "rotate", "ckks-limb"):
         a_step = a_limbs * 8 * n
         res["pipeline_roofline"] = {"A_step_GBps": value / world * a_step / 1e9,
                                     "frac_of_hbm_peak": value / world * a_step / 1e9 / HBM_PEAK_GBS}
-        if wl != "rotate":   # the two other yardsticks of SURVEY.md 8d: every primitive its own pass / I-O lower bound
+        if wl in ("ckks", "bgv"):   # the two other yardsticks of SURVEY.md 8d: every primitive its own pass / I-O lower bound
             a_prim = (6 * L * L + 67 * L) * 8 * n
             a_min = (6 * L - 2) * 8 * n + 2 * L * (L + 1) * 8 * n / B
             res["pipeline_roofline"].update({"A_prim_frac_of_hbm_peak": value / world * a_prim / 1e9 / HBM_PEAK_GBS,
@@ -245,7 +260,7 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline(wl, P, args.cpu_seconds)
+                res["cpu_baseline"] = cpu_baseline("ckks" if wl == "ckks-limb" else wl, P, args.cpu_seconds)
             except Exception as e:  # the checker is optional infrastructure; the GPU number stands on its own
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res))

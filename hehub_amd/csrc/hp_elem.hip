@@ -179,11 +179,11 @@ hipError_t hp_launch_vec(int op, const HpVecConsts &c, size_t n, const u64 *a, c
 
 // ---- fused tensor product: ckks/arith.cpp:55-62 / bgv/arith.cpp:59-69 -------------------
 // d0 = a0*b0, d1 = (a0*b1) + (a1*b0), d2 = a1*b1.  Reads 4 limbs, writes 3: 56n bytes per limb index.
-__global__ void __launch_bounds__(ELEM_THREADS) k_tensor(const HpLimb *__restrict__ limbs, u32 L, u32 n, u32 chunks,
-                                                        const u64 *__restrict__ ct1, const u64 *__restrict__ ct2,
-                                                        u64 *__restrict__ quad) {
-    const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;   // row = p*L + k
-    const u32 p = row / L, k = row % L;
+__global__ void __launch_bounds__(ELEM_THREADS) k_tensor(const HpLimb *__restrict__ limbs, u32 L, u32 k_first, u32 kc,
+                                                        u32 n, u32 chunks, const u64 *__restrict__ ct1,
+                                                        const u64 *__restrict__ ct2, u64 *__restrict__ quad) {
+    const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;   // row = p*kc + (k - k_first)
+    const u32 p = row / kc, k = k_first + row % kc;
     const HpLimb m = limbs[k];
     const size_t poly = (size_t)L * n;
     const u64 *a0 = ct1 + (size_t)p * 2 * poly + (size_t)k * n, *a1 = a0 + poly;
@@ -213,11 +213,12 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_tensor(const HpLimb *__restric
     }
 }
 
-hipError_t hp_launch_tensor(const HpLimb *limbs, u32 L, u32 n, u32 P, const u64 *ct1, const u64 *ct2, u64 *quad,
-                            hipStream_t stream) {
+hipError_t hp_launch_tensor(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32 n, u32 P, const u64 *ct1,
+                            const u64 *ct2, u64 *quad, hipStream_t stream) {
+    if (kc == 0) return hipSuccess;
     u32 chunks; dim3 grid;
-    elem_grid(n, P * L, chunks, grid);
-    k_tensor<<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, n, chunks, ct1, ct2, quad);
+    elem_grid(n, P * kc, chunks, grid);
+    k_tensor<<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, kc, n, chunks, ct1, ct2, quad);
     return hipGetLastError();
 }
 
@@ -225,15 +226,15 @@ hipError_t hp_launch_tensor(const HpLimb *limbs, u32 L, u32 n, u32 P, const u64 
 // out[p][half][k][i] = montgomery_128( sum_j D[p][j][k][i] * key[j][half][k][i] ), 128-bit accumulators
 // in registers, both halves from one pass over the digits.  Per (p, k, i): reads L digit words and 2L key
 // words (the key is shared by the whole batch and stays in L2 / Infinity Cache), writes 2 words.
-__global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner(const HpLimb *__restrict__ limbs, u32 L, u32 n, u32 chunks,
-                                                          const u64 *__restrict__ digits, const u64 *__restrict__ pt,
+__global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner(const HpLimb *__restrict__ limbs, u32 L, u32 k_first, u32 P,
+                                                          u32 n, u32 chunks, const u64 *__restrict__ digits,
+                                                          const u64 *__restrict__ pt,
                                                           u32 pt_pstride, const u64 *__restrict__ key,
                                                           u64 *__restrict__ out) {
     const u32 Le = L + 1;
     const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;   // row = k*P' ... decoded below
     // modulus-major numbering keeps one key column (2L limbs) hot per XCD slice
-    const u32 P = gridDim.x / (chunks * Le);
-    const u32 k = row / P, p = row % P;
+    const u32 k = k_first + row / P, p = row % P;
     const u64 q = limbs[k].q, mqinv = limbs[k].mqinv;
     const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
     for (u32 i = chunk * ELEM_CHUNK + threadIdx.x * 2; i < end; i += ELEM_THREADS * 2) {
@@ -278,11 +279,12 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner(const HpLimb *__restr
     }
 }
 
-hipError_t hp_launch_ks_inner(const HpLimb *limbs, u32 L, u32 n, u32 P, const u64 *digits, const u64 *pt,
-                              u32 pt_pstride, const u64 *key, u64 *out, hipStream_t stream) {
+hipError_t hp_launch_ks_inner(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32 n, u32 P, const u64 *digits,
+                              const u64 *pt, u32 pt_pstride, const u64 *key, u64 *out, hipStream_t stream) {
+    if (kc == 0) return hipSuccess;
     u32 chunks; dim3 grid;
-    elem_grid(n, P * (L + 1), chunks, grid);
-    k_ks_inner<<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, n, chunks, digits, pt, pt_pstride, key, out);
+    elem_grid(n, P * kc, chunks, grid);
+    k_ks_inner<<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, n, chunks, digits, pt, pt_pstride, key, out);
     return hipGetLastError();
 }
 
@@ -315,13 +317,14 @@ hipError_t hp_launch_drop_rem(const HpLimb *limbs, const HpDropConsts &dc, u32 L
 
 // out = ((x - rem) * inv) [* (q_last mod t)] [+ addend]     (rns.cpp:89-118, :155-171, :58-87)
 __global__ void __launch_bounds__(ELEM_THREADS) k_drop_fin(const HpLimb *__restrict__ limbs, HpDropConsts dc, u32 L,
-                                                          u32 n, u32 chunks, const u64 *__restrict__ x,
+                                                          u32 kc, u32 n, u32 chunks, const u64 *__restrict__ x,
                                                           const u64 *__restrict__ rem, const u64 *__restrict__ addend,
                                                           u32 add_poly_stride, u32 add_ct_stride, u32 add_mask,
                                                           u64 *__restrict__ out) {
-    const u32 Lm1 = L - 1;
-    const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;   // row = p2*Lm1 + k
-    const u32 p2 = row / Lm1, k = row % Lm1;
+    // kc limbs per polynomial are processed (all L-1, or a limb range whose first limb the pointers/constants
+    // have been shifted to); x rows have stride L, out rows stride L-1, rem rows are compact [P2][kc]
+    const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;   // row = p2*kc + k
+    const u32 p2 = row / kc, k = row % kc;
     const u64 q = limbs[k].q, two_q = limbs[k].two_q;
     const u64 *xs = x + ((size_t)p2 * L + k) * n;
     const u64 *as = (addend && ((add_mask >> (p2 & 1)) & 1u))
@@ -332,16 +335,17 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_drop_fin(const HpLimb *__restr
         v = hp_harvey_lazy(v, dc.inv[k], dc.inv_h[k], q);
         if (dc.bgv) v = hp_harvey_lazy(v, dc.qlt[k], dc.qlt_h[k], q);
         if (as) v = hp_add_lazy(v, as[i], two_q);
-        out[(size_t)row * n + i] = v;
+        out[((size_t)p2 * (L - 1) + k) * n + i] = v;
     }
 }
 
-hipError_t hp_launch_drop_fin(const HpLimb *limbs, const HpDropConsts &dc, u32 L, u32 n, u32 P2, const u64 *x,
+hipError_t hp_launch_drop_fin(const HpLimb *limbs, const HpDropConsts &dc, u32 L, u32 kc, u32 n, u32 P2, const u64 *x,
                               const u64 *rem, const u64 *addend, u32 add_poly_stride, u32 add_ct_stride, u32 add_mask,
                               u64 *out, hipStream_t stream) {
+    if (kc == 0) return hipSuccess;
     u32 chunks; dim3 grid;
-    elem_grid(n, P2 * (L - 1), chunks, grid);
-    k_drop_fin<<<grid, ELEM_THREADS, 0, stream>>>(limbs, dc, L, n, chunks, x, rem, addend, add_poly_stride,
+    elem_grid(n, P2 * kc, chunks, grid);
+    k_drop_fin<<<grid, ELEM_THREADS, 0, stream>>>(limbs, dc, L, kc, n, chunks, x, rem, addend, add_poly_stride,
                                                   add_ct_stride, add_mask, out);
     return hipGetLastError();
 }

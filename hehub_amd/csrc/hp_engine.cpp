@@ -275,37 +275,51 @@ bool logn_ok(size_t logn) { return logn >= 1 && logn <= 15; }
 // workspace: coef [P][L][N], digits [P][L][L+1][N]
 size_t ext_prod_ws_words(size_t n, size_t L, size_t P) { return padded(P * L * n) / 8 + padded(P * L * (L + 1) * n) / 8; }
 
+// (i) c[j] = strict(INTT(pt[j])) for the digits j in [j0, j1)                          rgsw.cpp:103-105
+int ks_coef(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P, size_t j0, size_t j1, const u64 *pt,
+            size_t pt_pstride, u64 *coef) {
+    const size_t n = (size_t)1 << logn;
+    HpNttJob j = batch_job(plan, logn, j1 - j0, P, pt + j0 * n, coef + j0 * n, pt_pstride, L, 1, 1);
+    j.limbs = plan->d_limbs + j0;
+    return run_ntt(ctx, j);
+}
+
+// (ii) + (iii) for the output moduli k in [k0, k1) of q_0..q_{L-1}, p: every digit limb is needed, only the
+// owned columns of digits / key / out are touched
+int ks_digits_inner(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P, size_t k0, size_t k1, const u64 *coef,
+                    const u64 *pt, size_t pt_pstride, const u64 *key, u64 *out, u64 *digits) {
+    const size_t n = (size_t)1 << logn;
+    int rc;
+    // (ii) D[j][k] = NTT_{q_k}(c[j]), k != j                       rgsw.cpp:108-119
+    HpNttJob sj;
+    memset(&sj, 0, sizeof(sj));
+    sj.limbs = plan->d_limbs; sj.src = coef; sj.dst = digits; sj.logn = (u32)logn; sj.L = (u32)L; sj.P = (u32)P;
+    sj.k_first = (u32)k0; sj.W = (u32)((k1 - k0) * P * L); sj.mode = HP_NTT_SPREAD;
+    if ((rc = run_ntt(ctx, sj))) return rc;
+    // (iii) u128 inner product + Montgomery                         rgsw.cpp:121-153
+    {
+        ProfScope ps(ctx, "ks_inner");
+        rc = chk(ctx, hp_launch_ks_inner(plan->d_limbs, (u32)L, (u32)k0, (u32)(k1 - k0), (u32)n, (u32)P, digits, pt,
+                                         (u32)pt_pstride, key, out, ctx->stream), "ks_inner");
+    }
+    return rc;
+}
+
 int ext_prod(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P, const u64 *pt, size_t pt_pstride,
              const u64 *key, u64 *out, Carver &cv) {
     const size_t n = (size_t)1 << logn;
     u64 *coef = cv.take(P * L * n);
     u64 *digits = cv.take(P * L * (L + 1) * n);
     int rc;
-    // (i) c = strict(INTT(pt))                                    rgsw.cpp:103-105
-    if ((rc = run_ntt(ctx, batch_job(plan, logn, L, P, pt, coef, pt_pstride, L, 1, 1)))) return rc;
-    // (ii) D[j][k] = NTT_{q_k}(c[j]), k != j                       rgsw.cpp:108-119
-    HpNttJob sj;
-    memset(&sj, 0, sizeof(sj));
-    sj.limbs = plan->d_limbs; sj.src = coef; sj.dst = digits; sj.logn = (u32)logn; sj.L = (u32)L; sj.P = (u32)P;
-    sj.W = (u32)((L + 1) * P * L); sj.mode = HP_NTT_SPREAD;
-    if ((rc = run_ntt(ctx, sj))) return rc;
-    // (iii) u128 inner product + Montgomery                         rgsw.cpp:121-153
-    {
-        ProfScope ps(ctx, "ks_inner");
-        rc = chk(ctx, hp_launch_ks_inner(plan->d_limbs, (u32)L, (u32)n, (u32)P, digits, pt, (u32)pt_pstride, key, out,
-                                         ctx->stream), "ks_inner");
-    }
-    return rc;
+    if ((rc = ks_coef(ctx, plan, logn, L, P, 0, L, pt, pt_pstride, coef))) return rc;
+    return ks_digits_inner(ctx, plan, logn, L, P, 0, L + 1, coef, pt, pt_pstride, key, out, digits);
 }
 
 // rescaling.cpp:46-75 / mod_switch.cpp:45-77 on P2 polynomials of L limbs (x rows: poly p2 at x + p2*L limbs)
 size_t drop_ws_words(size_t n, size_t L, size_t P2) { return padded(P2 * n) / 8 + padded(P2 * (L - 1) * n) / 8; }
 
-int drop_last(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, bool bgv, u64 t, const u64 *x,
-              const u64 *addend, size_t add_poly_stride, size_t add_ct_stride, u32 add_mask, u64 *out, Carver &cv) {
-    const size_t n = (size_t)1 << logn;
+void make_drop_consts(const Plan *plan, size_t L, bool bgv, u64 t, HpDropConsts &dc) {
     const u64 q_last = plan->consts[L - 1].q;
-    HpDropConsts dc;
     memset(&dc, 0, sizeof(dc));
     dc.q_last = q_last;
     dc.half_q_last = q_last / 2;
@@ -323,10 +337,13 @@ int drop_last(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, b
             dc.qlt_h[k] = hp::harvey_quotient(dc.qlt[k], q);
         }
     }
-    u64 *clast = cv.take(P2 * n);
-    u64 *rem = cv.take(P2 * (L - 1) * n);
-    // c = strict(INTT_{q_last}(x[last]))  (BGV: times t^-1 before the strict reduction)
-    // a one-limb batch whose rows are the last limbs of the P2 polynomials
+}
+
+// clast[p2] = strict(INTT_{q_last}(x[p2][last]))  (BGV: times t^-1 before the strict reduction):
+// a one-limb batch whose rows are the last limbs of the P2 polynomials
+int drop_coeffs(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, bool bgv, u64 t, const u64 *x, u64 *clast) {
+    const size_t n = (size_t)1 << logn;
+    const u64 q_last = plan->consts[L - 1].q;
     HpNttJob lj;
     memset(&lj, 0, sizeof(lj));
     lj.limbs = plan->d_limbs + (L - 1); lj.src = x + (L - 1) * n; lj.dst = clast; lj.logn = (u32)logn; lj.L = 1;
@@ -338,11 +355,31 @@ int drop_last(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, b
         lj.post_scalar_h = hp::harvey_quotient(s, q_last);
         lj.use_post_scalar = 1;
     }
+    return run_ntt(ctx, lj);
+}
+
+// out[k] = ((x[k] - NTT_k(centre(barrett_k(clast)))) * inv_k) [* (q_last mod t)] [+ addend[k]] for the limbs k in [k0, k1)
+// of the L-1 that remain.  rem: workspace of P2*(k1-k0)*n words (unused by the fused tiled path).
+int drop_apply(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, size_t k0, size_t k1, const HpDropConsts &dc0,
+               const u64 *x, const u64 *clast, const u64 *addend, size_t add_poly_stride, size_t add_ct_stride, u32 add_mask,
+               u64 *out, u64 *rem) {
+    const size_t n = (size_t)1 << logn, kc = k1 - k0;
+    if (kc == 0) return HP_OK;
+    // shift everything that is indexed by the limb number to the first limb of the range
+    HpDropConsts dc = dc0;
+    for (size_t k = 0; k < kc; k++) {
+        dc.r[k] = dc0.r[k0 + k]; dc.inv[k] = dc0.inv[k0 + k]; dc.inv_h[k] = dc0.inv_h[k0 + k];
+        dc.t[k] = dc0.t[k0 + k]; dc.t_h[k] = dc0.t_h[k0 + k]; dc.qlt[k] = dc0.qlt[k0 + k]; dc.qlt_h[k] = dc0.qlt_h[k0 + k];
+    }
+    const HpLimb *limbs = plan->d_limbs + k0;
+    x += k0 * n;
+    out += k0 * n;
+    if (addend) addend += k0 * n;
     int rc;
-    if ((rc = run_ntt(ctx, lj))) return rc;
     // tiled sizes: Barrett + centring fused into the remainder NTT's loads, (x - rem)*inv [+ addend] into its stores
     if (!ctx->force_generic && logn >= 11 && logn <= 15 && !getenv("HP_NO_FUSED_DROP")) {
-        HpNttJob fj = batch_job(plan, logn, L - 1, P2, clast, nullptr, 1, 0, 0, 0);
+        HpNttJob fj = batch_job(plan, logn, kc, P2, clast, nullptr, 1, 0, 0, 0);
+        fj.limbs = limbs;
         fj.src_kstride = 0;
         HpDropArgs da;
         memset(&da, 0, sizeof(da));
@@ -353,17 +390,29 @@ int drop_last(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, b
     }
     {
         ProfScope ps(ctx, "drop_rem");
-        if ((rc = chk(ctx, hp_launch_drop_rem(plan->d_limbs, dc, (u32)(L - 1), (u32)n, (u32)P2, clast, rem, ctx->stream),
-                      "drop_rem")))
-            return rc;
+        if ((rc = chk(ctx, hp_launch_drop_rem(limbs, dc, (u32)kc, (u32)n, (u32)P2, clast, rem, ctx->stream), "drop_rem"))) return rc;
     }
-    if ((rc = run_ntt(ctx, batch_job(plan, logn, L - 1, P2, rem, rem, L - 1, L - 1, 0, 0)))) return rc;
+    HpNttJob rj = batch_job(plan, logn, kc, P2, rem, rem, kc, kc, 0, 0);
+    rj.limbs = limbs;
+    if ((rc = run_ntt(ctx, rj))) return rc;
     {
         ProfScope ps(ctx, "drop_fin");
-        rc = chk(ctx, hp_launch_drop_fin(plan->d_limbs, dc, (u32)L, (u32)n, (u32)P2, x, rem, addend, (u32)add_poly_stride,
+        rc = chk(ctx, hp_launch_drop_fin(limbs, dc, (u32)L, (u32)kc, (u32)n, (u32)P2, x, rem, addend, (u32)add_poly_stride,
                                          (u32)add_ct_stride, add_mask, out, ctx->stream), "drop_fin");
     }
     return rc;
+}
+
+int drop_last(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, bool bgv, u64 t, const u64 *x,
+              const u64 *addend, size_t add_poly_stride, size_t add_ct_stride, u32 add_mask, u64 *out, Carver &cv) {
+    const size_t n = (size_t)1 << logn;
+    HpDropConsts dc;
+    make_drop_consts(plan, L, bgv, t, dc);
+    u64 *clast = cv.take(P2 * n);
+    u64 *rem = cv.take(P2 * (L - 1) * n);
+    int rc;
+    if ((rc = drop_coeffs(ctx, plan, logn, L, P2, bgv, t, x, clast))) return rc;
+    return drop_apply(ctx, plan, logn, L, P2, 0, L - 1, dc, x, clast, addend, add_poly_stride, add_ct_stride, add_mask, out, rem);
 }
 
 int check_ext_args(hp_ctx *ctx, size_t logn, size_t L, size_t batch) {
@@ -664,7 +713,7 @@ int hp_dev_mult_low_level(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *mo
     int rc = get_plan(ctx, 0, moduli, L, false, &plan);
     if (rc) return rc;
     ProfScope ps(ctx, "tensor");
-    return chk(ctx, hp_launch_tensor(plan->d_limbs, (u32)L, (u32)1 << logn, (u32)batch, ct1, ct2, quad, ctx->stream),
+    return chk(ctx, hp_launch_tensor(plan->d_limbs, (u32)L, 0, (u32)L, (u32)1 << logn, (u32)batch, ct1, ct2, quad, ctx->stream),
                "tensor");
 }
 
@@ -816,7 +865,7 @@ static int dev_mult(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_e
         u64 *lin = cv.take(P * 2 * L * n);
         {
             ProfScope ps(ctx, "tensor");
-            rc = chk(ctx, hp_launch_tensor(plan->d_limbs, (u32)L, (u32)n, (u32)P, ct1 + b0 * 2 * L * n,
+            rc = chk(ctx, hp_launch_tensor(plan->d_limbs, (u32)L, 0, (u32)L, (u32)n, (u32)P, ct1 + b0 * 2 * L * n,
                                            ct2 + b0 * 2 * L * n, quad, ctx->stream), "tensor");
         }
         // the reference's bgv::relinearize runs its inner mod switch with plain_modulus == 1 (bgv.h:32)
@@ -852,6 +901,84 @@ int hp_dev_bgv_mult_relin_modswitch(hp_ctx *ctx, size_t logn, size_t L, const ui
 }
 
 // ---- profiling ------------------------------------------------------------------------------
+// ---- limb-range stages (limb-sharded "latency" mode across GPUs) ---------------------------------
+static int range_ok(hp_ctx *ctx, size_t lo, size_t hi, size_t limit) {
+    if (lo > hi || hi > limit) return fail(ctx, HP_EINVAL, "limb range out of bounds");
+    return HP_OK;
+}
+
+int hp_dev_mult_low_level_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, size_t k0,
+                                size_t k1, const uint64_t *ct1, const uint64_t *ct2, uint64_t *quad) {
+    Guard g(ctx);
+    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    int rc = range_ok(ctx, k0, k1, L);
+    if (rc) return rc;
+    if (batch == 0 || k0 == k1) return HP_OK;
+    const Plan *plan;
+    if ((rc = get_plan(ctx, 0, moduli, L, false, &plan))) return rc;
+    ProfScope ps(ctx, "tensor");
+    return chk(ctx, hp_launch_tensor(plan->d_limbs, (u32)L, (u32)k0, (u32)(k1 - k0), (u32)1 << logn, (u32)batch, ct1, ct2, quad,
+                                     ctx->stream), "tensor");
+}
+
+int hp_dev_ks_coef_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch, size_t j0, size_t j1,
+                         const uint64_t *pt, size_t pt_pstride, uint64_t *coef) {
+    Guard g(ctx);
+    int rc = check_ext_args(ctx, logn, L, batch);
+    if (rc || (rc = range_ok(ctx, j0, j1, L))) return rc;
+    if (j0 == j1) return HP_OK;
+    const Plan *plan;
+    if ((rc = get_plan(ctx, logn, moduli_ext, L + 1, true, &plan))) return rc;
+    return ks_coef(ctx, plan, logn, L, batch, j0, j1, pt, pt_pstride, coef);
+}
+
+int hp_dev_ks_inner_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch, size_t k0, size_t k1,
+                          const uint64_t *coef, const uint64_t *pt, size_t pt_pstride, const uint64_t *key, uint64_t *out) {
+    Guard g(ctx);
+    int rc = check_ext_args(ctx, logn, L, batch);
+    if (rc || (rc = range_ok(ctx, k0, k1, L + 1))) return rc;
+    if (k0 == k1) return HP_OK;
+    const Plan *plan;
+    if ((rc = get_plan(ctx, logn, moduli_ext, L + 1, true, &plan))) return rc;
+    const size_t n = (size_t)1 << logn;
+    if ((rc = ws_reserve(ctx, padded(batch * L * (L + 1) * n)))) return rc;
+    Carver cv(ctx->ws);
+    u64 *digits = cv.take(batch * L * (L + 1) * n);
+    return ks_digits_inner(ctx, plan, logn, L, batch, k0, k1, coef, pt, pt_pstride, key, out, digits);
+}
+
+int hp_dev_drop_coeffs(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, uint64_t plain_modulus, size_t P2,
+                       const uint64_t *x, uint64_t *clast) {
+    Guard g(ctx);
+    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (L < 2) return fail(ctx, HP_EINVAL, "Unable to drop the only one prime.");
+    if (P2 == 0) return HP_OK;
+    const Plan *plan;
+    int rc = get_plan(ctx, logn, moduli, L, true, &plan);
+    if (rc) return rc;
+    return drop_coeffs(ctx, plan, logn, L, P2, plain_modulus != 0, plain_modulus, x, clast);
+}
+
+int hp_dev_drop_apply_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, uint64_t plain_modulus, size_t P2,
+                            size_t k0, size_t k1, const uint64_t *x, const uint64_t *clast, const uint64_t *addend,
+                            size_t add_poly_stride, size_t add_ct_stride, unsigned add_mask, uint64_t *out) {
+    Guard g(ctx);
+    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (L < 2) return fail(ctx, HP_EINVAL, "Unable to drop the only one prime.");
+    int rc = range_ok(ctx, k0, k1, L - 1);
+    if (rc) return rc;
+    if (P2 == 0 || k0 == k1) return HP_OK;
+    const Plan *plan;
+    if ((rc = get_plan(ctx, logn, moduli, L, true, &plan))) return rc;
+    const size_t n = (size_t)1 << logn;
+    if ((rc = ws_reserve(ctx, padded(P2 * (k1 - k0) * n)))) return rc;
+    Carver cv(ctx->ws);
+    u64 *rem = cv.take(P2 * (k1 - k0) * n);
+    HpDropConsts dc;
+    make_drop_consts(plan, L, plain_modulus != 0, plain_modulus, dc);
+    return drop_apply(ctx, plan, logn, L, P2, k0, k1, dc, x, clast, addend, add_poly_stride, add_ct_stride, add_mask, out, rem);
+}
+
 int hp_prof_begin(hp_ctx *ctx, const char *family) {
     Guard g(ctx);
     for (auto &ev : ctx->prof_events) { ctx->event_pool.push_back(ev.a); ctx->event_pool.push_back(ev.b); }

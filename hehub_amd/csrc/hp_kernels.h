@@ -12,7 +12,8 @@
 enum HpNttMode : int {
     HP_NTT_BATCH = 0,   // rows [P][L][N]: item w = k*P + p         -> src/dst row p*L + k, limb k
     HP_NTT_SPREAD = 1,  // digit spread (rgsw.cpp:108-119): item w = k*(P*L) + p*L + j, k in [0,L]:
-                        //   src = coef row p*L + j, dst = digit row (p*L + j)*(L+1) + k, limb k; k == j is skipped
+                        //   src = coef row p*L + j, dst = digit row (p*L + j)*(L+1) + k, limb k; k == j is skipped;
+                        //   a launch may cover only k in [k_first, k_first + W/(P*L))
 };
 
 struct HpNttJob {
@@ -26,6 +27,7 @@ struct HpNttJob {
     u32 dst_pstride;  // HP_NTT_BATCH: same for dst
     u32 src_kstride;  // HP_NTT_BATCH: rows between consecutive limbs of src (1; 0 = every limb reads the same row)
     u32 W;          // work items
+    u32 k_first;    // HP_NTT_SPREAD: first output modulus of the launch (items cover k_first .. k_first + W/(P*L) - 1)
     int mode;
     int inverse;
     int strict;     // inverse only: reduce_strict epilogue (ntt.h:88-92)
@@ -75,12 +77,14 @@ hipError_t hp_launch_vec(int op, const HpVecConsts &c, size_t n, const u64 *a, c
 
 // ---- scheme-level kernels ---------------------------------------------------------
 // ckks/arith.cpp:55-62: ct1, ct2 [P][2][L][n] -> quad [P][3][L][n]
-hipError_t hp_launch_tensor(const HpLimb *limbs, u32 L, u32 n, u32 P, const u64 *ct1, const u64 *ct2,
-                            u64 *quad, hipStream_t stream);
+// only limbs [k_first, k_first + kc) are computed (kc = L: all)
+hipError_t hp_launch_tensor(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32 n, u32 P, const u64 *ct1,
+                            const u64 *ct2, u64 *quad, hipStream_t stream);
 // rgsw.cpp:121-153: digits [P][L][L+1][n] (diagonal taken from pt [P][L][n]), key [L][2][L+1][n]
 //   -> out [P][2][L+1][n]
-hipError_t hp_launch_ks_inner(const HpLimb *limbs, u32 L, u32 n, u32 P, const u64 *digits, const u64 *pt,
-                              u32 pt_pstride, const u64 *key, u64 *out, hipStream_t stream);
+// only output moduli [k_first, k_first + kc) of the L+1 are computed (kc = L+1: all)
+hipError_t hp_launch_ks_inner(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32 n, u32 P, const u64 *digits,
+                              const u64 *pt, u32 pt_pstride, const u64 *key, u64 *out, hipStream_t stream);
 
 // drop-last-prime helpers (rescaling.cpp:46-75 / mod_switch.cpp:45-77)
 struct HpDropConsts {
@@ -112,6 +116,7 @@ hipError_t hp_launch_drop_rem(const HpLimb *limbs, const HpDropConsts &dc, u32 L
                               const u64 *clast, u64 *rem, hipStream_t stream);
 // x [P2][L][n] (first L-1 limbs used), rem [P2][L-1][n] (NTT form), optional addend [P2][addL][n]
 //   -> out [P2][L-1][n]:  out = ((x - rem) * inv) [* qlt]  [+ addend]
-hipError_t hp_launch_drop_fin(const HpLimb *limbs, const HpDropConsts &dc, u32 L, u32 n, u32 P2, const u64 *x,
+// kc limbs per polynomial (L-1: all); for a limb range the caller shifts limbs / dc / x / addend / out to its first limb
+hipError_t hp_launch_drop_fin(const HpLimb *limbs, const HpDropConsts &dc, u32 L, u32 kc, u32 n, u32 P2, const u64 *x,
                               const u64 *rem, const u64 *addend, u32 add_poly_stride, u32 add_ct_stride,
                               u32 add_mask, u64 *out, hipStream_t stream);

@@ -21,7 +21,7 @@ HP_DEV bool hp_decode_item(const HpNttJob &job, u32 w, HpItem &it) {
     }
     if (job.mode == HP_NTT_SPREAD) {
         const u32 per = job.P * job.L;
-        const u32 k = w / per, rest = w % per;   // rest = p*L + j
+        const u32 k = job.k_first + w / per, rest = w % per;   // rest = p*L + j
         const u32 j = rest % job.L;
         if (k == j) return false;
         it.src = job.src + (size_t)rest * n;

@@ -158,6 +158,37 @@ int hp_dev_bgv_mult_relin_modswitch(hp_ctx *ctx, size_t logn, size_t L, const ui
                                     uint64_t plain_modulus, size_t batch, const uint64_t *d_ct1,
                                     const uint64_t *d_ct2, const uint64_t *d_key, uint64_t *d_out);
 
+/* ---- limb-range stages: the limb-sharded ("latency") mode across GPUs -------------------------------------
+ * one ciphertext operation is cut by OUTPUT MODULUS.  Rank g owns a contiguous range
+ * [k0,k1) of the extended moduli q_0..q_{L-1},p.  Every buffer keeps the single-GPU layout of the entry points
+ * above; a stage reads what it needs and writes only the limbs it is asked for, so ranks owning disjoint ranges
+ * fill disjoint parts of identical buffers and exchange them between stages (hehub_amd/sharded.py: all-gather of
+ * the coefficient-form digit limbs, broadcast of the one coefficient limb a drop needs).  Every sum over the
+ * digits j is still formed on ONE GPU in the reference's order, so results stay bit-identical (Level B). */
+/* ckks/arith.cpp:55-62 for the limbs k in [k0,k1) of L */
+int hp_dev_mult_low_level_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, size_t k0,
+                                size_t k1, const uint64_t *d_ct1, const uint64_t *d_ct2, uint64_t *d_quad);
+/* rgsw.cpp:103-105 for the digits j in [j0,j1) of L: coef[p][j] = strict(INTT(pt[p][j])).
+ * pt: polynomial p starts pt_pstride limbs after polynomial p-1; coef u64[batch][L][N] */
+int hp_dev_ks_coef_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch, size_t j0,
+                         size_t j1, const uint64_t *d_pt, size_t pt_pstride, uint64_t *d_coef);
+/* rgsw.cpp:108-153 for the output moduli k in [k0,k1) of L+1: needs ALL L limbs of coef, writes out[p][half][k] */
+int hp_dev_ks_inner_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch, size_t k0,
+                          size_t k1, const uint64_t *d_coef, const uint64_t *d_pt, size_t pt_pstride,
+                          const uint64_t *d_key, uint64_t *d_out);
+/* rescaling.cpp:47-50 / mod_switch.cpp:47-50 (plain_modulus 0 = CKKS): clast[p2] = strict(INTT_{q_last}(x[p2][L-1]))
+ * for P2 polynomials of L limbs; run by the owner of the limb that is being dropped.  clast u64[P2][N] */
+int hp_dev_drop_coeffs(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, uint64_t plain_modulus, size_t P2,
+                       const uint64_t *d_x, uint64_t *d_clast);
+/* rescaling.cpp:54-74 / mod_switch.cpp:52-76 for the limbs k in [k0,k1) of the L-1 that stay, given clast:
+ * out[p2][k] = ((x[p2][k] - NTT_k(rem_k(clast[p2]))) * q_last^-1) [* (q_last mod t)] [+ addend], x u64[P2][L][N],
+ * out u64[P2][L-1][N]; addend row of polynomial p2, limb k: (p2>>1)*add_ct_stride + (p2&1)*add_poly_stride + k,
+ * applied to polynomial h = p2&1 of each ciphertext when bit h of add_mask is set (NULL: none) */
+int hp_dev_drop_apply_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, uint64_t plain_modulus,
+                            size_t P2, size_t k0, size_t k1, const uint64_t *d_x, const uint64_t *d_clast,
+                            const uint64_t *d_addend, size_t add_poly_stride, size_t add_ct_stride, unsigned add_mask,
+                            uint64_t *d_out);
+
 /* ---- in-library kernel timing (HIP events on the ctx stream) -------------- */
 /* Between hp_prof_begin and hp_prof_end every kernel launch of the named
  * family is bracketed by hipEvents on the stream it is launched on.
