@@ -5,6 +5,7 @@
 // limb with 16-byte loads/stores; the limb's constants are wave-uniform and
 // come from scalar loads of the plan entry.
 #include "hp_kernels.h"
+#include <cstdlib>
 
 #define ELEM_THREADS 256
 #define ELEM_CHUNK 2048u   // words per workgroup = 256 threads x 4 x 16 B
@@ -279,12 +280,80 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner(const HpLimb *__restr
     }
 }
 
+// Same sums, PT ciphertexts per thread: the 2L key words of a (k, i) pair are loaded once and multiplied into PT
+// ciphertexts' accumulators, so the key traffic through L2 / Infinity Cache (2L of the 3L+2 words per (p,k,i) above)
+// drops by PT.  n is even for every supported ring (N >= 2) and chunks are even-sized: always two words per lane.
+template <int PT>
+__global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner_blk(const HpLimb *__restrict__ limbs, u32 L, u32 k_first, u32 P,
+                                                              u32 n, u32 chunks, const u64 *__restrict__ digits,
+                                                              const u64 *__restrict__ pt, u32 pt_pstride,
+                                                              const u64 *__restrict__ key, u64 *__restrict__ out) {
+    typedef u64 __attribute__((ext_vector_type(2))) vv;
+    const u32 Le = L + 1;
+    const u32 PG = (P + PT - 1) / PT;
+    const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    const u32 k = k_first + row / PG, p0 = (row % PG) * PT;
+    const u64 q = limbs[k].q, mqinv = limbs[k].mqinv;
+    const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
+    for (u32 i = chunk * ELEM_CHUNK + threadIdx.x * 2; i < end; i += ELEM_THREADS * 2) {
+        u64 al[PT][2][2], ah[PT][2][2];   // [ciphertext][half][word]
+#pragma unroll
+        for (int c = 0; c < PT; c++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) al[c][h][0] = al[c][h][1] = ah[c][h][0] = ah[c][h][1] = 0;
+        for (u32 j = 0; j < L; j++) {
+            const U2 g0 = *reinterpret_cast<const U2 *>(key + (((size_t)j * 2 + 0) * Le + k) * n + i);
+            const U2 g1 = *reinterpret_cast<const U2 *>(key + (((size_t)j * 2 + 1) * Le + k) * n + i);
+            const u64 kw[2][2] = {{g0.x, g0.y}, {g1.x, g1.y}};
+#pragma unroll
+            for (int c = 0; c < PT; c++) {
+                const u32 p = p0 + c;
+                if (p < P) {   // uniform per workgroup
+                    const u64 *d = (j == k) ? pt + ((size_t)p * pt_pstride + j) * n : digits + (((size_t)p * L + j) * Le + k) * n;
+                    const vv dvv = __builtin_nontemporal_load(reinterpret_cast<const vv *>(d + i));
+                    const u64 dv[2] = {dvv.x, dvv.y};
+#pragma unroll
+                    for (int h = 0; h < 2; h++)
+#pragma unroll
+                        for (int e = 0; e < 2; e++) {
+                            u64 lo, hi;
+                            hp_mul128(dv[e], kw[h][e], lo, hi);
+                            al[c][h][e] += lo;
+                            ah[c][h][e] += hi + (al[c][h][e] < lo ? 1ull : 0ull);
+                        }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < PT; c++) {
+            const u32 p = p0 + c;
+            if (p < P) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    U2 v{hp_montgomery128_lazy(al[c][h][0], ah[c][h][0], q, mqinv), hp_montgomery128_lazy(al[c][h][1], ah[c][h][1], q, mqinv)};
+                    *reinterpret_cast<U2 *>(out + (((size_t)p * 2 + h) * Le + k) * n + i) = v;
+                }
+            }
+        }
+    }
+}
+
 hipError_t hp_launch_ks_inner(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32 n, u32 P, const u64 *digits,
                               const u64 *pt, u32 pt_pstride, const u64 *key, u64 *out, hipStream_t stream) {
     if (kc == 0) return hipSuccess;
     u32 chunks; dim3 grid;
-    elem_grid(n, P * kc, chunks, grid);
-    k_ks_inner<<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, n, chunks, digits, pt, pt_pstride, key, out);
+    static const int pt_env = getenv("HP_KS_PT") ? atoi(getenv("HP_KS_PT")) : 4;   // tuning knob: ciphertexts per thread
+    const int PT = (n >= 2 && P >= 2) ? pt_env : 1;
+    if (PT >= 4) {
+        elem_grid(n, ((P + 3) / 4) * kc, chunks, grid);
+        k_ks_inner_blk<4><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, n, chunks, digits, pt, pt_pstride, key, out);
+    } else if (PT >= 2) {
+        elem_grid(n, ((P + 1) / 2) * kc, chunks, grid);
+        k_ks_inner_blk<2><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, n, chunks, digits, pt, pt_pstride, key, out);
+    } else {
+        elem_grid(n, P * kc, chunks, grid);
+        k_ks_inner<<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, n, chunks, digits, pt, pt_pstride, key, out);
+    }
     return hipGetLastError();
 }
 
