@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="ckks", choices=["ckks", "ntt", "ntt15", "intt", "intt15", "bgv", "rotate", "ckks-limb"])
+    ap.add_argument("--workload", default="ckks", choices=["ckks", "ntt", "ntt15", "intt", "intt15", "bgv", "rotate", "ckks-limb", "encdec"])
     ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (0 = BASELINE config value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")
@@ -82,6 +82,17 @@ def cpu_baseline(workload, P, budget_s):
             per = (time.perf_counter() - t0) / iters
         return {"value": 1.0 / per, "unit": "limb-NTT/s", "cores": 1, "kind": kind,
                 "sample": f"{iters} {'inverse' if inv else 'forward'} NTTs of one limb, N={1 << logn}, q={q}, single thread, tables warm"}
+    if workload == "encdec":
+        logn, moduli = P.C3_LOGN, P.C3_Q
+        noise, c1, pt, sk = P.edge_case(rng, logn, moduli)
+        f = lambda: lib.rlwe_decrypt_core(moduli, lib.rlwe_encrypt_core(moduli, noise, c1, pt, sk), sk)
+        f()
+        iters, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            f(); iters += 1
+        per = (time.perf_counter() - t0) / iters
+        return {"value": 1.0 / per, "unit": "ciphertext/s", "cores": 1, "kind": kind,
+                "sample": f"{iters} x (encrypt_core on given samples + decrypt_core) of one ciphertext, N={1 << logn}, L={len(moduli)}, single thread, tables warm"}
     if workload == "rotate":   # the reference's own benchmark workload (bench/benchmarks.cpp:21-37) at the C3 shape
         logn, mext = P.C3_LOGN, P.C3_MODULI_EXT
         n, L = 1 << logn, len(mext) - 1
@@ -155,6 +166,23 @@ def main():
         metric, unit = "limb_ntt_per_s", "limb-NTT/s"
         cfg = {"workload": f"{'C2' if logn == 14 else 'C3-shape'}: batched {'inverse' if inverse else 'forward'} negacyclic NTT, N={n}, {L} RNS limbs, batch={B} polynomials per GPU",
                "N": n, "limbs": L, "batch_per_gpu": B}
+    elif wl == "encdec":
+        # either side of the path: encrypt_core on caller-supplied samples, then decrypt_core
+        logn, moduli = P.C3_LOGN, P.C3_Q
+        B = args.batch or P.C3_BATCH
+        n, L = 1 << logn, len(moduli)
+        c1 = rand_words(torch, (B, L, n), moduli, dev, 11 + rank)
+        pt = rand_words(torch, (B, L, n), moduli, dev, 12 + rank)
+        sk = rand_words(torch, (L, n), moduli, dev, 13)
+        noise = torch.randint(-19, 20, (B, n), dtype=torch.int64, device=dev)
+        units_per_step = B
+        step = lambda: eng.rlwe_decrypt_core(moduli, eng.rlwe_encrypt_core(moduli, noise, c1, pt, sk), sk)
+        family = "ntt"
+        alg_bytes_per_step = 16.0 * n * 2 * L * B      # the two forward transforms per ciphertext (noise, plaintext)
+        launches_per_step = 2
+        metric, unit = "rlwe_encrypt_decrypt_per_s", "ciphertext/s"
+        cfg = {"workload": f"C3 shape: rlwe encrypt_core (given samples) + decrypt_core, N={n}, L={L}, batch={B} ciphertexts per GPU",
+               "N": n, "L": L, "batch_per_gpu": B, "A_step_bytes_per_op": (15 * L + 1) * 8 * n}
     else:
         if wl in ("ckks", "rotate", "ckks-limb"):
             logn, mext, t, B0 = P.C3_LOGN, P.C3_MODULI_EXT, 0, (P.C3_BATCH if wl != "ckks-limb" else 8)

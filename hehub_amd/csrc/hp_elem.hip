@@ -418,3 +418,129 @@ hipError_t hp_launch_drop_fin(const HpLimb *limbs, const HpDropConsts &dc, u32 L
                                                   add_ct_stride, add_mask, out);
     return hipGetLastError();
 }
+
+// ---- either side of the path: encrypt / decrypt cores and RNS base transforms ------
+// Simple one-word-per-lane streaming kernels: these run once per ciphertext, not once per multiplication.
+
+// sampling.cpp:77-83: ex[p][k][i] = q_k + (u64)e[p][i], minus q_k if that reached q_k
+__global__ void __launch_bounds__(ELEM_THREADS) k_lift_noise(const HpLimb *__restrict__ limbs, u32 L, u32 n, u32 chunks,
+                                                            const long long *__restrict__ noise, u64 *__restrict__ out,
+                                                            u32 out_pstride) {
+    const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;   // row = p*L + k
+    const u32 p = row / L, k = row % L;
+    const u64 q = limbs[k].q;
+    const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
+    for (u32 i = chunk * ELEM_CHUNK + threadIdx.x; i < end; i += ELEM_THREADS) {
+        u64 v = q + (u64)noise[(size_t)p * n + i];
+        out[((size_t)p * out_pstride + k) * n + i] = v - ((v >= q) ? q : 0);
+    }
+}
+
+// rlwe.cpp:52 and :70: c0 = (ex - c1*sk) + NTT(pt); ct[p] = (c0, c1).  ex is read from ct[p][0] (in place).
+__global__ void __launch_bounds__(ELEM_THREADS) k_enc_fin(const HpLimb *__restrict__ limbs, u32 L, u32 n, u32 chunks,
+                                                         const u64 *__restrict__ c1, const u64 *__restrict__ sk,
+                                                         const u64 *__restrict__ ptn, u64 *__restrict__ ct) {
+    const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;   // row = p*L + k
+    const u32 p = row / L, k = row % L;
+    const HpLimb m = limbs[k];
+    u64 *c0 = ct + ((size_t)p * 2 * L + k) * n, *o1 = c0 + (size_t)L * n;
+    const u64 *a = c1 + (size_t)row * n, *s = sk + (size_t)k * n, *t = ptn + (size_t)row * n;
+    const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
+    for (u32 i = chunk * ELEM_CHUNK + threadIdx.x; i < end; i += ELEM_THREADS) {
+        const u64 av = a[i];
+        u64 v = hp_sub_lazy(c0[i], hp_mul_hybrid_lazy(av, s[i], m), m.two_q);
+        c0[i] = hp_add_lazy(v, t[i], m.two_q);
+        o1[i] = av;
+    }
+}
+
+// rlwe.cpp:76: c0 + c1*sk (the INTT and the strict reduction follow as a transform launch)
+__global__ void __launch_bounds__(ELEM_THREADS) k_dec_fma(const HpLimb *__restrict__ limbs, u32 L, u32 n, u32 chunks,
+                                                         const u64 *__restrict__ ct, const u64 *__restrict__ sk,
+                                                         u64 *__restrict__ out) {
+    const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;   // row = p*L + k
+    const u32 p = row / L, k = row % L;
+    const HpLimb m = limbs[k];
+    const u64 *c0 = ct + ((size_t)p * 2 * L + k) * n, *c1 = c0 + (size_t)L * n, *s = sk + (size_t)k * n;
+    const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
+    for (u32 i = chunk * ELEM_CHUNK + threadIdx.x; i < end; i += ELEM_THREADS)
+        out[(size_t)row * n + i] = hp_add_lazy(c0[i], hp_mul_hybrid_lazy(c1[i], s[i], m), m.two_q);
+}
+
+// rns_transform.cpp:113 + :11-37: strict(x) mod old -> centred lift into every new modulus (+ lazy Barrett when q < old)
+__global__ void __launch_bounds__(ELEM_THREADS) k_base_from_single(const HpLimb *__restrict__ limbs, u64 old_q, u32 L, u32 n,
+                                                                  u32 chunks, const u64 *__restrict__ in,
+                                                                  u64 *__restrict__ out) {
+    const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;   // row = p*L + k
+    const u32 p = row / L, k = row % L;
+    const u64 q = limbs[k].q, bc = limbs[k].barrett_c;
+    const u64 half = old_q / 2, multiple = (old_q / q + 1) * q;
+    const bool reduce = q < old_q;
+    const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
+    for (u32 i = chunk * ELEM_CHUNK + threadIdx.x; i < end; i += ELEM_THREADS) {
+        const u64 x = hp_strict(in[(size_t)p * n + i], old_q);
+        u64 v = (x < half) ? x : multiple - old_q + x;
+        if (reduce) v = hp_barrett_lazy(v, q, bc);
+        out[(size_t)row * n + i] = v;
+    }
+}
+
+// rns_transform.cpp:113 + :39-84 (small-coefficient branch): consistency check over the limbs (any violation sets
+// not_small[p]) and the centred lift of limb 0 into the new modulus, strictly Barrett-reduced
+__global__ void __launch_bounds__(ELEM_THREADS) k_base_to_single(const HpLimb *__restrict__ limbs, u32 L, u32 n, u32 chunks,
+                                                                u64 new_q, u64 new_bc, const u64 *__restrict__ in,
+                                                                u64 *__restrict__ out, u32 *__restrict__ not_small) {
+    const u32 p = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    const u64 q0 = limbs[0].q, half = q0 / 2, multiple = (q0 / new_q + 1) * new_q;
+    const u64 *x = in + (size_t)p * L * n;
+    const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
+    bool bad = false;
+    for (u32 i = chunk * ELEM_CHUNK + threadIdx.x; i < end; i += ELEM_THREADS) {
+        const u64 x0 = hp_strict(x[i], q0);
+        for (u32 k = 1; k < L; k++) {
+            const u64 qk = limbs[k].q, xk = hp_strict(x[(size_t)k * n + i], qk);
+            bad |= (x0 < half) ? (xk != x0) : (qk - xk != q0 - x0);
+        }
+        const u64 v = (x0 < half) ? x0 : multiple - q0 + x0;
+        out[(size_t)p * n + i] = hp_strict(hp_barrett_lazy(v, new_q, new_bc), new_q);
+    }
+    if (bad) atomicOr(not_small + p, 1u);
+}
+
+hipError_t hp_launch_lift_noise(const HpLimb *limbs, u32 L, u32 n, u32 P, const long long *noise, u64 *out, u32 out_pstride,
+                                hipStream_t stream) {
+    u32 chunks; dim3 grid;
+    elem_grid(n, P * L, chunks, grid);
+    k_lift_noise<<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, n, chunks, noise, out, out_pstride);
+    return hipGetLastError();
+}
+hipError_t hp_launch_enc_fin(const HpLimb *limbs, u32 L, u32 n, u32 P, const u64 *c1, const u64 *sk, const u64 *ptn, u64 *ct,
+                             hipStream_t stream) {
+    u32 chunks; dim3 grid;
+    elem_grid(n, P * L, chunks, grid);
+    k_enc_fin<<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, n, chunks, c1, sk, ptn, ct);
+    return hipGetLastError();
+}
+hipError_t hp_launch_dec_fma(const HpLimb *limbs, u32 L, u32 n, u32 P, const u64 *ct, const u64 *sk, u64 *out,
+                             hipStream_t stream) {
+    u32 chunks; dim3 grid;
+    elem_grid(n, P * L, chunks, grid);
+    k_dec_fma<<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, n, chunks, ct, sk, out);
+    return hipGetLastError();
+}
+hipError_t hp_launch_base_from_single(const HpLimb *limbs, u64 old_q, u32 L, u32 n, u32 P, const u64 *in, u64 *out,
+                                      hipStream_t stream) {
+    u32 chunks; dim3 grid;
+    elem_grid(n, P * L, chunks, grid);
+    k_base_from_single<<<grid, ELEM_THREADS, 0, stream>>>(limbs, old_q, L, n, chunks, in, out);
+    return hipGetLastError();
+}
+hipError_t hp_launch_base_to_single(const HpLimb *limbs, u32 L, u32 n, u32 P, u64 new_q, const u64 *in, u64 *out,
+                                    u32 *not_small, hipStream_t stream) {
+    u32 chunks; dim3 grid;
+    elem_grid(n, P, chunks, grid);
+    hipError_t e = hipMemsetAsync(not_small, 0, (size_t)P * sizeof(u32), stream);
+    if (e != hipSuccess) return e;
+    k_base_to_single<<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, n, chunks, new_q, (~(u64)0) / new_q, in, out, not_small);
+    return hipGetLastError();
+}

@@ -901,6 +901,74 @@ int hp_dev_bgv_mult_relin_modswitch(hp_ctx *ctx, size_t logn, size_t L, const ui
 }
 
 // ---- profiling ------------------------------------------------------------------------------
+// ---- either side of the path: encrypt / decrypt cores, RNS base transforms ------------------------
+int hp_dev_rlwe_encrypt_core(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, const int64_t *noise,
+                             const uint64_t *c1, const uint64_t *pt, const uint64_t *sk, uint64_t *ct) {
+    Guard g(ctx);
+    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (L < 1 || L > HP_MAX_LIMBS) return fail(ctx, HP_EINVAL, "invalid component number");
+    if (batch == 0) return HP_OK;
+    const Plan *plan;
+    int rc = get_plan(ctx, logn, moduli, L, true, &plan);
+    if (rc) return rc;
+    const size_t n = (size_t)1 << logn;
+    if ((rc = ws_reserve(ctx, padded(batch * L * n)))) return rc;
+    Carver cv(ctx->ws);
+    u64 *ptn = cv.take(batch * L * n);
+    {   // ex = NTT(lift(noise)) into ct[p][0]                          sampling.cpp:77-86
+        ProfScope ps(ctx, "elem");
+        if ((rc = chk(ctx, hp_launch_lift_noise(plan->d_limbs, (u32)L, (u32)n, (u32)batch, (const long long *)noise, ct, (u32)(2 * L),
+                                                ctx->stream), "lift_noise"))) return rc;
+    }
+    if ((rc = run_ntt(ctx, batch_job(plan, logn, L, batch, ct, ct, 2 * L, 2 * L, 0, 0)))) return rc;
+    if ((rc = run_ntt(ctx, batch_job(plan, logn, L, batch, pt, ptn, L, L, 0, 0)))) return rc;   // rlwe.cpp:66-67
+    ProfScope ps(ctx, "elem");
+    return chk(ctx, hp_launch_enc_fin(plan->d_limbs, (u32)L, (u32)n, (u32)batch, c1, sk, ptn, ct, ctx->stream), "enc_fin");
+}
+
+int hp_dev_rlwe_decrypt_core(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, const uint64_t *ct,
+                             const uint64_t *sk, uint64_t *pt) {
+    Guard g(ctx);
+    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (L < 1 || L > HP_MAX_LIMBS) return fail(ctx, HP_EINVAL, "invalid component number");
+    if (batch == 0) return HP_OK;
+    const Plan *plan;
+    int rc = get_plan(ctx, logn, moduli, L, true, &plan);
+    if (rc) return rc;
+    const size_t n = (size_t)1 << logn;
+    {
+        ProfScope ps(ctx, "elem");
+        if ((rc = chk(ctx, hp_launch_dec_fma(plan->d_limbs, (u32)L, (u32)n, (u32)batch, ct, sk, pt, ctx->stream), "dec_fma"))) return rc;
+    }
+    return run_ntt(ctx, batch_job(plan, logn, L, batch, pt, pt, L, L, 1, 1));   // rlwe.cpp:78-80
+}
+
+int hp_dev_rns_base_from_single(hp_ctx *ctx, size_t n, uint64_t old_modulus, size_t L, const uint64_t *new_moduli, size_t batch,
+                                const uint64_t *in, uint64_t *out) {
+    Guard g(ctx);
+    if (old_modulus < 2 || L < 1 || L > HP_MAX_LIMBS) return fail(ctx, HP_EINVAL, "invalid moduli");
+    if (batch == 0 || n == 0) return HP_OK;
+    const Plan *plan;
+    int rc = get_plan(ctx, 0, new_moduli, L, false, &plan);
+    if (rc) return rc;
+    ProfScope ps(ctx, "elem");
+    return chk(ctx, hp_launch_base_from_single(plan->d_limbs, old_modulus, (u32)L, (u32)n, (u32)batch, in, out, ctx->stream),
+               "base_from_single");
+}
+
+int hp_dev_rns_base_to_single_small(hp_ctx *ctx, size_t n, size_t L, const uint64_t *old_moduli, uint64_t new_modulus,
+                                    size_t batch, const uint64_t *in, uint64_t *out, uint32_t *not_small) {
+    Guard g(ctx);
+    if (new_modulus < 2 || L < 1 || L > HP_MAX_LIMBS) return fail(ctx, HP_EINVAL, "invalid moduli");
+    if (batch == 0 || n == 0) return HP_OK;
+    const Plan *plan;
+    int rc = get_plan(ctx, 0, old_moduli, L, false, &plan);
+    if (rc) return rc;
+    ProfScope ps(ctx, "elem");
+    return chk(ctx, hp_launch_base_to_single(plan->d_limbs, (u32)L, (u32)n, (u32)batch, new_modulus, in, out, not_small, ctx->stream),
+               "base_to_single");
+}
+
 // ---- limb-range stages (limb-sharded "latency" mode across GPUs) ---------------------------------
 static int range_ok(hp_ctx *ctx, size_t lo, size_t hi, size_t limit) {
     if (lo > hi || hi > limit) return fail(ctx, HP_EINVAL, "limb range out of bounds");

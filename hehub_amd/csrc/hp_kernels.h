@@ -120,3 +120,19 @@ hipError_t hp_launch_drop_rem(const HpLimb *limbs, const HpDropConsts &dc, u32 L
 hipError_t hp_launch_drop_fin(const HpLimb *limbs, const HpDropConsts &dc, u32 L, u32 kc, u32 n, u32 P2, const u64 *x,
                               const u64 *rem, const u64 *addend, u32 add_poly_stride, u32 add_ct_stride,
                               u32 add_mask, u64 *out, hipStream_t stream);
+
+// ---- either side of the path ---------------------------------------
+// noise [P][n] (int64) -> out rows p*out_pstride + k: the per-modulus lift of sampling.cpp:77-83
+hipError_t hp_launch_lift_noise(const HpLimb *limbs, u32 L, u32 n, u32 P, const long long *noise, u64 *out, u32 out_pstride,
+                                hipStream_t stream);
+// ct[p][0] holds NTT(lift(noise)) on entry; c1, ptn [P][L][n], sk [L][n] -> ct [P][2][L][n]   (rlwe.cpp:52,70)
+hipError_t hp_launch_enc_fin(const HpLimb *limbs, u32 L, u32 n, u32 P, const u64 *c1, const u64 *sk, const u64 *ptn, u64 *ct,
+                             hipStream_t stream);
+// out [P][L][n] = c0 + c1*sk   (rlwe.cpp:76)
+hipError_t hp_launch_dec_fma(const HpLimb *limbs, u32 L, u32 n, u32 P, const u64 *ct, const u64 *sk, u64 *out,
+                             hipStream_t stream);
+// rns_transform.cpp:11-37 / :39-84; limbs = plan of the NEW (from_single) / OLD (to_single) moduli
+hipError_t hp_launch_base_from_single(const HpLimb *limbs, u64 old_q, u32 L, u32 n, u32 P, const u64 *in, u64 *out,
+                                      hipStream_t stream);
+hipError_t hp_launch_base_to_single(const HpLimb *limbs, u32 L, u32 n, u32 P, u64 new_q, const u64 *in, u64 *out,
+                                    u32 *not_small, hipStream_t stream);

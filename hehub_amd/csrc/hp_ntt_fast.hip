@@ -286,7 +286,10 @@ struct alignas(16) V2 {
 
 HP_DEV void stagger_start(const HpNttJob &job) {
     if (blockIdx.x < job.stagger_first && job.stagger_phases > 1) {
-        const u32 phase = (blockIdx.x >> 3) % job.stagger_phases;
+        // stagger_phases >= 0x100: experiment, offset the workgroups that share a CU (dispatch fills the 32 CUs of an
+        // XCD once before it doubles up) instead of neighbouring CUs
+        const u32 phase = (job.stagger_phases >= 0x100) ? ((blockIdx.x >> 3) / 32u) % (job.stagger_phases & 0xffu)
+                                                        : (blockIdx.x >> 3) % job.stagger_phases;
         const u64 until = __builtin_amdgcn_s_memtime() + (u64)phase * job.stagger_ticks;
         while (__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(32);
     }

@@ -263,6 +263,38 @@ class Engine:
                                                  self._ptr(key), self._ptr(out)))
         return out
 
+    # -- either side of the path -------------------------------------------
+    def rlwe_encrypt_core(self, moduli, noise, c1, pt, sk):
+        B, L, n = c1.shape
+        ct = self.empty((B, 2, L, n))
+        self._chk(self.lib.hp_dev_rlwe_encrypt_core(self.h, n.bit_length() - 1, L, _u64arr(moduli), B, self._ptr(noise),
+                                                    self._ptr(c1), self._ptr(pt), self._ptr(sk), self._ptr(ct)))
+        return ct
+
+    def rlwe_decrypt_core(self, moduli, ct, sk):
+        B, _, L, n = ct.shape
+        pt = self.empty((B, L, n))
+        self._chk(self.lib.hp_dev_rlwe_decrypt_core(self.h, n.bit_length() - 1, L, _u64arr(moduli), B, self._ptr(ct),
+                                                    self._ptr(sk), self._ptr(pt)))
+        return pt
+
+    def rns_base_from_single(self, old_modulus, new_moduli, x):
+        B, n = x.shape
+        L = len(new_moduli)
+        out = self.empty((B, L, n))
+        self._chk(self.lib.hp_dev_rns_base_from_single(self.h, n, old_modulus, L, _u64arr(new_moduli), B, self._ptr(x),
+                                                       self._ptr(out)))
+        return out
+
+    def rns_base_to_single_small(self, old_moduli, new_modulus, x):
+        """returns (out[B][n], not_small[B]); not_small != 0 marks polynomials that need the host CRT branch."""
+        B, L, n = x.shape
+        out = self.empty((B, n))
+        flags = self.torch.empty((B,), dtype=self.torch.int32, device=x.device)
+        self._chk(self.lib.hp_dev_rns_base_to_single_small(self.h, n, L, _u64arr(old_moduli), new_modulus, B, self._ptr(x),
+                                                           self._ptr(out), C.c_void_p(flags.data_ptr())))
+        return out, flags
+
     def ckks_mult(self, moduli_ext, ct1, ct2, key, out=None):
         B, two, L, n = ct1.shape
         out = self.empty((B, 2, L - 1, n)) if out is None else out

@@ -456,6 +456,37 @@ RlweCt ext_prod_montgomery(const RlwePt &pt, const RgswCt &rgsw) {
     return make_ct(n, L + 1, mext, dout.p);
 }
 
+#ifdef HEHUB_AMD_BIND_REFERENCE
+// rlwe.h decrypt_core (rlwe.cpp:74-81): `c0 + c1 * sk`, INTT, reduce_strict as ONE device call instead of 3L host
+// round trips; the argument checks are the ones the reference's operator* / operator+ perform, in their order.
+RlwePt decrypt_core(const RlweCt &ct, const RlweSk &sk) {
+    const RnsPolynomial &c0 = ct[0], &c1 = ct[1];
+    if (c1.rep_form == PolyRepForm::coeff) throw std::invalid_argument("Operand a is in coefficient form.");
+    if (sk.rep_form == PolyRepForm::coeff) throw std::invalid_argument("Operand b is in coefficient form.");
+    if (c1.dimension() != sk.dimension()) throw std::invalid_argument("Operands' poly len mismatch.");
+    const size_t Lp = std::min(c1.component_count(), sk.component_count());
+    std::vector<u64> m1(c1.modulus_vec()), ms(sk.modulus_vec());
+    m1.resize(Lp); ms.resize(Lp);
+    if (m1 != ms) throw std::invalid_argument("Operands' moduli mismatch.");
+    if (c0.rep_form != PolyRepForm::value) throw std::invalid_argument("Operands are in different representation form.");
+    if (c0.dimension() != c1.dimension()) throw std::invalid_argument("Operands' poly len mismatch.");
+    const size_t L = c0.component_count(), n = c0.dimension();
+    if (Lp < L) throw std::invalid_argument("Operand b contains less components than self.");
+    m1.resize(L);
+    if (c0.modulus_vec() != m1) throw std::invalid_argument("Operands' moduli mismatch.");
+    RnsPolynomial pt(n, L, m1);
+    pt.rep_form = PolyRepForm::coeff;
+    if (L == 0) return pt;
+    DevBuf dct(2 * L * n), dsk(L * n), dpt(L * n);
+    put_poly(dct.p, c0, L);
+    put_poly(dct.p + L * n, c1, L);
+    put_poly(dsk.p, sk, L);
+    check(hp_dev_rlwe_decrypt_core(amd::engine(), c0.log_dimension(), L, m1.data(), 1, dct.p, dsk.p, dpt.p));
+    get_poly(pt, dpt.p, L);
+    return pt;
+}
+#endif
+
 // =====================================================================================================
 // ckks.h
 // =====================================================================================================

@@ -158,6 +158,27 @@ int hp_dev_bgv_mult_relin_modswitch(hp_ctx *ctx, size_t logn, size_t L, const ui
                                     uint64_t plain_modulus, size_t batch, const uint64_t *d_ct1,
                                     const uint64_t *d_ct2, const uint64_t *d_key, uint64_t *d_out);
 
+/* ---- either side of the path: what a pipeline needs to keep ciphertexts on the device ---- */
+/* rlwe.cpp:57-72 encrypt_core with the samples of get_rlwe_sample supplied by the caller (sampling stays on the host):
+ * noise int64[batch][N] rounded Gaussian integers (lifted per modulus and transformed as sampling.cpp:76-86 does),
+ * c1 u64[batch][L][N] uniform NTT-form words, pt u64[batch][L][N] coefficient form, sk u64[L][N] NTT form
+ * -> ct u64[batch][2][L][N] */
+int hp_dev_rlwe_encrypt_core(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch,
+                             const int64_t *d_noise, const uint64_t *d_c1, const uint64_t *d_pt, const uint64_t *d_sk,
+                             uint64_t *d_ct);
+/* rlwe.h decrypt_core (rlwe.cpp:74-81): pt u64[batch][L][N] = strict(INTT(c0 + c1*sk)) */
+int hp_dev_rlwe_decrypt_core(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch,
+                             const uint64_t *d_ct, const uint64_t *d_sk, uint64_t *d_pt);
+/* rns_transform.h rns_base_transform, one modulus -> many (rns_transform.cpp:113 + :11-37):
+ * in u64[batch][N] (mod old_modulus, lazy allowed) -> out u64[batch][L][N] */
+int hp_dev_rns_base_from_single(hp_ctx *ctx, size_t n, uint64_t old_modulus, size_t L, const uint64_t *new_moduli,
+                                size_t batch, const uint64_t *d_in, uint64_t *d_out);
+/* rns_base_transform, many -> one, small-coefficient branch (rns_transform.cpp:113 + :39-84):
+ * in u64[batch][L][N] -> out u64[batch][N]; d_not_small u32[batch] is set non-zero for a polynomial whose coefficients
+ * are not all small -- the reference then composes by CRT with BigInt (:86-104), which stays on the host */
+int hp_dev_rns_base_to_single_small(hp_ctx *ctx, size_t n, size_t L, const uint64_t *old_moduli, uint64_t new_modulus,
+                                    size_t batch, const uint64_t *d_in, uint64_t *d_out, uint32_t *d_not_small);
+
 /* ---- limb-range stages: the limb-sharded ("latency") mode across GPUs -------------------------------------
  * one ciphertext operation is cut by OUTPUT MODULUS.  Rank g owns a contiguous range
  * [k0,k1) of the extended moduli q_0..q_{L-1},p.  Every buffer keeps the single-GPU layout of the entry points

@@ -638,6 +638,87 @@ int orc_bgv_mult_relin_modswitch(size_t logn, size_t L, const u64 *moduli_ext, u
 }
 
 /* ===================================================================== */
+/* either side of the path: encrypt / decrypt cores, base transforms     */
+/* ===================================================================== */
+
+/* sampling.cpp:76-86 lift + NTT, rlwe.cpp:52 (ex - c1*sk), rlwe.cpp:65-69 (NTT(pt), c0 += pt_ntt) */
+int orc_rlwe_encrypt_core(size_t logn, size_t L, const u64 *moduli, const int64_t *noise, const u64 *c1,
+                          const u64 *pt, const u64 *sk, u64 *ct) {
+    const size_t n = (size_t)1 << logn;
+    u64 *c0 = ct, *prod = (u64 *)malloc(L * n * sizeof(u64)), *ptn = (u64 *)malloc(L * n * sizeof(u64));
+    for (size_t k = 0; k < L; k++) {
+        const u64 q = moduli[k];
+        for (size_t i = 0; i < n; i++) {
+            u64 v = q + (u64)noise[i];
+            v -= (v >= q) ? q : 0;
+            c0[k * n + i] = v;
+        }
+    }
+    int rc = orc_poly_ntt(logn, L, moduli, c0);
+    orc_poly_mul(n, L, moduli, c1, sk, prod);
+    orc_poly_sub_inplace(n, L, moduli, c0, prod);
+    memcpy(ptn, pt, L * n * sizeof(u64));
+    if (rc == 0) rc = orc_poly_ntt(logn, L, moduli, ptn);
+    orc_poly_add_inplace(n, L, moduli, c0, ptn);
+    memcpy(ct + L * n, c1, L * n * sizeof(u64));
+    free(prod);
+    free(ptn);
+    return rc;
+}
+
+/* rlwe.cpp:74-81 */
+int orc_rlwe_decrypt_core(size_t logn, size_t L, const u64 *moduli, const u64 *ct, const u64 *sk, u64 *pt) {
+    const size_t n = (size_t)1 << logn;
+    u64 *prod = (u64 *)malloc(L * n * sizeof(u64));
+    orc_poly_mul(n, L, moduli, ct + L * n, sk, prod);
+    memcpy(pt, ct, L * n * sizeof(u64));
+    orc_poly_add_inplace(n, L, moduli, pt, prod);
+    int rc = orc_poly_intt(logn, L, moduli, pt);
+    orc_poly_reduce_strict(n, L, moduli, pt);
+    free(prod);
+    return rc;
+}
+
+/* rns_transform.cpp:11-37 (input strictly reduced by :113 first) */
+void orc_rns_base_from_single(size_t n, u64 old_modulus, size_t L, const u64 *new_moduli, const u64 *in, u64 *out) {
+    const u64 half = old_modulus / 2;
+    for (size_t k = 0; k < L; k++) {
+        const u64 q = new_moduli[k];
+        const u64 multiple = (old_modulus / q + 1) * q;
+        for (size_t i = 0; i < n; i++) {
+            u64 x = in[i];
+            x -= (x >= old_modulus) ? old_modulus : 0;
+            out[k * n + i] = (x < half) ? x : multiple - old_modulus + x;
+        }
+        if (q < old_modulus) orc_batched_barrett_lazy(q, n, out + k * n);
+    }
+}
+
+/* rns_transform.cpp:39-84 */
+int orc_rns_base_to_single_small(size_t n, size_t L, const u64 *old_moduli, u64 new_modulus, const u64 *in, u64 *out) {
+    const u64 q0 = old_moduli[0], half = q0 / 2;
+    int small = 1;
+    for (size_t i = 0; i < n && small; i++) {
+        u64 x0 = in[i];
+        x0 -= (x0 >= q0) ? q0 : 0;
+        for (size_t k = 1; k < L; k++) {
+            u64 xk = in[k * n + i];
+            xk -= (xk >= old_moduli[k]) ? old_moduli[k] : 0;
+            if (x0 < half ? (xk != x0) : (old_moduli[k] - xk != q0 - x0)) { small = 0; break; }
+        }
+    }
+    if (!small) return 0;
+    const u64 multiple = (q0 / new_modulus + 1) * new_modulus;
+    for (size_t i = 0; i < n; i++) {
+        u64 x0 = in[i];
+        x0 -= (x0 >= q0) ? q0 : 0;
+        out[i] = (x0 < half) ? x0 : multiple - q0 + x0;
+    }
+    orc_batched_barrett(new_modulus, n, out);
+    return 1;
+}
+
+/* ===================================================================== */
 /* digests / generators                                                  */
 /* ===================================================================== */
 

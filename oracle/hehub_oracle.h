@@ -132,6 +132,23 @@ int orc_bgv_mult_relin_modswitch(size_t logn, size_t L, const orc_u64 *moduli_ex
                                  const orc_u64 *ct2, const orc_u64 *key,
                                  orc_u64 *out);
 
+/* ---- either side of the path ------------------- */
+/* rlwe.cpp:57-72 encrypt_core, with the samples of get_rlwe_sample (rlwe.cpp:33-55) supplied by the caller:
+ * noise int64[N] = the rounded Gaussian integers (sampling.cpp:60-88 lifts them per modulus and transforms),
+ * c1 u64[L][N] uniform NTT-form words, pt u64[L][N] coefficient form, sk u64[L][N] NTT form -> ct u64[2][L][N] */
+int orc_rlwe_encrypt_core(size_t logn, size_t L, const orc_u64 *moduli, const int64_t *noise, const orc_u64 *c1,
+                          const orc_u64 *pt, const orc_u64 *sk, orc_u64 *ct);
+/* rlwe.cpp:74-81 decrypt_core: pt u64[L][N] = strict(INTT(c0 + c1*sk)) */
+int orc_rlwe_decrypt_core(size_t logn, size_t L, const orc_u64 *moduli, const orc_u64 *ct, const orc_u64 *sk,
+                          orc_u64 *pt);
+/* rns_transform.cpp:11-37 after the reduce_strict of :113: in u64[N] mod old_modulus -> out u64[L][N] */
+void orc_rns_base_from_single(size_t n, orc_u64 old_modulus, size_t L, const orc_u64 *new_moduli, const orc_u64 *in,
+                              orc_u64 *out);
+/* rns_transform.cpp:39-84, small-coefficient branch (after the reduce_strict of :113): in u64[L][N] -> out u64[N].
+ * returns 1 when every coefficient is small (out valid), 0 when the CRT branch (:86-104, BigInt) would run */
+int orc_rns_base_to_single_small(size_t n, size_t L, const orc_u64 *old_moduli, orc_u64 new_modulus,
+                                 const orc_u64 *in, orc_u64 *out);
+
 /* ---- digests / generators shared by tests, fixtures and bench ------- */
 orc_u64 orc_fnv1a64(const void *bytes, size_t nbytes);
 /* x[i] = splitmix64 stream (state advanced per word) mod q (q==0: raw) */

@@ -101,6 +101,10 @@ class Oracle:
         self._brelin = f("bgv_relinearize", C.c_int, [szt, szt, P, u64, P, P, P])
         self._crot = f("ckks_rotate", C.c_int, [szt, szt, P, szt, P, P, P])
         self._cconj = f("ckks_conjugate", C.c_int, [szt, szt, P, P, P, P])
+        self._enc = f("rlwe_encrypt_core", C.c_int, [szt, szt, P, P, P, P, P, P])
+        self._dec = f("rlwe_decrypt_core", C.c_int, [szt, szt, P, P, P, P])
+        self._bfs = f("rns_base_from_single", None, [szt, u64, szt, P, P, P])
+        self._bts = f("rns_base_to_single_small", C.c_int, [szt, szt, P, u64, P, P])
         self._cmult = f("ckks_mult_relin_rescale", C.c_int, [szt, szt, P, P, P, P, P])
         self._bmult = f("bgv_mult_relin_modswitch", C.c_int, [szt, szt, P, u64, P, P, P, P])
         if self.kind == "orc":
@@ -278,6 +282,36 @@ class Oracle:
         if rc != 0:
             raise ValueError(f"conjugate rc={rc}")
         return out
+
+    def rlwe_encrypt_core(self, moduli, noise, c1, pt, sk):
+        L, n = c1.shape
+        assert noise.dtype == np.int64 and noise.flags["C_CONTIGUOUS"]
+        ct = np.empty((2, L, n), dtype=np.uint64)
+        rc = self._enc(n.bit_length() - 1, L, _p(_mods(moduli)), noise.ctypes.data_as(P), _p(c1), _p(pt), _p(sk), _p(ct))
+        if rc != 0:
+            raise ValueError(f"encrypt_core rc={rc}")
+        return ct
+
+    def rlwe_decrypt_core(self, moduli, ct, sk):
+        _, L, n = ct.shape
+        pt = np.empty((L, n), dtype=np.uint64)
+        rc = self._dec(n.bit_length() - 1, L, _p(_mods(moduli)), _p(ct), _p(sk), _p(pt))
+        if rc != 0:
+            raise ValueError(f"decrypt_core rc={rc}")
+        return pt
+
+    def rns_base_from_single(self, old_modulus, new_moduli, x):
+        n, L = x.size, len(new_moduli)
+        out = np.empty((L, n), dtype=np.uint64)
+        self._bfs(n, old_modulus, L, _p(_mods(new_moduli)), _p(x), _p(out))
+        return out
+
+    def rns_base_to_single_small(self, old_moduli, new_modulus, x):
+        """returns (all_small, out[n]); the compiled reference always reports 1 (it falls into its CRT branch itself)."""
+        L, n = x.shape
+        out = np.empty(n, dtype=np.uint64)
+        ok = self._bts(n, L, _p(_mods(old_moduli)), new_modulus, _p(x), _p(out))
+        return bool(ok), out
 
     def ckks_mult(self, moduli_ext, ct1, ct2, key):
         _, L, n = ct1.shape

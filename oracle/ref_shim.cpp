@@ -19,6 +19,7 @@
 #include "fhe/primitives/keys.h"
 #include "fhe/primitives/rgsw.h"
 #include "fhe/primitives/rlwe.h"
+#include "fhe/common/rns_transform.h"
 
 #include <chrono>
 #include <cstring>
@@ -268,6 +269,51 @@ int ref_ckks_rotate(size_t logn, size_t L, const u64 *moduli_ext, size_t step, c
 }
 int ref_ckks_conjugate(size_t logn, size_t L, const u64 *moduli_ext, const u64 *ct, const u64 *key, u64 *out) {
     return ref_automorphism(logn, L, moduli_ext, true, 0, ct, key, out);
+}
+
+// encrypt_core (rlwe.cpp:57-72) draws its samples from the library's private RNG, so the same four lines are
+// replayed here on caller-supplied samples with the reference's own operators and transforms
+int ref_rlwe_encrypt_core(size_t logn, size_t L, const u64 *moduli, const int64_t *noise, const u64 *c1, const u64 *pt,
+                          const u64 *sk, u64 *ct) {
+    const size_t n = (size_t)1 << logn;
+    return guarded([&] {
+        RnsPolynomial ex(n, L, mods(moduli, L));
+        for (size_t k = 0; k < L; k++)
+            for (size_t i = 0; i < n; i++) {   // sampling.cpp:77-83
+                u64 coeff = moduli[k] + (u64)noise[i];
+                coeff -= (coeff >= moduli[k]) ? moduli[k] : 0;
+                ex[k][i] = coeff;
+            }
+        ntt_negacyclic_inplace_lazy(ex);                                   // sampling.cpp:86
+        auto c1p = load_poly(n, L, moduli, c1, PolyRepForm::value);
+        auto skp = load_poly(n, L, moduli, sk, PolyRepForm::value);
+        auto c0 = ex - c1p * skp;                                          // rlwe.cpp:52
+        auto pt_ntt = load_poly(n, L, moduli, pt, PolyRepForm::coeff);
+        ntt_negacyclic_inplace_lazy(pt_ntt);                               // rlwe.cpp:66-67
+        c0 += pt_ntt;                                                      // rlwe.cpp:70
+        store_poly(c0, ct);
+        store_poly(c1p, ct + L * n);
+    });
+}
+int ref_rlwe_decrypt_core(size_t logn, size_t L, const u64 *moduli, const u64 *ct, const u64 *sk, u64 *pt) {
+    const size_t n = (size_t)1 << logn;
+    return guarded([&] {
+        RlweCt c{load_poly(n, L, moduli, ct, PolyRepForm::value), load_poly(n, L, moduli, ct + L * n, PolyRepForm::value)};
+        RlweSk s(n, L, mods(moduli, L));
+        for (size_t k = 0; k < L; k++) std::memcpy(s[k].data(), sk + k * n, n * sizeof(u64));
+        s.rep_form = PolyRepForm::value;
+        store_poly(decrypt_core(c, s), pt);
+    });
+}
+void ref_rns_base_from_single(size_t n, u64 old_modulus, size_t L, const u64 *new_moduli, const u64 *in, u64 *out) {
+    u64 m = old_modulus;
+    auto p = load_poly(n, 1, &m, in, PolyRepForm::coeff);
+    store_poly(rns_base_transform(p, mods(new_moduli, L)), out);
+}
+int ref_rns_base_to_single_small(size_t n, size_t L, const u64 *old_moduli, u64 new_modulus, const u64 *in, u64 *out) {
+    auto p = load_poly(n, L, old_moduli, in, PolyRepForm::coeff);
+    store_poly(rns_base_transform(p, std::vector<u64>{new_modulus}), out);   // takes the CRT branch by itself when needed
+    return 1;
 }
 
 int ref_bgv_mult_relin_modswitch(size_t logn, size_t L, const u64 *moduli_ext, u64 t,

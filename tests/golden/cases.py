@@ -104,4 +104,12 @@ def run_cases(lib, big: bool = True) -> dict:
         out[f"ckks_conjugate_{tag}"] = summary(lib.ckks_conjugate(mext, ct2, key))
         out[f"ckks_mult_{tag}"] = summary(lib.ckks_mult(mext, ct1, ct2, key))
         out[f"bgv_mult_{tag}"] = summary(lib.bgv_mult(mext, 65537, ct1, ct2, key))
+        # ---- either side of the path ------------------------
+        noise, c1, pt, sk = P.edge_case(rng, logn, q)
+        enc = lib.rlwe_encrypt_core(q, noise, c1, pt, sk)
+        out[f"rlwe_encrypt_core_{tag}"] = summary(enc)
+        out[f"rlwe_decrypt_core_{tag}"] = summary(lib.rlwe_decrypt_core(q, enc, sk))
+        out[f"base_from_single_t65537_{tag}"] = summary(lib.rns_base_from_single(65537, q, rng.words(n, 2 * 65537)))
+        out[f"base_from_single_p_{tag}"] = summary(lib.rns_base_from_single(mext[L], q, rng.words(n, 2 * mext[L])))
+        out[f"base_to_single_t65537_{tag}"] = summary(lib.rns_base_to_single_small(q, 65537, P.small_rns_poly(rng, n, q))[1])
     return out

@@ -42,3 +42,26 @@ C5_P = P40[6]
 C5_MODULI_EXT = C5_Q + [C5_P]
 C5_T = 65537
 C5_BATCH = 4096
+
+
+def edge_case(rng, logn, moduli):
+    """Inputs for the functions either side of the path, from one splitmix64 stream:
+    noise int64[N] in [-19, 19] (6 sigma of the reference's sigma = 3.2), c1 / sk uniform NTT-form words,
+    pt uniform coefficient-form words."""
+    import numpy as np
+
+    n, L = 1 << logn, len(moduli)
+    noise = (rng.words(n, 39).astype(np.int64) - 19)
+    c1 = rng.poly((L, n), moduli)
+    pt = rng.poly((L, n), moduli)
+    sk = rng.poly((L, n), moduli)
+    return noise, c1, pt, sk
+
+
+def small_rns_poly(rng, n, moduli, bound=1000):
+    """RNS limbs of a polynomial whose centred coefficients are in (-bound, bound): the small-coefficient case of
+    rns_base_transform_to_single (rns_transform.cpp:45-82)."""
+    import numpy as np
+
+    v = rng.words(n, 2 * bound - 1).astype(np.int64) - (bound - 1)
+    return np.stack([np.where(v >= 0, v, v + int(q)).astype(np.uint64) for q in moduli])

@@ -178,3 +178,41 @@ def test_error_behaviour(eng):
         eng.ntt_([12289], eng.empty((1, 1, 1 << 15)))
     with pytest.raises(InvalidArgument):
         eng.poly_scalar_mul([65537], x, [1, 2])
+
+
+# ---- either side of the path ----------------------------------------------
+@pytest.mark.parametrize("logn,moduli,B", [(3, P.P40[:2], 3), (8, [P.P50[1]] + P.P40[:2], 2), (12, P.P40[:4], 3),
+                                           (13, P.C5_Q, 2), (15, P.C3_Q, 1)])
+def test_dev_encrypt_decrypt_cores(eng, orc, logn, moduli, B):
+    import torch
+
+    rng = SplitMix(700 + logn)
+    cases = [P.edge_case(rng, logn, moduli) for _ in range(B)]
+    sk = cases[0][3]                                             # one secret key for the batch
+    noise = np.stack([c[0] for c in cases]); c1 = np.stack([c[1] for c in cases]); pt = np.stack([c[2] for c in cases])
+    d_noise = torch.from_numpy(noise).to("cuda:0")
+    ct = eng.rlwe_encrypt_core(moduli, d_noise, eng.to_device(c1), eng.to_device(pt), eng.to_device(sk))
+    exp = np.stack([orc.rlwe_encrypt_core(moduli, noise[i], c1[i], pt[i], sk) for i in range(B)])
+    assert np.array_equal(eng.to_host(ct), exp)
+    back = eng.rlwe_decrypt_core(moduli, ct, eng.to_device(sk))
+    assert np.array_equal(eng.to_host(back), np.stack([orc.rlwe_decrypt_core(moduli, exp[i], sk) for i in range(B)]))
+
+
+@pytest.mark.parametrize("n", [8, 4096, 32768])
+def test_dev_rns_base_transforms(eng, orc, n):
+    rng = SplitMix(800 + n)
+    B = 3
+    for old, new in ((65537, P.P40[:3]), (P.P50[0], P.P40[:3]), (P.P40[0], [65537, P.P50[1]])):
+        x = np.stack([rng.words(n, 2 * old) for _ in range(B)])
+        got = eng.to_host(eng.rns_base_from_single(old, new, eng.to_device(x)))
+        assert np.array_equal(got, np.stack([orc.rns_base_from_single(old, new, x[i]) for i in range(B)]))
+    for old, new in ((P.P40[:3], 65537), ([P.P50[0], P.P40[1]], 65537), (P.P40[:2], P.P50[2])):
+        x = np.stack([P.small_rns_poly(rng, n, old) for _ in range(B)])
+        x[1] = rng.poly((len(old), n), old)                      # polynomial 1 is not small: flagged, CRT stays on the host
+        out, flags = eng.rns_base_to_single_small(old, new, eng.to_device(x))
+        flags = flags.cpu().numpy()
+        assert flags[0] == 0 and flags[1] != 0 and flags[2] == 0
+        assert not orc.rns_base_to_single_small(old, new, x[1])[0]
+        for i in (0, 2):
+            ok, exp = orc.rns_base_to_single_small(old, new, x[i])
+            assert ok and np.array_equal(eng.to_host(out)[i], exp)

@@ -177,3 +177,33 @@ def test_c3_shape_single_ct(orc, ref):
     ct2 = rng.poly((2, L, n), mext[:L])
     key = rng.poly((L, 2, L + 1, n), mext)
     assert (orc.ckks_mult(mext, ct1, ct2, key) == ref.ckks_mult(mext, ct1, ct2, key)).all()
+
+
+@pytest.mark.parametrize("logn,moduli", [(3, P.P40[:2]), (8, [P.P50[1]] + P.P40[:2]), (12, P.P40[:4]), (13, P.C5_Q)])
+def test_encrypt_decrypt_cores(orc, ref, logn, moduli):
+    rng = SplitMix(500 + logn)
+    noise, c1, pt, sk = P.edge_case(rng, logn, moduli)
+    ct_o, ct_r = orc.rlwe_encrypt_core(moduli, noise, c1, pt, sk), ref.rlwe_encrypt_core(moduli, noise, c1, pt, sk)
+    assert (ct_o == ct_r).all()
+    back_o, back_r = orc.rlwe_decrypt_core(moduli, ct_o, sk), ref.rlwe_decrypt_core(moduli, ct_o, sk)
+    assert (back_o == back_r).all()
+    # decrypt(encrypt(pt)) = pt + e: the noise comes back as its lift
+    n = 1 << logn
+    for k, q in enumerate(moduli):
+        exp = (pt[k].astype(object) + noise.astype(object)) % q
+        assert (back_o[k].astype(object) == exp).all()
+
+
+@pytest.mark.parametrize("n", [8, 4096])
+def test_rns_base_transforms(orc, ref, n):
+    rng = SplitMix(600 + n)
+    for old, new in ((65537, P.P40[:3]), (P.P50[0], P.P40[:3]), (P.P40[0], [65537, P.P50[1]])):
+        x = rng.words(n, 2 * old)                      # lazy input: rns_transform.cpp:113 reduces it strictly first
+        assert (orc.rns_base_from_single(old, new, x) == ref.rns_base_from_single(old, new, x)).all()
+    for old, new in ((P.P40[:3], 65537), ([P.P50[0], P.P40[1]], 65537), (P.P40[:2], P.P50[2])):
+        x = P.small_rns_poly(rng, n, old)
+        x[0, 0] += np.uint64(old[0])                   # one lazy word
+        ok, got = orc.rns_base_to_single_small(old, new, x)
+        assert ok and (got == ref.rns_base_to_single_small(old, new, x)[1]).all()
+        big = rng.poly((len(old), n), old)             # uniform limbs are not a small polynomial: CRT branch
+        assert not orc.rns_base_to_single_small(old, new, big)[0]
