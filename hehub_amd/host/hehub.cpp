@@ -33,6 +33,7 @@ namespace hehub { namespace amd { hp_ctx *engine(); } }
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <mutex>
 #include <string>
 
@@ -171,6 +172,54 @@ void put_key(u64 *dst, const RgswCt &rgsw, size_t L, size_t n) {
         for (size_t h = 0; h < 2; h++) put_poly(dst + ((j * 2 + h) * (L + 1)) * n, rgsw[j][h], L + 1);
 }
 
+// Device copy of a key-switching key for one call.  A key is 2L(L+1) limbs (55 MiB at N=32768, L=10) and is the same
+// object call after call, so staging it every time dominates the host-pointer path.  With HEHUB_AMD_KEY_CACHE=<entries>
+// the layer keeps up to that many keys resident, recognised by the address of their first limb, their shape and four
+// sampled words of every limb (a key that is modified in place between calls without touching any sampled word would go
+// unnoticed: that is why the cache is opt-in).  Default: no cache, the key is staged per call.
+class DevKey {
+public:
+    DevKey(const RgswCt &rgsw, size_t L, size_t n) {
+        static const size_t cap = std::getenv("HEHUB_AMD_KEY_CACHE") ? (size_t)std::atoi(std::getenv("HEHUB_AMD_KEY_CACHE")) : 0;
+        const size_t words = L * 2 * (L + 1) * n;
+        if (cap == 0) {
+            own_.reset(new DevBuf(words));
+            put_key(own_->p, rgsw, L, n);
+            p_ = own_->p;
+            return;
+        }
+        std::vector<u64> sig{(u64)(uintptr_t)rgsw[0][0][0].data(), (u64)L, (u64)n};
+        for (size_t j = 0; j < L; j++)
+            for (size_t h = 0; h < 2; h++)
+                for (size_t k = 0; k <= L; k++) {
+                    const u64 *w = rgsw[j][h][(int)k].data();
+                    sig.insert(sig.end(), {w[0], w[n / 3], w[(2 * n) / 3], w[n - 1]});
+                }
+        static std::mutex mu;
+        static std::vector<std::pair<std::vector<u64>, std::shared_ptr<DevBuf>>> cache;   // most recently used last
+        std::lock_guard<std::mutex> lock(mu);
+        for (size_t i = 0; i < cache.size(); i++)
+            if (cache[i].first == sig) {
+                auto hit = cache[i];
+                cache.erase(cache.begin() + i);
+                cache.push_back(hit);
+                own_ = hit.second;
+                p_ = own_->p;
+                return;
+            }
+        own_.reset(new DevBuf(words));
+        put_key(own_->p, rgsw, L, n);
+        p_ = own_->p;
+        if (cache.size() >= cap) cache.erase(cache.begin());
+        cache.emplace_back(std::move(sig), own_);
+    }
+    const u64 *p() const { return p_; }
+
+private:
+    std::shared_ptr<DevBuf> own_;
+    u64 *p_ = nullptr;
+};
+
 RlweCt make_ct(size_t n, size_t L, const std::vector<u64> &moduli, const u64 *src) {
     RlweCt ct{RnsPolynomial(n, L, moduli), RnsPolynomial(n, L, moduli)};
     for (int h = 0; h < 2; h++) {
@@ -185,12 +234,12 @@ RlweCt relinearize_common(const std::array<RnsPolynomial, 3> &quad, const RlweKs
     std::vector<u64> mext;
     check_ext_prod(quad[2], key, mext);
     const size_t n = quad[2].dimension(), L = quad[2].component_count();
-    DevBuf dq(3 * L * n), dk(L * 2 * (L + 1) * n), dout(2 * L * n);
+    DevBuf dq(3 * L * n), dout(2 * L * n);
+    DevKey dk(key, L, n);
     for (int h = 0; h < 3; h++) put_poly(dq.p + (size_t)h * L * n, quad[h], L);
-    put_key(dk.p, key, L, n);
     const size_t logn = quad[2].log_dimension();
-    if (bgv) check(hp_dev_bgv_relinearize(amd::engine(), logn, L, mext.data(), 1 /* bgv.h:32 */, 1, dq.p, dk.p, dout.p));
-    else check(hp_dev_ckks_relinearize(amd::engine(), logn, L, mext.data(), 1, dq.p, dk.p, dout.p));
+    if (bgv) check(hp_dev_bgv_relinearize(amd::engine(), logn, L, mext.data(), 1 /* bgv.h:32 */, 1, dq.p, dk.p(), dout.p));
+    else check(hp_dev_ckks_relinearize(amd::engine(), logn, L, mext.data(), 1, dq.p, dk.p(), dout.p));
     std::vector<u64> q(mext.begin(), mext.begin() + L);
     return make_ct(n, L, q, dout.p);
 }
@@ -449,10 +498,10 @@ RlweCt ext_prod_montgomery(const RlwePt &pt, const RgswCt &rgsw) {
     std::vector<u64> mext;
     check_ext_prod(pt, rgsw, mext);
     const size_t n = pt.dimension(), L = pt.component_count();
-    DevBuf dp(L * n), dk(L * 2 * (L + 1) * n), dout(2 * (L + 1) * n);
+    DevBuf dp(L * n), dout(2 * (L + 1) * n);
+    DevKey dk(rgsw, L, n);
     put_poly(dp.p, pt, L);
-    put_key(dk.p, rgsw, L, n);
-    check(hp_dev_ext_prod_montgomery(amd::engine(), pt.log_dimension(), L, mext.data(), 1, dp.p, dk.p, dout.p));
+    check(hp_dev_ext_prod_montgomery(amd::engine(), pt.log_dimension(), L, mext.data(), 1, dp.p, dk.p(), dout.p));
     return make_ct(n, L + 1, mext, dout.p);
 }
 
@@ -546,11 +595,11 @@ static CkksCt key_switched(const CkksCt &ct, const RlweKsk &key, bool conj, size
     check_ext_prod(ct[1], key, mext);
     const size_t n = ct[1].dimension(), L = ct[1].component_count(), logn = ct[1].log_dimension();
     if (ct[0].dimension() != n || ct[0].component_count() != L) throw std::invalid_argument("Ill-formed ciphertext.");
-    DevBuf dct(2 * L * n), dk(L * 2 * (L + 1) * n), dout(2 * L * n);
+    DevBuf dct(2 * L * n), dout(2 * L * n);
+    DevKey dk(key, L, n);
     for (int h = 0; h < 2; h++) put_poly(dct.p + (size_t)h * L * n, ct[h], L);
-    put_key(dk.p, key, L, n);
-    if (conj) check(hp_dev_ckks_conjugate(amd::engine(), logn, L, mext.data(), 1, dct.p, dk.p, dout.p));
-    else check(hp_dev_ckks_rotate(amd::engine(), logn, L, mext.data(), 1, step, dct.p, dk.p, dout.p));
+    if (conj) check(hp_dev_ckks_conjugate(amd::engine(), logn, L, mext.data(), 1, dct.p, dk.p(), dout.p));
+    else check(hp_dev_ckks_rotate(amd::engine(), logn, L, mext.data(), 1, step, dct.p, dk.p(), dout.p));
     std::vector<u64> q(mext.begin(), mext.begin() + L);
     CkksCt r = make_ct(n, L, q, dout.p);
     r.scaling_factor = ct.scaling_factor;
