@@ -72,6 +72,12 @@ SIGNATURES = {
     "hp_dev_drop_apply_range": (INT, [P, szt, szt, P, u64, szt, szt, szt, P, P, P, szt, szt, C.c_uint, P]),
     "hp_dev_ckks_mult_relin_rescale": (INT, [P, szt, szt, P, szt, P, P, P, P]),
     "hp_dev_bgv_mult_relin_modswitch": (INT, [P, szt, szt, P, u64, szt, P, P, P, P]),
+    "hp_wire_payload_words": (szt, [P]),
+    "hp_wire_bytes": (szt, [P]),
+    "hp_wire_pack": (INT, [P, P, P, P, szt]),
+    "hp_wire_unpack": (INT, [P, szt, P, P, szt, P]),
+    "hp_dev_wire_load": (INT, [P, P, szt, P]),
+    "hp_dev_wire_store": (INT, [P, P, P, P, P, szt]),
     "hp_prof_begin": (INT, [P, C.c_char_p]),
     "hp_prof_end": (INT, [P, C.POINTER(szt), C.POINTER(C.c_double)]),
 }

@@ -210,6 +210,29 @@ int hp_dev_drop_apply_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *
                             const uint64_t *d_addend, size_t add_poly_stride, size_t add_ct_stride, unsigned add_mask,
                             uint64_t *d_out);
 
+/* ---- wire / on-disk format (hehub itself has none) -------------------------------------
+ * "HEHUBAMD" header + moduli + the words in device order + FNV-1a-64 trailer; the exact byte layout is documented in
+ * hehub_amd/csrc/hp_wire.cpp.  Loading a key or ciphertext is one validation pass and one host-to-device copy. */
+typedef enum { HP_WIRE_POLY = 1, HP_WIRE_CT = 2, HP_WIRE_QUAD_CT = 3, HP_WIRE_KSK = 4 } hp_wire_kind;
+typedef struct {
+    uint32_t kind;           /* hp_wire_kind */
+    uint32_t log_dimension;  /* log2 N */
+    uint32_t limbs;          /* limbs per polynomial (a key: L+1) */
+    uint32_t polys;          /* 1, 2, 3; a key: 2*digits, rgsw[j][half] digit-major */
+    uint32_t rep_form;       /* 0 coefficient, 1 NTT value */
+    uint64_t scheme_scalar;  /* IEEE-754 bits of the CKKS scaling factor / BGV plain modulus / 0 */
+} hp_wire_desc;
+size_t hp_wire_payload_words(const hp_wire_desc *d);   /* 0 for an invalid descriptor */
+size_t hp_wire_bytes(const hp_wire_desc *d);
+/* host words -> buffer, and back (payload_offset: where the words start inside buf) */
+int hp_wire_pack(const hp_wire_desc *d, const uint64_t *moduli, const uint64_t *words, void *buf, size_t cap);
+int hp_wire_unpack(const void *buf, size_t len, hp_wire_desc *d, uint64_t *moduli, size_t moduli_cap,
+                   size_t *payload_offset);
+/* buffer -> device words (validated: magic, version, sizes, checksum), device words -> buffer */
+int hp_dev_wire_load(hp_ctx *ctx, const void *buf, size_t len, uint64_t *d_words);
+int hp_dev_wire_store(hp_ctx *ctx, const hp_wire_desc *d, const uint64_t *moduli, const uint64_t *d_words, void *buf,
+                      size_t cap);
+
 /* ---- in-library kernel timing (HIP events on the ctx stream) -------------- */
 /* Between hp_prof_begin and hp_prof_end every kernel launch of the named
  * family is bracketed by hipEvents on the stream it is launched on.

@@ -113,3 +113,14 @@ def run_cases(lib, big: bool = True) -> dict:
         out[f"base_from_single_p_{tag}"] = summary(lib.rns_base_from_single(mext[L], q, rng.words(n, 2 * mext[L])))
         out[f"base_to_single_t65537_{tag}"] = summary(lib.rns_base_to_single_small(q, 65537, P.small_rns_poly(rng, n, q))[1])
     return out
+
+
+def wire_fixture_case():
+    """inputs of tests/golden/ckks_mult_n8.hehubamd: the "n8" scheme case above"""
+    mext = [1099510054913, 1073479681, 1072496641, 1099507695617]
+    n, L = 8, 3
+    rng = SplitMix(8)
+    ct1 = rng.poly((2, L, n), mext[:L])
+    ct2 = rng.poly((2, L, n), mext[:L])
+    key = rng.poly((L, 2, L + 1, n), mext)
+    return mext, ct1, ct2, key
