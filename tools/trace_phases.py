@@ -1,3 +1,9 @@
+"""Phase timing of the tiled forward NTT from shader-clock stamps (DESIGN.md 4.1 "What bounds it").
+
+Needs the -DHP_TRACE variant of the library (tools/build_variant.sh trace -DHP_TRACE) and a GPU:
+    gpurun -- 'python tools/trace_phases.py'
+Prints the median cycles spent between the phase marks of ntt_fwd_body for the first and the last wave of a
+workgroup, for launches of 1, 3, 24 and 256 polynomials at the C3 transform shape."""
 import ctypes as C, numpy as np, os, sys
 sys.path.insert(0,'.'); sys.path.insert(0,'tests')
 os.environ["HEHUB_AMD_LIB"]=os.path.abspath("hehub_amd/lib_variants/libhehub_amd_trace.so")
