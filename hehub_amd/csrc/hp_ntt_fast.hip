@@ -355,6 +355,16 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
     HpItem it;
     if (!hp_decode_item(job, w, it)) return;
     stagger_start(job);
+#ifdef HP_PRIO_SKEW
+    // experiment: the four waves that share a SIMD get different issue priorities so that they drift apart after
+    // the one workgroup-wide exchange and overlap each other's LDS / memory phases with integer multiplies
+    switch ((threadIdx.x >> 8) & 3u) {
+    case 0: __builtin_amdgcn_s_setprio(HP_PRIO_SKEW == 2 ? 0 : 3); break;
+    case 1: __builtin_amdgcn_s_setprio(HP_PRIO_SKEW == 2 ? 3 : 2); break;
+    case 2: __builtin_amdgcn_s_setprio(HP_PRIO_SKEW == 2 ? 0 : 1); break;
+    default: __builtin_amdgcn_s_setprio(HP_PRIO_SKEW == 2 ? 3 : 0); break;
+    }
+#endif
     const HpLimb *lp = job.limbs + it.limb;
     const u64 q = lp->q, two_q = lp->two_q, nq = lp->neg_q;
     const u32 tid = threadIdx.x;
@@ -511,6 +521,16 @@ __global__ void HP_NTT_VGPR_ATTR __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW
     HpItem it;
     if (!hp_decode_item(job, w, it)) return;
     stagger_start(job);
+#ifdef HP_PRIO_SKEW
+    // experiment: the four waves that share a SIMD get different issue priorities so that they drift apart after
+    // the one workgroup-wide exchange and overlap each other's LDS / memory phases with integer multiplies
+    switch ((threadIdx.x >> 8) & 3u) {
+    case 0: __builtin_amdgcn_s_setprio(HP_PRIO_SKEW == 2 ? 0 : 3); break;
+    case 1: __builtin_amdgcn_s_setprio(HP_PRIO_SKEW == 2 ? 3 : 2); break;
+    case 2: __builtin_amdgcn_s_setprio(HP_PRIO_SKEW == 2 ? 0 : 1); break;
+    default: __builtin_amdgcn_s_setprio(HP_PRIO_SKEW == 2 ? 3 : 0); break;
+    }
+#endif
     const HpLimb *lp = job.limbs + it.limb;
     const u64 q = lp->q, two_q = lp->two_q, nq = lp->neg_q;
     const u32 tid = threadIdx.x;
