@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="ckks", choices=["ckks", "ntt", "ntt15", "intt", "intt15", "bgv", "rotate", "ckks-limb", "encdec"])
+    ap.add_argument("--workload", default="ckks", choices=["ckks", "ntt", "ntt15", "intt", "intt15", "bgv", "rotate", "ckks-limb", "encdec", "mul", "add"])
     ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (0 = BASELINE config value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")
@@ -68,6 +68,17 @@ def cpu_baseline(workload, P, budget_s):
     kind = "reference" if have_ref() else "port"
     lib = Oracle("ref" if kind == "reference" else "orc")
     rng = SplitMix(3)
+    if workload in ("mul", "add"):
+        q, n = P.C2_MODULI[0], 1 << P.C2_LOGN
+        a, b = rng.words(n, q), rng.words(n, q)
+        f = (lambda: lib.mul_hybrid_lazy(q, a, b)) if workload == "mul" else (lambda: lib.poly_add([q], a[None], b[None]))
+        f()
+        iters, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            f(); iters += 1
+        per = (time.perf_counter() - t0) / iters
+        return {"value": 1.0 / per, "unit": "limb-op/s", "cores": 1, "kind": kind,
+                "sample": f"{iters} x one-limb {workload}, N={n}, q={q}, single thread (includes the ctypes call and one result allocation)"}
     if "ntt" in workload:
         logn, q = (P.C3_LOGN, P.C3_P) if workload.endswith("15") else (P.C2_LOGN, P.C2_MODULI[0])
         inv = int(workload.startswith("intt"))
@@ -175,6 +186,23 @@ def main():
         metric, unit = "limb_ntt_per_s", "limb-NTT/s"
         cfg = {"workload": f"{'C2' if logn == 14 else 'C3-shape'}: batched {'inverse' if inverse else 'forward'} negacyclic NTT, N={n}, {L} RNS limbs, batch={B} polynomials per GPU",
                "N": n, "limbs": L, "batch_per_gpu": B}
+    elif wl in ("mul", "add"):
+        # coefficient-wise kernels at the C2 shape: RnsPolynomial operator* (hybrid Montgomery+Harvey product,
+        # rns.cpp:120-140) / operator+= (rns.cpp:58-87); 24*N algorithmic bytes per limb
+        logn, moduli = P.C2_LOGN, P.C2_MODULI
+        B = args.batch or P.C2_BATCH
+        n, L = 1 << logn, len(moduli)
+        a = rand_words(torch, (B, L, n), moduli, dev, 21 + rank)
+        b = rand_words(torch, (B, L, n), moduli, dev, 22 + rank)
+        out = eng.empty((B, L, n))
+        units_per_step = B * L
+        step = (lambda: eng.poly_mul(moduli, a, b, out=out)) if wl == "mul" else (lambda: eng.poly_add(moduli, a, b, out=out))
+        family = "elem"
+        alg_bytes_per_step = 24.0 * n * B * L
+        launches_per_step = 1
+        metric, unit = f"limb_{wl}_per_s", "limb-op/s"
+        cfg = {"workload": f"C2 shape: coefficient-wise modular {'multiply' if wl == 'mul' else 'add'}, N={n}, {L} RNS limbs, batch={B} polynomials per GPU",
+               "N": n, "limbs": L, "batch_per_gpu": B}
     elif wl == "encdec":
         # either side of the path: encrypt_core on caller-supplied samples, then decrypt_core
         logn, moduli = P.C3_LOGN, P.C3_Q
@@ -269,7 +297,9 @@ def main():
         bytes_per_launch = alg_bytes_per_step * args.steps / launches
         avg_s = kern_ms * 1e-3 / launches
         achieved = bytes_per_launch / avg_s / 1e9
-        res["roofline"] = {"bound": "hbm", "kernel": "k_ntt_inv (register/LDS-tiled inverse NTT)" if family == "intt" else "k_ntt_fwd (register/LDS-tiled forward NTT)",
+        kname = {"intt": "k_ntt_inv (register/LDS-tiled inverse NTT)", "elem": "k_poly_binary (coefficient-wise)"}.get(
+            family, "k_ntt_fwd (register/LDS-tiled forward NTT)")
+        res["roofline"] = {"bound": "hbm", "kernel": kname,
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": None, "launches": launches, "avg_launch_ms": kern_ms / launches,
                            "algorithmic_bytes_per_launch": bytes_per_launch,
