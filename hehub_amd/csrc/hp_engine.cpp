@@ -56,6 +56,10 @@ struct hp_ctx {
     // two auxiliary streams for software-pipelined sub-batches (dev_mult)
     hipStream_t aux[2] = {nullptr, nullptr};
     hipEvent_t ev_start = nullptr, ev_done[2] = {nullptr, nullptr};
+    // tuning / A-B knobs, read from the environment once when the context is created
+    bool no_fused_drop = false;   // HP_NO_FUSED_DROP: separate drop_rem / NTT / drop_fin launches
+    int mult_streams = 1;         // HP_MULT_STREAMS=2: software-pipeline two sub-batches in dev_mult
+    size_t mult_chunk = 0;        // HP_MULT_CHUNK: sub-batch size of dev_mult (0 = whole batch, or half with 2 streams)
 };
 
 namespace {
@@ -377,7 +381,7 @@ int drop_apply(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, 
     if (addend) addend += k0 * n;
     int rc;
     // tiled sizes: Barrett + centring fused into the remainder NTT's loads, (x - rem)*inv [+ addend] into its stores
-    if (!ctx->force_generic && logn >= 11 && logn <= 15 && !getenv("HP_NO_FUSED_DROP")) {
+    if (!ctx->force_generic && logn >= 11 && logn <= 15 && !ctx->no_fused_drop) {
         HpNttJob fj = batch_job(plan, logn, kc, P2, clast, nullptr, 1, 0, 0, 0);
         fj.limbs = limbs;
         fj.src_kstride = 0;
@@ -486,6 +490,9 @@ int hp_ctx_create(int device, hp_ctx **out) {
         return HP_EHIP;
     }
     c->stream = c->own_stream;
+    c->no_fused_drop = getenv("HP_NO_FUSED_DROP") != nullptr;
+    if (const char *e = getenv("HP_MULT_STREAMS")) c->mult_streams = atoi(e) >= 2 ? 2 : 1;
+    if (const char *e = getenv("HP_MULT_CHUNK")) c->mult_chunk = (size_t)atol(e);
     *out = c;
     return HP_OK;
 }
@@ -835,13 +842,9 @@ static int dev_mult(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_e
     // but concurrent launches make per-kernel timings (hp_prof_*, rocprofv3) overlap, so the default keeps one
     // stream and one sub-batch and every reported kernel duration is that of a kernel running alone.
     size_t chunk = batch;
-    if (const char *e = getenv("HP_MULT_STREAMS")) if (atoi(e) >= 2 && batch >= 2) chunk = (batch + 1) / 2;
-    if (const char *e = getenv("HP_MULT_CHUNK")) {
-        size_t c = (size_t)atol(e);
-        if (c > 0) chunk = c < batch ? c : batch;
-    }
-    size_t nstreams = (chunk < batch) ? 2 : 1;
-    if (const char *e = getenv("HP_MULT_STREAMS")) nstreams = (atoi(e) >= 2 && chunk < batch) ? 2 : 1;
+    if (ctx->mult_streams >= 2 && batch >= 2) chunk = (batch + 1) / 2;
+    if (ctx->mult_chunk > 0) chunk = ctx->mult_chunk < batch ? ctx->mult_chunk : batch;
+    const size_t nstreams = (ctx->mult_streams >= 2 && chunk < batch) ? 2 : 1;
     const size_t chunk_words = padded(chunk * 3 * L * n) / 8 + padded(chunk * 2 * L * n) / 8 + relin_ws_words(n, L, chunk) +
                                drop_ws_words(n, L, 2 * chunk);
     if ((rc = ws_reserve(ctx, nstreams * chunk_words * 8))) return rc;
