@@ -280,6 +280,10 @@ HP_DEV void exchange(u64 (&x)[32], u32 *lds, const Addr<LOGN> &ad) {
     }
 }
 
+#ifndef HP_EPI_DEPTH
+#define HP_EPI_DEPTH 4   // rows of the fused drop epilogue whose operand loads are in flight
+#endif
+
 struct alignas(16) V2 {
     u64 x, y;
 };
@@ -478,9 +482,27 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
         const u64 inv = da->dc.inv[k], invh = da->dc.inv_h[k], ql = da->dc.qlt[k], qlh = da->dc.qlt_h[k];
         const bool bgv = da->dc.bgv != 0;
         const u32 n0 = (u32)nq, n1 = (u32)(nq >> 32);
+        // The 16 rows are software-pipelined by hand: the operand loads run EPI_DEPTH rows ahead of their use (ring in
+        // registers, the twiddle ring is dead by now), otherwise every row waits for its own two loads with
+        // vmcnt(0) -- which also drains the stores of the previous row -- and the epilogue costs 32 exposed round trips.
+        constexpr int EPI_DEPTH = HP_EPI_DEPTH;
+        V2 xr[EPI_DEPTH], ar[EPI_DEPTH];
+#pragma unroll
+        for (int s = 0; s < EPI_DEPTH; ++s) {
+            xr[s] = ld_stream(xs + ((size_t)s << 7));
+            if (as) ar[s] = ld_stream(as + ((size_t)s << 7));
+        }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const V2 xv = ld_stream(xs + ((size_t)s << 7));
+            const V2 xv = xr[s % EPI_DEPTH];
+            V2 av{0, 0};
+            if (as) av = ar[s % EPI_DEPTH];
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + EPI_DEPTH < 16) {
+                xr[s % EPI_DEPTH] = ld_stream(xs + ((size_t)(s + EPI_DEPTH) << 7));
+                if (as) ar[s % EPI_DEPTH] = ld_stream(as + ((size_t)(s + EPI_DEPTH) << 7));
+            }
+            __builtin_amdgcn_sched_barrier(0);
             u64 v0 = hp_harvey_lazy_nq(hp_sub_lazy(xv.x, x[2 * s], two_q), inv, invh, n0, n1);
             u64 v1 = hp_harvey_lazy_nq(hp_sub_lazy(xv.y, x[2 * s + 1], two_q), inv, invh, n0, n1);
             if (bgv) {
@@ -488,7 +510,6 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
                 v1 = hp_harvey_lazy_nq(v1, ql, qlh, n0, n1);
             }
             if (as) {
-                const V2 av = ld_stream(as + ((size_t)s << 7));
                 v0 = hp_add_lazy(v0, av.x, two_q);
                 v1 = hp_add_lazy(v1, av.y, two_q);
             }
