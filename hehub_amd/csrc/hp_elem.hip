@@ -283,17 +283,59 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner(const HpLimb *__restr
 // Same sums, PT ciphertexts per thread: the 2L key words of a (k, i) pair are loaded once and multiplied into PT
 // ciphertexts' accumulators, so the key traffic through L2 / Infinity Cache (2L of the 3L+2 words per (p,k,i) above)
 // drops by PT.  n is even for every supported ring (N >= 2) and chunks are even-sized: always two words per lane.
+// The digit loop is branch-free (a ragged last group re-reads its last ciphertext and skips the store) and
+// double-buffered by hand: the PT + 2 loads of digit j+1 are in flight while digit j is multiplied.
+template <int PT> struct KsRow {
+    U2 g0, g1;
+    U2 d[PT];
+};
+
+template <int PT>
+HP_DEV void ks_load(KsRow<PT> &r, u32 j, u32 k, u32 L, u32 Le, u32 n, u32 i, const u32 (&pc)[PT], const u64 *digits,
+                    const u64 *pt, u32 pt_pstride, const u64 *key) {
+    typedef u64 __attribute__((ext_vector_type(2))) vv;
+    r.g0 = *reinterpret_cast<const U2 *>(key + (((size_t)j * 2 + 0) * Le + k) * n + i);
+    r.g1 = *reinterpret_cast<const U2 *>(key + (((size_t)j * 2 + 1) * Le + k) * n + i);
+#pragma unroll
+    for (int c = 0; c < PT; c++) {
+        const u64 *d = (j == k) ? pt + ((size_t)pc[c] * pt_pstride + j) * n : digits + (((size_t)pc[c] * L + j) * Le + k) * n;
+        // digits are read exactly once: non-temporal, so they do not evict the key column from L2
+        const vv t = __builtin_nontemporal_load(reinterpret_cast<const vv *>(d + i));
+        r.d[c].x = t.x;
+        r.d[c].y = t.y;
+    }
+}
+
+template <int PT> HP_DEV void ks_mac(const KsRow<PT> &r, u64 (&al)[PT][2][2], u64 (&ah)[PT][2][2]) {
+    const u64 kw[2][2] = {{r.g0.x, r.g0.y}, {r.g1.x, r.g1.y}};
+#pragma unroll
+    for (int c = 0; c < PT; c++) {
+        const u64 dv[2] = {r.d[c].x, r.d[c].y};
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                u64 lo, hi;
+                hp_mul128(dv[e], kw[h][e], lo, hi);
+                al[c][h][e] += lo;
+                ah[c][h][e] += hi + (al[c][h][e] < lo ? 1ull : 0ull);
+            }
+    }
+}
+
 template <int PT>
 __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner_blk(const HpLimb *__restrict__ limbs, u32 L, u32 k_first, u32 P,
                                                               u32 n, u32 chunks, const u64 *__restrict__ digits,
                                                               const u64 *__restrict__ pt, u32 pt_pstride,
                                                               const u64 *__restrict__ key, u64 *__restrict__ out) {
-    typedef u64 __attribute__((ext_vector_type(2))) vv;
     const u32 Le = L + 1;
     const u32 PG = (P + PT - 1) / PT;
     const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
     const u32 k = k_first + row / PG, p0 = (row % PG) * PT;
     const u64 q = limbs[k].q, mqinv = limbs[k].mqinv;
+    u32 pc[PT];
+#pragma unroll
+    for (int c = 0; c < PT; c++) pc[c] = min(p0 + c, P - 1);
     const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
     for (u32 i = chunk * ELEM_CHUNK + threadIdx.x * 2; i < end; i += ELEM_THREADS * 2) {
         u64 al[PT][2][2], ah[PT][2][2];   // [ciphertext][half][word]
@@ -301,29 +343,16 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner_blk(const HpLimb *__r
         for (int c = 0; c < PT; c++)
 #pragma unroll
             for (int h = 0; h < 2; h++) al[c][h][0] = al[c][h][1] = ah[c][h][0] = ah[c][h][1] = 0;
-        for (u32 j = 0; j < L; j++) {
-            const U2 g0 = *reinterpret_cast<const U2 *>(key + (((size_t)j * 2 + 0) * Le + k) * n + i);
-            const U2 g1 = *reinterpret_cast<const U2 *>(key + (((size_t)j * 2 + 1) * Le + k) * n + i);
-            const u64 kw[2][2] = {{g0.x, g0.y}, {g1.x, g1.y}};
-#pragma unroll
-            for (int c = 0; c < PT; c++) {
-                const u32 p = p0 + c;
-                if (p < P) {   // uniform per workgroup
-                    const u64 *d = (j == k) ? pt + ((size_t)p * pt_pstride + j) * n : digits + (((size_t)p * L + j) * Le + k) * n;
-                    const vv dvv = __builtin_nontemporal_load(reinterpret_cast<const vv *>(d + i));
-                    const u64 dv[2] = {dvv.x, dvv.y};
-#pragma unroll
-                    for (int h = 0; h < 2; h++)
-#pragma unroll
-                        for (int e = 0; e < 2; e++) {
-                            u64 lo, hi;
-                            hp_mul128(dv[e], kw[h][e], lo, hi);
-                            al[c][h][e] += lo;
-                            ah[c][h][e] += hi + (al[c][h][e] < lo ? 1ull : 0ull);
-                        }
-                }
-            }
+        KsRow<PT> ra, rb;
+        ks_load<PT>(ra, 0, k, L, Le, n, i, pc, digits, pt, pt_pstride, key);
+        u32 j = 0;
+        for (; j + 2 <= L; j += 2) {
+            ks_load<PT>(rb, j + 1, k, L, Le, n, i, pc, digits, pt, pt_pstride, key);
+            ks_mac<PT>(ra, al, ah);
+            ks_load<PT>(ra, min(j + 2, L - 1), k, L, Le, n, i, pc, digits, pt, pt_pstride, key);   // last: harmless re-read
+            ks_mac<PT>(rb, al, ah);
         }
+        if (j < L) ks_mac<PT>(ra, al, ah);
 #pragma unroll
         for (int c = 0; c < PT; c++) {
             const u32 p = p0 + c;
