@@ -298,7 +298,9 @@ int ks_digits_inner(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t
     HpNttJob sj;
     memset(&sj, 0, sizeof(sj));
     sj.limbs = plan->d_limbs; sj.src = coef; sj.dst = digits; sj.logn = (u32)logn; sj.L = (u32)L; sj.P = (u32)P;
-    sj.k_first = (u32)k0; sj.W = (u32)((k1 - k0) * P * L); sj.mode = HP_NTT_SPREAD;
+    // items: (L-1)*P per modulus k < L (the diagonal digit is not transformed), L*P for the special prime k = L
+    const size_t n_lo = (k1 < L ? k1 : L) - (k0 < L ? k0 : L);
+    sj.k_first = (u32)k0; sj.W = (u32)(n_lo * (L - 1) * P + (k1 > L ? L * P : 0)); sj.mode = HP_NTT_SPREAD;
     if ((rc = run_ntt(ctx, sj))) return rc;
     // (iii) u128 inner product + Montgomery                         rgsw.cpp:121-153
     {

@@ -11,9 +11,10 @@
 // table; hp_xcd_remap() then gives each XCD a contiguous slice of them.
 enum HpNttMode : int {
     HP_NTT_BATCH = 0,   // rows [P][L][N]: item w = k*P + p         -> src/dst row p*L + k, limb k
-    HP_NTT_SPREAD = 1,  // digit spread (rgsw.cpp:108-119): item w = k*(P*L) + p*L + j, k in [0,L]:
-                        //   src = coef row p*L + j, dst = digit row (p*L + j)*(L+1) + k, limb k; k == j is skipped;
-                        //   a launch may cover only k in [k_first, k_first + W/(P*L))
+    HP_NTT_SPREAD = 1,  // digit spread (rgsw.cpp:108-119): one item per (k, j != k, p), k in [0,L], numbered modulus-major
+                        //   then digit then polynomial without holes (hp_ntt_job.h): src = coef row p*L + j,
+                        //   dst = digit row (p*L + j)*(L+1) + k, limb k; a launch may cover only the moduli
+                        //   k_first .. k_first + kc - 1 (W = their item count)
 };
 
 struct HpNttJob {
@@ -27,7 +28,7 @@ struct HpNttJob {
     u32 dst_pstride;  // HP_NTT_BATCH: same for dst
     u32 src_kstride;  // HP_NTT_BATCH: rows between consecutive limbs of src (1; 0 = every limb reads the same row)
     u32 W;          // work items
-    u32 k_first;    // HP_NTT_SPREAD: first output modulus of the launch (items cover k_first .. k_first + W/(P*L) - 1)
+    u32 k_first;    // HP_NTT_SPREAD: first output modulus of the launch
     int mode;
     int inverse;
     int strict;     // inverse only: reduce_strict epilogue (ntt.h:88-92)
