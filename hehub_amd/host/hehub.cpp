@@ -505,7 +505,6 @@ RlweCt ext_prod_montgomery(const RlwePt &pt, const RgswCt &rgsw) {
     return make_ct(n, L + 1, mext, dout.p);
 }
 
-#ifdef HEHUB_AMD_BIND_REFERENCE
 // rlwe.h decrypt_core (rlwe.cpp:74-81): `c0 + c1 * sk`, INTT, reduce_strict as ONE device call instead of 3L host
 // round trips; the argument checks are the ones the reference's operator* / operator+ perform, in their order.
 RlwePt decrypt_core(const RlweCt &ct, const RlweSk &sk) {
@@ -534,6 +533,37 @@ RlwePt decrypt_core(const RlweCt &ct, const RlweSk &sk) {
     get_poly(pt, dpt.p, L);
     return pt;
 }
+
+#ifndef HEHUB_AMD_BIND_REFERENCE
+// rns_transform.cpp:106-127 with :11-37 and the small-coefficient branch of :39-84 on the device
+RnsPolynomial rns_base_transform(RnsPolynomial in, const std::vector<u64> &new_moduli) {
+    if (in.rep_form == PolyRepForm::value)
+        throw std::logic_error("Trying to perform RNS base transformation on NTT values.");
+    const size_t n = in.dimension(), L = in.component_count();
+    if (L == 1) {
+        RnsPolynomial out(n, new_moduli.size(), new_moduli);
+        if (new_moduli.empty()) return out;
+        DevBuf din(n), dout(new_moduli.size() * n);
+        put_poly(din.p, in, 1);
+        check(hp_dev_rns_base_from_single(amd::engine(), n, in.modulus_at(0), new_moduli.size(), new_moduli.data(), 1, din.p, dout.p));
+        get_poly(out, dout.p, new_moduli.size());
+        return out;
+    }
+    if (new_moduli.size() == 1) {
+        RnsPolynomial out(n, 1, new_moduli);
+        DevBuf din(L * n), dout(n), dflag(1);
+        put_poly(din.p, in, L);
+        check(hp_dev_rns_base_to_single_small(amd::engine(), n, L, in.modulus_vec().data(), new_moduli[0], 1, din.p, dout.p,
+                                              reinterpret_cast<uint32_t *>(dflag.p)));
+        u64 flag = 0;
+        check(hp_memcpy_d2h(amd::engine(), &flag, dflag.p, sizeof(uint32_t)));
+        if ((uint32_t)flag != 0)
+            throw std::logic_error("hehub_amd: CRT composition of large coefficients (rns_transform.cpp:86-104) is not part of this layer");
+        get_poly(out, dout.p, 1);
+        return out;
+    }
+    throw "under development";   // rns_transform.cpp:123
+}
 #endif
 
 // =====================================================================================================
@@ -557,6 +587,32 @@ CkksCt sub(const CkksCt &a, const CkksCt &b) {
     check_scaling_factor(a.scaling_factor, b.scaling_factor);
     CkksCt r = ::hehub::sub((const RlweCt &)a, (const RlweCt &)b);
     r.scaling_factor = a.scaling_factor;
+    return r;
+}
+
+CkksCt add_plain(const CkksCt &ct, const CkksPt &pt) {   // ckks/arith.cpp:22-29
+    check_scaling_factor(ct.scaling_factor, pt.scaling_factor);
+    RnsPolynomial pt_ntt(pt);
+    ntt_negacyclic_inplace_lazy(pt_ntt);
+    CkksCt r = add_plain_core(ct, pt_ntt);
+    r.scaling_factor = ct.scaling_factor;
+    return r;
+}
+
+CkksCt sub_plain(const CkksCt &ct, const CkksPt &pt) {   // ckks/arith.cpp:38-45
+    check_scaling_factor(ct.scaling_factor, pt.scaling_factor);
+    RnsPolynomial pt_ntt(pt);
+    ntt_negacyclic_inplace_lazy(pt_ntt);
+    CkksCt r = sub_plain_core(ct, pt_ntt);
+    r.scaling_factor = ct.scaling_factor;
+    return r;
+}
+
+CkksCt mult_plain(const CkksCt &ct, const CkksPt &pt) {   // ckks/arith.cpp:47-53
+    RnsPolynomial pt_ntt(pt);
+    ntt_negacyclic_inplace_lazy(pt_ntt);
+    CkksCt r = mult_plain_core(ct, pt_ntt);
+    r.scaling_factor = ct.scaling_factor * pt.scaling_factor;
     return r;
 }
 #endif
@@ -629,6 +685,30 @@ BgvCt sub(const BgvCt &a, const BgvCt &b) {
     if (a.plain_modulus != b.plain_modulus) throw std::invalid_argument("Plain moduli mismatch.");
     BgvCt r = ::hehub::sub((const RlweCt &)a, (const RlweCt &)b);
     r.plain_modulus = a.plain_modulus;
+    return r;
+}
+
+// bgv/arith.cpp:17-57: the plaintext (one component modulo t) is lifted into the ciphertext's moduli, transformed
+// and combined with the RLWE core operation
+static RnsPolynomial lift_plain(const BgvCt &ct, const BgvPt &pt) {
+    if (pt.component_count() != 1 || pt.modulus_at(0) != ct.plain_modulus) throw std::invalid_argument("plain moduli mismatch.");
+    auto lifted = rns_base_transform(pt, ct[0].modulus_vec());
+    ntt_negacyclic_inplace_lazy(lifted);
+    return lifted;
+}
+BgvCt add_plain(const BgvCt &ct, const BgvPt &pt) {
+    BgvCt r = ::hehub::add_plain_core(ct, lift_plain(ct, pt));
+    r.plain_modulus = ct.plain_modulus;
+    return r;
+}
+BgvCt sub_plain(const BgvCt &ct, const BgvPt &pt) {
+    BgvCt r = ::hehub::sub_plain_core(ct, lift_plain(ct, pt));
+    r.plain_modulus = ct.plain_modulus;
+    return r;
+}
+BgvCt mult_plain(const BgvCt &ct, const BgvPt &pt) {
+    BgvCt r = ::hehub::mult_plain_core(ct, lift_plain(ct, pt));
+    r.plain_modulus = ct.plain_modulus;
     return r;
 }
 #endif

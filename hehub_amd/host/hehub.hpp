@@ -154,6 +154,15 @@ RlweCt sub(const RlweCt &ct1, const RlweCt &ct2);
 RlweCt add_plain_core(const RlweCt &ct, const RlwePt &pt);
 RlweCt sub_plain_core(const RlweCt &ct, const RlwePt &pt);
 RlweCt mult_plain_core(const RlweCt &ct, const RlwePt &pt);
+struct RlweSk : public RnsPolynomial {   // rlwe.h:34 (sampling the key is the caller's business here)
+    using RnsPolynomial::RnsPolynomial;
+    RlweSk() {}
+    RlweSk(RnsPolynomial &&p) : RnsPolynomial(std::move(p)) {}
+};
+RlwePt decrypt_core(const RlweCt &ct, const RlweSk &sk);   // rlwe.cpp:74-81
+// rns_transform.h: one modulus -> many, and many -> one for small coefficients; the BigInt CRT branch of the
+// reference (rns_transform.cpp:86-104) is not part of this layer and throws std::logic_error
+RnsPolynomial rns_base_transform(RnsPolynomial input_rns_poly, const std::vector<u64> &new_moduli);
 
 using RgswCt = std::vector<RlweCt>;
 struct RlweKsk : public RgswCt {
@@ -174,8 +183,17 @@ struct CkksCt : public RlweCt {
 struct CkksQuadraticCt : public std::array<RnsPolynomial, 3> {
     double scaling_factor = 1.0;
 };
+struct CkksPt : public RlwePt {   // ckks.h:58-67
+    using RlwePt::RlwePt;
+    CkksPt() {}
+    CkksPt(RlwePt &&other) : RlwePt(std::move(other)) {}
+    double scaling_factor = 1.0;
+};
 CkksCt add(const CkksCt &ct1, const CkksCt &ct2);
 CkksCt sub(const CkksCt &ct1, const CkksCt &ct2);
+CkksCt add_plain(const CkksCt &ct, const CkksPt &pt);
+CkksCt sub_plain(const CkksCt &ct, const CkksPt &pt);
+CkksCt mult_plain(const CkksCt &ct, const CkksPt &pt);
 CkksQuadraticCt mult_low_level(const CkksCt &ct1, const CkksCt &ct2);
 CkksCt relinearize(const CkksQuadraticCt &ct, const RlweKsk &relin_key);
 inline CkksCt mult(const CkksCt &ct1, const CkksCt &ct2, const RlweKsk &relin_key) {
@@ -198,8 +216,12 @@ struct BgvCt : public RlweCt {
 struct BgvQuadraticCt : public std::array<RnsPolynomial, 3> {
     u64 plain_modulus = 1;
 };
+using BgvPt = RlwePt;   // bgv.h:18: one component modulo the plain modulus
 BgvCt add(const BgvCt &ct1, const BgvCt &ct2);
 BgvCt sub(const BgvCt &ct1, const BgvCt &ct2);
+BgvCt add_plain(const BgvCt &ct, const BgvPt &pt);
+BgvCt sub_plain(const BgvCt &ct, const BgvPt &pt);
+BgvCt mult_plain(const BgvCt &ct, const BgvPt &pt);
 BgvQuadraticCt mult_low_level(const BgvCt &ct1, const BgvCt &ct2);
 BgvCt relinearize(const BgvQuadraticCt &ct, const RlweKsk &relin_key);
 void mod_switch_inplace(BgvCt &ct, size_t dropping_primes = 1);

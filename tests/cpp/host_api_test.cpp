@@ -272,6 +272,107 @@ static void test_scheme_level_vs_oracle() {   // raw lazy words of ckks::mult+re
     REQUIRE_THROWS_AS(ckks::add(a, b), std::invalid_argument);
 }
 
+static void test_plain_ops_and_decrypt_core() {   // ckks/arith.cpp:22-53, bgv/arith.cpp:17-57, rlwe.cpp:74-81, rns_transform.cpp
+    const size_t logn = 9, N = 1 << logn, L = 3;
+    std::vector<u64> q{1099510054913ull, 1099507695617ull, 1099506515969ull};
+    ckks::CkksCt ct;
+    for (int h = 0; h < 2; h++) {
+        ct[h] = RnsPolynomial(N, L, q);
+        for (size_t k = 0; k < L; k++) for (auto &w : ct[h][(int)k]) w = rnd() % q[k];
+        ct[h].rep_form = PolyRepForm::value;
+    }
+    ct.scaling_factor = 1024.0;
+    ckks::CkksPt pt(N, L, q);
+    for (size_t k = 0; k < L; k++) for (auto &w : pt[(int)k]) w = rnd() % q[k];
+    pt.rep_form = PolyRepForm::coeff;
+    pt.scaling_factor = 1024.0;
+    std::vector<u64> c0, c1, ptn;
+    flatten(ct[0], c0); flatten(ct[1], c1); flatten(pt, ptn);
+    REQUIRE(orc_poly_ntt(logn, L, q.data(), ptn.data()) == 0);
+
+    {   // add_plain / sub_plain touch c0 only; mult_plain multiplies both and the scaling factors
+        auto r = ckks::add_plain(ct, pt);
+        std::vector<u64> exp(c0), got;
+        orc_poly_add_inplace(N, L, q.data(), exp.data(), ptn.data());
+        flatten(r[0], got);
+        REQUIRE(got == exp);
+        got.clear(); flatten(r[1], got);
+        REQUIRE(got == c1);
+        REQUIRE(r.scaling_factor == 1024.0);
+        r = ckks::sub_plain(ct, pt);
+        exp = c0;
+        orc_poly_sub_inplace(N, L, q.data(), exp.data(), ptn.data());
+        got.clear(); flatten(r[0], got);
+        REQUIRE(got == exp);
+        r = ckks::mult_plain(ct, pt);
+        std::vector<u64> e0(L * N), e1(L * N);
+        orc_poly_mul(N, L, q.data(), c0.data(), ptn.data(), e0.data());
+        orc_poly_mul(N, L, q.data(), c1.data(), ptn.data(), e1.data());
+        got.clear(); flatten(r[0], got);
+        REQUIRE(got == e0);
+        got.clear(); flatten(r[1], got);
+        REQUIRE(got == e1);
+        REQUIRE(r.scaling_factor == 1024.0 * 1024.0);
+        ckks::CkksPt other(pt);
+        other.scaling_factor = 3.0;
+        REQUIRE_THROWS_AS(ckks::add_plain(ct, other), std::invalid_argument);
+    }
+    {   // decrypt_core = strict(INTT(c0 + c1*sk))
+        RlweSk sk(N, L, q);
+        for (size_t k = 0; k < L; k++) for (auto &w : sk[(int)k]) w = rnd() % q[k];
+        sk.rep_form = PolyRepForm::value;
+        std::vector<u64> fct(c0), fsk, exp(L * N), got;
+        fct.insert(fct.end(), c1.begin(), c1.end());
+        flatten(sk, fsk);
+        REQUIRE(orc_rlwe_decrypt_core(logn, L, q.data(), fct.data(), fsk.data(), exp.data()) == 0);
+        auto back = decrypt_core(ct, sk);
+        flatten(back, got);
+        REQUIRE(got == exp);
+        REQUIRE(back.rep_form == PolyRepForm::coeff);
+    }
+    {   // BGV: plaintext modulo t lifted into the ciphertext moduli (rns_base_transform one -> many), then as above
+        const u64 t = 65537;
+        bgv::BgvCt bct;
+        bct[0] = ct[0]; bct[1] = ct[1];
+        bct.plain_modulus = t;
+        bgv::BgvPt bpt(N, 1, std::vector<u64>{t});
+        for (auto &w : bpt[0]) w = rnd() % t;
+        bpt.rep_form = PolyRepForm::coeff;
+        std::vector<u64> lifted(L * N);
+        orc_rns_base_from_single(N, t, L, q.data(), bpt[0].data(), lifted.data());
+        REQUIRE(orc_poly_ntt(logn, L, q.data(), lifted.data()) == 0);
+        auto r = bgv::add_plain(bct, bpt);
+        std::vector<u64> exp(c0), got;
+        orc_poly_add_inplace(N, L, q.data(), exp.data(), lifted.data());
+        flatten(r[0], got);
+        REQUIRE(got == exp);
+        REQUIRE(r.plain_modulus == t);
+        r = bgv::mult_plain(bct, bpt);
+        std::vector<u64> e1(L * N);
+        orc_poly_mul(N, L, q.data(), c1.data(), lifted.data(), e1.data());
+        got.clear(); flatten(r[1], got);
+        REQUIRE(got == e1);
+        bgv::BgvPt wrong(N, 1, std::vector<u64>{257});
+        wrong.rep_form = PolyRepForm::coeff;
+        REQUIRE_THROWS_AS(bgv::add_plain(bct, wrong), std::invalid_argument);
+
+        // many -> one: small coefficients come back modulo t; NTT-form input is a logic_error (rns_transform.cpp:108-111)
+        RnsPolynomial small(N, L, q);
+        for (size_t i = 0; i < N; i++) {
+            const long long v = (long long)(rnd() % 2001) - 1000;
+            for (size_t k = 0; k < L; k++) small[(int)k][i] = v >= 0 ? (u64)v : q[k] - (u64)(-v);
+        }
+        small.rep_form = PolyRepForm::coeff;
+        std::vector<u64> fin, exp1(N);
+        flatten(small, fin);
+        REQUIRE(orc_rns_base_to_single_small(N, L, q.data(), t, fin.data(), exp1.data()) == 1);
+        auto one = rns_base_transform(small, std::vector<u64>{t});
+        REQUIRE(std::equal(exp1.begin(), exp1.end(), one[0].begin()));
+        small.rep_form = PolyRepForm::value;
+        REQUIRE_THROWS_AS(rns_base_transform(small, std::vector<u64>{t}), std::logic_error);
+    }
+}
+
 int main() {
     test_batched_barrett();
     test_batched_mul_mod();
@@ -280,6 +381,7 @@ int main() {
     test_rns_polynomial();
     test_ckks_rescaling();
     test_scheme_level_vs_oracle();
+    test_plain_ops_and_decrypt_core();
     std::printf("%s: %d checks, %d failures\n", g_fail ? "FAILED" : "All tests passed", g_checks, g_fail);
     return g_fail ? 1 : 0;
 }
