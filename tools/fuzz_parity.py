@@ -1,0 +1,113 @@
+"""Randomised bit-exact parity sweep on a GPU: random ring sizes, moduli sets, batch sizes and entry points, every
+result compared word for word with the oracle (test infrastructure).    gpurun -- 'python tools/fuzz_parity.py 300'
+Argument: seconds to run (default 120).  Exits non-zero on the first mismatch and prints the case."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import params as P  # noqa: E402
+from hehub_amd.engine import Engine  # noqa: E402
+from hehub_amd.sharded import ShardedMult  # noqa: E402
+from oracle.pyoracle import Oracle, SplitMix  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+orc, eng = Oracle("orc"), Engine(0)
+pool = P.P40 + P.P50          # every list prime supports 2N | q-1 up to N = 32768
+t0, cases, rs = time.time(), 0, np.random.RandomState(seed0)
+hist = {}
+
+
+def check(name, got, exp, **kw):
+    if not np.array_equal(got, exp):
+        print("MISMATCH", name, kw, "first bad index", np.argwhere(got != exp)[:3].tolist())
+        sys.exit(1)
+
+
+while time.time() - t0 < budget:
+    logn = int(rs.choice([1, 2, 3, 5, 8, 10, 11, 12, 13, 14, 15], p=[.04, .04, .05, .07, .1, .1, .15, .15, .12, .1, .08]))
+    n = 1 << logn
+    L = int(rs.randint(1, 7)) if logn < 14 else int(rs.randint(1, 4))
+    B = int(rs.randint(1, 5)) if logn < 13 else int(rs.randint(1, 3))
+    idx = rs.choice(len(pool), L + 1, replace=False)
+    mext = [pool[i] for i in idx]
+    q = mext[:L]
+    rng = SplitMix(int(rs.randint(1, 1 << 30)))
+    kw = dict(logn=logn, L=L, B=B, mext=mext)
+    op = rs.choice(["ntt", "elem", "perm", "mult", "bgv", "rot", "drop", "encdec", "sharded"])
+    if op == "ntt":
+        x = np.stack([rng.poly((L, n), q) for _ in range(B)])
+        d = eng.to_device(x); eng.ntt_(q, d)
+        y = np.stack([orc.poly_ntt(q, x[i]) for i in range(B)])
+        check("ntt", eng.to_host(d), y, **kw)
+        strict = bool(rs.randint(2))
+        eng.intt_(q, d, strict=strict)
+        z = np.stack([orc.poly_intt(q, y[i]) for i in range(B)])
+        if strict:
+            z = np.stack([orc.poly_reduce_strict(q, z[i]) for i in range(B)])
+        check("intt", eng.to_host(d), z, strict=strict, **kw)
+    elif op == "elem":
+        a = np.stack([rng.poly((L, n), [2 * m for m in q]) for _ in range(B)])   # lazy operands in [0, 2q)
+        b = np.stack([rng.poly((L, n), [2 * m for m in q]) for _ in range(B)])
+        da, db = eng.to_device(a), eng.to_device(b)
+        check("add", eng.to_host(eng.poly_add(q, da, db)), np.stack([orc.poly_add(q, a[i], b[i]) for i in range(B)]), **kw)
+        check("sub", eng.to_host(eng.poly_sub(q, da, db)), np.stack([orc.poly_sub(q, a[i], b[i]) for i in range(B)]), **kw)
+        check("mul", eng.to_host(eng.poly_mul(q, da, db)), np.stack([orc.poly_mul(q, a[i], b[i]) for i in range(B)]), **kw)
+        sc = [int(w) for w in rng.words(L)]
+        check("smul", eng.to_host(eng.poly_scalar_mul(q, da, sc)), np.stack([orc.poly_rns_scalar_mul(q, a[i], sc) for i in range(B)]), **kw)
+    elif op == "perm":
+        a = np.stack([rng.poly((L, n), q) for _ in range(B)])
+        da = eng.to_device(a)
+        step = int(rs.randint(0, max(1, n // 2)))
+        check("cycle", eng.to_host(eng.poly_cycle(da, step)), np.stack([orc.poly_cycle(a[i], step) for i in range(B)]), step=step, **kw)
+        check("invol", eng.to_host(eng.poly_involution(da)), np.stack([orc.poly_involution(a[i]) for i in range(B)]), **kw)
+    else:
+        if L < 2:
+            continue
+        ct1 = np.stack([rng.poly((2, L, n), q) for _ in range(B)]); ct2 = np.stack([rng.poly((2, L, n), q) for _ in range(B)])
+        key = rng.poly((L, 2, L + 1, n), mext)
+        d1, d2, dk = eng.to_device(ct1), eng.to_device(ct2), eng.to_device(key)
+        if op == "mult":
+            check("ckks_mult", eng.to_host(eng.ckks_mult(mext, d1, d2, dk)), np.stack([orc.ckks_mult(mext, ct1[i], ct2[i], key) for i in range(B)]), **kw)
+        elif op == "bgv":
+            t = int(rs.choice([2, 257, 65537, 786433]))
+            check("bgv_mult", eng.to_host(eng.bgv_mult(mext, t, d1, d2, dk)), np.stack([orc.bgv_mult(mext, t, ct1[i], ct2[i], key) for i in range(B)]), t=t, **kw)
+        elif op == "rot":
+            step = int(rs.randint(0, max(1, n // 2)))
+            check("rotate", eng.to_host(eng.ckks_rotate(mext, d1, dk, step)), np.stack([orc.ckks_rotate(mext, ct1[i], key, step) for i in range(B)]), step=step, **kw)
+            check("conj", eng.to_host(eng.ckks_conjugate(mext, d2, dk)), np.stack([orc.ckks_conjugate(mext, ct2[i], key) for i in range(B)]), **kw)
+        elif op == "drop":
+            t = int(rs.choice([2, 257, 65537]))
+            check("rescale", eng.to_host(eng.ckks_rescale(q, d1)), np.stack([orc.ckks_rescale(q, ct1[i]) for i in range(B)]), **kw)
+            check("modsw", eng.to_host(eng.bgv_mod_switch(q, t, d2)), np.stack([orc.bgv_mod_drop(q, t, ct2[i]) for i in range(B)]), t=t, **kw)
+        elif op == "encdec":
+            import torch
+            cs = [P.edge_case(rng, logn, q) for _ in range(B)]
+            sk = cs[0][3]
+            noise = np.stack([c[0] for c in cs]); c1 = np.stack([c[1] for c in cs]); pt = np.stack([c[2] for c in cs])
+            ct = eng.rlwe_encrypt_core(q, torch.from_numpy(noise).to("cuda:0"), eng.to_device(c1), eng.to_device(pt), eng.to_device(sk))
+            exp = np.stack([orc.rlwe_encrypt_core(q, noise[i], c1[i], pt[i], sk) for i in range(B)])
+            check("enc", eng.to_host(ct), exp, **kw)
+            check("dec", eng.to_host(eng.rlwe_decrypt_core(q, ct, eng.to_device(sk))), np.stack([orc.rlwe_decrypt_core(q, exp[i], sk) for i in range(B)]), **kw)
+        else:
+            world = int(rs.randint(1, 6))
+            t = int(rs.choice([0, 65537]))
+            sm = ShardedMult(eng, mext, world, plain_modulus=t)
+            bufs = sm.buffers(B, n)
+            for b in bufs.values():
+                b.fill_(-1)
+            gens = [sm.stages(r, d1, d2, dk, bufs) for r in range(world)]
+            while any([next(g, None) is not None for g in gens]):
+                pass
+            exp = np.stack([orc.ckks_mult(mext, ct1[i], ct2[i], key) if t == 0 else orc.bgv_mult(mext, t, ct1[i], ct2[i], key) for i in range(B)])
+            check("sharded", eng.to_host(bufs["out"]), exp, world=world, t=t, **kw)
+    cases += 1
+    hist[(op, logn)] = hist.get((op, logn), 0) + 1
+print(f"fuzz ok: {cases} random cases in {time.time() - t0:.0f} s (seed {seed0})")
+ops = sorted({k[0] for k in hist})
+for o in ops:
+    print(f"  {o:8s}", " ".join(f"2^{l}:{hist[(o, l)]}" for l in sorted({k[1] for k in hist if k[0] == o})))
