@@ -31,6 +31,7 @@ def init(backend: str, device=None):
     world, rank, _ = env_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL peer buffers)
         kwargs = {"device_id": device} if (device is not None and backend == "nccl") else {}
         dist.init_process_group(backend, **kwargs)
     return world, rank
