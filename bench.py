@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="ckks", choices=["ckks", "ntt", "ntt15", "intt", "intt15", "bgv", "rotate", "ckks-limb", "encdec", "mul", "add"])
     ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (0 = BASELINE config value)")
+    ap.add_argument("--logn", type=int, default=0,
+                    help="override log2 of the ring degree for the ntt/intt/ckks/rotate workloads (same moduli); "
+                         "0 = the BASELINE config's N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")
     ap.add_argument("--cpu-procs", type=int, default=1,
@@ -59,6 +62,9 @@ def rand_words(torch, shape, moduli, device, seed):
         out.select(-2, k).copy_(torch.randint(0, int(q), out.select(-2, k).shape, generator=g, device=device,
                                               dtype=torch.int64))
     return out
+
+
+LOGN_OVERRIDE = 0   # set from --logn so that the CPU leg times the same ring degree
 
 
 def cpu_baseline(workload, P, budget_s):
@@ -84,6 +90,7 @@ def cpu_baseline(workload, P, budget_s):
                 "sample": f"{iters} x one-limb {workload}, N={n}, q={q}, single thread (includes the ctypes call and one result allocation)"}
     if "ntt" in workload:
         logn, q = (P.C3_LOGN, P.C3_P) if workload.endswith("15") else (P.C2_LOGN, P.C2_MODULI[0])
+        logn = LOGN_OVERRIDE or logn
         inv = int(workload.startswith("intt"))
         x = rng.words(1 << logn, q)
         if kind == "reference":
@@ -111,7 +118,7 @@ def cpu_baseline(workload, P, budget_s):
         return {"value": 1.0 / per, "unit": "ciphertext/s", "cores": 1, "kind": kind,
                 "sample": f"{iters} x (encrypt_core on given samples + decrypt_core) of one ciphertext, N={1 << logn}, L={len(moduli)}, single thread, tables warm"}
     if workload == "rotate":   # the reference's own benchmark workload (bench/benchmarks.cpp:21-37) at the C3 shape
-        logn, mext = P.C3_LOGN, P.C3_MODULI_EXT
+        logn, mext = LOGN_OVERRIDE or P.C3_LOGN, P.C3_MODULI_EXT
         n, L = 1 << logn, len(mext) - 1
         ct = rng.poly((2, L, n), mext[:L])
         key = rng.poly((L, 2, L + 1, n), mext)
@@ -123,7 +130,7 @@ def cpu_baseline(workload, P, budget_s):
         return {"value": 1.0 / per, "unit": "rotation/s", "cores": 1, "kind": kind,
                 "sample": f"{iters} x ckks::rotate(ct, key, 1) on one ciphertext, N={n}, L={L}, single thread, tables warm"}
     if workload == "ckks":
-        logn, mext, t = P.C3_LOGN, P.C3_MODULI_EXT, 0
+        logn, mext, t = LOGN_OVERRIDE or P.C3_LOGN, P.C3_MODULI_EXT, 0
     else:
         logn, mext, t = P.C5_LOGN, P.C5_MODULI_EXT, P.C5_T
     n, L = 1 << logn, len(mext) - 1
@@ -148,14 +155,18 @@ def cpu_baseline(workload, P, budget_s):
             "sample": f"{iters} x {name} on one ciphertext pair, N={n}, L={L}, single thread, tables warm"}
 
 
-def _cpu_baseline_worker(workload, budget_s):
+def _cpu_baseline_worker(workload, budget_s, logn_override=0):
     import params as P
 
+    global LOGN_OVERRIDE
+    LOGN_OVERRIDE = logn_override
     return cpu_baseline(workload, P, budget_s)
 
 
 def main():
+    global LOGN_OVERRIDE
     args = parse()
+    LOGN_OVERRIDE = args.logn
     import torch
 
     import params as P
@@ -179,6 +190,7 @@ def main():
         else:
             logn, moduli = P.C2_LOGN, P.C2_MODULI
             B = args.batch or P.C2_BATCH
+        logn = args.logn or logn
         n, L = 1 << logn, len(moduli)
         x = rand_words(torch, (B, L, n), moduli, dev, 2 + rank)
         units_per_step = B * L
@@ -187,7 +199,7 @@ def main():
         alg_bytes_per_step = 16.0 * n * B * L
         launches_per_step = 1
         metric, unit = "limb_ntt_per_s", "limb-NTT/s"
-        cfg = {"workload": f"{'C2' if logn == 14 else 'C3-shape'}: batched {'inverse' if inverse else 'forward'} negacyclic NTT, N={n}, {L} RNS limbs, batch={B} polynomials per GPU",
+        cfg = {"workload": f"{'C2' if (logn == 14 and L == 4) else 'C3-shape' if logn == 15 else 'custom'}: batched {'inverse' if inverse else 'forward'} negacyclic NTT, N={n}, {L} RNS limbs, batch={B} polynomials per GPU",
                "N": n, "limbs": L, "batch_per_gpu": B}
     elif wl in ("mul", "add"):
         # coefficient-wise kernels at the C2 shape: RnsPolynomial operator* (hybrid Montgomery+Harvey product,
@@ -229,6 +241,8 @@ def main():
         else:
             logn, mext, t, B0 = P.C5_LOGN, P.C5_MODULI_EXT, P.C5_T, 512
         B = args.batch or B0
+        if wl in ("ckks", "rotate"):
+            logn = args.logn or logn
         n, L = 1 << logn, len(mext) - 1
         ct1 = rand_words(torch, (B, 2, L, n), mext[:L], dev, 3 + rank)
         ct2 = rand_words(torch, (B, 2, L, n), mext[:L], dev, 1003 + rank)
@@ -335,7 +349,7 @@ def main():
                     import multiprocessing as mp
 
                     with mp.get_context("spawn").Pool(args.cpu_procs) as pool:
-                        parts = pool.starmap(_cpu_baseline_worker, [(cwl, args.cpu_seconds)] * args.cpu_procs)
+                        parts = pool.starmap(_cpu_baseline_worker, [(cwl, args.cpu_seconds, args.logn)] * args.cpu_procs)
                     res["cpu_baseline"] = dict(parts[0], value=sum(p["value"] for p in parts), cores=args.cpu_procs,
                                                sample=f"{args.cpu_procs} concurrent processes, each: " + parts[0]["sample"])
                 else:
