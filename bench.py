@@ -252,7 +252,10 @@ def main():
         # compulsory bytes per op in limbs (S = 8N): SURVEY.md 8d for hom-mult; for a rotation the tensor product
         # (7L) becomes the gather (4L), there is no second drop and only c0 gets the moved addend
         a_limbs = 5 * L * L + 36 * L
-        fwd_per_ct = L * L + 4 * L - 2          # forward limb transforms per hom-mult
+        # the dominant kernel is k_ntt_fwd in its digit-spread launch (rgsw.cpp:108-119): L*L limb transforms per
+        # ciphertext, one launch per step; the fused drop-last-prime launches are a different kernel (k_ntt_fwd_drop,
+        # profiling family "ntt_drop") and are not mixed into this roofline
+        fwd_per_ct = L * L
         scaling = "weak"
         if wl == "ckks-limb":
             # latency mode (hehub_amd/sharded.py): the SAME small batch on every rank, cut by output modulus, with
@@ -273,7 +276,6 @@ def main():
             metric, unit = "ckks_rotation_per_s", "rotation/s"
             name = "C3 shape: ckks::rotate (gather + key switch + drop of the special prime)"
             a_limbs = 5 * L * L + 22 * L + 6
-            fwd_per_ct = L * L + L
         elif wl == "ckks":
             step = lambda: eng.ckks_mult(mext, ct1, ct2, key, out=out)
             metric, unit = "ckks_hom_mult_per_s", "hom-mult/s"
