@@ -216,3 +216,39 @@ def test_dev_rns_base_transforms(eng, orc, n):
         for i in (0, 2):
             ok, exp = orc.rns_base_to_single_small(old, new, x[i])
             assert ok and np.array_equal(eng.to_host(out)[i], exp)
+
+
+def test_abi_rejects_bad_arguments(eng):
+    """Status codes of the C ABI for misuse: nothing may crash or silently compute on nonsense."""
+    import ctypes as C
+
+    from hehub_amd import capi
+    from hehub_amd.engine import HpError, InvalidArgument, _u64arr
+
+    lib, h = eng.lib, eng.h
+    q40 = P.P40
+    buf = eng.empty((2, 2, 3, 1 << 11))
+    ptr = eng._ptr(buf)
+    # ring degree out of range, zero / too many limbs
+    assert lib.hp_dev_ntt(h, 16, 1, _u64arr(q40[:1]), 1, ptr) == capi.HP_EINVAL
+    assert lib.hp_dev_ntt(h, 0, 1, _u64arr(q40[:1]), 1, ptr) == capi.HP_EINVAL
+    assert lib.hp_dev_ckks_mult_relin_rescale(h, 11, 1, _u64arr(q40[:2]), 1, ptr, ptr, ptr, ptr) == capi.HP_EINVAL   # only one prime
+    assert lib.hp_dev_ext_prod_montgomery(h, 11, 40, _u64arr(q40[:1] * 41), 1, ptr, ptr, ptr) == capi.HP_EINVAL
+    # a modulus the transform cannot use: 60 bits, or 2N does not divide q - 1
+    with pytest.raises(InvalidArgument, match="59"):
+        eng.ntt_([(1 << 60) - 93], eng.empty((1, 1, 8)))
+    with pytest.raises(InvalidArgument, match="2N doesn't divide"):
+        eng.ckks_rescale([12289, 40961], eng.empty((1, 2, 2, 1 << 14)))
+    # BGV with plain modulus 0, limb ranges outside the ciphertext
+    assert lib.hp_dev_bgv_mod_switch(h, 11, 3, _u64arr(q40[:3]), 0, 1, ptr, ptr) == capi.HP_EINVAL
+    assert lib.hp_dev_mult_low_level_range(h, 11, 3, _u64arr(q40[:3]), 1, 2, 5, ptr, ptr, ptr) == capi.HP_EINVAL
+    assert lib.hp_dev_drop_apply_range(h, 11, 3, _u64arr(q40[:3]), 0, 2, 1, 3, ptr, ptr, None, 0, 0, 0, ptr) == capi.HP_EINVAL
+    msg = lib.hp_last_error(h)
+    assert msg and b"range" in msg
+    # empty batches are no-ops, not errors
+    assert lib.hp_dev_ntt(h, 11, 3, _u64arr(q40[:3]), 0, ptr) == capi.HP_OK
+    assert lib.hp_dev_ckks_rescale(h, 11, 3, _u64arr(q40[:3]), 0, ptr, ptr) == capi.HP_OK
+    # the engine is still healthy afterwards
+    x = eng.to_device(np.arange(8, dtype=np.uint64).reshape(1, 1, 8))
+    eng.ntt_([65537], x); eng.intt_([65537], x, strict=True)
+    assert np.array_equal(eng.to_host(x).ravel(), np.arange(8, dtype=np.uint64))
