@@ -208,12 +208,14 @@ template <int LOGN> struct Addr {
     u32 c_base;   // (tid << 5) | (tid & 31)
     u32 s_base;   // (wave << 11) | ((lane >> 4) << 5) | (((lane & 15) << 1) ^ (lane >> 4))
     HP_DEV void init(u32 tid) {
+        // all four are BYTE offsets into the exchange buffer (word index * 4): an access then costs one v_xor, the
+        // additive part of lay_addr() folds into the ds instruction's immediate offset
         const u32 t = tid << G::PB;
-        a_base = t ^ ((t >> 5) & 31u);
-        b_base = ((tid >> 5) << 10) | (tid & 31u);
-        c_base = (tid << 5) | (tid & 31u);
+        a_base = (t ^ ((t >> 5) & 31u)) << 2;
+        b_base = (((tid >> 5) << 10) | (tid & 31u)) << 2;
+        c_base = ((tid << 5) | (tid & 31u)) << 2;
         const u32 lane = tid & 63u, wave = tid >> 6;
-        s_base = (wave << 11) | ((lane >> 4) << 5) | (((lane & 15u) << 1) ^ (lane >> 4));
+        s_base = ((wave << 11) | ((lane >> 4) << 5) | (((lane & 15u) << 1) ^ (lane >> 4))) << 2;
     }
 };
 
@@ -236,11 +238,14 @@ template <int LOGN, int LAY> HP_DEV u32 lay_base(const Addr<LOGN> &ad) {
 
 template <int LOGN, int LAY> HP_DEV u32 lay_addr(u32 base, int r) {
     using G = Geo<LOGN>;
-    if (LAY == LAY_A) return (base ^ (u32)(r & ((1 << G::PB) - 1))) + (u32)((r >> G::PB) << 10);
-    if (LAY == LAY_B) return (base ^ (u32)r) + (u32)(r << 5);
-    if (LAY == LAY_C) return base ^ (u32)r;
-    return (base ^ (u32)((r & 1) | (((r >> 1) & 7) << 2))) + (u32)((r >> 1) << 7);
+    if (LAY == LAY_A) return (base ^ ((u32)(r & ((1 << G::PB) - 1)) << 2)) + ((u32)((r >> G::PB) << 10) << 2);
+    if (LAY == LAY_B) return (base ^ ((u32)r << 2)) + ((u32)(r << 5) << 2);
+    if (LAY == LAY_C) return base ^ ((u32)r << 2);
+    return (base ^ ((u32)((r & 1) | (((r >> 1) & 7) << 2)) << 2)) + ((u32)((r >> 1) << 7) << 2);
 }
+
+// word of the exchange buffer at a byte offset
+HP_DEV u32 &lds_w(u32 *lds, u32 byte_off) { return *reinterpret_cast<u32 *>(reinterpret_cast<char *>(lds) + byte_off); }
 
 // Transpose the workgroup's coefficients from register layout FROM to layout TO through LDS, one
 // 32-bit half at a time.  WG: the exchange crosses waves (needs s_barrier); otherwise it is
@@ -255,7 +260,7 @@ HP_DEV void exchange(u64 (&x)[32], u32 *lds, const Addr<LOGN> &ad) {
         const u32 fb = opaque(lay_base<LOGN, FROM>(ad));
 #pragma unroll
         for (int r = 0; r < 32; ++r) {
-            lds[lay_addr<LOGN, FROM>(fb, r)] = lo32(x[r]);
+            lds_w(lds, lay_addr<LOGN, FROM>(fb, r)) = lo32(x[r]);
             keep[r] = hi32(x[r]);
         }
     }
@@ -264,19 +269,19 @@ HP_DEV void exchange(u64 (&x)[32], u32 *lds, const Addr<LOGN> &ad) {
     {
         const u32 tb = opaque(lay_base<LOGN, TO>(ad));
 #pragma unroll
-        for (int r = 0; r < 32; ++r) nlo[r] = lds[lay_addr<LOGN, TO>(tb, r)];
+        for (int r = 0; r < 32; ++r) nlo[r] = lds_w(lds, lay_addr<LOGN, TO>(tb, r));
     }
     if (WG) __syncthreads();
     {
         const u32 fb = opaque(lay_base<LOGN, FROM>(ad));
 #pragma unroll
-        for (int r = 0; r < 32; ++r) lds[lay_addr<LOGN, FROM>(fb, r)] = keep[r];
+        for (int r = 0; r < 32; ++r) lds_w(lds, lay_addr<LOGN, FROM>(fb, r)) = keep[r];
     }
     if (WG) __syncthreads();
     {
         const u32 tb = opaque(lay_base<LOGN, TO>(ad));
 #pragma unroll
-        for (int r = 0; r < 32; ++r) x[r] = mk64(nlo[r], lds[lay_addr<LOGN, TO>(tb, r)]);
+        for (int r = 0; r < 32; ++r) x[r] = mk64(nlo[r], lds_w(lds, lay_addr<LOGN, TO>(tb, r)));
     }
 }
 
