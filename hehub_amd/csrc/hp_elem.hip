@@ -228,7 +228,7 @@ hipError_t hp_launch_tensor(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32
 // in registers, both halves from one pass over the digits.  Per (p, k, i): reads L digit words and 2L key
 // words (the key is shared by the whole batch and stays in L2 / Infinity Cache), writes 2 words.
 __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner(const HpLimb *__restrict__ limbs, u32 L, u32 k_first, u32 P,
-                                                          u32 n, u32 chunks, const u64 *__restrict__ digits,
+                                                          u32 key_Le, u32 n, u32 chunks, const u64 *__restrict__ digits,
                                                           const u64 *__restrict__ pt,
                                                           u32 pt_pstride, const u64 *__restrict__ key,
                                                           u64 *__restrict__ out) {
@@ -243,8 +243,10 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner(const HpLimb *__restr
         u64 a0l[2] = {0, 0}, a0h[2] = {0, 0}, a1l[2] = {0, 0}, a1h[2] = {0, 0};
         for (u32 j = 0; j < L; j++) {
             const u64 *d = (j == k) ? pt + ((size_t)p * pt_pstride + j) * n : digits + (((size_t)p * L + j) * Le + k) * n;
-            const u64 *g0 = key + (((size_t)j * 2 + 0) * Le + k) * n;
-            const u64 *g1 = key + (((size_t)j * 2 + 1) * Le + k) * n;
+            // a key made for more moduli than the ciphertext has (extension): its special-prime column is the last one
+            const u32 kcol = (k == L) ? key_Le - 1 : k;
+            const u64 *g0 = key + (((size_t)j * 2 + 0) * key_Le + kcol) * n;
+            const u64 *g1 = key + (((size_t)j * 2 + 1) * key_Le + kcol) * n;
             u64 dv[2], k0[2], k1[2];
             if (two) {
                 // digits are read exactly once: non-temporal, so they do not evict the key column from L2
@@ -291,11 +293,11 @@ template <int PT> struct KsRow {
 };
 
 template <int PT>
-HP_DEV void ks_load(KsRow<PT> &r, u32 j, u32 k, u32 L, u32 Le, u32 n, u32 i, const u32 (&pc)[PT], const u64 *digits,
-                    const u64 *pt, u32 pt_pstride, const u64 *key) {
+HP_DEV void ks_load(KsRow<PT> &r, u32 j, u32 k, u32 L, u32 Le, u32 key_Le, u32 kcol, u32 n, u32 i, const u32 (&pc)[PT],
+                    const u64 *digits, const u64 *pt, u32 pt_pstride, const u64 *key) {
     typedef u64 __attribute__((ext_vector_type(2))) vv;
-    r.g0 = *reinterpret_cast<const U2 *>(key + (((size_t)j * 2 + 0) * Le + k) * n + i);
-    r.g1 = *reinterpret_cast<const U2 *>(key + (((size_t)j * 2 + 1) * Le + k) * n + i);
+    r.g0 = *reinterpret_cast<const U2 *>(key + (((size_t)j * 2 + 0) * key_Le + kcol) * n + i);
+    r.g1 = *reinterpret_cast<const U2 *>(key + (((size_t)j * 2 + 1) * key_Le + kcol) * n + i);
 #pragma unroll
     for (int c = 0; c < PT; c++) {
         const u64 *d = (j == k) ? pt + ((size_t)pc[c] * pt_pstride + j) * n : digits + (((size_t)pc[c] * L + j) * Le + k) * n;
@@ -325,7 +327,7 @@ template <int PT> HP_DEV void ks_mac(const KsRow<PT> &r, u64 (&al)[PT][2][2], u6
 
 template <int PT>
 __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner_blk(const HpLimb *__restrict__ limbs, u32 L, u32 k_first, u32 P,
-                                                              u32 n, u32 chunks, const u64 *__restrict__ digits,
+                                                              u32 key_Le, u32 n, u32 chunks, const u64 *__restrict__ digits,
                                                               const u64 *__restrict__ pt, u32 pt_pstride,
                                                               const u64 *__restrict__ key, u64 *__restrict__ out) {
     const u32 Le = L + 1;
@@ -333,6 +335,7 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner_blk(const HpLimb *__r
     const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
     const u32 k = k_first + row / PG, p0 = (row % PG) * PT;
     const u64 q = limbs[k].q, mqinv = limbs[k].mqinv;
+    const u32 kcol = (k == L) ? key_Le - 1 : k;   // key made for more moduli (extension): special prime = its last column
     u32 pc[PT];
 #pragma unroll
     for (int c = 0; c < PT; c++) pc[c] = min(p0 + c, P - 1);
@@ -344,12 +347,12 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner_blk(const HpLimb *__r
 #pragma unroll
             for (int h = 0; h < 2; h++) al[c][h][0] = al[c][h][1] = ah[c][h][0] = ah[c][h][1] = 0;
         KsRow<PT> ra, rb;
-        ks_load<PT>(ra, 0, k, L, Le, n, i, pc, digits, pt, pt_pstride, key);
+        ks_load<PT>(ra, 0, k, L, Le, key_Le, kcol, n, i, pc, digits, pt, pt_pstride, key);
         u32 j = 0;
         for (; j + 2 <= L; j += 2) {
-            ks_load<PT>(rb, j + 1, k, L, Le, n, i, pc, digits, pt, pt_pstride, key);
+            ks_load<PT>(rb, j + 1, k, L, Le, key_Le, kcol, n, i, pc, digits, pt, pt_pstride, key);
             ks_mac<PT>(ra, al, ah);
-            ks_load<PT>(ra, min(j + 2, L - 1), k, L, Le, n, i, pc, digits, pt, pt_pstride, key);   // last: harmless re-read
+            ks_load<PT>(ra, min(j + 2, L - 1), k, L, Le, key_Le, kcol, n, i, pc, digits, pt, pt_pstride, key);   // last: harmless re-read
             ks_mac<PT>(rb, al, ah);
         }
         if (j < L) ks_mac<PT>(ra, al, ah);
@@ -367,7 +370,7 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner_blk(const HpLimb *__r
     }
 }
 
-hipError_t hp_launch_ks_inner(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32 n, u32 P, const u64 *digits,
+hipError_t hp_launch_ks_inner(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32 key_Le, u32 n, u32 P, const u64 *digits,
                               const u64 *pt, u32 pt_pstride, const u64 *key, u64 *out, hipStream_t stream) {
     if (kc == 0) return hipSuccess;
     u32 chunks; dim3 grid;
@@ -375,13 +378,13 @@ hipError_t hp_launch_ks_inner(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u
     const int PT = (n >= 2 && P >= 2) ? pt_env : 1;
     if (PT >= 4) {
         elem_grid(n, ((P + 3) / 4) * kc, chunks, grid);
-        k_ks_inner_blk<4><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, n, chunks, digits, pt, pt_pstride, key, out);
+        k_ks_inner_blk<4><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, key_Le, n, chunks, digits, pt, pt_pstride, key, out);
     } else if (PT >= 2) {
         elem_grid(n, ((P + 1) / 2) * kc, chunks, grid);
-        k_ks_inner_blk<2><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, n, chunks, digits, pt, pt_pstride, key, out);
+        k_ks_inner_blk<2><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, key_Le, n, chunks, digits, pt, pt_pstride, key, out);
     } else {
         elem_grid(n, P * kc, chunks, grid);
-        k_ks_inner<<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, n, chunks, digits, pt, pt_pstride, key, out);
+        k_ks_inner<<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, key_Le, n, chunks, digits, pt, pt_pstride, key, out);
     }
     return hipGetLastError();
 }

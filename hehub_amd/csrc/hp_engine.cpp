@@ -290,8 +290,9 @@ int ks_coef(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P, size
 
 // (ii) + (iii) for the output moduli k in [k0, k1) of q_0..q_{L-1}, p: every digit limb is needed, only the
 // owned columns of digits / key / out are touched
+// key_L0: number of ciphertext moduli the key was generated for (>= L; its polynomials have key_L0 + 1 limbs)
 int ks_digits_inner(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P, size_t k0, size_t k1, const u64 *coef,
-                    const u64 *pt, size_t pt_pstride, const u64 *key, u64 *out, u64 *digits) {
+                    const u64 *pt, size_t pt_pstride, const u64 *key, size_t key_L0, u64 *out, u64 *digits) {
     const size_t n = (size_t)1 << logn;
     int rc;
     // (ii) D[j][k] = NTT_{q_k}(c[j]), k != j                       rgsw.cpp:108-119
@@ -305,20 +306,20 @@ int ks_digits_inner(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t
     // (iii) u128 inner product + Montgomery                         rgsw.cpp:121-153
     {
         ProfScope ps(ctx, "ks_inner");
-        rc = chk(ctx, hp_launch_ks_inner(plan->d_limbs, (u32)L, (u32)k0, (u32)(k1 - k0), (u32)n, (u32)P, digits, pt,
+        rc = chk(ctx, hp_launch_ks_inner(plan->d_limbs, (u32)L, (u32)k0, (u32)(k1 - k0), (u32)(key_L0 + 1), (u32)n, (u32)P, digits, pt,
                                          (u32)pt_pstride, key, out, ctx->stream), "ks_inner");
     }
     return rc;
 }
 
 int ext_prod(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P, const u64 *pt, size_t pt_pstride,
-             const u64 *key, u64 *out, Carver &cv) {
+             const u64 *key, size_t key_L0, u64 *out, Carver &cv) {
     const size_t n = (size_t)1 << logn;
     u64 *coef = cv.take(P * L * n);
     u64 *digits = cv.take(P * L * (L + 1) * n);
     int rc;
     if ((rc = ks_coef(ctx, plan, logn, L, P, 0, L, pt, pt_pstride, coef))) return rc;
-    return ks_digits_inner(ctx, plan, logn, L, P, 0, L + 1, coef, pt, pt_pstride, key, out, digits);
+    return ks_digits_inner(ctx, plan, logn, L, P, 0, L + 1, coef, pt, pt_pstride, key, key_L0, out, digits);
 }
 
 // rescaling.cpp:46-75 / mod_switch.cpp:45-77 on P2 polynomials of L limbs (x rows: poly p2 at x + p2*L limbs)
@@ -726,17 +727,30 @@ int hp_dev_mult_low_level(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *mo
                "tensor");
 }
 
-int hp_dev_ext_prod_montgomery(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch,
-                               const uint64_t *pt, const uint64_t *key, uint64_t *out) {
+static int key_level_ok(hp_ctx *ctx, size_t L, size_t key_L0) {
+    if (key_L0 < L || key_L0 + 1 > HP_MAX_LIMBS) return fail(ctx, HP_EINVAL, "Inconsistent RGSW ciphertext.");
+    return HP_OK;
+}
+
+static int dev_ext_prod(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, size_t batch,
+                        const uint64_t *pt, const uint64_t *key, uint64_t *out) {
     Guard g(ctx);
     int rc = check_ext_args(ctx, logn, L, batch);
-    if (rc) return rc;
+    if (rc || (rc = key_level_ok(ctx, L, key_L0))) return rc;
     const Plan *plan;
     if ((rc = get_plan(ctx, logn, moduli_ext, L + 1, true, &plan))) return rc;
     const size_t n = (size_t)1 << logn;
     if ((rc = ws_reserve(ctx, ext_prod_ws_words(n, L, batch) * 8))) return rc;
     Carver cv(ctx->ws);
-    return ext_prod(ctx, plan, logn, L, batch, pt, L, key, out, cv);
+    return ext_prod(ctx, plan, logn, L, batch, pt, L, key, key_L0, out, cv);
+}
+int hp_dev_ext_prod_montgomery(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch,
+                               const uint64_t *pt, const uint64_t *key, uint64_t *out) {
+    return dev_ext_prod(ctx, logn, L, L, moduli_ext, batch, pt, key, out);
+}
+int hp_dev_ext_prod_montgomery_at(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, size_t batch,
+                                  const uint64_t *pt, const uint64_t *key, uint64_t *out) {
+    return dev_ext_prod(ctx, logn, L, key_L0, moduli_ext, batch, pt, key, out);
 }
 
 static int dev_drop(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, bool bgv, uint64_t t, size_t batch,
@@ -756,15 +770,32 @@ static int dev_drop(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, 
 }
 int hp_dev_ckks_rescale(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, const uint64_t *ct,
                         uint64_t *out) { return dev_drop(ctx, logn, L, moduli, false, 0, batch, ct, out); }
+// extension (the reference throws "under development" for dropping_primes >= 2, rescaling.cpp:83-85): `drops` successive
+// exact one-prime drops; tmp holds the intermediate levels in two alternating halves of batch*2*(L-1)*N words each
+// (unused when drops == 1)
+int hp_dev_ckks_rescale_n(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t drops, size_t batch,
+                          const uint64_t *ct, uint64_t *tmp, uint64_t *out) {
+    if (drops < 1 || drops >= L) return fail(ctx, HP_EINVAL, "The number of primes to be dropped is not positive.");
+    if (drops > 1 && !tmp) return fail(ctx, HP_EINVAL, "rescale by several primes needs the intermediate buffer");
+    const size_t n = (size_t)1 << logn, half = batch * 2 * (L - 1) * n;
+    const uint64_t *src = ct;
+    for (size_t d = 0; d < drops; d++) {
+        uint64_t *dst = (d + 1 == drops) ? out : tmp + (d & 1) * half;
+        int rc = dev_drop(ctx, logn, L - d, moduli, false, 0, batch, src, dst);
+        if (rc) return rc;
+        src = dst;
+    }
+    return HP_OK;
+}
 int hp_dev_bgv_mod_switch(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, uint64_t t, size_t batch,
                           const uint64_t *ct, uint64_t *out) { return dev_drop(ctx, logn, L, moduli, true, t, batch, ct, out); }
 
 // relinearize on a batch: ext_prod(quad[2]) -> drop p -> += quad[0], quad[1]
 static int relin_core(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P, bool bgv, u64 inner_t,
-                      const u64 *quad, const u64 *key, u64 *out, Carver &cv) {
+                      const u64 *quad, const u64 *key, size_t key_L0, u64 *out, Carver &cv) {
     const size_t n = (size_t)1 << logn;
     u64 *ext = cv.take(P * 2 * (L + 1) * n);
-    int rc = ext_prod(ctx, plan, logn, L, P, quad + 2 * L * n, 3 * L, key, ext, cv);
+    int rc = ext_prod(ctx, plan, logn, L, P, quad + 2 * L * n, 3 * L, key, key_L0, ext, cv);
     if (rc) return rc;
     return drop_last(ctx, plan, logn, L + 1, 2 * P, bgv, inner_t, ext, quad, L, 3 * L, 3, out, cv);
 }
@@ -772,35 +803,39 @@ static size_t relin_ws_words(size_t n, size_t L, size_t P) {
     return padded(P * 2 * (L + 1) * n) / 8 + ext_prod_ws_words(n, L, P) + drop_ws_words(n, L + 1, 2 * P);
 }
 
-static int dev_relin(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, bool bgv, u64 inner_t,
+static int dev_relin(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, bool bgv, u64 inner_t,
                      size_t batch, const uint64_t *quad, const uint64_t *key, uint64_t *out) {
     Guard g(ctx);
     int rc = check_ext_args(ctx, logn, L, batch);
-    if (rc) return rc;
+    if (rc || (rc = key_level_ok(ctx, L, key_L0))) return rc;
     if (bgv && inner_t == 0) return fail(ctx, HP_EINVAL, "plain modulus must be positive");
     const Plan *plan;
     if ((rc = get_plan(ctx, logn, moduli_ext, L + 1, true, &plan))) return rc;
     const size_t n = (size_t)1 << logn;
     if ((rc = ws_reserve(ctx, relin_ws_words(n, L, batch) * 8))) return rc;
     Carver cv(ctx->ws);
-    return relin_core(ctx, plan, logn, L, batch, bgv, inner_t, quad, key, out, cv);
+    return relin_core(ctx, plan, logn, L, batch, bgv, inner_t, quad, key, key_L0, out, cv);
 }
 int hp_dev_ckks_relinearize(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch,
                             const uint64_t *quad, const uint64_t *key, uint64_t *out) {
-    return dev_relin(ctx, logn, L, moduli_ext, false, 0, batch, quad, key, out);
+    return dev_relin(ctx, logn, L, L, moduli_ext, false, 0, batch, quad, key, out);
+}
+int hp_dev_ckks_relinearize_at(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, size_t batch,
+                               const uint64_t *quad, const uint64_t *key, uint64_t *out) {
+    return dev_relin(ctx, logn, L, key_L0, moduli_ext, false, 0, batch, quad, key, out);
 }
 int hp_dev_bgv_relinearize(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, uint64_t inner_t,
                            size_t batch, const uint64_t *quad, const uint64_t *key, uint64_t *out) {
-    return dev_relin(ctx, logn, L, moduli_ext, true, inner_t, batch, quad, key, out);
+    return dev_relin(ctx, logn, L, L, moduli_ext, true, inner_t, batch, quad, key, out);
 }
 
 // ckks/arith.cpp:75-93: rotate (cycle by `step`) or conjugate (involution) a batch and switch back to the
 // original key: moved = gather(ct); ext = ext_prod(moved[1], key); drop p; out[0] += moved[0]
-static int dev_ckks_automorphism(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch,
+static int dev_ckks_automorphism(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, size_t batch,
                                  bool conj, size_t step, const uint64_t *ct, const uint64_t *key, uint64_t *out) {
     Guard g(ctx);
     int rc = check_ext_args(ctx, logn, L, batch);
-    if (rc) return rc;
+    if (rc || (rc = key_level_ok(ctx, L, key_L0))) return rc;
     if (!conj && step >= ((size_t)1 << 17)) return fail(ctx, HP_EINVAL, "rotation step out of range");
     const Plan *plan;
     if ((rc = get_plan(ctx, logn, moduli_ext, L + 1, true, &plan))) return rc;
@@ -822,17 +857,17 @@ static int dev_ckks_automorphism(hp_ctx *ctx, size_t logn, size_t L, const uint6
         }
     }
     if (rc) return rc;
-    if ((rc = ext_prod(ctx, plan, logn, L, batch, moved + L * n, 2 * L, key, ext, cv))) return rc;
+    if ((rc = ext_prod(ctx, plan, logn, L, batch, moved + L * n, 2 * L, key, key_L0, ext, cv))) return rc;
     return drop_last(ctx, plan, logn, L + 1, 2 * batch, false, 0, ext, moved, L, 2 * L, 1, out, cv);
 }
 
 // mult_low_level + relinearize + drop q_last, processed in sub-batches so the working set
 // (dominated by the L(L+1) digit limbs per ciphertext) stays small
-static int dev_mult(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, bool bgv, u64 t, size_t batch,
+static int dev_mult(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, bool bgv, u64 t, size_t batch,
                     const uint64_t *ct1, const uint64_t *ct2, const uint64_t *key, uint64_t *out) {
     Guard g(ctx);
     int rc = check_ext_args(ctx, logn, L, batch);
-    if (rc) return rc;
+    if (rc || (rc = key_level_ok(ctx, L, key_L0))) return rc;
     if (L < 2) return fail(ctx, HP_EINVAL, "Unable to drop the only one prime.");
     if (bgv && t == 0) return fail(ctx, HP_EINVAL, "plain modulus must be positive");
     const Plan *plan;
@@ -874,7 +909,7 @@ static int dev_mult(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_e
                                            ct2 + b0 * 2 * L * n, quad, ctx->stream), "tensor");
         }
         // the reference's bgv::relinearize runs its inner mod switch with plain_modulus == 1 (bgv.h:32)
-        if (!rc) rc = relin_core(ctx, plan, logn, L, P, bgv, 1, quad, key, lin, cv);
+        if (!rc) rc = relin_core(ctx, plan, logn, L, P, bgv, 1, quad, key, key_L0, lin, cv);
         if (!rc) rc = drop_last(ctx, plan, logn, L, 2 * P, bgv, t, lin, nullptr, 0, 0, 0, out + b0 * 2 * (L - 1) * n, cv);
         if (rc) break;
     }
@@ -889,20 +924,33 @@ static int dev_mult(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_e
 }
 int hp_dev_ckks_rotate(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch, size_t step,
                        const uint64_t *ct, const uint64_t *rot_key, uint64_t *out) {
-    return dev_ckks_automorphism(ctx, logn, L, moduli_ext, batch, false, step, ct, rot_key, out);
+    return dev_ckks_automorphism(ctx, logn, L, L, moduli_ext, batch, false, step, ct, rot_key, out);
+}
+int hp_dev_ckks_rotate_at(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, size_t batch,
+                          size_t step, const uint64_t *ct, const uint64_t *rot_key, uint64_t *out) {
+    return dev_ckks_automorphism(ctx, logn, L, key_L0, moduli_ext, batch, false, step, ct, rot_key, out);
 }
 int hp_dev_ckks_conjugate(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch,
                           const uint64_t *ct, const uint64_t *conj_key, uint64_t *out) {
-    return dev_ckks_automorphism(ctx, logn, L, moduli_ext, batch, true, 0, ct, conj_key, out);
+    return dev_ckks_automorphism(ctx, logn, L, L, moduli_ext, batch, true, 0, ct, conj_key, out);
+}
+int hp_dev_ckks_conjugate_at(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, size_t batch,
+                             const uint64_t *ct, const uint64_t *conj_key, uint64_t *out) {
+    return dev_ckks_automorphism(ctx, logn, L, key_L0, moduli_ext, batch, true, 0, ct, conj_key, out);
 }
 int hp_dev_ckks_mult_relin_rescale(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch,
                                    const uint64_t *ct1, const uint64_t *ct2, const uint64_t *key, uint64_t *out) {
-    return dev_mult(ctx, logn, L, moduli_ext, false, 0, batch, ct1, ct2, key, out);
+    return dev_mult(ctx, logn, L, L, moduli_ext, false, 0, batch, ct1, ct2, key, out);
+}
+int hp_dev_ckks_mult_relin_rescale_at(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext,
+                                      size_t batch, const uint64_t *ct1, const uint64_t *ct2, const uint64_t *key,
+                                      uint64_t *out) {
+    return dev_mult(ctx, logn, L, key_L0, moduli_ext, false, 0, batch, ct1, ct2, key, out);
 }
 int hp_dev_bgv_mult_relin_modswitch(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, uint64_t t,
                                     size_t batch, const uint64_t *ct1, const uint64_t *ct2, const uint64_t *key,
                                     uint64_t *out) {
-    return dev_mult(ctx, logn, L, moduli_ext, true, t, batch, ct1, ct2, key, out);
+    return dev_mult(ctx, logn, L, L, moduli_ext, true, t, batch, ct1, ct2, key, out);
 }
 
 // ---- profiling ------------------------------------------------------------------------------
@@ -1017,7 +1065,7 @@ int hp_dev_ks_inner_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *mo
     if ((rc = ws_reserve(ctx, padded(batch * L * (L + 1) * n)))) return rc;
     Carver cv(ctx->ws);
     u64 *digits = cv.take(batch * L * (L + 1) * n);
-    return ks_digits_inner(ctx, plan, logn, L, batch, k0, k1, coef, pt, pt_pstride, key, out, digits);
+    return ks_digits_inner(ctx, plan, logn, L, batch, k0, k1, coef, pt, pt_pstride, key, L, out, digits);
 }
 
 int hp_dev_drop_coeffs(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, uint64_t plain_modulus, size_t P2,

@@ -84,7 +84,8 @@ hipError_t hp_launch_tensor(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32
 // rgsw.cpp:121-153: digits [P][L][L+1][n] (diagonal taken from pt [P][L][n]), key [L][2][L+1][n]
 //   -> out [P][2][L+1][n]
 // only output moduli [k_first, k_first + kc) of the L+1 are computed (kc = L+1: all)
-hipError_t hp_launch_ks_inner(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32 n, u32 P, const u64 *digits,
+// key_Le: limbs per key polynomial (L+1, or more for a key generated at a higher level: its last column is the special prime)
+hipError_t hp_launch_ks_inner(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32 key_Le, u32 n, u32 P, const u64 *digits,
                               const u64 *pt, u32 pt_pstride, const u64 *key, u64 *out, hipStream_t stream);
 
 // drop-last-prime helpers (rescaling.cpp:46-75 / mod_switch.cpp:45-77)

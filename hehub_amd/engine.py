@@ -263,6 +263,37 @@ class Engine:
                                                  self._ptr(key), self._ptr(out)))
         return out
 
+    # -- extensions beyond the reference (include/hehub_amd.h) ----------------
+    def ckks_mult_at(self, moduli_ext, key_L0: int, ct1, ct2, key):
+        """ckks::mult + rescale at level L = ct limbs with a key generated for key_L0 >= L ciphertext moduli."""
+        B, _, L, n = ct1.shape
+        out = self.empty((B, 2, L - 1, n))
+        self._chk(self.lib.hp_dev_ckks_mult_relin_rescale_at(self.h, n.bit_length() - 1, L, key_L0, _u64arr(moduli_ext), B,
+                                                             self._ptr(ct1), self._ptr(ct2), self._ptr(key), self._ptr(out)))
+        return out
+
+    def ckks_rotate_at(self, moduli_ext, key_L0: int, ct, key, step: int):
+        B, _, L, n = ct.shape
+        out = self.empty((B, 2, L, n))
+        self._chk(self.lib.hp_dev_ckks_rotate_at(self.h, n.bit_length() - 1, L, key_L0, _u64arr(moduli_ext), B, step,
+                                                 self._ptr(ct), self._ptr(key), self._ptr(out)))
+        return out
+
+    def ext_prod_at(self, moduli_ext, key_L0: int, pt, key):
+        B, L, n = pt.shape
+        out = self.empty((B, 2, L + 1, n))
+        self._chk(self.lib.hp_dev_ext_prod_montgomery_at(self.h, n.bit_length() - 1, L, key_L0, _u64arr(moduli_ext), B,
+                                                         self._ptr(pt), self._ptr(key), self._ptr(out)))
+        return out
+
+    def ckks_rescale_n(self, moduli, ct, drops: int):
+        B, _, L, n = ct.shape
+        out = self.empty((B, 2, L - drops, n))
+        tmp = self.empty((2, B, 2, L - 1, n)) if drops > 1 else None
+        self._chk(self.lib.hp_dev_ckks_rescale_n(self.h, n.bit_length() - 1, L, _u64arr(moduli), drops, B, self._ptr(ct),
+                                                 self._ptr(tmp) if tmp is not None else None, self._ptr(out)))
+        return out
+
     # -- either side of the path -------------------------------------------
     def rlwe_encrypt_core(self, moduli, noise, c1, pt, sk):
         B, L, n = c1.shape

@@ -147,24 +147,35 @@ void check_ct_wellformed(const RlweCt &ct) {   // rescaling.cpp:15-29, mod_switc
     if (ct[0].component_count() == 1) throw std::invalid_argument("Unable to drop the only one prime.");
 }
 
-// rgsw.cpp:58-89
-void check_ext_prod(const RlwePt &pt, const RgswCt &rgsw, std::vector<u64> &extended_moduli) {
+// HEHUB_AMD_EXTENSIONS=1 turns on what hehub itself throws for (include/hehub_amd.h "extensions"): a key generated
+// for more ciphertext moduli than the operand has, and rescale_inplace by several primes
+bool extensions_on() {
+    static const bool on = std::getenv("HEHUB_AMD_EXTENSIONS") && std::atoi(std::getenv("HEHUB_AMD_EXTENSIONS")) != 0;
+    return on;
+}
+
+// rgsw.cpp:58-89; returns the number of ciphertext moduli the key was generated for (== pt's unless extensions are on)
+size_t check_ext_prod(const RlwePt &pt, const RgswCt &rgsw, std::vector<u64> &extended_moduli) {
     if (rgsw.empty()) throw std::invalid_argument("Empty RGSW ciphertext.");
     extended_moduli = rgsw[0][0].modulus_vec();
     const auto original = pt.component_count();
     const auto extended = original + 1;
     if (extended_moduli.size() < extended) throw std::invalid_argument("Invalid component number in RGSW ciphertext.");
+    const std::vector<u64> key_moduli(extended_moduli);
     extended_moduli.resize(extended);
     *extended_moduli.rbegin() = *rgsw[0][0].modulus_vec().crbegin();
     for (size_t i = 0; i < original; i++)
         if (extended_moduli[i] != pt.modulus_at((int)i)) throw std::invalid_argument("Moduli mismatch.");
+    const bool higher = extensions_on() && rgsw.size() > original;
     for (auto &sample : rgsw)
         for (auto &poly : sample) {
             if (poly.dimension() != pt.dimension()) throw std::invalid_argument("Polynomial lengths mismatch.");
-            if (poly.component_count() != extended || poly.modulus_vec() != extended_moduli)
+            if (higher ? (poly.component_count() != rgsw.size() + 1 || poly.modulus_vec() != key_moduli)
+                       : (poly.component_count() != extended || poly.modulus_vec() != extended_moduli))
                 throw std::invalid_argument("Inconsistent RGSW ciphertext.");
         }
-    if (rgsw.size() != original) throw std::invalid_argument("Inconsistent RGSW ciphertext.");
+    if (!higher && rgsw.size() != original) throw std::invalid_argument("Inconsistent RGSW ciphertext.");
+    return rgsw.size();
 }
 
 void put_key(u64 *dst, const RgswCt &rgsw, size_t L, size_t n) {
@@ -232,14 +243,15 @@ RlweCt make_ct(size_t n, size_t L, const std::vector<u64> &moduli, const u64 *sr
 // shared body of ckks::relinearize / bgv::relinearize
 RlweCt relinearize_common(const std::array<RnsPolynomial, 3> &quad, const RlweKsk &key, bool bgv) {
     std::vector<u64> mext;
-    check_ext_prod(quad[2], key, mext);
+    const size_t L0 = check_ext_prod(quad[2], key, mext);
     const size_t n = quad[2].dimension(), L = quad[2].component_count();
     DevBuf dq(3 * L * n), dout(2 * L * n);
-    DevKey dk(key, L, n);
+    DevKey dk(key, L0, n);
     for (int h = 0; h < 3; h++) put_poly(dq.p + (size_t)h * L * n, quad[h], L);
     const size_t logn = quad[2].log_dimension();
+    if (bgv && L0 != L) throw std::invalid_argument("Inconsistent RGSW ciphertext.");   // no higher-level keys for the BGV quirk path
     if (bgv) check(hp_dev_bgv_relinearize(amd::engine(), logn, L, mext.data(), 1 /* bgv.h:32 */, 1, dq.p, dk.p(), dout.p));
-    else check(hp_dev_ckks_relinearize(amd::engine(), logn, L, mext.data(), 1, dq.p, dk.p(), dout.p));
+    else check(hp_dev_ckks_relinearize_at(amd::engine(), logn, L, L0, mext.data(), 1, dq.p, dk.p(), dout.p));
     std::vector<u64> q(mext.begin(), mext.begin() + L);
     return make_ct(n, L, q, dout.p);
 }
@@ -496,12 +508,12 @@ RlweCt mult_plain_core(const RlweCt &ct, const RlwePt &pt) { return RlweCt{ct[0]
 
 RlweCt ext_prod_montgomery(const RlwePt &pt, const RgswCt &rgsw) {
     std::vector<u64> mext;
-    check_ext_prod(pt, rgsw, mext);
+    const size_t L0 = check_ext_prod(pt, rgsw, mext);
     const size_t n = pt.dimension(), L = pt.component_count();
     DevBuf dp(L * n), dout(2 * (L + 1) * n);
-    DevKey dk(rgsw, L, n);
+    DevKey dk(rgsw, L0, n);
     put_poly(dp.p, pt, L);
-    check(hp_dev_ext_prod_montgomery(amd::engine(), pt.log_dimension(), L, mext.data(), 1, dp.p, dk.p(), dout.p));
+    check(hp_dev_ext_prod_montgomery_at(amd::engine(), pt.log_dimension(), L, L0, mext.data(), 1, dp.p, dk.p(), dout.p));
     return make_ct(n, L + 1, mext, dout.p);
 }
 
@@ -636,7 +648,8 @@ void rescale_inplace(CkksCt &ct, size_t dropping_primes) {   // rescaling.cpp:80
         drop_last_prime(ct, false, 0);
         ct.scaling_factor /= q_last;
     } else if (dropping_primes >= 2) {
-        throw "under development";
+        if (!extensions_on()) throw "under development";
+        for (size_t d = 0; d < dropping_primes; d++) rescale_inplace(ct, 1);   // successive exact one-prime drops
     } else {
         throw std::invalid_argument("The number of primes to be dropped is not positive.");
     }
@@ -648,14 +661,14 @@ static CkksCt key_switched(const CkksCt &ct, const RlweKsk &key, bool conj, size
     for (int h = 0; h < 2; h++)
         if (ct[h].rep_form != PolyRepForm::value) throw std::invalid_argument("poly_ntt is expected to be in NTT value form");
     std::vector<u64> mext;
-    check_ext_prod(ct[1], key, mext);
+    const size_t L0 = check_ext_prod(ct[1], key, mext);
     const size_t n = ct[1].dimension(), L = ct[1].component_count(), logn = ct[1].log_dimension();
     if (ct[0].dimension() != n || ct[0].component_count() != L) throw std::invalid_argument("Ill-formed ciphertext.");
     DevBuf dct(2 * L * n), dout(2 * L * n);
-    DevKey dk(key, L, n);
+    DevKey dk(key, L0, n);
     for (int h = 0; h < 2; h++) put_poly(dct.p + (size_t)h * L * n, ct[h], L);
-    if (conj) check(hp_dev_ckks_conjugate(amd::engine(), logn, L, mext.data(), 1, dct.p, dk.p(), dout.p));
-    else check(hp_dev_ckks_rotate(amd::engine(), logn, L, mext.data(), 1, step, dct.p, dk.p(), dout.p));
+    if (conj) check(hp_dev_ckks_conjugate_at(amd::engine(), logn, L, L0, mext.data(), 1, dct.p, dk.p(), dout.p));
+    else check(hp_dev_ckks_rotate_at(amd::engine(), logn, L, L0, mext.data(), 1, step, dct.p, dk.p(), dout.p));
     std::vector<u64> q(mext.begin(), mext.begin() + L);
     CkksCt r = make_ct(n, L, q, dout.p);
     r.scaling_factor = ct.scaling_factor;

@@ -210,6 +210,29 @@ int hp_dev_drop_apply_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *
                             const uint64_t *d_addend, size_t add_poly_stride, size_t add_ct_stride, unsigned add_mask,
                             uint64_t *d_out);
 
+/* ---- extensions beyond the reference ---------------------------------------------------
+ * hehub throws for both cases; these entry points are additions, not replacements, and are pinned by equivalence to
+ * the reference-parity entry points (tests/test_extensions.py):
+ * (1) a key-switching key generated for key_L0 ciphertext moduli used at a LOWER level L <= key_L0 (hehub requires
+ *     exactly L+1 limbs, rgsw.cpp:84-87, so one key serves one level only): key u64[key_L0][2][key_L0+1][N]; digit rows
+ *     j >= L and modulus columns L..key_L0-1 are ignored, the special prime is the last column.  moduli_ext stays
+ *     q_0..q_{L-1}, p.  Identical, word for word, to calling the plain entry point with the extracted sub-key.
+ * (2) rescale by several primes (hehub: "under development", rescaling.cpp:83-85) = successive exact one-prime drops. */
+int hp_dev_ext_prod_montgomery_at(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext,
+                                  size_t batch, const uint64_t *d_pt, const uint64_t *d_key, uint64_t *d_out);
+int hp_dev_ckks_relinearize_at(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext,
+                               size_t batch, const uint64_t *d_quad, const uint64_t *d_key, uint64_t *d_out);
+int hp_dev_ckks_rotate_at(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, size_t batch,
+                          size_t step, const uint64_t *d_ct, const uint64_t *d_rot_key, uint64_t *d_out);
+int hp_dev_ckks_conjugate_at(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext,
+                             size_t batch, const uint64_t *d_ct, const uint64_t *d_conj_key, uint64_t *d_out);
+int hp_dev_ckks_mult_relin_rescale_at(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext,
+                                      size_t batch, const uint64_t *d_ct1, const uint64_t *d_ct2,
+                                      const uint64_t *d_key, uint64_t *d_out);
+/* ct u64[batch][2][L][N] -> out u64[batch][2][L-drops][N]; d_tmp: 2 * batch*2*(L-1)*N words (may be NULL for drops == 1) */
+int hp_dev_ckks_rescale_n(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t drops, size_t batch,
+                          const uint64_t *d_ct, uint64_t *d_tmp, uint64_t *d_out);
+
 /* ---- wire / on-disk format (hehub itself has none) -------------------------------------
  * "HEHUBAMD" header + moduli + the words in device order + FNV-1a-64 trailer; the exact byte layout is documented in
  * hehub_amd/csrc/hp_wire.cpp.  Loading a key or ciphertext is one validation pass and one host-to-device copy. */

@@ -74,6 +74,24 @@ static int ckks_c3(size_t dimension, std::vector<size_t> bits) {
     CHECK(err <= std::pow(2.0, -24), "mult+relin+rescale         max slot error 2^%.1f  (bound 2^-24; %.1f ms through the host-pointer API)",
           std::log2(err), 1e3 * (t1 - t0));
 
+    // Depth 2 with ONE relinearisation key (extension, HEHUB_AMD_EXTENSIONS=1): hehub alone rejects a key whose level
+    // differs from the operand's (rgsw.cpp:84-87), so a second multiplication needs a second key there.
+    try {
+        auto sq = ckks::mult(prod, prod, relin_key);
+        ckks::rescale_inplace(sq);
+        auto got2 = ckks::simd_decode(ckks::decrypt(sq, sk));
+        double err2 = 0;
+        for (size_t i = 0; i < slots; i++) {
+            const double want = d1[i] * d2[i];
+            err2 = std::max(err2, std::abs(got2[i] - want * want));
+        }
+        CHECK(sq[0].component_count() == params.moduli.size() - 2 && err2 <= std::pow(2.0, -16),
+              "second multiplication with the same key (extension): %zu limbs left, max slot error 2^%.1f  (bound 2^-16)",
+              sq[0].component_count(), std::log2(err2));
+    } catch (const std::invalid_argument &e) {
+        std::printf("note  second multiplication with the same key is not available here: %s\n", e.what());
+    }
+
     auto rot = ckks::rotate(ct1, rot_key);
     auto rgot = ckks::simd_decode(ckks::decrypt(rot, sk));
     double err_l = 0, err_r = 0;

@@ -63,3 +63,7 @@ def test_end_to_end_tolerance_at_baseline_shapes():
     out = subprocess.run([REF_E2E], capture_output=True, text=True, timeout=900)
     print(out.stdout[-3000:], out.stderr[-2000:])
     assert out.returncode == 0 and "All end-to-end checks passed" in out.stdout
+    # with the extensions on, the same relinearisation key serves a second multiplication one level down
+    out = subprocess.run([REF_E2E], capture_output=True, text=True, timeout=900, env=dict(os.environ, HEHUB_AMD_EXTENSIONS="1"))
+    print(out.stdout[-3000:], out.stderr[-2000:])
+    assert out.returncode == 0 and "ok    second multiplication with the same key" in out.stdout
