@@ -343,6 +343,26 @@ def main():
             a_min = (6 * L - 2) * 8 * n + 2 * L * (L + 1) * 8 * n / B
             res["pipeline_roofline"].update({"A_prim_frac_of_hbm_peak": value / world * a_prim / 1e9 / HBM_PEAK_GBS,
                                              "A_min_frac_of_hbm_peak": value / world * a_min / 1e9 / HBM_PEAK_GBS})
+    if wl == "ckks":
+        # BASELINE.json's metric names both rates ("NTT/s and CKKS hom-mult/s ... N=32768"): the line also carries the
+        # limb-transform rates at the same ring degree (all limbs of the same batch of ciphertexts, forward and inverse
+        # timed separately, same fences; outside the timed region of `value`)
+        xq = ct1.view(B * 2, L, n)
+        rates = {}
+        for name, fn in (("forward", lambda: eng.ntt_(mext[:L], xq)), ("inverse", lambda: eng.intt_(mext[:L], xq))):
+            fn()
+            hd.barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                fn()
+            torch.cuda.synchronize()
+            dt = hd.max_over_ranks(time.perf_counter() - t0, device=dev)
+            hd.barrier()
+            rates[name] = B * 2 * L * world * args.steps / dt
+        res["ntt"] = {"N": n, "limbs_per_launch": B * 2 * L, "forward_limb_ntt_per_s": rates["forward"],
+                      "inverse_limb_ntt_per_s": rates["inverse"],
+                      "forward_frac_of_hbm_peak": rates["forward"] / world * 16.0 * n / 1e9 / HBM_PEAK_GBS,
+                      "inverse_frac_of_hbm_peak": rates["inverse"] / world * 16.0 * n / 1e9 / HBM_PEAK_GBS}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
