@@ -56,3 +56,14 @@ def test_product_never_touches_the_oracle():
                 if re.search(r"hehub_oracle|pyoracle|oracle/|from oracle|import oracle|orc_[a-z]", text):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/hehub_amd.h must be usable from C (the boundary is a C ABI) and from C++."""
+    import subprocess
+
+    src = tmp_path / "use.c"
+    src.write_text('#include "hehub_amd.h"\nint main(void) { hp_wire_desc d; hp_ctx *c = 0; (void)d; (void)c; return HP_OK; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{inc}", "-fsyntax-only", str(src)], check=True)
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", f"-I{inc}", "-fsyntax-only", "-x", "c++", str(src)], check=True)
