@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <new>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -78,6 +79,17 @@ int fail(hp_ctx *ctx, int code, const std::string &msg) {
     return code;
 }
 
+// Host-side containers (table / plan / gather-map caches, profiling lists) may throw; nothing may cross the C ABI.
+template <class F> int contained(hp_ctx *ctx, F &&f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, HP_ENOMEM, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(ctx, HP_ELOGIC, e.what());
+    }
+}
+
 struct Guard {
     hp_ctx *ctx;
     std::unique_lock<std::mutex> lk;
@@ -92,7 +104,7 @@ int upload(hp_ctx *ctx, const void *host, size_t bytes, void **dptr) {
 
 // twiddle tables of one (modulus, logn), built on first use (the reference fills global maps
 // lazily in the same way, ntt.cpp:117-143)
-int get_tables(hp_ctx *ctx, u64 q, size_t logn, DevTables &out) {
+int get_tables_impl(hp_ctx *ctx, u64 q, size_t logn, DevTables &out) {
     auto key = std::make_pair(q, logn);
     auto it = ctx->tables.find(key);
     if (it != ctx->tables.end()) {
@@ -118,9 +130,12 @@ int get_tables(hp_ctx *ctx, u64 q, size_t logn, DevTables &out) {
     out = t;
     return HP_OK;
 }
+int get_tables(hp_ctx *ctx, u64 q, size_t logn, DevTables &out) {
+    return contained(ctx, [&] { return get_tables_impl(ctx, q, logn, out); });
+}
 
 // device array of per-limb constants for a modulus chain; with_ntt == false skips the twiddles
-int get_plan(hp_ctx *ctx, size_t logn, const uint64_t *moduli, size_t count, bool with_ntt, const Plan **out) {
+int get_plan_impl(hp_ctx *ctx, size_t logn, const uint64_t *moduli, size_t count, bool with_ntt, const Plan **out) {
     if (count == 0 || count > HP_MAX_LIMBS) return fail(ctx, HP_EINVAL, "unsupported number of RNS components");
     std::vector<u64> mv(moduli, moduli + count);
     for (u64 q : mv)
@@ -152,6 +167,9 @@ int get_plan(hp_ctx *ctx, size_t logn, const uint64_t *moduli, size_t count, boo
     auto ins = ctx->plans.emplace(key, std::move(plan));
     *out = &ins.first->second;
     return HP_OK;
+}
+int get_plan(hp_ctx *ctx, size_t logn, const uint64_t *moduli, size_t count, bool with_ntt, const Plan **out) {
+    return contained(ctx, [&] { return get_plan_impl(ctx, logn, moduli, count, with_ntt, out); });
 }
 
 // grow-only workspace; stream order makes reuse across calls safe
@@ -245,7 +263,7 @@ HpNttJob batch_job(const Plan *plan, size_t logn, size_t L, size_t P, const u64 
 }
 
 // gather map of cycle(poly, step) (permutation.cpp:39-53): out[to] = in[perm[to]]; cached per (logn, step)
-int get_cycle_perm(hp_ctx *ctx, size_t logn, size_t step, const u32 **out) {
+int get_cycle_perm_impl(hp_ctx *ctx, size_t logn, size_t step, const u32 **out) {
     const size_t n = (size_t)1 << logn;
     auto key = std::make_pair(logn, step);
     auto it = ctx->perms.find(key);
@@ -271,6 +289,9 @@ int get_cycle_perm(hp_ctx *ctx, size_t logn, size_t step, const u32 **out) {
     }
     *out = it->second;
     return HP_OK;
+}
+int get_cycle_perm(hp_ctx *ctx, size_t logn, size_t step, const u32 **out) {
+    return contained(ctx, [&] { return get_cycle_perm_impl(ctx, logn, step, out); });
 }
 
 bool logn_ok(size_t logn) { return logn >= 1 && logn <= 15; }
@@ -486,7 +507,8 @@ int hp_ctx_create(int device, hp_ctx **out) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return HP_EHIP;
     if (hipSetDevice(device) != hipSuccess) return HP_EHIP;
-    hp_ctx *c = new hp_ctx();
+    hp_ctx *c = new (std::nothrow) hp_ctx();
+    if (!c) return HP_ENOMEM;
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
@@ -1102,11 +1124,13 @@ int hp_dev_drop_apply_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *
 
 int hp_prof_begin(hp_ctx *ctx, const char *family) {
     Guard g(ctx);
-    for (auto &ev : ctx->prof_events) { ctx->event_pool.push_back(ev.a); ctx->event_pool.push_back(ev.b); }
-    ctx->prof_events.clear();
-    ctx->prof_family = family ? family : "";
-    ctx->prof_on = true;
-    return HP_OK;
+    return contained(ctx, [&] {
+        for (auto &ev : ctx->prof_events) { ctx->event_pool.push_back(ev.a); ctx->event_pool.push_back(ev.b); }
+        ctx->prof_events.clear();
+        ctx->prof_family = family ? family : "";
+        ctx->prof_on = true;
+        return (int)HP_OK;
+    });
 }
 int hp_prof_end(hp_ctx *ctx, size_t *launches, double *total_ms) {
     Guard g(ctx);
