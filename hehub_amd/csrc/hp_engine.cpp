@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <map>
 #include <new>
 #include <mutex>
@@ -89,6 +90,15 @@ template <class F> int contained(hp_ctx *ctx, F &&f) {
         return fail(ctx, HP_ELOGIC, e.what());
     }
 }
+
+// a NULL operand would fault on the device and take the process down: reject it at the boundary
+inline bool any_null(std::initializer_list<const void *> ptrs) {
+    for (const void *p : ptrs)
+        if (!p) return true;
+    return false;
+}
+#define HP_REQUIRE(ctx, ...) \
+    if (any_null({__VA_ARGS__})) return fail(ctx, HP_EINVAL, "NULL pointer argument")
 
 struct Guard {
     hp_ctx *ctx;
@@ -642,6 +652,7 @@ int hp_batched_montgomery_128_lazy(hp_ctx *ctx, uint64_t q, size_t n, const uint
 // ---- device-resident batches ---------------------------------------------------------------
 int hp_dev_ntt(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *d_x) {
     Guard g(ctx);
+    HP_REQUIRE(ctx, moduli, d_x);
     if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (batch == 0) return HP_OK;
     const Plan *plan;
@@ -652,6 +663,7 @@ int hp_dev_ntt(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_
 
 int hp_dev_intt(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *d_x, int strict) {
     Guard g(ctx);
+    HP_REQUIRE(ctx, moduli, d_x);
     if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (batch == 0) return HP_OK;
     const Plan *plan;
@@ -663,6 +675,7 @@ int hp_dev_intt(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size
 static int dev_binary(hp_ctx *ctx, int op, size_t n, size_t L, const uint64_t *moduli, size_t batch,
                       const uint64_t *a, const uint64_t *b, uint64_t *out) {
     Guard g(ctx);
+    HP_REQUIRE(ctx, moduli, a, b, out);
     if (n == 0 || (n & (n - 1))) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (batch == 0) return HP_OK;
     const Plan *plan;
@@ -685,6 +698,7 @@ int hp_dev_poly_mul(hp_ctx *ctx, size_t n, size_t L, const uint64_t *m, size_t b
 int hp_dev_poly_scalar_mul(hp_ctx *ctx, size_t n, size_t L, const uint64_t *moduli, size_t batch,
                            const uint64_t *rns_scalar, const uint64_t *a, uint64_t *out) {
     Guard g(ctx);
+    HP_REQUIRE(ctx, moduli, rns_scalar, a, out);
     if (n == 0 || (n & (n - 1))) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (batch == 0) return HP_OK;
     const Plan *plan;
@@ -703,6 +717,7 @@ int hp_dev_poly_scalar_mul(hp_ctx *ctx, size_t n, size_t L, const uint64_t *modu
 
 int hp_dev_poly_reduce_strict(hp_ctx *ctx, size_t n, size_t L, const uint64_t *moduli, size_t batch, uint64_t *x) {
     Guard g(ctx);
+    HP_REQUIRE(ctx, moduli, x);
     if (n == 0 || (n & (n - 1))) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (batch == 0) return HP_OK;
     const Plan *plan;
@@ -714,6 +729,7 @@ int hp_dev_poly_reduce_strict(hp_ctx *ctx, size_t n, size_t L, const uint64_t *m
 
 int hp_dev_poly_involution(hp_ctx *ctx, size_t logn, size_t L, size_t batch, const uint64_t *in, uint64_t *out) {
     Guard g(ctx);
+    HP_REQUIRE(ctx, in, out);
     if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (batch == 0) return HP_OK;
     if (in == out) return fail(ctx, HP_EINVAL, "involution cannot run in place");
@@ -724,6 +740,7 @@ int hp_dev_poly_involution(hp_ctx *ctx, size_t logn, size_t L, size_t batch, con
 int hp_dev_poly_cycle(hp_ctx *ctx, size_t logn, size_t L, size_t batch, size_t step, const uint64_t *in,
                       uint64_t *out) {
     Guard g(ctx);
+    HP_REQUIRE(ctx, in, out);
     if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (batch == 0) return HP_OK;
     if (in == out) return fail(ctx, HP_EINVAL, "cycle cannot run in place");
@@ -739,6 +756,7 @@ int hp_dev_poly_cycle(hp_ctx *ctx, size_t logn, size_t L, size_t batch, size_t s
 int hp_dev_mult_low_level(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch,
                           const uint64_t *ct1, const uint64_t *ct2, uint64_t *quad) {
     Guard g(ctx);
+    HP_REQUIRE(ctx, moduli, ct1, ct2, quad);
     if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (batch == 0) return HP_OK;
     const Plan *plan;
@@ -757,6 +775,7 @@ static int key_level_ok(hp_ctx *ctx, size_t L, size_t key_L0) {
 static int dev_ext_prod(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, size_t batch,
                         const uint64_t *pt, const uint64_t *key, uint64_t *out) {
     Guard g(ctx);
+    HP_REQUIRE(ctx, moduli_ext, pt, key, out);
     int rc = check_ext_args(ctx, logn, L, batch);
     if (rc || (rc = key_level_ok(ctx, L, key_L0))) return rc;
     const Plan *plan;
@@ -778,6 +797,7 @@ int hp_dev_ext_prod_montgomery_at(hp_ctx *ctx, size_t logn, size_t L, size_t key
 static int dev_drop(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, bool bgv, uint64_t t, size_t batch,
                     const uint64_t *ct, uint64_t *out) {
     Guard g(ctx);
+    HP_REQUIRE(ctx, moduli, ct, out);
     if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (L < 2) return fail(ctx, HP_EINVAL, "Unable to drop the only one prime.");
     if (bgv && t == 0) return fail(ctx, HP_EINVAL, "plain modulus must be positive");
@@ -828,6 +848,7 @@ static size_t relin_ws_words(size_t n, size_t L, size_t P) {
 static int dev_relin(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, bool bgv, u64 inner_t,
                      size_t batch, const uint64_t *quad, const uint64_t *key, uint64_t *out) {
     Guard g(ctx);
+    HP_REQUIRE(ctx, moduli_ext, quad, key, out);
     int rc = check_ext_args(ctx, logn, L, batch);
     if (rc || (rc = key_level_ok(ctx, L, key_L0))) return rc;
     if (bgv && inner_t == 0) return fail(ctx, HP_EINVAL, "plain modulus must be positive");
@@ -856,6 +877,7 @@ int hp_dev_bgv_relinearize(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *m
 static int dev_ckks_automorphism(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, size_t batch,
                                  bool conj, size_t step, const uint64_t *ct, const uint64_t *key, uint64_t *out) {
     Guard g(ctx);
+    HP_REQUIRE(ctx, moduli_ext, ct, key, out);
     int rc = check_ext_args(ctx, logn, L, batch);
     if (rc || (rc = key_level_ok(ctx, L, key_L0))) return rc;
     if (!conj && step >= ((size_t)1 << 17)) return fail(ctx, HP_EINVAL, "rotation step out of range");
@@ -888,6 +910,7 @@ static int dev_ckks_automorphism(hp_ctx *ctx, size_t logn, size_t L, size_t key_
 static int dev_mult(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, bool bgv, u64 t, size_t batch,
                     const uint64_t *ct1, const uint64_t *ct2, const uint64_t *key, uint64_t *out) {
     Guard g(ctx);
+    HP_REQUIRE(ctx, moduli_ext, ct1, ct2, key, out);
     int rc = check_ext_args(ctx, logn, L, batch);
     if (rc || (rc = key_level_ok(ctx, L, key_L0))) return rc;
     if (L < 2) return fail(ctx, HP_EINVAL, "Unable to drop the only one prime.");
@@ -980,6 +1003,7 @@ int hp_dev_bgv_mult_relin_modswitch(hp_ctx *ctx, size_t logn, size_t L, const ui
 int hp_dev_rlwe_encrypt_core(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, const int64_t *noise,
                              const uint64_t *c1, const uint64_t *pt, const uint64_t *sk, uint64_t *ct) {
     Guard g(ctx);
+    HP_REQUIRE(ctx, moduli, noise, c1, pt, sk, ct);
     if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (L < 1 || L > HP_MAX_LIMBS) return fail(ctx, HP_EINVAL, "invalid component number");
     if (batch == 0) return HP_OK;
@@ -1004,6 +1028,7 @@ int hp_dev_rlwe_encrypt_core(hp_ctx *ctx, size_t logn, size_t L, const uint64_t 
 int hp_dev_rlwe_decrypt_core(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, const uint64_t *ct,
                              const uint64_t *sk, uint64_t *pt) {
     Guard g(ctx);
+    HP_REQUIRE(ctx, moduli, ct, sk, pt);
     if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (L < 1 || L > HP_MAX_LIMBS) return fail(ctx, HP_EINVAL, "invalid component number");
     if (batch == 0) return HP_OK;
@@ -1021,6 +1046,7 @@ int hp_dev_rlwe_decrypt_core(hp_ctx *ctx, size_t logn, size_t L, const uint64_t 
 int hp_dev_rns_base_from_single(hp_ctx *ctx, size_t n, uint64_t old_modulus, size_t L, const uint64_t *new_moduli, size_t batch,
                                 const uint64_t *in, uint64_t *out) {
     Guard g(ctx);
+    HP_REQUIRE(ctx, new_moduli, in, out);
     if (old_modulus < 2 || L < 1 || L > HP_MAX_LIMBS) return fail(ctx, HP_EINVAL, "invalid moduli");
     if (batch == 0 || n == 0) return HP_OK;
     const Plan *plan;
@@ -1034,6 +1060,7 @@ int hp_dev_rns_base_from_single(hp_ctx *ctx, size_t n, uint64_t old_modulus, siz
 int hp_dev_rns_base_to_single_small(hp_ctx *ctx, size_t n, size_t L, const uint64_t *old_moduli, uint64_t new_modulus,
                                     size_t batch, const uint64_t *in, uint64_t *out, uint32_t *not_small) {
     Guard g(ctx);
+    HP_REQUIRE(ctx, old_moduli, in, out, not_small);
     if (new_modulus < 2 || L < 1 || L > HP_MAX_LIMBS) return fail(ctx, HP_EINVAL, "invalid moduli");
     if (batch == 0 || n == 0) return HP_OK;
     const Plan *plan;
@@ -1053,6 +1080,7 @@ static int range_ok(hp_ctx *ctx, size_t lo, size_t hi, size_t limit) {
 int hp_dev_mult_low_level_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, size_t k0,
                                 size_t k1, const uint64_t *ct1, const uint64_t *ct2, uint64_t *quad) {
     Guard g(ctx);
+    HP_REQUIRE(ctx, moduli, ct1, ct2, quad);
     if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     int rc = range_ok(ctx, k0, k1, L);
     if (rc) return rc;
@@ -1067,6 +1095,7 @@ int hp_dev_mult_low_level_range(hp_ctx *ctx, size_t logn, size_t L, const uint64
 int hp_dev_ks_coef_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch, size_t j0, size_t j1,
                          const uint64_t *pt, size_t pt_pstride, uint64_t *coef) {
     Guard g(ctx);
+    HP_REQUIRE(ctx, moduli_ext, pt, coef);
     int rc = check_ext_args(ctx, logn, L, batch);
     if (rc || (rc = range_ok(ctx, j0, j1, L))) return rc;
     if (j0 == j1) return HP_OK;
@@ -1078,6 +1107,7 @@ int hp_dev_ks_coef_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *mod
 int hp_dev_ks_inner_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch, size_t k0, size_t k1,
                           const uint64_t *coef, const uint64_t *pt, size_t pt_pstride, const uint64_t *key, uint64_t *out) {
     Guard g(ctx);
+    HP_REQUIRE(ctx, moduli_ext, coef, pt, key, out);
     int rc = check_ext_args(ctx, logn, L, batch);
     if (rc || (rc = range_ok(ctx, k0, k1, L + 1))) return rc;
     if (k0 == k1) return HP_OK;
@@ -1093,6 +1123,7 @@ int hp_dev_ks_inner_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *mo
 int hp_dev_drop_coeffs(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, uint64_t plain_modulus, size_t P2,
                        const uint64_t *x, uint64_t *clast) {
     Guard g(ctx);
+    HP_REQUIRE(ctx, moduli, x, clast);
     if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (L < 2) return fail(ctx, HP_EINVAL, "Unable to drop the only one prime.");
     if (P2 == 0) return HP_OK;
@@ -1106,6 +1137,7 @@ int hp_dev_drop_apply_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *
                             size_t k0, size_t k1, const uint64_t *x, const uint64_t *clast, const uint64_t *addend,
                             size_t add_poly_stride, size_t add_ct_stride, unsigned add_mask, uint64_t *out) {
     Guard g(ctx);
+    HP_REQUIRE(ctx, moduli, x, clast, out);
     if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (L < 2) return fail(ctx, HP_EINVAL, "Unable to drop the only one prime.");
     int rc = range_ok(ctx, k0, k1, L - 1);

@@ -245,6 +245,9 @@ def test_abi_rejects_bad_arguments(eng):
     assert lib.hp_dev_drop_apply_range(h, 11, 3, _u64arr(q40[:3]), 0, 2, 1, 3, ptr, ptr, None, 0, 0, 0, ptr) == capi.HP_EINVAL
     msg = lib.hp_last_error(h)
     assert msg and b"range" in msg
+    # NULL operands are rejected before anything is launched
+    assert lib.hp_dev_ntt(h, 11, 3, _u64arr(q40[:3]), 1, None) == capi.HP_EINVAL
+    assert lib.hp_dev_ckks_mult_relin_rescale(h, 11, 3, _u64arr(q40[:3] + [P.P50[0]]), 1, ptr, None, ptr, ptr) == capi.HP_EINVAL
     # empty batches are no-ops, not errors
     assert lib.hp_dev_ntt(h, 11, 3, _u64arr(q40[:3]), 0, ptr) == capi.HP_OK
     assert lib.hp_dev_ckks_rescale(h, 11, 3, _u64arr(q40[:3]), 0, ptr, ptr) == capi.HP_OK
