@@ -67,3 +67,28 @@ def test_end_to_end_tolerance_at_baseline_shapes():
     out = subprocess.run([REF_E2E], capture_output=True, text=True, timeout=900, env=dict(os.environ, HEHUB_AMD_EXTENSIONS="1"))
     print(out.stdout[-3000:], out.stderr[-2000:])
     assert out.returncode == 0 and "ok    second multiplication with the same key" in out.stdout
+
+
+EXAMPLE_SRC = os.path.join(ROOT, "examples", "ckks_throughput.c")
+EXAMPLE_BIN = os.path.join(ROOT, "examples", "ckks_throughput")
+
+
+def build_example():
+    from hehub_amd.build import LIBDIR, build_lib
+
+    build_lib(verbose=False)
+    subprocess.run(["gcc", "-O2", "-std=c99", "-Wall", "-Wextra", "-Werror", EXAMPLE_SRC, f"-I{ROOT}/include", f"-L{LIBDIR}",
+                    "-lhehub_amd", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-o", EXAMPLE_BIN], check=True)
+    return EXAMPLE_BIN
+
+
+def test_plain_c_example_builds():
+    """examples/ckks_throughput.c uses nothing but include/hehub_amd.h (C99): the C ABI is self-sufficient."""
+    assert os.path.exists(build_example())
+
+
+@pytest.mark.gpu
+def test_plain_c_example_runs():
+    out = subprocess.run([build_example(), "12", "8", "3"], capture_output=True, text=True, timeout=600)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0 and "hom-mult/s" in out.stdout
