@@ -92,3 +92,28 @@ def test_plain_c_example_runs():
     out = subprocess.run([build_example(), "12", "8", "3"], capture_output=True, text=True, timeout=600)
     print(out.stdout, out.stderr)
     assert out.returncode == 0 and "hom-mult/s" in out.stdout
+
+
+MULTI_SRC = os.path.join(ROOT, "examples", "multi_ctx.c")
+MULTI_BIN = os.path.join(ROOT, "examples", "multi_ctx")
+
+
+def build_multi():
+    from hehub_amd.build import LIBDIR, build_lib
+
+    build_lib(verbose=False)
+    subprocess.run(["gcc", "-O2", "-std=c99", "-pthread", "-Wall", "-Wextra", "-Werror", MULTI_SRC, f"-I{ROOT}/include",
+                    f"-L{LIBDIR}", "-lhehub_amd", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-o", MULTI_BIN], check=True)
+    return MULTI_BIN
+
+
+def test_multi_context_example_builds():
+    assert os.path.exists(build_multi())
+
+
+@pytest.mark.gpu
+def test_contexts_are_independent_across_threads():
+    """examples/multi_ctx.c: four host threads, four engine contexts sharing GPU 0, identical results everywhere."""
+    out = subprocess.run([build_multi(), "4", "1", "12", "3", "2"], capture_output=True, text=True, timeout=600)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0 and "digest" in out.stdout and "everywhere" in out.stdout
