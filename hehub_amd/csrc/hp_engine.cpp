@@ -99,6 +99,14 @@ inline bool any_null(std::initializer_list<const void *> ptrs) {
 }
 #define HP_REQUIRE(ctx, ...) \
     if (any_null({__VA_ARGS__})) return fail(ctx, HP_EINVAL, "NULL pointer argument")
+// the kernels move 16 bytes per lane: device operands must be 16-byte aligned (every allocator's blocks are)
+inline bool any_misaligned(std::initializer_list<const void *> ptrs) {
+    for (const void *p : ptrs)
+        if ((uintptr_t)p & 15u) return true;
+    return false;
+}
+#define HP_ALIGNED(ctx, ...) \
+    if (any_misaligned({__VA_ARGS__})) return fail(ctx, HP_EINVAL, "device pointers must be 16-byte aligned")
 
 struct Guard {
     hp_ctx *ctx;
@@ -653,6 +661,7 @@ int hp_batched_montgomery_128_lazy(hp_ctx *ctx, uint64_t q, size_t n, const uint
 int hp_dev_ntt(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *d_x) {
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, d_x);
+    HP_ALIGNED(ctx, d_x);
     if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (batch == 0) return HP_OK;
     const Plan *plan;
@@ -664,6 +673,7 @@ int hp_dev_ntt(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_
 int hp_dev_intt(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *d_x, int strict) {
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, d_x);
+    HP_ALIGNED(ctx, d_x);
     if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (batch == 0) return HP_OK;
     const Plan *plan;
@@ -676,6 +686,7 @@ static int dev_binary(hp_ctx *ctx, int op, size_t n, size_t L, const uint64_t *m
                       const uint64_t *a, const uint64_t *b, uint64_t *out) {
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, a, b, out);
+    HP_ALIGNED(ctx, a, b, out);
     if (n == 0 || (n & (n - 1))) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (batch == 0) return HP_OK;
     const Plan *plan;
@@ -699,6 +710,7 @@ int hp_dev_poly_scalar_mul(hp_ctx *ctx, size_t n, size_t L, const uint64_t *modu
                            const uint64_t *rns_scalar, const uint64_t *a, uint64_t *out) {
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, rns_scalar, a, out);
+    HP_ALIGNED(ctx, a, out);
     if (n == 0 || (n & (n - 1))) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (batch == 0) return HP_OK;
     const Plan *plan;
@@ -718,6 +730,7 @@ int hp_dev_poly_scalar_mul(hp_ctx *ctx, size_t n, size_t L, const uint64_t *modu
 int hp_dev_poly_reduce_strict(hp_ctx *ctx, size_t n, size_t L, const uint64_t *moduli, size_t batch, uint64_t *x) {
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, x);
+    HP_ALIGNED(ctx, x);
     if (n == 0 || (n & (n - 1))) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (batch == 0) return HP_OK;
     const Plan *plan;
@@ -730,6 +743,7 @@ int hp_dev_poly_reduce_strict(hp_ctx *ctx, size_t n, size_t L, const uint64_t *m
 int hp_dev_poly_involution(hp_ctx *ctx, size_t logn, size_t L, size_t batch, const uint64_t *in, uint64_t *out) {
     Guard g(ctx);
     HP_REQUIRE(ctx, in, out);
+    HP_ALIGNED(ctx, in, out);
     if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (batch == 0) return HP_OK;
     if (in == out) return fail(ctx, HP_EINVAL, "involution cannot run in place");
@@ -741,6 +755,7 @@ int hp_dev_poly_cycle(hp_ctx *ctx, size_t logn, size_t L, size_t batch, size_t s
                       uint64_t *out) {
     Guard g(ctx);
     HP_REQUIRE(ctx, in, out);
+    HP_ALIGNED(ctx, in, out);
     if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (batch == 0) return HP_OK;
     if (in == out) return fail(ctx, HP_EINVAL, "cycle cannot run in place");
@@ -757,6 +772,7 @@ int hp_dev_mult_low_level(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *mo
                           const uint64_t *ct1, const uint64_t *ct2, uint64_t *quad) {
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, ct1, ct2, quad);
+    HP_ALIGNED(ctx, ct1, ct2, quad);
     if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (batch == 0) return HP_OK;
     const Plan *plan;
@@ -776,6 +792,7 @@ static int dev_ext_prod(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const
                         const uint64_t *pt, const uint64_t *key, uint64_t *out) {
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli_ext, pt, key, out);
+    HP_ALIGNED(ctx, pt, key, out);
     int rc = check_ext_args(ctx, logn, L, batch);
     if (rc || (rc = key_level_ok(ctx, L, key_L0))) return rc;
     const Plan *plan;
@@ -798,6 +815,7 @@ static int dev_drop(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, 
                     const uint64_t *ct, uint64_t *out) {
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, ct, out);
+    HP_ALIGNED(ctx, ct, out);
     if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (L < 2) return fail(ctx, HP_EINVAL, "Unable to drop the only one prime.");
     if (bgv && t == 0) return fail(ctx, HP_EINVAL, "plain modulus must be positive");
@@ -849,6 +867,7 @@ static int dev_relin(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const ui
                      size_t batch, const uint64_t *quad, const uint64_t *key, uint64_t *out) {
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli_ext, quad, key, out);
+    HP_ALIGNED(ctx, quad, key, out);
     int rc = check_ext_args(ctx, logn, L, batch);
     if (rc || (rc = key_level_ok(ctx, L, key_L0))) return rc;
     if (bgv && inner_t == 0) return fail(ctx, HP_EINVAL, "plain modulus must be positive");
@@ -878,6 +897,7 @@ static int dev_ckks_automorphism(hp_ctx *ctx, size_t logn, size_t L, size_t key_
                                  bool conj, size_t step, const uint64_t *ct, const uint64_t *key, uint64_t *out) {
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli_ext, ct, key, out);
+    HP_ALIGNED(ctx, ct, key, out);
     int rc = check_ext_args(ctx, logn, L, batch);
     if (rc || (rc = key_level_ok(ctx, L, key_L0))) return rc;
     if (!conj && step >= ((size_t)1 << 17)) return fail(ctx, HP_EINVAL, "rotation step out of range");
@@ -911,6 +931,7 @@ static int dev_mult(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uin
                     const uint64_t *ct1, const uint64_t *ct2, const uint64_t *key, uint64_t *out) {
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli_ext, ct1, ct2, key, out);
+    HP_ALIGNED(ctx, ct1, ct2, key, out);
     int rc = check_ext_args(ctx, logn, L, batch);
     if (rc || (rc = key_level_ok(ctx, L, key_L0))) return rc;
     if (L < 2) return fail(ctx, HP_EINVAL, "Unable to drop the only one prime.");
@@ -1004,6 +1025,7 @@ int hp_dev_rlwe_encrypt_core(hp_ctx *ctx, size_t logn, size_t L, const uint64_t 
                              const uint64_t *c1, const uint64_t *pt, const uint64_t *sk, uint64_t *ct) {
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, noise, c1, pt, sk, ct);
+    HP_ALIGNED(ctx, noise, c1, pt, sk, ct);
     if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (L < 1 || L > HP_MAX_LIMBS) return fail(ctx, HP_EINVAL, "invalid component number");
     if (batch == 0) return HP_OK;
@@ -1029,6 +1051,7 @@ int hp_dev_rlwe_decrypt_core(hp_ctx *ctx, size_t logn, size_t L, const uint64_t 
                              const uint64_t *sk, uint64_t *pt) {
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, ct, sk, pt);
+    HP_ALIGNED(ctx, ct, sk, pt);
     if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (L < 1 || L > HP_MAX_LIMBS) return fail(ctx, HP_EINVAL, "invalid component number");
     if (batch == 0) return HP_OK;
@@ -1047,6 +1070,7 @@ int hp_dev_rns_base_from_single(hp_ctx *ctx, size_t n, uint64_t old_modulus, siz
                                 const uint64_t *in, uint64_t *out) {
     Guard g(ctx);
     HP_REQUIRE(ctx, new_moduli, in, out);
+    HP_ALIGNED(ctx, in, out);
     if (old_modulus < 2 || L < 1 || L > HP_MAX_LIMBS) return fail(ctx, HP_EINVAL, "invalid moduli");
     if (batch == 0 || n == 0) return HP_OK;
     const Plan *plan;
@@ -1061,6 +1085,7 @@ int hp_dev_rns_base_to_single_small(hp_ctx *ctx, size_t n, size_t L, const uint6
                                     size_t batch, const uint64_t *in, uint64_t *out, uint32_t *not_small) {
     Guard g(ctx);
     HP_REQUIRE(ctx, old_moduli, in, out, not_small);
+    HP_ALIGNED(ctx, in, out, not_small);
     if (new_modulus < 2 || L < 1 || L > HP_MAX_LIMBS) return fail(ctx, HP_EINVAL, "invalid moduli");
     if (batch == 0 || n == 0) return HP_OK;
     const Plan *plan;
@@ -1081,6 +1106,7 @@ int hp_dev_mult_low_level_range(hp_ctx *ctx, size_t logn, size_t L, const uint64
                                 size_t k1, const uint64_t *ct1, const uint64_t *ct2, uint64_t *quad) {
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, ct1, ct2, quad);
+    HP_ALIGNED(ctx, ct1, ct2, quad);
     if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     int rc = range_ok(ctx, k0, k1, L);
     if (rc) return rc;
@@ -1096,6 +1122,7 @@ int hp_dev_ks_coef_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *mod
                          const uint64_t *pt, size_t pt_pstride, uint64_t *coef) {
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli_ext, pt, coef);
+    HP_ALIGNED(ctx, pt, coef);
     int rc = check_ext_args(ctx, logn, L, batch);
     if (rc || (rc = range_ok(ctx, j0, j1, L))) return rc;
     if (j0 == j1) return HP_OK;
@@ -1108,6 +1135,7 @@ int hp_dev_ks_inner_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *mo
                           const uint64_t *coef, const uint64_t *pt, size_t pt_pstride, const uint64_t *key, uint64_t *out) {
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli_ext, coef, pt, key, out);
+    HP_ALIGNED(ctx, coef, pt, key, out);
     int rc = check_ext_args(ctx, logn, L, batch);
     if (rc || (rc = range_ok(ctx, k0, k1, L + 1))) return rc;
     if (k0 == k1) return HP_OK;
@@ -1124,6 +1152,7 @@ int hp_dev_drop_coeffs(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *modul
                        const uint64_t *x, uint64_t *clast) {
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, x, clast);
+    HP_ALIGNED(ctx, x, clast);
     if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (L < 2) return fail(ctx, HP_EINVAL, "Unable to drop the only one prime.");
     if (P2 == 0) return HP_OK;
@@ -1138,6 +1167,7 @@ int hp_dev_drop_apply_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *
                             size_t add_poly_stride, size_t add_ct_stride, unsigned add_mask, uint64_t *out) {
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, x, clast, out);
+    HP_ALIGNED(ctx, x, clast, out);
     if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
     if (L < 2) return fail(ctx, HP_EINVAL, "Unable to drop the only one prime.");
     int rc = range_ok(ctx, k0, k1, L - 1);

@@ -23,6 +23,8 @@
  *     the caller, by hp_dev_alloc, or by any other allocator in the process,
  *     e.g. a torch tensor's data_ptr()), enqueue on the ctx stream and return
  *     without synchronising.
+ *   - device pointers must be 16-byte aligned (the kernels move 16 bytes per lane; every allocator's blocks are, and
+ *     so is every limb inside them); a NULL or misaligned operand is rejected with HP_EINVAL before anything runs.
  *   - all words are uint64_t, little-endian, in the reference's lazy
  *     (redundant) representation; outputs are bit-identical to the
  *     reference's for identical inputs.

@@ -248,6 +248,8 @@ def test_abi_rejects_bad_arguments(eng):
     # NULL operands are rejected before anything is launched
     assert lib.hp_dev_ntt(h, 11, 3, _u64arr(q40[:3]), 1, None) == capi.HP_EINVAL
     assert lib.hp_dev_ckks_mult_relin_rescale(h, 11, 3, _u64arr(q40[:3] + [P.P50[0]]), 1, ptr, None, ptr, ptr) == capi.HP_EINVAL
+    mis = C.c_void_p(buf.data_ptr() + 8)
+    assert lib.hp_dev_ntt(h, 11, 3, _u64arr(q40[:3]), 1, mis) == capi.HP_EINVAL          # 8-byte aligned only
     # empty batches are no-ops, not errors
     assert lib.hp_dev_ntt(h, 11, 3, _u64arr(q40[:3]), 0, ptr) == capi.HP_OK
     assert lib.hp_dev_ckks_rescale(h, 11, 3, _u64arr(q40[:3]), 0, ptr, ptr) == capi.HP_OK
