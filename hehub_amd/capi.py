@@ -65,6 +65,7 @@ SIGNATURES = {
     "hp_dev_rlwe_decrypt_core": (INT, [P, szt, szt, P, szt, P, P, P]),
     "hp_dev_rns_base_from_single": (INT, [P, szt, u64, szt, P, szt, P, P]),
     "hp_dev_rns_base_to_single_small": (INT, [P, szt, szt, P, u64, szt, P, P, P]),
+    "hp_dev_rns_base_to_single": (INT, [P, szt, szt, P, u64, szt, P, P]),
     "hp_dev_mult_low_level_range": (INT, [P, szt, szt, P, szt, szt, szt, P, P, P]),
     "hp_dev_ks_coef_range": (INT, [P, szt, szt, P, szt, szt, szt, P, szt, P]),
     "hp_dev_ks_inner_range": (INT, [P, szt, szt, P, szt, szt, szt, P, P, szt, P, P]),

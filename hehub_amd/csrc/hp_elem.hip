@@ -576,3 +576,57 @@ hipError_t hp_launch_base_to_single(const HpLimb *limbs, u32 L, u32 n, u32 P, u6
     k_base_to_single<<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, n, chunks, new_q, (~(u64)0) / new_q, in, out, not_small);
     return hipGetLastError();
 }
+
+// rns_transform.cpp:86-104 on the device, without big integers: mixed-radix (Garner) digits v_i of the CRT value
+// x = v_0 + v_1 q_0 + v_2 q_0 q_1 + ... (0 <= v_i < q_i) are computed with word arithmetic, x < floor(Q/2) is a
+// lexicographic comparison with the digits of floor(Q/2), and x mod t is sum v_i (q_0...q_{i-1} mod t).  The result is the
+// reference's: x mod t below the half, t - ((Q - x) mod t) from the half on (which is t itself, not 0, when t | Q - x).
+// Only polynomials flagged not_small are touched; the others keep the small-coefficient result.
+__global__ void __launch_bounds__(ELEM_THREADS) k_base_to_single_crt(const HpLimb *__restrict__ limbs, const HpCrtConsts *__restrict__ cc,
+                                                                    u32 L, u32 n, u32 chunks, const u64 *__restrict__ in,
+                                                                    u64 *__restrict__ out, const u32 *__restrict__ not_small) {
+    const u32 p = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    if (!not_small[p]) return;
+    const u64 t = cc->t;
+    const u64 *x = in + (size_t)p * L * n;
+    const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
+    for (u32 i = chunk * ELEM_CHUNK + threadIdx.x; i < end; i += ELEM_THREADS) {
+        u64 v[HP_CRT_MAX_LIMBS];
+        for (u32 a = 0; a < L; a++) {
+            const u64 qa = limbs[a].q, bc = limbs[a].barrett_c;
+            u64 u = hp_strict(x[(size_t)a * n + i], qa);
+            for (u32 b = 0; b < a; b++) {
+                const u64 vb = hp_strict(hp_barrett_lazy(v[b], qa, bc), qa);          // v_b mod q_a
+                const u64 d = u + qa - vb;                                            // in (0, 2 q_a)
+                u = hp_strict(hp_harvey_lazy(d, cc->inv[b][a], cc->inv_h[b][a], qa), qa);   // (u - v_b) / q_b mod q_a
+            }
+            v[a] = u;
+        }
+        bool below = false, decided = false;   // x < floor(Q/2): compare digits from the most significant one down
+        for (int a = (int)L - 1; a >= 0 && !decided; a--) {
+            if (v[a] != cc->half[a]) { below = v[a] < cc->half[a]; decided = true; }
+        }
+        u64 r = 0;   // x mod t
+        for (u32 a = 0; a < L; a++) {
+            r += hp_strict(hp_harvey_lazy(v[a], cc->pref[a], cc->pref_h[a], t), t);
+            r -= (r >= t) ? t : 0;
+        }
+        u64 res;
+        if (below) {
+            res = r;
+        } else {
+            u64 abs = cc->q_mod_t + t - r;   // (Q - x) mod t
+            abs -= (abs >= t) ? t : 0;
+            res = t - abs;
+        }
+        out[(size_t)p * n + i] = res;
+    }
+}
+
+hipError_t hp_launch_base_to_single_crt(const HpLimb *limbs, const HpCrtConsts *cc, u32 L, u32 n, u32 P, const u64 *in, u64 *out,
+                                        const u32 *not_small, hipStream_t stream) {
+    u32 chunks; dim3 grid;
+    elem_grid(n, P, chunks, grid);
+    k_base_to_single_crt<<<grid, ELEM_THREADS, 0, stream>>>(limbs, cc, L, n, chunks, in, out, not_small);
+    return hipGetLastError();
+}

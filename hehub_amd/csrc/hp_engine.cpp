@@ -48,6 +48,7 @@ struct hp_ctx {
     std::map<std::pair<u64, size_t>, DevTables> tables;          // (q, logn)
     std::map<std::pair<size_t, std::vector<u64>>, Plan> plans;   // (logn, moduli); logn == 0: no transforms needed
     std::map<std::pair<size_t, size_t>, u32 *> perms;            // (logn, step) -> gather map
+    std::map<std::pair<std::vector<u64>, u64>, HpCrtConsts *> crt;   // (old moduli, new modulus) -> CRT-branch constants
     void *ws = nullptr;
     size_t ws_bytes = 0;
     // profiling
@@ -550,6 +551,7 @@ void hp_ctx_destroy(hp_ctx *ctx) {
     }
     for (auto &kv : ctx->plans) (void)hipFree(kv.second.d_limbs);
     for (auto &kv : ctx->perms) (void)hipFree(kv.second);
+    for (auto &kv : ctx->crt) (void)hipFree(kv.second);
     if (ctx->ws) (void)hipFree(ctx->ws);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; i++) {
@@ -1094,6 +1096,75 @@ int hp_dev_rns_base_to_single_small(hp_ctx *ctx, size_t n, size_t L, const uint6
     ProfScope ps(ctx, "elem");
     return chk(ctx, hp_launch_base_to_single(plan->d_limbs, (u32)L, (u32)n, (u32)batch, new_modulus, in, out, not_small, ctx->stream),
                "base_to_single");
+}
+
+// constants of the CRT branch of the many -> one base transform (rns_transform.cpp:86-104), cached per (moduli, t)
+static int get_crt_consts(hp_ctx *ctx, const uint64_t *moduli, size_t L, u64 t, const HpCrtConsts **out) {
+    return contained(ctx, [&] {
+        auto key = std::make_pair(std::vector<u64>(moduli, moduli + L), t);
+        auto it = ctx->crt.find(key);
+        if (it == ctx->crt.end()) {
+            HpCrtConsts c;
+            memset(&c, 0, sizeof(c));
+            c.t = t;
+            typedef unsigned __int128 u128;
+            u64 prod_t = 1 % t;
+            for (size_t a = 0; a < L; a++) {
+                c.pref[a] = prod_t;
+                c.pref_h[a] = hp::harvey_quotient(prod_t, t);
+                prod_t = (u64)((u128)prod_t * (moduli[a] % t) % t);
+                for (size_t b = 0; b < a; b++) {
+                    if (moduli[b] % moduli[a] == 0) return fail(ctx, HP_EINVAL, "moduli are not pairwise coprime");
+                    c.inv[b][a] = hp::inverse_mod_prime(moduli[b] % moduli[a], moduli[a]) % moduli[a];
+                    c.inv_h[b][a] = hp::harvey_quotient(c.inv[b][a], moduli[a]);
+                }
+            }
+            c.q_mod_t = prod_t;
+            // floor(Q/2) = (Q-1)/2 has the residues (q_a - 1)/2; its mixed-radix digits by the same recurrence
+            for (size_t a = 0; a < L; a++) {
+                const u64 qa = moduli[a];
+                u64 u = (qa - 1) / 2;
+                for (size_t b = 0; b < a; b++) {
+                    const u64 vb = c.half[b] % qa;
+                    u = (u64)((u128)((u + qa - vb) % qa) * c.inv[b][a] % qa);
+                }
+                c.half[a] = u;
+            }
+            HpCrtConsts *d = nullptr;
+            int rc = upload(ctx, &c, sizeof(c), (void **)&d);
+            if (rc) return rc;
+            it = ctx->crt.emplace(key, d).first;
+        }
+        *out = it->second;
+        return (int)HP_OK;
+    });
+}
+
+// rns_transform.h rns_base_transform(poly, {new_modulus}) complete: small-coefficient branch for the polynomials whose
+// coefficients are all small, CRT composition for the others -- decided per polynomial on the device, no host round trip
+int hp_dev_rns_base_to_single(hp_ctx *ctx, size_t n, size_t L, const uint64_t *old_moduli, uint64_t new_modulus, size_t batch,
+                              const uint64_t *in, uint64_t *out) {
+    Guard g(ctx);
+    HP_REQUIRE(ctx, old_moduli, in, out);
+    HP_ALIGNED(ctx, in, out);
+    if (new_modulus < 2 || L < 1) return fail(ctx, HP_EINVAL, "invalid moduli");
+    if (L > HP_CRT_MAX_LIMBS || new_modulus >> 62) return fail(ctx, HP_EUNSUPPORTED, "CRT branch: at most 16 moduli and a new modulus below 2^62");
+    for (size_t a = 0; a < L; a++)
+        if (!(old_moduli[a] & 1) || old_moduli[a] < 3) return fail(ctx, HP_EUNSUPPORTED, "CRT branch needs odd moduli");
+    if (batch == 0 || n == 0) return HP_OK;
+    const Plan *plan;
+    int rc = get_plan(ctx, 0, old_moduli, L, false, &plan);
+    if (rc) return rc;
+    const HpCrtConsts *cc;
+    if ((rc = get_crt_consts(ctx, old_moduli, L, new_modulus, &cc))) return rc;
+    if ((rc = ws_reserve(ctx, padded((batch + 1) / 2)))) return rc;
+    u32 *flags = (u32 *)ctx->ws;
+    ProfScope ps(ctx, "elem");
+    if ((rc = chk(ctx, hp_launch_base_to_single(plan->d_limbs, (u32)L, (u32)n, (u32)batch, new_modulus, in, out, flags, ctx->stream),
+                  "base_to_single")))
+        return rc;
+    return chk(ctx, hp_launch_base_to_single_crt(plan->d_limbs, cc, (u32)L, (u32)n, (u32)batch, in, out, flags, ctx->stream),
+               "base_to_single_crt");
 }
 
 // ---- limb-range stages (limb-sharded "latency" mode across GPUs) ---------------------------------

@@ -123,6 +123,17 @@ hipError_t hp_launch_drop_fin(const HpLimb *limbs, const HpDropConsts &dc, u32 L
                               const u64 *rem, const u64 *addend, u32 add_poly_stride, u32 add_ct_stride,
                               u32 add_mask, u64 *out, hipStream_t stream);
 
+// constants of the CRT branch of rns_base_transform many -> one (device memory; built by the engine)
+#define HP_CRT_MAX_LIMBS 16
+struct HpCrtConsts {
+    u64 t, q_mod_t;                                                  // new modulus, (q_0 ... q_{L-1}) mod t
+    u64 inv[HP_CRT_MAX_LIMBS][HP_CRT_MAX_LIMBS], inv_h[HP_CRT_MAX_LIMBS][HP_CRT_MAX_LIMBS];   // [b][a], b < a: q_b^-1 mod q_a (+ Harvey word)
+    u64 half[HP_CRT_MAX_LIMBS];                                      // mixed-radix digits of floor(Q/2)
+    u64 pref[HP_CRT_MAX_LIMBS], pref_h[HP_CRT_MAX_LIMBS];            // q_0 ... q_{a-1} mod t (+ Harvey word)
+};
+hipError_t hp_launch_base_to_single_crt(const HpLimb *limbs, const HpCrtConsts *cc, u32 L, u32 n, u32 P, const u64 *in, u64 *out,
+                                        const u32 *not_small, hipStream_t stream);
+
 // ---- either side of the path ---------------------------------------
 // noise [P][n] (int64) -> out rows p*out_pstride + k: the per-modulus lift of sampling.cpp:77-83
 hipError_t hp_launch_lift_noise(const HpLimb *limbs, u32 L, u32 n, u32 P, const long long *noise, u64 *out, u32 out_pstride,

@@ -326,6 +326,14 @@ class Engine:
                                                            self._ptr(out), C.c_void_p(flags.data_ptr())))
         return out, flags
 
+    def rns_base_to_single(self, old_moduli, new_modulus, x):
+        """rns_base_transform(poly, {new_modulus}) complete: small-coefficient or CRT branch per polynomial."""
+        B, L, n = x.shape
+        out = self.empty((B, n))
+        self._chk(self.lib.hp_dev_rns_base_to_single(self.h, n, L, _u64arr(old_moduli), new_modulus, B, self._ptr(x),
+                                                     self._ptr(out)))
+        return out
+
     def ckks_mult(self, moduli_ext, ct1, ct2, key, out=None):
         B, two, L, n = ct1.shape
         out = self.empty((B, 2, L - 1, n)) if out is None else out

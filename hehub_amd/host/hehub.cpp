@@ -547,7 +547,7 @@ RlwePt decrypt_core(const RlweCt &ct, const RlweSk &sk) {
 }
 
 #ifndef HEHUB_AMD_BIND_REFERENCE
-// rns_transform.cpp:106-127 with :11-37 and the small-coefficient branch of :39-84 on the device
+// rns_transform.cpp:106-127 on the device: one -> many (:11-37) and many -> one (:39-104, both branches)
 RnsPolynomial rns_base_transform(RnsPolynomial in, const std::vector<u64> &new_moduli) {
     if (in.rep_form == PolyRepForm::value)
         throw std::logic_error("Trying to perform RNS base transformation on NTT values.");
@@ -561,16 +561,11 @@ RnsPolynomial rns_base_transform(RnsPolynomial in, const std::vector<u64> &new_m
         get_poly(out, dout.p, new_moduli.size());
         return out;
     }
-    if (new_moduli.size() == 1) {
+    if (new_moduli.size() == 1) {   // both branches of rns_transform.cpp:39-104 on the device
         RnsPolynomial out(n, 1, new_moduli);
-        DevBuf din(L * n), dout(n), dflag(1);
+        DevBuf din(L * n), dout(n);
         put_poly(din.p, in, L);
-        check(hp_dev_rns_base_to_single_small(amd::engine(), n, L, in.modulus_vec().data(), new_moduli[0], 1, din.p, dout.p,
-                                              reinterpret_cast<uint32_t *>(dflag.p)));
-        u64 flag = 0;
-        check(hp_memcpy_d2h(amd::engine(), &flag, dflag.p, sizeof(uint32_t)));
-        if ((uint32_t)flag != 0)
-            throw std::logic_error("hehub_amd: CRT composition of large coefficients (rns_transform.cpp:86-104) is not part of this layer");
+        check(hp_dev_rns_base_to_single(amd::engine(), n, L, in.modulus_vec().data(), new_moduli[0], 1, din.p, dout.p));
         get_poly(out, dout.p, 1);
         return out;
     }

@@ -160,8 +160,7 @@ struct RlweSk : public RnsPolynomial {   // rlwe.h:34 (sampling the key is the c
     RlweSk(RnsPolynomial &&p) : RnsPolynomial(std::move(p)) {}
 };
 RlwePt decrypt_core(const RlweCt &ct, const RlweSk &sk);   // rlwe.cpp:74-81
-// rns_transform.h: one modulus -> many, and many -> one for small coefficients; the BigInt CRT branch of the
-// reference (rns_transform.cpp:86-104) is not part of this layer and throws std::logic_error
+// rns_transform.h: one modulus -> many, and many -> one (small-coefficient and CRT branches, rns_transform.cpp:39-104)
 RnsPolynomial rns_base_transform(RnsPolynomial input_rns_poly, const std::vector<u64> &new_moduli);
 
 using RgswCt = std::vector<RlweCt>;

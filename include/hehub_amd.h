@@ -181,6 +181,13 @@ int hp_dev_rns_base_from_single(hp_ctx *ctx, size_t n, uint64_t old_modulus, siz
 int hp_dev_rns_base_to_single_small(hp_ctx *ctx, size_t n, size_t L, const uint64_t *old_moduli, uint64_t new_modulus,
                                     size_t batch, const uint64_t *d_in, uint64_t *d_out, uint32_t *d_not_small);
 
+/* rns_base_transform, many -> one, COMPLETE (rns_transform.cpp:106-127 with one new modulus): per polynomial the
+ * small-coefficient branch when all its coefficients are small, otherwise the CRT composition the reference does with
+ * big integers (:86-104) -- here with mixed-radix word arithmetic, same values (including its returning new_modulus
+ * itself when new_modulus divides Q - x).  At most 16 odd pairwise-coprime old moduli, new_modulus < 2^62. */
+int hp_dev_rns_base_to_single(hp_ctx *ctx, size_t n, size_t L, const uint64_t *old_moduli, uint64_t new_modulus,
+                              size_t batch, const uint64_t *d_in, uint64_t *d_out);
+
 /* ---- limb-range stages: the limb-sharded ("latency") mode across GPUs -------------------------------------
  * one ciphertext operation is cut by OUTPUT MODULUS.  Rank g owns a contiguous range
  * [k0,k1) of the extended moduli q_0..q_{L-1},p.  Every buffer keeps the single-GPU layout of the entry points

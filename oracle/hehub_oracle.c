@@ -694,6 +694,8 @@ void orc_rns_base_from_single(size_t n, u64 old_modulus, size_t L, const u64 *ne
     }
 }
 
+int orc_rns_base_to_single_small(size_t n, size_t L, const u64 *old_moduli, u64 new_modulus, const u64 *in, u64 *out);
+
 /* rns_transform.cpp:39-84 */
 int orc_rns_base_to_single_small(size_t n, size_t L, const u64 *old_moduli, u64 new_modulus, const u64 *in, u64 *out) {
     const u64 q0 = old_moduli[0], half = q0 / 2;
@@ -717,6 +719,88 @@ int orc_rns_base_to_single_small(size_t n, size_t L, const u64 *old_moduli, u64 
     orc_batched_barrett(new_modulus, n, out);
     return 1;
 }
+
+/* ---- a minimal fixed-width big integer (little-endian u64 words) for the CRT branch ---- */
+#define BN_WORDS 17 /* 16 moduli of < 2^64 plus headroom for the sum of L terms */
+typedef struct { u64 w[BN_WORDS]; } bn_t;
+
+static void bn_set(bn_t *a, u64 v) { memset(a, 0, sizeof(*a)); a->w[0] = v; }
+static void bn_mul_small(bn_t *a, u64 m) {
+    u64 carry = 0;
+    for (int i = 0; i < BN_WORDS; i++) {
+        u128 p = (u128)a->w[i] * m + carry;
+        a->w[i] = (u64)p;
+        carry = (u64)(p >> 64);
+    }
+}
+static void bn_add(bn_t *a, const bn_t *b) {
+    u64 carry = 0;
+    for (int i = 0; i < BN_WORDS; i++) {
+        u128 s = (u128)a->w[i] + b->w[i] + carry;
+        a->w[i] = (u64)s;
+        carry = (u64)(s >> 64);
+    }
+}
+static void bn_sub(bn_t *a, const bn_t *b) { /* a >= b */
+    u64 borrow = 0;
+    for (int i = 0; i < BN_WORDS; i++) {
+        u128 d = (u128)a->w[i] - b->w[i] - borrow;
+        a->w[i] = (u64)d;
+        borrow = (u64)(d >> 64) & 1;
+    }
+}
+static int bn_cmp(const bn_t *a, const bn_t *b) {
+    for (int i = BN_WORDS - 1; i >= 0; i--)
+        if (a->w[i] != b->w[i]) return a->w[i] < b->w[i] ? -1 : 1;
+    return 0;
+}
+static u64 bn_mod_small(const bn_t *a, u64 m) {
+    u128 r = 0;
+    for (int i = BN_WORDS - 1; i >= 0; i--) r = ((r << 64) | a->w[i]) % m;
+    return (u64)r;
+}
+static void bn_shr1(bn_t *a) {
+    for (int i = 0; i < BN_WORDS; i++) a->w[i] = (a->w[i] >> 1) | (i + 1 < BN_WORDS ? a->w[i + 1] << 63 : 0);
+}
+
+/* rns_transform.cpp:106-127 for one new modulus: :113 reduce_strict, then :39-84 when every coefficient is small,
+ * else :86-104 (CRT composition, centred around Q/2; note that the second case returns new_modulus itself -- not 0 --
+ * when Q - x is a multiple of it) */
+void orc_rns_base_to_single(size_t n, size_t L, const u64 *old_moduli, u64 new_modulus, const u64 *in, u64 *out) {
+    if (orc_rns_base_to_single_small(n, L, old_moduli, new_modulus, in, out)) return;
+    bn_t Q, half, Mi[16];
+    u64 ci[16]; /* (Q/q_i)^-1 mod q_i */
+    bn_set(&Q, 1);
+    for (size_t i = 0; i < L; i++) bn_mul_small(&Q, old_moduli[i]);
+    half = Q;
+    bn_shr1(&half);
+    for (size_t i = 0; i < L; i++) {
+        bn_set(&Mi[i], 1);
+        for (size_t j = 0; j < L; j++)
+            if (j != i) bn_mul_small(&Mi[i], old_moduli[j]);
+        ci[i] = orc_inverse_mod_prime(bn_mod_small(&Mi[i], old_moduli[i]), old_moduli[i]);
+    }
+    for (size_t c = 0; c < n; c++) {
+        bn_t big, term;
+        bn_set(&big, 0);
+        for (size_t i = 0; i < L; i++) {
+            u64 x = in[i * n + c];
+            x -= (x >= old_moduli[i]) ? old_moduli[i] : 0;
+            term = Mi[i];
+            bn_mul_small(&term, (u64)((u128)x * ci[i] % old_moduli[i]));
+            bn_add(&big, &term);
+        }
+        while (bn_cmp(&big, &Q) >= 0) bn_sub(&big, &Q);
+        if (bn_cmp(&big, &half) < 0) {
+            out[c] = bn_mod_small(&big, new_modulus);
+        } else {
+            bn_t abs = Q;
+            bn_sub(&abs, &big);
+            out[c] = new_modulus - bn_mod_small(&abs, new_modulus);
+        }
+    }
+}
+
 
 /* ===================================================================== */
 /* digests / generators                                                  */

@@ -149,6 +149,11 @@ void orc_rns_base_from_single(size_t n, orc_u64 old_modulus, size_t L, const orc
 int orc_rns_base_to_single_small(size_t n, size_t L, const orc_u64 *old_moduli, orc_u64 new_modulus,
                                  const orc_u64 *in, orc_u64 *out);
 
+/* rns_transform.cpp:106-127 with a single new modulus, BOTH branches (:39-84 small coefficients, :86-104 CRT
+ * composition with the reference's big integers): in u64[L][N] (lazy allowed) -> out u64[N].  L <= 16. */
+void orc_rns_base_to_single(size_t n, size_t L, const orc_u64 *old_moduli, orc_u64 new_modulus, const orc_u64 *in,
+                            orc_u64 *out);
+
 /* ---- digests / generators shared by tests, fixtures and bench ------- */
 orc_u64 orc_fnv1a64(const void *bytes, size_t nbytes);
 /* x[i] = splitmix64 stream (state advanced per word) mod q (q==0: raw) */

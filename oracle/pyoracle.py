@@ -105,6 +105,7 @@ class Oracle:
         self._dec = f("rlwe_decrypt_core", C.c_int, [szt, szt, P, P, P, P])
         self._bfs = f("rns_base_from_single", None, [szt, u64, szt, P, P, P])
         self._bts = f("rns_base_to_single_small", C.c_int, [szt, szt, P, u64, P, P])
+        self._bt1 = f("rns_base_to_single", None, [szt, szt, P, u64, P, P])
         self._cmult = f("ckks_mult_relin_rescale", C.c_int, [szt, szt, P, P, P, P, P])
         self._bmult = f("bgv_mult_relin_modswitch", C.c_int, [szt, szt, P, u64, P, P, P, P])
         if self.kind == "orc":
@@ -312,6 +313,13 @@ class Oracle:
         out = np.empty(n, dtype=np.uint64)
         ok = self._bts(n, L, _p(_mods(old_moduli)), new_modulus, _p(x), _p(out))
         return bool(ok), out
+
+    def rns_base_to_single(self, old_moduli, new_modulus, x):
+        """rns_base_transform(poly, {new_modulus}): small-coefficient branch or CRT composition, as the reference decides."""
+        L, n = x.shape
+        out = np.empty(n, dtype=np.uint64)
+        self._bt1(n, L, _p(_mods(old_moduli)), new_modulus, _p(x), _p(out))
+        return out
 
     def ckks_mult(self, moduli_ext, ct1, ct2, key):
         _, L, n = ct1.shape

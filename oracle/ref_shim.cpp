@@ -310,6 +310,10 @@ void ref_rns_base_from_single(size_t n, u64 old_modulus, size_t L, const u64 *ne
     auto p = load_poly(n, 1, &m, in, PolyRepForm::coeff);
     store_poly(rns_base_transform(p, mods(new_moduli, L)), out);
 }
+void ref_rns_base_to_single(size_t n, size_t L, const u64 *old_moduli, u64 new_modulus, const u64 *in, u64 *out) {
+    auto p = load_poly(n, L, old_moduli, in, PolyRepForm::coeff);
+    store_poly(rns_base_transform(p, std::vector<u64>{new_modulus}), out);
+}
 int ref_rns_base_to_single_small(size_t n, size_t L, const u64 *old_moduli, u64 new_modulus, const u64 *in, u64 *out) {
     auto p = load_poly(n, L, old_moduli, in, PolyRepForm::coeff);
     store_poly(rns_base_transform(p, std::vector<u64>{new_modulus}), out);   // takes the CRT branch by itself when needed

@@ -368,6 +368,15 @@ static void test_plain_ops_and_decrypt_core() {   // ckks/arith.cpp:22-53, bgv/a
         REQUIRE(orc_rns_base_to_single_small(N, L, q.data(), t, fin.data(), exp1.data()) == 1);
         auto one = rns_base_transform(small, std::vector<u64>{t});
         REQUIRE(std::equal(exp1.begin(), exp1.end(), one[0].begin()));
+        // coefficients that are not small: the CRT branch (big integers in the reference, mixed radix on the device)
+        RnsPolynomial big(N, L, q);
+        for (size_t k = 0; k < L; k++) for (auto &w : big[(int)k]) w = rnd() % q[k];
+        big.rep_form = PolyRepForm::coeff;
+        std::vector<u64> fbig, expb(N);
+        flatten(big, fbig);
+        orc_rns_base_to_single(N, L, q.data(), t, fbig.data(), expb.data());
+        auto oneb = rns_base_transform(big, std::vector<u64>{t});
+        REQUIRE(std::equal(expb.begin(), expb.end(), oneb[0].begin()));
         small.rep_form = PolyRepForm::value;
         REQUIRE_THROWS_AS(rns_base_transform(small, std::vector<u64>{t}), std::logic_error);
     }

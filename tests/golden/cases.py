@@ -112,6 +112,7 @@ def run_cases(lib, big: bool = True) -> dict:
         out[f"base_from_single_t65537_{tag}"] = summary(lib.rns_base_from_single(65537, q, rng.words(n, 2 * 65537)))
         out[f"base_from_single_p_{tag}"] = summary(lib.rns_base_from_single(mext[L], q, rng.words(n, 2 * mext[L])))
         out[f"base_to_single_t65537_{tag}"] = summary(lib.rns_base_to_single_small(q, 65537, P.small_rns_poly(rng, n, q))[1])
+        out[f"base_to_single_crt_t65537_{tag}"] = summary(lib.rns_base_to_single(q, 65537, rng.poly((L, n), q)))
     return out
 
 

@@ -257,3 +257,16 @@ def test_abi_rejects_bad_arguments(eng):
     x = eng.to_device(np.arange(8, dtype=np.uint64).reshape(1, 1, 8))
     eng.ntt_([65537], x); eng.intt_([65537], x, strict=True)
     assert np.array_equal(eng.to_host(x).ravel(), np.arange(8, dtype=np.uint64))
+
+
+@pytest.mark.parametrize("n", [8, 4096, 32768])
+def test_dev_rns_base_to_single_complete(eng, orc, n):
+    """rns_transform.cpp:106-127, one new modulus: small and CRT branches decided per polynomial on the device."""
+    rng = SplitMix(850 + n)
+    for old, new in ((P.P40[:3], 65537), ([P.P50[0], P.P40[1]], 65537), (P.P40[:5], 257), (P.P40[:2], P.P50[2]), (P.C3_Q, 786433)):
+        x = np.stack([P.small_rns_poly(rng, n, old), rng.poly((len(old), n), old), rng.poly((len(old), n), old)])
+        x[1, 0, 0] += np.uint64(old[0])                             # a lazy word
+        x[2, :, 0] = [(q - new % q) % q for q in old]               # x = -new: the reference returns new itself, not 0
+        got = eng.to_host(eng.rns_base_to_single(old, new, eng.to_device(x)))
+        exp = np.stack([orc.rns_base_to_single(old, new, x[i]) for i in range(3)])
+        assert np.array_equal(got, exp) and got[2, 0] == new

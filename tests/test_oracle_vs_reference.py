@@ -207,3 +207,20 @@ def test_rns_base_transforms(orc, ref, n):
         assert ok and (got == ref.rns_base_to_single_small(old, new, x)[1]).all()
         big = rng.poly((len(old), n), old)             # uniform limbs are not a small polynomial: CRT branch
         assert not orc.rns_base_to_single_small(old, new, big)[0]
+
+
+@pytest.mark.parametrize("n", [8, 512])
+def test_rns_base_to_single_crt_branch(orc, ref, n):
+    """rns_transform.cpp:86-104: coefficients that are not small go through the reference's big-integer CRT."""
+    rng = SplitMix(650 + n)
+    for old, new in ((P.P40[:3], 65537), ([P.P50[0], P.P40[1]], 65537), (P.P40[:5], 257), (P.P40[:2], P.P50[2]), (P.C3_Q, 786433)):
+        x = rng.poly((len(old), n), old)
+        x[0, 0] += np.uint64(old[0])                               # one lazy word
+        assert (orc.rns_base_to_single(old, new, x) == ref.rns_base_to_single(old, new, x)).all()
+        # values just around Q/2 and the "multiple of the new modulus" corner: x = -new (mod Q) gives new itself, not 0
+        y = np.stack([np.full(n, (q - new % q) % q, dtype=np.uint64) for q in old])
+        y[:, 1:] = x[:, 1:]
+        got = orc.rns_base_to_single(old, new, y)
+        assert (got == ref.rns_base_to_single(old, new, y)).all() and got[0] == new
+        small = P.small_rns_poly(rng, n, old)
+        assert (orc.rns_base_to_single(old, new, small) == ref.rns_base_to_single(old, new, small)).all()
