@@ -38,7 +38,7 @@ while time.time() - t0 < budget:
     q = mext[:L]
     rng = SplitMix(int(rs.randint(1, 1 << 30)))
     kw = dict(logn=logn, L=L, B=B, mext=mext)
-    op = rs.choice(["ntt", "elem", "perm", "mult", "bgv", "rot", "drop", "encdec", "sharded"])
+    op = rs.choice(["ntt", "elem", "perm", "base", "mult", "bgv", "rot", "drop", "encdec", "sharded"])
     if op == "ntt":
         x = np.stack([rng.poly((L, n), q) for _ in range(B)])
         d = eng.to_device(x); eng.ntt_(q, d)
@@ -59,6 +59,15 @@ while time.time() - t0 < budget:
         check("mul", eng.to_host(eng.poly_mul(q, da, db)), np.stack([orc.poly_mul(q, a[i], b[i]) for i in range(B)]), **kw)
         sc = [int(w) for w in rng.words(L)]
         check("smul", eng.to_host(eng.poly_scalar_mul(q, da, sc)), np.stack([orc.poly_rns_scalar_mul(q, a[i], sc) for i in range(B)]), **kw)
+    elif op == "base":
+        t = int(rs.choice([2, 257, 65537, 786433, P.P50[3]]))
+        x1 = np.stack([rng.words(n, 2 * t) for _ in range(B)])                       # one modulus -> many (lazy input)
+        check("from_single", eng.to_host(eng.rns_base_from_single(t, q, eng.to_device(x1))),
+              np.stack([orc.rns_base_from_single(t, q, x1[i]) for i in range(B)]), t=t, **kw)
+        if t % 2 and t not in q:
+            xs = np.stack([P.small_rns_poly(rng, n, q) if rs.randint(2) else rng.poly((L, n), q) for _ in range(B)])
+            check("to_single", eng.to_host(eng.rns_base_to_single(q, t, eng.to_device(xs))),
+                  np.stack([orc.rns_base_to_single(q, t, xs[i]) for i in range(B)]), t=t, **kw)
     elif op == "perm":
         a = np.stack([rng.poly((L, n), q) for _ in range(B)])
         da = eng.to_device(a)
