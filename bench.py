@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--logn", type=int, default=0,
                     help="override log2 of the ring degree for the ntt/intt/ckks/rotate workloads (same moduli); "
                          "0 = the BASELINE config's N")
+    ap.add_argument("--ntt-rates", action="store_true",
+                    help="ckks workload: also time forward / inverse limb transforms of the same batch (outside the timed "
+                         "region) and report them under \"ntt\".  Off by default so that a rocprofv3 summary of the default "
+                         "command shows k_ntt_fwd in its digit-spread launches only, as the roofline object does")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")
     ap.add_argument("--cpu-procs", type=int, default=1,
@@ -343,7 +347,7 @@ def main():
             a_min = (6 * L - 2) * 8 * n + 2 * L * (L + 1) * 8 * n / B
             res["pipeline_roofline"].update({"A_prim_frac_of_hbm_peak": value / world * a_prim / 1e9 / HBM_PEAK_GBS,
                                              "A_min_frac_of_hbm_peak": value / world * a_min / 1e9 / HBM_PEAK_GBS})
-    if wl == "ckks":
+    if wl == "ckks" and args.ntt_rates:
         # BASELINE.json's metric names both rates ("NTT/s and CKKS hom-mult/s ... N=32768"): the line also carries the
         # limb-transform rates at the same ring degree (all limbs of the same batch of ciphertexts, forward and inverse
         # timed separately, same fences; outside the timed region of `value`)
