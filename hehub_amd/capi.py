@@ -30,6 +30,8 @@ SIGNATURES = {
     "hp_ctx_reset_stream": (INT, [P]),
     "hp_ctx_get_stream": (P, [P]),
     "hp_sync": (INT, [P]),
+    "hp_ctx_workspace_bytes": (szt, [P]),
+    "hp_ctx_release_workspace": (INT, [P]),
     "hp_dev_alloc": (INT, [P, szt, C.POINTER(P)]),
     "hp_dev_free": (INT, [P, P]),
     "hp_memcpy_h2d": (INT, [P, P, P, szt]),

@@ -577,6 +577,17 @@ int hp_ctx_reset_stream(hp_ctx *ctx) {
 }
 void *hp_ctx_get_stream(hp_ctx *ctx) { return (void *)ctx->stream; }
 
+// The scratch workspace only grows (the largest call so far defines it: 10+ GiB for a C3 batch of 256); this gives it back.
+int hp_ctx_release_workspace(hp_ctx *ctx) {
+    Guard g(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->ws) HIP_TRY(ctx, hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+    return HP_OK;
+}
+size_t hp_ctx_workspace_bytes(hp_ctx *ctx) { return ctx ? ctx->ws_bytes : 0; }
+
 int hp_sync(hp_ctx *ctx) {
     Guard g(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -67,6 +67,9 @@ int hp_ctx_set_stream(hp_ctx *ctx, void *hip_stream);
 int hp_ctx_reset_stream(hp_ctx *ctx);
 void *hp_ctx_get_stream(hp_ctx *ctx);
 int hp_sync(hp_ctx *ctx);
+/* the engine's scratch workspace grows to the largest call so far and is reused; these report / release it */
+size_t hp_ctx_workspace_bytes(hp_ctx *ctx);
+int hp_ctx_release_workspace(hp_ctx *ctx);
 int hp_dev_alloc(hp_ctx *ctx, size_t bytes, void **dptr);
 int hp_dev_free(hp_ctx *ctx, void *dptr);
 int hp_memcpy_h2d(hp_ctx *ctx, void *dst, const void *src, size_t bytes);

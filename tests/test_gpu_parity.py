@@ -270,3 +270,18 @@ def test_dev_rns_base_to_single_complete(eng, orc, n):
         got = eng.to_host(eng.rns_base_to_single(old, new, eng.to_device(x)))
         exp = np.stack([orc.rns_base_to_single(old, new, x[i]) for i in range(3)])
         assert np.array_equal(got, exp) and got[2, 0] == new
+
+
+def test_workspace_grows_and_can_be_released(eng, orc):
+    mext = P.P40[:3] + [P.P50[0]]
+    rng = SplitMix(31)
+    n, L = 1 << 11, 3
+    ct1 = np.stack([rng.poly((2, L, n), mext[:L])]); ct2 = np.stack([rng.poly((2, L, n), mext[:L])])
+    key = rng.poly((L, 2, L + 1, n), mext)
+    d1, d2, dk = eng.to_device(ct1), eng.to_device(ct2), eng.to_device(key)
+    exp = orc.ckks_mult(mext, ct1[0], ct2[0], key)
+    assert np.array_equal(eng.to_host(eng.ckks_mult(mext, d1, d2, dk))[0], exp)
+    assert eng.lib.hp_ctx_workspace_bytes(eng.h) > 0
+    eng._chk(eng.lib.hp_ctx_release_workspace(eng.h))
+    assert eng.lib.hp_ctx_workspace_bytes(eng.h) == 0
+    assert np.array_equal(eng.to_host(eng.ckks_mult(mext, d1, d2, dk))[0], exp)      # it simply grows again
