@@ -285,3 +285,55 @@ def test_workspace_grows_and_can_be_released(eng, orc):
     eng._chk(eng.lib.hp_ctx_release_workspace(eng.h))
     assert eng.lib.hp_ctx_workspace_bytes(eng.h) == 0
     assert np.array_equal(eng.to_host(eng.ckks_mult(mext, d1, d2, dk))[0], exp)      # it simply grows again
+
+
+def _ntt_primes(count, logn, bits=40):
+    """the first `count` primes q = 1 (mod 2N) below 2^bits (deterministic Miller-Rabin for 64-bit)"""
+    def is_prime(n):
+        if n < 2:
+            return False
+        for p in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+            if n % p == 0:
+                return n == p
+        d, r = n - 1, 0
+        while d % 2 == 0:
+            d //= 2; r += 1
+        for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+            x = pow(a, d, n)
+            if x in (1, n - 1):
+                continue
+            for _ in range(r - 1):
+                x = x * x % n
+                if x == n - 1:
+                    break
+            else:
+                return False
+        return True
+
+    step, q, out = 2 << logn, ((1 << bits) // (2 << logn)) * (2 << logn) + 1, []
+    while len(out) < count:
+        q -= step
+        if is_prime(q):
+            out.append(q)
+    return out
+
+
+@pytest.mark.parametrize("logn", [6, 11])
+def test_maximum_number_of_moduli(eng, orc, logn):
+    """HP_MAX_LIMBS = 32: a ciphertext of 31 moduli plus the special prime through the whole pipeline (generic and
+    tiled kernels, the latter with the fused drop-last-prime constants at their full width)."""
+    L = 31
+    mext = _ntt_primes(L + 1, logn)
+    n = 1 << logn
+    rng = SplitMix(4242)
+    ct1 = np.stack([rng.poly((2, L, n), mext[:L]) for _ in range(2)]); ct2 = np.stack([rng.poly((2, L, n), mext[:L]) for _ in range(2)])
+    key = rng.poly((L, 2, L + 1, n), mext)
+    d1, d2, dk = eng.to_device(ct1), eng.to_device(ct2), eng.to_device(key)
+    assert np.array_equal(eng.to_host(eng.ckks_mult(mext, d1, d2, dk)), np.stack([orc.ckks_mult(mext, ct1[i], ct2[i], key) for i in range(2)]))
+    assert np.array_equal(eng.to_host(eng.bgv_mult(mext, 65537, d1, d2, dk)),
+                          np.stack([orc.bgv_mult(mext, 65537, ct1[i], ct2[i], key) for i in range(2)]))
+    assert np.array_equal(eng.to_host(eng.ckks_rotate(mext, d1, dk, 5)), np.stack([orc.ckks_rotate(mext, ct1[i], key, 5) for i in range(2)]))
+    from hehub_amd.engine import InvalidArgument
+
+    with pytest.raises(InvalidArgument):      # one more modulus does not fit
+        eng.ckks_rotate(mext + _ntt_primes(L + 2, logn)[-1:], eng.empty((1, 2, L + 1, n)), eng.empty((L + 1, 2, L + 2, n)), 1)
