@@ -382,6 +382,45 @@ static void test_plain_ops_and_decrypt_core() {   // ckks/arith.cpp:22-53, bgv/a
     }
 }
 
+static void test_ragged_operands() {   // rns.cpp:59-72 (+= on the first self.component_count() limbs of b), :120-140 (min components)
+    const size_t N = 256;
+    std::vector<u64> q{1099510054913ull, 1099507695617ull, 1099506515969ull};
+    RnsPolynomial a(N, 2, q), b(N, 3, q);
+    for (size_t k = 0; k < 2; k++) for (auto &w : a[(int)k]) w = rnd() % (2 * q[k]);
+    for (size_t k = 0; k < 3; k++) for (auto &w : b[(int)k]) w = rnd() % (2 * q[k]);
+    a.rep_form = b.rep_form = PolyRepForm::value;
+    std::vector<u64> fa, fb;
+    flatten(a, fa); flatten(b, fb);
+    {   // a += b uses b's first two limbs
+        auto s = a;
+        s += b;
+        std::vector<u64> exp(fa), got;
+        orc_poly_add_inplace(N, 2, q.data(), exp.data(), fb.data());
+        flatten(s, got);
+        REQUIRE(s.component_count() == 2 && got == exp);
+    }
+    {   // b += a is an error: a has fewer components than b
+        auto s = b;
+        REQUIRE_THROWS_AS(s += a, std::invalid_argument);
+    }
+    {   // a * b and b * a both have two components
+        auto p1 = a * b, p2 = b * a;
+        std::vector<u64> exp(2 * N), got;
+        orc_poly_mul(N, 2, q.data(), fa.data(), fb.data(), exp.data());
+        flatten(p1, got);
+        REQUIRE(p1.component_count() == 2 && got == exp);
+        got.clear(); flatten(p2, got);
+        REQUIRE(p2.component_count() == 2 && got == exp);
+    }
+    {   // empty polynomial: operators are no-ops, not errors
+        RnsPolynomial e1(N, 0, std::vector<u64>{}), e2(N, 0, std::vector<u64>{});
+        e1.rep_form = e2.rep_form = PolyRepForm::value;
+        e1 += e2;
+        auto p = e1 * e2;
+        REQUIRE(p.component_count() == 0);
+    }
+}
+
 int main() {
     test_batched_barrett();
     test_batched_mul_mod();
@@ -391,6 +430,7 @@ int main() {
     test_ckks_rescaling();
     test_scheme_level_vs_oracle();
     test_plain_ops_and_decrypt_core();
+    test_ragged_operands();
     std::printf("%s: %d checks, %d failures\n", g_fail ? "FAILED" : "All tests passed", g_checks, g_fail);
     return g_fail ? 1 : 0;
 }
