@@ -169,6 +169,12 @@ struct RlweKsk : public RgswCt {
     RlweKsk() {}
     RlweKsk(RgswCt &&rgsw) : RgswCt(std::move(rgsw)) {}
 };
+struct RotKey : public RlweKsk {   // keys.h:63-68 (key generation itself -- sampling -- stays with the caller)
+    using RlweKsk::RlweKsk;
+    RotKey() {}
+    RotKey(RlweKsk &&ksk) : RlweKsk(std::move(ksk)) {}
+    size_t step = 0;
+};
 RlweCt ext_prod_montgomery(const RlwePt &pt, const RgswCt &rgsw);
 
 // ---- ckks.h -----------------------------------------------------------------------------------------------
@@ -201,6 +207,7 @@ inline CkksCt mult(const CkksCt &ct1, const CkksCt &ct2, const RlweKsk &relin_ke
 }
 CkksCt conjugate(const CkksCt &ct, const RlweKsk &conj_key);
 CkksCt rotate(const CkksCt &ct, const RlweKsk &rot_key, const size_t step);
+inline CkksCt rotate(const CkksCt &ct, const RotKey &rot_key) { return rotate(ct, rot_key, rot_key.step); }   // ckks.h:303
 void rescale_inplace(CkksCt &ct, size_t dropping_primes = 1);
 } // namespace ckks
 

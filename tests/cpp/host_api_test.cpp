@@ -254,6 +254,15 @@ static void test_scheme_level_vs_oracle() {   // raw lazy words of ckks::mult+re
     REQUIRE(orc_ckks_rotate(logn, L, mext.data(), 3, f1.data(), fk.data(), ext.data()) == 0);
     REQUIRE(std::equal(got.begin(), got.end(), ext.begin()));
     REQUIRE(rot.scaling_factor == a.scaling_factor);
+    {   // the RotKey overload carries the step with the key (keys.h:63-68, ckks.h:303)
+        RotKey rk;
+        for (auto &sample : key) rk.push_back(sample);
+        rk.step = 3;
+        auto rot2 = ckks::rotate(a, rk);
+        std::vector<u64> got2;
+        for (int h = 0; h < 2; h++) flatten(rot2[h], got2);
+        REQUIRE(got2 == got);
+    }
 
     auto cj = ckks::conjugate(b, key);
     REQUIRE(orc_ckks_conjugate(logn, L, mext.data(), f2.data(), fk.data(), ext.data()) == 0);
