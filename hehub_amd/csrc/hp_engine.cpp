@@ -463,7 +463,7 @@ int drop_last(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, b
 }
 
 int check_ext_args(hp_ctx *ctx, size_t logn, size_t L, size_t batch) {
-    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (!logn_ok(logn)) return fail(ctx, HP_EUNSUPPORTED, "ring degrees 2^1 .. 2^15 are supported");
     if (L < 1 || L + 1 > HP_MAX_LIMBS) return fail(ctx, HP_EINVAL, "Invalid component number in RGSW ciphertext.");
     if (batch == 0) return fail(ctx, HP_EINVAL, "empty batch");
     return HP_OK;
@@ -498,7 +498,7 @@ int host_vec(hp_ctx *ctx, int op, uint64_t q, size_t n, const uint64_t *a, const
 }
 
 int host_transform(hp_ctx *ctx, size_t logn, uint64_t q, uint64_t *x, int inverse) {
-    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (!logn_ok(logn)) return fail(ctx, HP_EUNSUPPORTED, "ring degrees 2^1 .. 2^15 are supported");
     const Plan *plan;
     int rc = get_plan(ctx, logn, &q, 1, true, &plan);
     if (rc) return rc;
@@ -635,7 +635,7 @@ int hp_intt_negacyclic_inplace_lazy(hp_ctx *ctx, size_t logn, uint64_t q, uint64
 }
 int hp_cache_ntt_factors_strict(hp_ctx *ctx, size_t logn, const uint64_t *moduli, size_t count) {
     Guard g(ctx);
-    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (!logn_ok(logn)) return fail(ctx, HP_EUNSUPPORTED, "ring degrees 2^1 .. 2^15 are supported");
     for (size_t i = 0; i < count; i++) {
         DevTables t;
         int rc = get_tables(ctx, moduli[i], logn, t);
@@ -675,7 +675,7 @@ int hp_dev_ntt(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, d_x);
     HP_ALIGNED(ctx, d_x);
-    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (!logn_ok(logn)) return fail(ctx, HP_EUNSUPPORTED, "ring degrees 2^1 .. 2^15 are supported");
     if (batch == 0) return HP_OK;
     const Plan *plan;
     int rc = get_plan(ctx, logn, moduli, L, true, &plan);
@@ -687,7 +687,7 @@ int hp_dev_intt(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, d_x);
     HP_ALIGNED(ctx, d_x);
-    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (!logn_ok(logn)) return fail(ctx, HP_EUNSUPPORTED, "ring degrees 2^1 .. 2^15 are supported");
     if (batch == 0) return HP_OK;
     const Plan *plan;
     int rc = get_plan(ctx, logn, moduli, L, true, &plan);
@@ -700,7 +700,7 @@ static int dev_binary(hp_ctx *ctx, int op, size_t n, size_t L, const uint64_t *m
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, a, b, out);
     HP_ALIGNED(ctx, a, b, out);
-    if (n == 0 || (n & (n - 1))) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (n == 0 || (n & (n - 1))) return fail(ctx, HP_EUNSUPPORTED, "ring degrees 2^1 .. 2^15 are supported");
     if (batch == 0) return HP_OK;
     const Plan *plan;
     int rc = get_plan(ctx, 0, moduli, L, false, &plan);
@@ -724,7 +724,7 @@ int hp_dev_poly_scalar_mul(hp_ctx *ctx, size_t n, size_t L, const uint64_t *modu
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, rns_scalar, a, out);
     HP_ALIGNED(ctx, a, out);
-    if (n == 0 || (n & (n - 1))) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (n == 0 || (n & (n - 1))) return fail(ctx, HP_EUNSUPPORTED, "ring degrees 2^1 .. 2^15 are supported");
     if (batch == 0) return HP_OK;
     const Plan *plan;
     int rc = get_plan(ctx, 0, moduli, L, false, &plan);
@@ -744,7 +744,7 @@ int hp_dev_poly_reduce_strict(hp_ctx *ctx, size_t n, size_t L, const uint64_t *m
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, x);
     HP_ALIGNED(ctx, x);
-    if (n == 0 || (n & (n - 1))) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (n == 0 || (n & (n - 1))) return fail(ctx, HP_EUNSUPPORTED, "ring degrees 2^1 .. 2^15 are supported");
     if (batch == 0) return HP_OK;
     const Plan *plan;
     int rc = get_plan(ctx, 0, moduli, L, false, &plan);
@@ -757,7 +757,7 @@ int hp_dev_poly_involution(hp_ctx *ctx, size_t logn, size_t L, size_t batch, con
     Guard g(ctx);
     HP_REQUIRE(ctx, in, out);
     HP_ALIGNED(ctx, in, out);
-    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (!logn_ok(logn)) return fail(ctx, HP_EUNSUPPORTED, "ring degrees 2^1 .. 2^15 are supported");
     if (batch == 0) return HP_OK;
     if (in == out) return fail(ctx, HP_EINVAL, "involution cannot run in place");
     ProfScope ps(ctx, "elem");
@@ -769,7 +769,7 @@ int hp_dev_poly_cycle(hp_ctx *ctx, size_t logn, size_t L, size_t batch, size_t s
     Guard g(ctx);
     HP_REQUIRE(ctx, in, out);
     HP_ALIGNED(ctx, in, out);
-    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (!logn_ok(logn)) return fail(ctx, HP_EUNSUPPORTED, "ring degrees 2^1 .. 2^15 are supported");
     if (batch == 0) return HP_OK;
     if (in == out) return fail(ctx, HP_EINVAL, "cycle cannot run in place");
     if (step >= ((size_t)1 << 17)) return fail(ctx, HP_EINVAL, "rotation step out of range");
@@ -786,7 +786,7 @@ int hp_dev_mult_low_level(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *mo
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, ct1, ct2, quad);
     HP_ALIGNED(ctx, ct1, ct2, quad);
-    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (!logn_ok(logn)) return fail(ctx, HP_EUNSUPPORTED, "ring degrees 2^1 .. 2^15 are supported");
     if (batch == 0) return HP_OK;
     const Plan *plan;
     int rc = get_plan(ctx, 0, moduli, L, false, &plan);
@@ -829,7 +829,7 @@ static int dev_drop(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, 
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, ct, out);
     HP_ALIGNED(ctx, ct, out);
-    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (!logn_ok(logn)) return fail(ctx, HP_EUNSUPPORTED, "ring degrees 2^1 .. 2^15 are supported");
     if (L < 2) return fail(ctx, HP_EINVAL, "Unable to drop the only one prime.");
     if (bgv && t == 0) return fail(ctx, HP_EINVAL, "plain modulus must be positive");
     if (batch == 0) return HP_OK;
@@ -1039,7 +1039,7 @@ int hp_dev_rlwe_encrypt_core(hp_ctx *ctx, size_t logn, size_t L, const uint64_t 
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, noise, c1, pt, sk, ct);
     HP_ALIGNED(ctx, noise, c1, pt, sk, ct);
-    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (!logn_ok(logn)) return fail(ctx, HP_EUNSUPPORTED, "ring degrees 2^1 .. 2^15 are supported");
     if (L < 1 || L > HP_MAX_LIMBS) return fail(ctx, HP_EINVAL, "invalid component number");
     if (batch == 0) return HP_OK;
     const Plan *plan;
@@ -1065,7 +1065,7 @@ int hp_dev_rlwe_decrypt_core(hp_ctx *ctx, size_t logn, size_t L, const uint64_t 
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, ct, sk, pt);
     HP_ALIGNED(ctx, ct, sk, pt);
-    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (!logn_ok(logn)) return fail(ctx, HP_EUNSUPPORTED, "ring degrees 2^1 .. 2^15 are supported");
     if (L < 1 || L > HP_MAX_LIMBS) return fail(ctx, HP_EINVAL, "invalid component number");
     if (batch == 0) return HP_OK;
     const Plan *plan;
@@ -1189,7 +1189,7 @@ int hp_dev_mult_low_level_range(hp_ctx *ctx, size_t logn, size_t L, const uint64
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, ct1, ct2, quad);
     HP_ALIGNED(ctx, ct1, ct2, quad);
-    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (!logn_ok(logn)) return fail(ctx, HP_EUNSUPPORTED, "ring degrees 2^1 .. 2^15 are supported");
     int rc = range_ok(ctx, k0, k1, L);
     if (rc) return rc;
     if (batch == 0 || k0 == k1) return HP_OK;
@@ -1235,7 +1235,7 @@ int hp_dev_drop_coeffs(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *modul
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, x, clast);
     HP_ALIGNED(ctx, x, clast);
-    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (!logn_ok(logn)) return fail(ctx, HP_EUNSUPPORTED, "ring degrees 2^1 .. 2^15 are supported");
     if (L < 2) return fail(ctx, HP_EINVAL, "Unable to drop the only one prime.");
     if (P2 == 0) return HP_OK;
     const Plan *plan;
@@ -1250,7 +1250,7 @@ int hp_dev_drop_apply_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli, x, clast, out);
     HP_ALIGNED(ctx, x, clast, out);
-    if (!logn_ok(logn)) return fail(ctx, HP_EINVAL, "dimension should be a 2-power.");
+    if (!logn_ok(logn)) return fail(ctx, HP_EUNSUPPORTED, "ring degrees 2^1 .. 2^15 are supported");
     if (L < 2) return fail(ctx, HP_EINVAL, "Unable to drop the only one prime.");
     int rc = range_ok(ctx, k0, k1, L - 1);
     if (rc) return rc;
