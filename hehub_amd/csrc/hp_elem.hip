@@ -584,9 +584,10 @@ hipError_t hp_launch_base_to_single(const HpLimb *limbs, u32 L, u32 n, u32 P, u6
 // Only polynomials flagged not_small are touched; the others keep the small-coefficient result.
 __global__ void __launch_bounds__(ELEM_THREADS) k_base_to_single_crt(const HpLimb *__restrict__ limbs, const HpCrtConsts *__restrict__ cc,
                                                                     u32 L, u32 n, u32 chunks, const u64 *__restrict__ in,
-                                                                    u64 *__restrict__ out, const u32 *__restrict__ not_small) {
+                                                                    u64 *__restrict__ out, u32 out_pstride,
+                                                                    const u32 *__restrict__ not_small) {
     const u32 p = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
-    if (!not_small[p]) return;
+    if (not_small && !not_small[p]) return;   // NULL: every polynomial takes the CRT composition
     const u64 t = cc->t;
     const u64 *x = in + (size_t)p * L * n;
     const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
@@ -619,14 +620,14 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_base_to_single_crt(const HpLim
             abs -= (abs >= t) ? t : 0;
             res = t - abs;
         }
-        out[(size_t)p * n + i] = res;
+        out[(size_t)p * out_pstride * n + i] = res;
     }
 }
 
 hipError_t hp_launch_base_to_single_crt(const HpLimb *limbs, const HpCrtConsts *cc, u32 L, u32 n, u32 P, const u64 *in, u64 *out,
-                                        const u32 *not_small, hipStream_t stream) {
+                                        u32 out_pstride, const u32 *not_small, hipStream_t stream) {
     u32 chunks; dim3 grid;
     elem_grid(n, P, chunks, grid);
-    k_base_to_single_crt<<<grid, ELEM_THREADS, 0, stream>>>(limbs, cc, L, n, chunks, in, out, not_small);
+    k_base_to_single_crt<<<grid, ELEM_THREADS, 0, stream>>>(limbs, cc, L, n, chunks, in, out, out_pstride, not_small);
     return hipGetLastError();
 }

@@ -1174,8 +1174,36 @@ int hp_dev_rns_base_to_single(hp_ctx *ctx, size_t n, size_t L, const uint64_t *o
     if ((rc = chk(ctx, hp_launch_base_to_single(plan->d_limbs, (u32)L, (u32)n, (u32)batch, new_modulus, in, out, flags, ctx->stream),
                   "base_to_single")))
         return rc;
-    return chk(ctx, hp_launch_base_to_single_crt(plan->d_limbs, cc, (u32)L, (u32)n, (u32)batch, in, out, flags, ctx->stream),
+    return chk(ctx, hp_launch_base_to_single_crt(plan->d_limbs, cc, (u32)L, (u32)n, (u32)batch, in, out, 1, flags, ctx->stream),
                "base_to_single_crt");
+}
+
+// extension (the reference throws "under development" for many -> many, rns_transform.cpp:123): the exact CRT value of
+// every coefficient, centred around Q/2 exactly as the many -> one CRT branch centres it, reduced into each new modulus
+int hp_dev_rns_base_many_to_many(hp_ctx *ctx, size_t n, size_t L, const uint64_t *old_moduli, size_t Lnew,
+                                 const uint64_t *new_moduli, size_t batch, const uint64_t *in, uint64_t *out) {
+    Guard g(ctx);
+    HP_REQUIRE(ctx, old_moduli, new_moduli, in, out);
+    HP_ALIGNED(ctx, in, out);
+    if (L < 1 || Lnew < 1 || Lnew > HP_MAX_LIMBS) return fail(ctx, HP_EINVAL, "invalid moduli");
+    if (L > HP_CRT_MAX_LIMBS) return fail(ctx, HP_EUNSUPPORTED, "CRT composition: at most 16 old moduli");
+    for (size_t a = 0; a < L; a++)
+        if (!(old_moduli[a] & 1) || old_moduli[a] < 3) return fail(ctx, HP_EUNSUPPORTED, "CRT composition needs odd moduli");
+    for (size_t k = 0; k < Lnew; k++)
+        if (new_moduli[k] < 2 || new_moduli[k] >> 62) return fail(ctx, HP_EUNSUPPORTED, "new moduli must be in [2, 2^62)");
+    if (batch == 0 || n == 0) return HP_OK;
+    const Plan *plan;
+    int rc = get_plan(ctx, 0, old_moduli, L, false, &plan);
+    if (rc) return rc;
+    ProfScope ps(ctx, "elem");
+    for (size_t k = 0; k < Lnew; k++) {
+        const HpCrtConsts *cc;
+        if ((rc = get_crt_consts(ctx, old_moduli, L, new_moduli[k], &cc))) return rc;
+        if ((rc = chk(ctx, hp_launch_base_to_single_crt(plan->d_limbs, cc, (u32)L, (u32)n, (u32)batch, in, out + k * n, (u32)Lnew,
+                                                        nullptr, ctx->stream), "base_many_to_many")))
+            return rc;
+    }
+    return HP_OK;
 }
 
 // ---- limb-range stages (limb-sharded "latency" mode across GPUs) ---------------------------------

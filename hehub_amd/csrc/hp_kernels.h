@@ -131,8 +131,9 @@ struct HpCrtConsts {
     u64 half[HP_CRT_MAX_LIMBS];                                      // mixed-radix digits of floor(Q/2)
     u64 pref[HP_CRT_MAX_LIMBS], pref_h[HP_CRT_MAX_LIMBS];            // q_0 ... q_{a-1} mod t (+ Harvey word)
 };
+// out: polynomial p at out + p*out_pstride*n; not_small == NULL: every polynomial takes the CRT composition
 hipError_t hp_launch_base_to_single_crt(const HpLimb *limbs, const HpCrtConsts *cc, u32 L, u32 n, u32 P, const u64 *in, u64 *out,
-                                        const u32 *not_small, hipStream_t stream);
+                                        u32 out_pstride, const u32 *not_small, hipStream_t stream);
 
 // ---- either side of the path ---------------------------------------
 // noise [P][n] (int64) -> out rows p*out_pstride + k: the per-modulus lift of sampling.cpp:77-83

@@ -286,6 +286,13 @@ class Engine:
                                                          self._ptr(pt), self._ptr(key), self._ptr(out)))
         return out
 
+    def rns_base_many_to_many(self, old_moduli, new_moduli, x):
+        B, L, n = x.shape
+        out = self.empty((B, len(new_moduli), n))
+        self._chk(self.lib.hp_dev_rns_base_many_to_many(self.h, n, L, _u64arr(old_moduli), len(new_moduli), _u64arr(new_moduli), B,
+                                                        self._ptr(x), self._ptr(out)))
+        return out
+
     def ckks_rescale_n(self, moduli, ct, drops: int):
         B, _, L, n = ct.shape
         out = self.empty((B, 2, L - drops, n))

@@ -241,6 +241,11 @@ int hp_dev_ckks_conjugate_at(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, 
 int hp_dev_ckks_mult_relin_rescale_at(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext,
                                       size_t batch, const uint64_t *d_ct1, const uint64_t *d_ct2,
                                       const uint64_t *d_key, uint64_t *d_out);
+/* (3) many -> many base conversion (hehub: "under development", rns_transform.cpp:123): the exact CRT value x of every
+ *     coefficient, centred around Q/2 the way the many -> one CRT branch does it (x mod m below the half,
+ *     m - ((Q - x) mod m) from the half on), in every new modulus.  in u64[batch][L][N] -> out u64[batch][Lnew][N] */
+int hp_dev_rns_base_many_to_many(hp_ctx *ctx, size_t n, size_t L, const uint64_t *old_moduli, size_t Lnew,
+                                 const uint64_t *new_moduli, size_t batch, const uint64_t *d_in, uint64_t *d_out);
 /* ct u64[batch][2][L][N] -> out u64[batch][2][L-drops][N]; d_tmp: 2 * batch*2*(L-1)*N words (may be NULL for drops == 1) */
 int hp_dev_ckks_rescale_n(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t drops, size_t batch,
                           const uint64_t *d_ct, uint64_t *d_tmp, uint64_t *d_out);

@@ -60,3 +60,23 @@ def test_rescale_by_several_primes(eng, orc, logn, L, drops):
 
     with pytest.raises(InvalidArgument):
         eng.ckks_rescale_n(q, eng.to_device(ct), L)
+
+
+@pytest.mark.parametrize("n", [8, 2048])
+def test_many_to_many_base_conversion(eng, orc, n):
+    """Pinned by equivalence: every output limb equals the reference-parity many -> one CRT composition into that modulus
+    (a polynomial that is not small makes the oracle take that branch), and for exact integers in Python."""
+    rng = SplitMix(990 + n)
+    old, new = P.P40[:4], [65537, P.P50[1], P.P40[6], 257]
+    x = np.stack([rng.poly((len(old), n), old) for _ in range(2)])
+    got = eng.to_host(eng.rns_base_many_to_many(old, new, eng.to_device(x)))
+    for i in range(2):
+        for k, m in enumerate(new):
+            assert np.array_equal(got[i, k], orc.rns_base_to_single(old, m, x[i]))
+    # exact integers: CRT compose coefficient 0 of polynomial 0 with Python ints
+    Q = 1
+    for q in old:
+        Q *= q
+    big = sum(int(x[0, a, 0]) * (Q // q) * pow(Q // q, -1, q) for a, q in enumerate(old)) % Q
+    for k, m in enumerate(new):
+        assert int(got[0, k, 0]) == (big % m if big < Q // 2 else m - ((Q - big) % m))
