@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="ckks", choices=["ckks", "ntt", "ntt15", "intt", "intt15", "bgv", "rotate", "ckks-limb", "encdec", "mul", "add"])
+    ap.add_argument("--workload", default="ckks", choices=["ckks", "ntt", "ntt15", "intt", "intt15", "bgv", "rotate", "ckks-limb", "encdec", "mul", "add", "ckks-hks"])
     ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (0 = BASELINE config value)")
     ap.add_argument("--logn", type=int, default=0,
                     help="override log2 of the ring degree for the ntt/intt/ckks/rotate workloads (same moduli); "
@@ -49,6 +49,8 @@ def parse():
                     help="ckks workload: also time forward / inverse limb transforms of the same batch (outside the timed "
                          "region) and report them under \"ntt\".  Off by default so that a rocprofv3 summary of the default "
                          "command shows k_ntt_fwd in its digit-spread launches only, as the roofline object does")
+    ap.add_argument("--hks-alpha", type=int, default=2, help="ckks-hks: ciphertext moduli per key-switch digit")
+    ap.add_argument("--hks-k", type=int, default=2, help="ckks-hks: number of (50-bit) special primes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")
     ap.add_argument("--cpu-procs", type=int, default=1,
@@ -222,6 +224,29 @@ def main():
         metric, unit = f"limb_{wl}_per_s", "limb-op/s"
         cfg = {"workload": f"C2 shape: coefficient-wise modular {'multiply' if wl == 'mul' else 'add'}, N={n}, {L} RNS limbs, batch={B} polynomials per GPU",
                "N": n, "limbs": L, "batch_per_gpu": B}
+    elif wl == "ckks-hks":
+        # EXTENSION, not comparable with the reference: the C3 ciphertext chain with a hybrid key switch (digits of
+        # --hks-alpha moduli, --hks-k special primes); keys in the hybrid format, results differ from hehub's by design
+        logn = args.logn or P.C3_LOGN
+        L, k, alpha = len(P.C3_Q), args.hks_k, args.hks_alpha
+        mext = P.C3_Q + P.ntt_primes(k, P.C3_LOGN, 50, exclude=P.C3_Q)
+        B = args.batch or P.C3_BATCH
+        n, nd = 1 << logn, (L + alpha - 1) // alpha
+        ct1 = rand_words(torch, (B, 2, L, n), mext[:L], dev, 3 + rank)
+        ct2 = rand_words(torch, (B, 2, L, n), mext[:L], dev, 1003 + rank)
+        key = rand_words(torch, (nd, 2, L + k, n), mext, dev, 7)
+        out = eng.empty((B, 2, L - 1, n))
+        units_per_step = B
+        step = lambda: eng.ckks_mult_hks(mext, k, alpha, ct1, ct2, key, out=out)
+        family = "ntt"
+        fwd = nd * (L + k) - L                       # lifted-digit transforms per ciphertext: the one k_ntt_fwd launch per step
+        alg_bytes_per_step = 16.0 * n * fwd * B      # (ModDown and rescale transforms are k_ntt_fwd_drop launches, family "ntt_drop")
+        launches_per_step = 1
+        metric, unit = "ckks_hks_hom_mult_per_s", "hom-mult/s"
+        cfg = {"workload": f"EXTENSION (not hehub-compatible keys): ckks mult + hybrid-key relinearisation (digits of {alpha} moduli, "
+                           f"{k} special primes) + rescale, N={n}, L={L}, batch={B} ciphertext pairs per GPU",
+               "N": n, "L": L, "batch_per_gpu": B, "hks_alpha": alpha, "hks_k": k, "digits": nd,
+               "forward_transforms_per_op": fwd + 2 * L + 2 * (L - 1), "reference_algorithm_forward_transforms_per_op": L * L + 4 * L - 2}
     elif wl == "encdec":
         # either side of the path: encrypt_core on caller-supplied samples, then decrypt_core
         logn, moduli = P.C3_LOGN, P.C3_Q
@@ -370,7 +395,7 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
-                cwl = "ckks" if wl == "ckks-limb" else wl
+                cwl = "ckks" if wl in ("ckks-limb", "ckks-hks") else wl
                 if args.cpu_procs > 1:
                     import multiprocessing as mp
 

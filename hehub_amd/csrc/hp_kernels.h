@@ -11,6 +11,8 @@
 // table; hp_xcd_remap() then gives each XCD a contiguous slice of them.
 enum HpNttMode : int {
     HP_NTT_BATCH = 0,   // rows [P][L][N]: item w = k*P + p         -> src/dst row p*L + k, limb k
+    HP_NTT_HKS = 2,     // hybrid key switch (extension): in-place transforms of the lifted digits [P][nd][E][N]; one item per
+                        //   (modulus m, digit d, polynomial p) with m outside digit d, modulus-major, hole-free
     HP_NTT_SPREAD = 1,  // digit spread (rgsw.cpp:108-119): one item per (k, j != k, p), k in [0,L], numbered modulus-major
                         //   then digit then polynomial without holes (hp_ntt_job.h): src = coef row p*L + j,
                         //   dst = digit row (p*L + j)*(L+1) + k, limb k; a launch may cover only the moduli
@@ -29,6 +31,7 @@ struct HpNttJob {
     u32 src_kstride;  // HP_NTT_BATCH: rows between consecutive limbs of src (1; 0 = every limb reads the same row)
     u32 W;          // work items
     u32 k_first;    // HP_NTT_SPREAD: first output modulus of the launch
+    u32 hks_nd, hks_E, hks_alpha;   // HP_NTT_HKS: digits, moduli of the extended chain, limbs per digit (L = ciphertext moduli)
     int mode;
     int inverse;
     int strict;     // inverse only: reduce_strict epilogue (ntt.h:88-92)
@@ -103,6 +106,9 @@ struct HpDropConsts {
 // loading, and finishes with out = ((x - NTT(rem)) * inv) [* (q_last mod t)] [+ addend] while storing.
 struct HpDropArgs {
     HpDropConsts dc;
+    int raw_input;         // 1: the transform's input rows already are the per-limb remainders (hybrid key switch): no
+                           //    Barrett / centring prologue
+    u32 out_stride;        // limbs between consecutive polynomials of out (L - 1 for a plain drop)
     const u64 *x;          // [P2][L][n]: polynomial p2 at x + p2*L*n, limb k at + k*n
     u32 L;                 // limbs of x (the last one is being dropped)
     const u64 *addend;     // optional [.][.][n]: row (p2>>1)*add_ct_stride + (p2&1)*add_poly_stride + k
@@ -150,3 +156,30 @@ hipError_t hp_launch_base_from_single(const HpLimb *limbs, u64 old_q, u32 L, u32
                                       hipStream_t stream);
 hipError_t hp_launch_base_to_single(const HpLimb *limbs, u32 L, u32 n, u32 P, u64 new_q, const u64 *in, u64 *out,
                                     u32 *not_small, hipStream_t stream);
+
+// ---- hybrid key switch (extension; hp_hks.hip) ---------------------------------------------------
+#define HP_HKS_MAX_ALPHA 8
+#define HP_HKS_MAX_DIGITS 16
+struct HpHksConsts {   // device memory, built by the engine per (moduli, k, alpha)
+    u32 L, k, alpha, nd, E;   // ciphertext moduli, special primes, limbs per digit, digits, L + k
+    // Garner inverses inside digit d: [d][b][a], b < a: (b-th modulus of the digit)^-1 mod (a-th modulus of the digit)
+    u64 inv[HP_HKS_MAX_DIGITS][HP_HKS_MAX_ALPHA][HP_HKS_MAX_ALPHA], inv_h[HP_HKS_MAX_DIGITS][HP_HKS_MAX_ALPHA][HP_HKS_MAX_ALPHA];
+    // [d][m][a]: product of the first a moduli of digit d, modulo modulus m of the extended chain
+    u64 pref[HP_HKS_MAX_DIGITS][HP_MAX_LIMBS][HP_HKS_MAX_ALPHA], pref_h[HP_HKS_MAX_DIGITS][HP_MAX_LIMBS][HP_HKS_MAX_ALPHA];
+    u64 pinv[HP_MAX_LIMBS], pinv_h[HP_MAX_LIMBS];   // (p_0...p_{k-1})^-1 mod q_i
+    // ModDown (k <= HP_HKS_MAX_ALPHA special primes): Garner inverses among them, digits of floor(P/2), and per ciphertext
+    // modulus q_i the prefix products p_0...p_{a-1} mod q_i and P mod q_i
+    u64 pg_inv[HP_HKS_MAX_ALPHA][HP_HKS_MAX_ALPHA], pg_inv_h[HP_HKS_MAX_ALPHA][HP_HKS_MAX_ALPHA];
+    u64 p_half[HP_HKS_MAX_ALPHA];
+    u64 p_pref[HP_MAX_LIMBS][HP_HKS_MAX_ALPHA], p_pref_h[HP_MAX_LIMBS][HP_HKS_MAX_ALPHA];
+    u64 p_mod_q[HP_MAX_LIMBS];
+};
+// yp [P2][k][n] (strict coefficients of the special-prime part) -> rem [P2][L][n]: the exact centred value in every q_i
+hipError_t hp_launch_hks_moddown(const HpLimb *limbs, const HpHksConsts *hc, u32 k, u32 n, u32 P2, const u64 *yp, u64 *rem,
+                                 hipStream_t stream);
+hipError_t hp_launch_hks_modup(const HpLimb *limbs, const HpHksConsts *hc, u32 alpha, u32 nd, u32 n, u32 P, const u64 *coef,
+                               u64 *lifted, hipStream_t stream);
+hipError_t hp_launch_hks_inner(const HpLimb *limbs, u32 L, u32 E, u32 nd, u32 alpha, u32 n, u32 P, const u64 *lifted, const u64 *pt,
+                               u32 pt_pstride, const u64 *key, u64 *out, hipStream_t stream);
+hipError_t hp_launch_hks_down_fin(const HpLimb *limbs, const HpHksConsts *hc, u32 L, u32 n, u32 P2, const u64 *x, const u64 *rem,
+                                  const u64 *addend, u32 add_poly_stride, u32 add_ct_stride, u64 *out, hipStream_t stream);

@@ -439,13 +439,15 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
         const u64 bc = lp->barrett_c, bump = q - da->dc.r[k], half = da->dc.half_q_last;
         const u64 tk = da->dc.t[k], tkh = da->dc.t_h[k];
         const bool bgv = da->dc.bgv != 0;
+        if (!da->raw_input) {
 #pragma unroll
-        for (int r = 0; r < 32; ++r) {
-            const u64 c = x[r];
-            u64 v = hp_strict(hp_barrett_lazy(c, q, bc), q);
-            if (c >= half) v += bump;
-            if (bgv) v = hp_harvey_lazy_nq(v, tk, tkh, (u32)nq, (u32)(nq >> 32));
-            x[r] = v;
+            for (int r = 0; r < 32; ++r) {
+                const u64 c = x[r];
+                u64 v = hp_strict(hp_barrett_lazy(c, q, bc), q);
+                if (c >= half) v += bump;
+                if (bgv) v = hp_harvey_lazy_nq(v, tk, tkh, (u32)nq, (u32)(nq >> 32));
+                x[r] = v;
+            }
         }
     }
 #ifdef HP_TRACE
@@ -496,7 +498,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
         const u64 *xs = da->x + ((size_t)p2 * da->L + k) * G::N + off;
         const u64 *as = (da->addend && ((da->add_mask >> (p2 & 1)) & 1u))
                             ? da->addend + ((size_t)(p2 >> 1) * da->add_ct_stride + (size_t)(p2 & 1) * da->add_poly_stride + k) * G::N + off : nullptr;
-        u64 *d = da->out + ((size_t)p2 * (da->L - 1) + k) * G::N + off;
+        u64 *d = da->out + ((size_t)p2 * da->out_stride + k) * G::N + off;
         const u64 inv = da->dc.inv[k], invh = da->dc.inv_h[k], ql = da->dc.qlt[k], qlh = da->dc.qlt_h[k];
         const bool bgv = da->dc.bgv != 0;
         const u32 n0 = (u32)nq, n1 = (u32)(nq >> 32);

@@ -44,5 +44,28 @@ HP_DEV bool hp_decode_item(const HpNttJob &job, u32 w, HpItem &it) {
         it.limb = k;
         return true;
     }
+    if (job.mode == HP_NTT_HKS) {
+        // modulus-major: a ciphertext modulus m < L is outside nd-1 digits, a special prime outside all nd
+        const u32 L = job.L, nd = job.hks_nd, E = job.hks_E;
+        const u32 per = (nd - 1) * job.P;
+        u32 m, j, p;
+        if (w < L * per) {
+            m = w / per;
+            const u32 r = w % per, jj = r / job.P, own = m / job.hks_alpha;
+            p = r % job.P;
+            j = jj + (jj >= own ? 1u : 0u);
+        } else {
+            const u32 r = w - L * per;
+            m = L + r / (nd * job.P);
+            const u32 rr = r % (nd * job.P);
+            j = rr / job.P;
+            p = rr % job.P;
+        }
+        u64 *row = job.dst + (((size_t)p * nd + j) * E + m) * n;
+        it.src = row;
+        it.dst = row;
+        it.limb = m;
+        return true;
+    }
     return false;
 }

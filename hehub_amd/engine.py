@@ -293,6 +293,21 @@ class Engine:
                                                         self._ptr(x), self._ptr(out)))
         return out
 
+    def hks_switch(self, moduli_ext, k: int, alpha: int, pt, key):
+        """hybrid key switch (extension): pt [B][L][n] NTT form, key [dnum][2][L+k][n] -> [B][2][L][n]."""
+        B, L, n = pt.shape
+        out = self.empty((B, 2, L, n))
+        self._chk(self.lib.hp_dev_hks_switch(self.h, n.bit_length() - 1, L, k, alpha, _u64arr(moduli_ext), B, self._ptr(pt),
+                                             self._ptr(key), self._ptr(out)))
+        return out
+
+    def ckks_mult_hks(self, moduli_ext, k: int, alpha: int, ct1, ct2, key, out=None):
+        B, _, L, n = ct1.shape
+        out = self.empty((B, 2, L - 1, n)) if out is None else out
+        self._chk(self.lib.hp_dev_ckks_mult_relin_rescale_hks(self.h, n.bit_length() - 1, L, k, alpha, _u64arr(moduli_ext), B,
+                                                              self._ptr(ct1), self._ptr(ct2), self._ptr(key), self._ptr(out)))
+        return out
+
     def ckks_rescale_n(self, moduli, ct, drops: int):
         B, _, L, n = ct.shape
         out = self.empty((B, 2, L - drops, n))

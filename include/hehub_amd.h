@@ -246,6 +246,20 @@ int hp_dev_ckks_mult_relin_rescale_at(hp_ctx *ctx, size_t logn, size_t L, size_t
  *     m - ((Q - x) mod m) from the half on), in every new modulus.  in u64[batch][L][N] -> out u64[batch][Lnew][N] */
 int hp_dev_rns_base_many_to_many(hp_ctx *ctx, size_t n, size_t L, const uint64_t *old_moduli, size_t Lnew,
                                  const uint64_t *new_moduli, size_t batch, const uint64_t *d_in, uint64_t *d_out);
+/* (4) hybrid key switch: alpha consecutive ciphertext moduli form one digit (dnum = ceil(L/alpha) digits) and k special
+ *     primes p_0..p_{k-1} (product >= every digit's modulus product) replace hehub's single one: dnum*(L+k) - L digit
+ *     transforms per switch instead of L*L.  moduli_ext = q_0..q_{L-1}, p_0..p_{k-1}.  The key has its own format,
+ *     u64[dnum][2][L+k][N], NTT + Montgomery form like hehub's: row d is an RLWE encryption, under all L+k moduli, of
+ *     (P mod q_i) * s_from in the limbs i of digit d and of 0 elsewhere -- hehub's key is the case alpha = 1, k = 1.
+ *     Every step is exact integer arithmetic (ModUp / ModDown by mixed-radix composition), pinned by an exact integer
+ *     model and by decryption (tests/test_hks.py); results are NOT comparable with hehub's (different keys, less noise).
+ *     hp_dev_hks_switch: pt u64[batch][L][N] (NTT form) -> out u64[batch][2][L][N] with out0 + out1*s ~ pt*s_from. */
+int hp_dev_hks_switch(hp_ctx *ctx, size_t logn, size_t L, size_t k, size_t alpha, const uint64_t *moduli_ext, size_t batch,
+                      const uint64_t *d_pt, const uint64_t *d_key, uint64_t *d_out);
+/* ckks::mult_low_level + relinearisation with a hybrid key + rescale by q_{L-1}: out u64[batch][2][L-1][N] */
+int hp_dev_ckks_mult_relin_rescale_hks(hp_ctx *ctx, size_t logn, size_t L, size_t k, size_t alpha,
+                                       const uint64_t *moduli_ext, size_t batch, const uint64_t *d_ct1,
+                                       const uint64_t *d_ct2, const uint64_t *d_key, uint64_t *d_out);
 /* ct u64[batch][2][L][N] -> out u64[batch][2][L-drops][N]; d_tmp: 2 * batch*2*(L-1)*N words (may be NULL for drops == 1) */
 int hp_dev_ckks_rescale_n(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t drops, size_t batch,
                           const uint64_t *d_ct, uint64_t *d_tmp, uint64_t *d_out);

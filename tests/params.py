@@ -65,3 +65,34 @@ def small_rns_poly(rng, n, moduli, bound=1000):
 
     v = rng.words(n, 2 * bound - 1).astype(np.int64) - (bound - 1)
     return np.stack([np.where(v >= 0, v, v + int(q)).astype(np.uint64) for q in moduli])
+
+
+def ntt_primes(count, logn, bits, exclude=()):
+    """the first `count` primes q = 1 (mod 2N) below 2^bits that are not in `exclude` (deterministic Miller-Rabin)"""
+    def is_prime(n):
+        if n < 2:
+            return False
+        for p in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+            if n % p == 0:
+                return n == p
+        d, r = n - 1, 0
+        while d % 2 == 0:
+            d //= 2; r += 1
+        for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+            x = pow(a, d, n)
+            if x in (1, n - 1):
+                continue
+            for _ in range(r - 1):
+                x = x * x % n
+                if x == n - 1:
+                    break
+            else:
+                return False
+        return True
+
+    step, q, out = 2 << logn, ((1 << bits) // (2 << logn)) * (2 << logn) + 1, []
+    while len(out) < count:
+        q -= step
+        if q not in exclude and is_prime(q):
+            out.append(q)
+    return out
