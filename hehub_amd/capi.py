@@ -82,6 +82,8 @@ SIGNATURES = {
     "hp_dev_ckks_mult_relin_rescale_at": (INT, [P, szt, szt, szt, P, szt, P, P, P, P]),
     "hp_dev_rns_base_many_to_many": (INT, [P, szt, szt, P, szt, P, szt, P, P]),
     "hp_dev_hks_switch": (INT, [P, szt, szt, szt, szt, P, szt, P, P, P]),
+    "hp_dev_ckks_rotate_hks": (INT, [P, szt, szt, szt, szt, P, szt, szt, P, P, P]),
+    "hp_dev_ckks_conjugate_hks": (INT, [P, szt, szt, szt, szt, P, szt, P, P, P]),
     "hp_dev_ckks_mult_relin_rescale_hks": (INT, [P, szt, szt, szt, szt, P, szt, P, P, P, P]),
     "hp_dev_ckks_rescale_n": (INT, [P, szt, szt, P, szt, szt, P, P, P]),
     "hp_wire_payload_words": (szt, [P]),

@@ -1298,7 +1298,7 @@ static size_t hks_ws_words(size_t n, size_t L, size_t k, size_t nd, size_t P) {
 // out [P][2][L][N] = ModDown( sum_d D_d * key_d ) [+ addend rows (p2>>1)*add_ct_stride + (p2&1)*add_poly_stride + i]
 static int hks_switch(hp_ctx *ctx, const Plan *plan, const HpHksConsts *hc, size_t logn, size_t L, size_t k, size_t alpha, size_t P,
                       const u64 *pt, size_t pt_pstride, const u64 *key, const u64 *addend, size_t add_poly_stride,
-                      size_t add_ct_stride, const uint64_t *mext, u64 *out, Carver &cv) {
+                      size_t add_ct_stride, u32 add_mask, const uint64_t *mext, u64 *out, Carver &cv) {
     const size_t n = (size_t)1 << logn, E = L + k, nd = (L + alpha - 1) / alpha;
     u64 *coef = cv.take(P * L * n), *lifted = cv.take(P * nd * E * n), *ks = cv.take(P * 2 * E * n);
     u64 *yp = cv.take(2 * P * k * n), *rem = cv.take(2 * P * L * n);
@@ -1354,14 +1354,14 @@ static int hks_switch(hp_ctx *ctx, const Plan *plan, const HpHksConsts *hc, size
         da.raw_input = 1;
         for (size_t i = 0; i < L; i++) { da.dc.inv[i] = hc_host_pinv(ctx, mext, L, k, i, &da.dc.inv_h[i]); }
         da.x = ks; da.L = (u32)E; da.addend = addend; da.add_poly_stride = (u32)add_poly_stride; da.add_ct_stride = (u32)add_ct_stride;
-        da.add_mask = addend ? 3u : 0u; da.out = out; da.out_stride = (u32)L;
+        da.add_mask = addend ? add_mask : 0u; da.out = out; da.out_stride = (u32)L;
         ProfScope ps(ctx, "ntt_drop");
         return chk(ctx, hp_launch_ntt_fast_drop(fj, da, ctx->stream), "hks fused ModDown");
     }
     if ((rc = run_ntt(ctx, batch_job(plan, logn, L, 2 * P, rem, rem, L, L, 0, 0)))) return rc;
     ProfScope ps(ctx, "hks_down_fin");
     return chk(ctx, hp_launch_hks_down_fin(plan->d_limbs, hc, (u32)L, (u32)n, (u32)(2 * P), ks, rem, addend, (u32)add_poly_stride,
-                                           (u32)add_ct_stride, out, ctx->stream), "hks_down_fin");
+                                           (u32)add_ct_stride, add_mask, out, ctx->stream), "hks_down_fin");
 }
 
 static int hks_args_ok(hp_ctx *ctx, size_t logn, size_t L, size_t k, size_t alpha, size_t batch) {
@@ -1387,7 +1387,46 @@ int hp_dev_hks_switch(hp_ctx *ctx, size_t logn, size_t L, size_t k, size_t alpha
     const size_t n = (size_t)1 << logn, nd = (L + alpha - 1) / alpha;
     if ((rc = ws_reserve(ctx, hks_ws_words(n, L, k, nd, batch) * 8))) return rc;
     Carver cv(ctx->ws);
-    return hks_switch(ctx, plan, hc, logn, L, k, alpha, batch, pt, L, key, nullptr, 0, 0, moduli_ext, out, cv);
+    return hks_switch(ctx, plan, hc, logn, L, k, alpha, batch, pt, L, key, nullptr, 0, 0, 0, moduli_ext, out, cv);
+}
+
+// ckks rotate / conjugate with a hybrid key: moved = gather(ct); out = hks_switch(moved[1]); out[0] += moved[0]
+static int dev_hks_automorphism(hp_ctx *ctx, size_t logn, size_t L, size_t k, size_t alpha, const uint64_t *mext, size_t batch,
+                                bool conj, size_t step, const uint64_t *ct, const uint64_t *key, uint64_t *out) {
+    Guard g(ctx);
+    HP_REQUIRE(ctx, mext, ct, key, out);
+    HP_ALIGNED(ctx, ct, key, out);
+    int rc = hks_args_ok(ctx, logn, L, k, alpha, batch);
+    if (rc) return rc;
+    if (!conj && step >= ((size_t)1 << 17)) return fail(ctx, HP_EINVAL, "rotation step out of range");
+    const Plan *plan;
+    if ((rc = get_plan(ctx, logn, mext, L + k, true, &plan))) return rc;
+    const HpHksConsts *hc;
+    if ((rc = get_hks_consts(ctx, mext, L, k, alpha, &hc))) return rc;
+    const size_t n = (size_t)1 << logn, nd = (L + alpha - 1) / alpha;
+    if ((rc = ws_reserve(ctx, (padded(batch * 2 * L * n) / 8 + hks_ws_words(n, L, k, nd, batch)) * 8))) return rc;
+    Carver cv(ctx->ws);
+    u64 *moved = cv.take(batch * 2 * L * n);
+    {
+        ProfScope ps(ctx, "elem");
+        if (conj) {
+            rc = chk(ctx, hp_launch_reverse((u32)n, (u32)(batch * 2 * L), ct, moved, ctx->stream), "involution");
+        } else {
+            const u32 *perm;
+            if ((rc = get_cycle_perm(ctx, logn, step, &perm))) return rc;
+            rc = chk(ctx, hp_launch_gather(perm, (u32)n, (u32)(batch * 2 * L), ct, moved, ctx->stream), "cycle");
+        }
+        if (rc) return rc;
+    }
+    return hks_switch(ctx, plan, hc, logn, L, k, alpha, batch, moved + L * n, 2 * L, key, moved, L, 2 * L, 1, mext, out, cv);
+}
+int hp_dev_ckks_rotate_hks(hp_ctx *ctx, size_t logn, size_t L, size_t k, size_t alpha, const uint64_t *moduli_ext, size_t batch,
+                           size_t step, const uint64_t *ct, const uint64_t *rot_key, uint64_t *out) {
+    return dev_hks_automorphism(ctx, logn, L, k, alpha, moduli_ext, batch, false, step, ct, rot_key, out);
+}
+int hp_dev_ckks_conjugate_hks(hp_ctx *ctx, size_t logn, size_t L, size_t k, size_t alpha, const uint64_t *moduli_ext, size_t batch,
+                              const uint64_t *ct, const uint64_t *conj_key, uint64_t *out) {
+    return dev_hks_automorphism(ctx, logn, L, k, alpha, moduli_ext, batch, true, 0, ct, conj_key, out);
 }
 
 // ckks::mult_low_level + relinearisation with a hybrid key + rescale by the last ciphertext modulus
@@ -1415,7 +1454,7 @@ int hp_dev_ckks_mult_relin_rescale_hks(hp_ctx *ctx, size_t logn, size_t L, size_
         if ((rc = chk(ctx, hp_launch_tensor(plan->d_limbs, (u32)L, 0, (u32)L, (u32)n, (u32)batch, ct1, ct2, quad, ctx->stream), "tensor")))
             return rc;
     }
-    if ((rc = hks_switch(ctx, plan, hc, logn, L, k, alpha, batch, quad + 2 * L * n, 3 * L, key, quad, L, 3 * L, moduli_ext, lin, cv)))
+    if ((rc = hks_switch(ctx, plan, hc, logn, L, k, alpha, batch, quad + 2 * L * n, 3 * L, key, quad, L, 3 * L, 3, moduli_ext, lin, cv)))
         return rc;
     return drop_last(ctx, plan, logn, L, 2 * batch, false, 0, lin, nullptr, 0, 0, 0, out, cv);
 }

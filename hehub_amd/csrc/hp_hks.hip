@@ -225,14 +225,16 @@ hipError_t hp_launch_hks_moddown(const HpLimb *limbs, const HpHksConsts *hc, u32
 __global__ void __launch_bounds__(HKS_THREADS) k_hks_down_fin(const HpLimb *__restrict__ limbs, const HpHksConsts *__restrict__ hc,
                                                              u32 n, u32 chunks, const u64 *__restrict__ x,
                                                              const u64 *__restrict__ rem, const u64 *__restrict__ addend,
-                                                             u32 add_poly_stride, u32 add_ct_stride, u64 *__restrict__ out) {
+                                                             u32 add_poly_stride, u32 add_ct_stride, u32 add_mask,
+                                                             u64 *__restrict__ out) {
     const u32 L = hc->L, E = hc->E;
     const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;   // row = p2*L + i
     const u32 p2 = row / L, k = row % L;
     const u64 q = limbs[k].q, two_q = limbs[k].two_q;
     const u64 *xs = x + ((size_t)p2 * E + k) * n;
     const u64 *rs = rem + (size_t)row * n;
-    const u64 *as = addend ? addend + ((size_t)(p2 >> 1) * add_ct_stride + (size_t)(p2 & 1) * add_poly_stride + k) * n : nullptr;
+    const u64 *as = (addend && ((add_mask >> (p2 & 1)) & 1u))
+                        ? addend + ((size_t)(p2 >> 1) * add_ct_stride + (size_t)(p2 & 1) * add_poly_stride + k) * n : nullptr;
     u64 *os = out + (size_t)row * n;
     const u32 end = min(n, (chunk + 1) * HKS_CHUNK);
     for (u32 i = chunk * HKS_CHUNK + threadIdx.x; i < end; i += HKS_THREADS) {
@@ -244,9 +246,10 @@ __global__ void __launch_bounds__(HKS_THREADS) k_hks_down_fin(const HpLimb *__re
 }
 
 hipError_t hp_launch_hks_down_fin(const HpLimb *limbs, const HpHksConsts *hc, u32 L, u32 n, u32 P2, const u64 *x, const u64 *rem,
-                                  const u64 *addend, u32 add_poly_stride, u32 add_ct_stride, u64 *out, hipStream_t stream) {
+                                  const u64 *addend, u32 add_poly_stride, u32 add_ct_stride, u32 add_mask, u64 *out,
+                                  hipStream_t stream) {
     u32 chunks; dim3 grid;
     hks_grid(n, P2 * L, chunks, grid);
-    k_hks_down_fin<<<grid, HKS_THREADS, 0, stream>>>(limbs, hc, n, chunks, x, rem, addend, add_poly_stride, add_ct_stride, out);
+    k_hks_down_fin<<<grid, HKS_THREADS, 0, stream>>>(limbs, hc, n, chunks, x, rem, addend, add_poly_stride, add_ct_stride, add_mask, out);
     return hipGetLastError();
 }

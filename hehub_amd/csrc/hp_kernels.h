@@ -182,4 +182,5 @@ hipError_t hp_launch_hks_modup(const HpLimb *limbs, const HpHksConsts *hc, u32 a
 hipError_t hp_launch_hks_inner(const HpLimb *limbs, u32 L, u32 E, u32 nd, u32 alpha, u32 n, u32 P, const u64 *lifted, const u64 *pt,
                                u32 pt_pstride, const u64 *key, u64 *out, hipStream_t stream);
 hipError_t hp_launch_hks_down_fin(const HpLimb *limbs, const HpHksConsts *hc, u32 L, u32 n, u32 P2, const u64 *x, const u64 *rem,
-                                  const u64 *addend, u32 add_poly_stride, u32 add_ct_stride, u64 *out, hipStream_t stream);
+                                  const u64 *addend, u32 add_poly_stride, u32 add_ct_stride, u32 add_mask, u64 *out,
+                                  hipStream_t stream);

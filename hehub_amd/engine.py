@@ -301,6 +301,20 @@ class Engine:
                                              self._ptr(key), self._ptr(out)))
         return out
 
+    def ckks_rotate_hks(self, moduli_ext, k: int, alpha: int, ct, key, step: int):
+        B, _, L, n = ct.shape
+        out = self.empty((B, 2, L, n))
+        self._chk(self.lib.hp_dev_ckks_rotate_hks(self.h, n.bit_length() - 1, L, k, alpha, _u64arr(moduli_ext), B, step,
+                                                  self._ptr(ct), self._ptr(key), self._ptr(out)))
+        return out
+
+    def ckks_conjugate_hks(self, moduli_ext, k: int, alpha: int, ct, key):
+        B, _, L, n = ct.shape
+        out = self.empty((B, 2, L, n))
+        self._chk(self.lib.hp_dev_ckks_conjugate_hks(self.h, n.bit_length() - 1, L, k, alpha, _u64arr(moduli_ext), B,
+                                                     self._ptr(ct), self._ptr(key), self._ptr(out)))
+        return out
+
     def ckks_mult_hks(self, moduli_ext, k: int, alpha: int, ct1, ct2, key, out=None):
         B, _, L, n = ct1.shape
         out = self.empty((B, 2, L - 1, n)) if out is None else out

@@ -256,6 +256,11 @@ int hp_dev_rns_base_many_to_many(hp_ctx *ctx, size_t n, size_t L, const uint64_t
  *     hp_dev_hks_switch: pt u64[batch][L][N] (NTT form) -> out u64[batch][2][L][N] with out0 + out1*s ~ pt*s_from. */
 int hp_dev_hks_switch(hp_ctx *ctx, size_t logn, size_t L, size_t k, size_t alpha, const uint64_t *moduli_ext, size_t batch,
                       const uint64_t *d_pt, const uint64_t *d_key, uint64_t *d_out);
+/* ckks::rotate / conjugate with a hybrid rotation / conjugation key: ct u64[batch][2][L][N] -> out u64[batch][2][L][N] */
+int hp_dev_ckks_rotate_hks(hp_ctx *ctx, size_t logn, size_t L, size_t k, size_t alpha, const uint64_t *moduli_ext,
+                           size_t batch, size_t step, const uint64_t *d_ct, const uint64_t *d_rot_key, uint64_t *d_out);
+int hp_dev_ckks_conjugate_hks(hp_ctx *ctx, size_t logn, size_t L, size_t k, size_t alpha, const uint64_t *moduli_ext,
+                              size_t batch, const uint64_t *d_ct, const uint64_t *d_conj_key, uint64_t *d_out);
 /* ckks::mult_low_level + relinearisation with a hybrid key + rescale by q_{L-1}: out u64[batch][2][L-1][N] */
 int hp_dev_ckks_mult_relin_rescale_hks(hp_ctx *ctx, size_t logn, size_t L, size_t k, size_t alpha,
                                        const uint64_t *moduli_ext, size_t batch, const uint64_t *d_ct1,

@@ -166,3 +166,22 @@ def test_mult_relin_rescale_with_a_hybrid_key(eng, orc):
     sw = model_switch(orc, logn, mext, L, k, alpha, quad[2], key)
     lin = np.stack([orc.poly_add(q, sw[0], quad[0]), orc.poly_add(q, sw[1], quad[1])])
     assert np.array_equal(got, orc.ckks_rescale(q, lin))
+
+
+@pytest.mark.parametrize("logn,L,k,alpha", [(5, 4, 2, 2), (11, 3, 2, 2)])
+def test_rotate_and_conjugate_with_a_hybrid_key(eng, orc, logn, L, k, alpha):
+    """gather + hybrid switch of the moved c1 + the moved c0 added to polynomial 0 only (ckks/arith.cpp:75-93 with the
+    hybrid switch in place of ext_prod + rescale)."""
+    mext = P.P40[:L] + P.P50[:k]
+    n, q = 1 << logn, mext[:L]
+    rng = SplitMix(1400 + logn)
+    nd = (L + alpha - 1) // alpha
+    ct = rng.poly((2, L, n), q)
+    key = rng.poly((nd, 2, L + k, n), mext)
+    d_ct, d_key = eng.to_device(ct[None]), eng.to_device(key)
+    for conj in (False, True):
+        moved = np.stack([orc.poly_involution(ct[h]) if conj else orc.poly_cycle(ct[h], 3) for h in range(2)])
+        sw = model_switch(orc, logn, mext, L, k, alpha, moved[1], key)
+        exp = np.stack([orc.poly_add(q, sw[0], moved[0]), sw[1]])
+        got = eng.ckks_conjugate_hks(mext, k, alpha, d_ct, d_key) if conj else eng.ckks_rotate_hks(mext, k, alpha, d_ct, d_key, 3)
+        assert np.array_equal(eng.to_host(got)[0], exp), conj
