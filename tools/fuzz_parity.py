@@ -15,6 +15,7 @@ from hehub_amd.sharded import ShardedMult  # noqa: E402
 from oracle.pyoracle import Oracle, SplitMix  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+HKS = len(sys.argv) > 3 and sys.argv[3] == "hks"   # third argument "hks": only the hybrid key switch against its exact integer model
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 orc, eng = Oracle("orc"), Engine(0)
 pool = P.P40 + P.P50          # every list prime supports 2N | q-1 up to N = 32768
@@ -38,7 +39,7 @@ while time.time() - t0 < budget:
     q = mext[:L]
     rng = SplitMix(int(rs.randint(1, 1 << 30)))
     kw = dict(logn=logn, L=L, B=B, mext=mext)
-    op = rs.choice(["ntt", "elem", "perm", "base", "mult", "bgv", "rot", "drop", "encdec", "sharded"])
+    op = rs.choice(["ntt", "elem", "perm", "base", "mult", "bgv", "rot", "drop", "encdec", "sharded", "hks"], p=[.1] * 10 + [0.0]) if not HKS else "hks"
     if op == "ntt":
         x = np.stack([rng.poly((L, n), q) for _ in range(B)])
         d = eng.to_device(x); eng.ntt_(q, d)
@@ -68,6 +69,16 @@ while time.time() - t0 < budget:
             xs = np.stack([P.small_rns_poly(rng, n, q) if rs.randint(2) else rng.poly((L, n), q) for _ in range(B)])
             check("to_single", eng.to_host(eng.rns_base_to_single(q, t, eng.to_device(xs))),
                   np.stack([orc.rns_base_to_single(q, t, xs[i]) for i in range(B)]), t=t, **kw)
+    elif op == "hks":
+        from test_hks import model_switch
+        logn = int(rs.choice([1, 2, 3, 4, 5, 11], p=[.1, .15, .2, .25, .25, .05])); n = 1 << logn
+        L = int(rs.randint(1, 7)); alpha = int(rs.randint(1, min(L, 8) + 1)); k = int(rs.randint(1, 5))
+        idx = rs.choice(len(pool), L + k, replace=False)
+        mext = [pool[i] for i in idx]
+        nd = (L + alpha - 1) // alpha
+        pt = rng.poly((L, n), mext[:L]); key = rng.poly((nd, 2, L + k, n), mext)
+        got = eng.to_host(eng.hks_switch(mext, k, alpha, eng.to_device(pt[None]), eng.to_device(key)))[0]
+        check("hks", got, model_switch(orc, logn, mext, L, k, alpha, pt, key), logn=logn, L=L, k=k, alpha=alpha, mext=mext)
     elif op == "perm":
         a = np.stack([rng.poly((L, n), q) for _ in range(B)])
         da = eng.to_device(a)
