@@ -253,6 +253,7 @@ int hp_dev_rns_base_many_to_many(hp_ctx *ctx, size_t n, size_t L, const uint64_t
  *     (P mod q_i) * s_from in the limbs i of digit d and of 0 elsewhere -- hehub's key is the case alpha = 1, k = 1.
  *     Every step is exact integer arithmetic (ModUp / ModDown by mixed-radix composition), pinned by an exact integer
  *     model and by decryption (tests/test_hks.py); results are NOT comparable with hehub's (different keys, less noise).
+ *     Limits: alpha <= 8, at most 16 digits, k <= 16 (one fused conversion kernel up to k = 8), L + k <= 32.
  *     hp_dev_hks_switch: pt u64[batch][L][N] (NTT form) -> out u64[batch][2][L][N] with out0 + out1*s ~ pt*s_from. */
 int hp_dev_hks_switch(hp_ctx *ctx, size_t logn, size_t L, size_t k, size_t alpha, const uint64_t *moduli_ext, size_t batch,
                       const uint64_t *d_pt, const uint64_t *d_key, uint64_t *d_out);
