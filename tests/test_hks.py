@@ -113,7 +113,7 @@ def centred_error(orc, logn, moduli, poly_ntt):
 
 
 @pytest.mark.parametrize("logn,L,k,alpha", [(4, 4, 2, 2), (5, 5, 2, 2), (11, 3, 1, 1), (6, 6, 3, 3), (5, 4, 4, 4), (4, 3, 9, 3), (11, 2, 9, 1),
-                                           (5, 8, 5, 8), (4, 5, 8, 2)])
+                                           (5, 8, 5, 8), (4, 5, 8, 2), (15, 3, 2, 2)])
 def test_switch_matches_the_exact_model(eng, orc, logn, L, k, alpha):
     mext = P.P40[:L] + (P.P50 + P.P40[L:])[:k]
     n = 1 << logn
