@@ -26,7 +26,8 @@ static inline void hks_grid(u32 n, u32 rows, u32 &chunks, dim3 &grid) {
     grid = dim3(chunks * rows, 1, 1);
 }
 
-// lifted[p][d][m][i] = x_d mod modulus_m for every modulus m outside digit d (slots inside the digit are not written)
+// lifted[p][d][m][i] = x_d mod modulus_m for every modulus m outside digit d (slots inside the digit are not written).
+// Two coefficients per lane and iteration: 16-byte accesses (n is even for every supported ring).
 template <int ALPHA>
 __global__ void __launch_bounds__(HKS_THREADS) k_hks_modup(const HpLimb *__restrict__ limbs, const HpHksConsts *__restrict__ hc,
                                                           u32 n, u32 chunks, const u64 *__restrict__ coef,
@@ -38,35 +39,45 @@ __global__ void __launch_bounds__(HKS_THREADS) k_hks_modup(const HpLimb *__restr
     const u64 *src = coef + ((size_t)p * L + first) * n;
     u64 *dst = lifted + (size_t)row * E * n;
     const u32 end = min(n, (chunk + 1) * HKS_CHUNK);
-    for (u32 i = chunk * HKS_CHUNK + threadIdx.x; i < end; i += HKS_THREADS) {
-        u64 v[ALPHA];
+    for (u32 i = chunk * HKS_CHUNK + threadIdx.x * 2; i < end; i += HKS_THREADS * 2) {
+        u64 v[ALPHA][2];
 #pragma unroll
         for (int a = 0; a < ALPHA; a++) {
             if ((u32)a < cnt) {
                 const u64 qa = limbs[first + a].q, bc = limbs[first + a].barrett_c;
-                u64 u = src[(size_t)a * n + i];   // strict residue
+                const U2 in = *reinterpret_cast<const U2 *>(src + (size_t)a * n + i);   // strict residues
+                u64 u[2] = {in.x, in.y};
 #pragma unroll
                 for (int b = 0; b < a; b++) {
-                    const u64 vb = hp_strict(hp_barrett_lazy(v[b], qa, bc), qa);
-                    u = hp_strict(hp_harvey_lazy(u + qa - vb, hc->inv[d][b][a], hc->inv_h[d][b][a], qa), qa);
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const u64 vb = hp_strict(hp_barrett_lazy(v[b][e], qa, bc), qa);
+                        u[e] = hp_strict(hp_harvey_lazy(u[e] + qa - vb, hc->inv[d][b][a], hc->inv_h[d][b][a], qa), qa);
+                    }
                 }
-                v[a] = u;
+                v[a][0] = u[0];
+                v[a][1] = u[1];
             } else {
-                v[a] = 0;
+                v[a][0] = v[a][1] = 0;
             }
         }
         for (u32 m = 0; m < E; m++) {
             if (m >= first && m < first + cnt) continue;
             const u64 qm = limbs[m].q;
-            u64 r = 0;
+            u64 r[2] = {0, 0};
 #pragma unroll
             for (int a = 0; a < ALPHA; a++) {
                 if ((u32)a < cnt) {
-                    r += hp_strict(hp_harvey_lazy(v[a], hc->pref[d][m][a], hc->pref_h[d][m][a], qm), qm);
-                    r -= (r >= qm) ? qm : 0;
+                    const u64 w = hc->pref[d][m][a], wh = hc->pref_h[d][m][a];
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        r[e] += hp_strict(hp_harvey_lazy(v[a][e], w, wh, qm), qm);
+                        r[e] -= (r[e] >= qm) ? qm : 0;
+                    }
                 }
             }
-            dst[(size_t)m * n + i] = r;
+            U2 o{r[0], r[1]};
+            *reinterpret_cast<U2 *>(dst + (size_t)m * n + i) = o;
         }
     }
 }
