@@ -62,6 +62,7 @@ struct hp_ctx {
     hipStream_t aux[2] = {nullptr, nullptr};
     hipEvent_t ev_start = nullptr, ev_done[2] = {nullptr, nullptr};
     // tuning / A-B knobs, read from the environment once when the context is created
+    bool hks_two_step = false;    // HP_HKS_TWO_STEP: hybrid mult = switch, then a separate rescale (instead of the merged transform)
     bool no_fused_drop = false;   // HP_NO_FUSED_DROP: separate drop_rem / NTT / drop_fin launches
     int mult_streams = 1;         // HP_MULT_STREAMS=2: software-pipeline two sub-batches in dev_mult
     size_t mult_chunk = 0;        // HP_MULT_CHUNK: sub-batch size of dev_mult (0 = whole batch, or half with 2 streams)
@@ -537,6 +538,7 @@ int hp_ctx_create(int device, hp_ctx **out) {
     }
     c->stream = c->own_stream;
     c->no_fused_drop = getenv("HP_NO_FUSED_DROP") != nullptr;
+    c->hks_two_step = getenv("HP_HKS_TWO_STEP") != nullptr;
     if (const char *e = getenv("HP_MULT_STREAMS")) c->mult_streams = atoi(e) >= 2 ? 2 : 1;
     if (const char *e = getenv("HP_MULT_CHUNK")) c->mult_chunk = (size_t)atol(e);
     *out = c;
@@ -1267,6 +1269,7 @@ static int get_hks_consts(hp_ctx *ctx, const uint64_t *mext, size_t L, size_t k,
                         prod = (u64)((u128)prod * (pm[a] % mext[i]) % mext[i]);
                     }
                     c.p_mod_q[i] = prod;
+                    c.p_mod_q_h[i] = hp::harvey_quotient(prod, mext[i]);
                 }
             }
             HpHksConsts *d = nullptr;
@@ -1296,12 +1299,14 @@ static size_t hks_ws_words(size_t n, size_t L, size_t k, size_t nd, size_t P) {
 
 // key switch of P polynomials pt (NTT form, L limbs, row stride pt_pstride) with a hybrid key u64[nd][2][L+k][N]:
 // out [P][2][L][N] = ModDown( sum_d D_d * key_d ) [+ addend rows (p2>>1)*add_ct_stride + (p2&1)*add_poly_stride + i]
-static int hks_switch(hp_ctx *ctx, const Plan *plan, const HpHksConsts *hc, size_t logn, size_t L, size_t k, size_t alpha, size_t P,
-                      const u64 *pt, size_t pt_pstride, const u64 *key, const u64 *addend, size_t add_poly_stride,
-                      size_t add_ct_stride, u32 add_mask, const uint64_t *mext, u64 *out, Carver &cv) {
+// first part: ks [P][2][E][N] = sum_d D_d * key_d (NTT form) and rem [2P][L][N] = the centred exact conversion of its P-part into
+// every q_i (coefficient form)
+static int hks_front(hp_ctx *ctx, const Plan *plan, const HpHksConsts *hc, size_t logn, size_t L, size_t k, size_t alpha, size_t P,
+                     const u64 *pt, size_t pt_pstride, const u64 *key, const uint64_t *mext, u64 **ks_out, u64 **rem_out, Carver &cv) {
     const size_t n = (size_t)1 << logn, E = L + k, nd = (L + alpha - 1) / alpha;
     u64 *coef = cv.take(P * L * n), *lifted = cv.take(P * nd * E * n), *ks = cv.take(P * 2 * E * n);
     u64 *yp = cv.take(2 * P * k * n), *rem = cv.take(2 * P * L * n);
+    *ks_out = ks; *rem_out = rem;
     int rc;
     // coefficients of the input, strictly reduced (as rgsw.cpp:103-105)
     if ((rc = ks_coef(ctx, plan, logn, L, P, 0, L, pt, pt_pstride, coef))) return rc;
@@ -1346,6 +1351,18 @@ static int hks_switch(hp_ctx *ctx, const Plan *plan, const HpHksConsts *hc, size
                 return rc;
         }
     }
+    return HP_OK;
+}
+
+static bool fused_drop_ok(const hp_ctx *ctx, size_t logn) { return !ctx->force_generic && logn >= 11 && logn <= 15 && !ctx->no_fused_drop; }
+
+static int hks_switch(hp_ctx *ctx, const Plan *plan, const HpHksConsts *hc, size_t logn, size_t L, size_t k, size_t alpha, size_t P,
+                      const u64 *pt, size_t pt_pstride, const u64 *key, const u64 *addend, size_t add_poly_stride,
+                      size_t add_ct_stride, u32 add_mask, const uint64_t *mext, u64 *out, Carver &cv) {
+    const size_t n = (size_t)1 << logn, E = L + k;
+    u64 *ks, *rem;
+    int rc;
+    if ((rc = hks_front(ctx, plan, hc, logn, L, k, alpha, P, pt, pt_pstride, key, mext, &ks, &rem, cv))) return rc;
     // transform of the remainders with the rest of ModDown fused into its stores: out = (x - NTT(rem)) * P^-1 [+ addend]
     if (!ctx->force_generic && logn >= 11 && logn <= 15 && !ctx->no_fused_drop) {
         HpNttJob fj = batch_job(plan, logn, L, 2 * P, rem, nullptr, L, 0, 0, 0);
@@ -1445,7 +1462,7 @@ int hp_dev_ckks_mult_relin_rescale_hks(hp_ctx *ctx, size_t logn, size_t L, size_
     if ((rc = get_hks_consts(ctx, moduli_ext, L, k, alpha, &hc))) return rc;
     const size_t n = (size_t)1 << logn, nd = (L + alpha - 1) / alpha;
     const size_t words = padded(batch * 3 * L * n) / 8 + padded(batch * 2 * L * n) / 8 + hks_ws_words(n, L, k, nd, batch) +
-                         drop_ws_words(n, L, 2 * batch);
+                         drop_ws_words(n, L, 2 * batch) + 2 * (padded(2 * batch * n) / 8);
     if ((rc = ws_reserve(ctx, words * 8))) return rc;
     Carver cv(ctx->ws);
     u64 *quad = cv.take(batch * 3 * L * n), *lin = cv.take(batch * 2 * L * n);
@@ -1453,6 +1470,57 @@ int hp_dev_ckks_mult_relin_rescale_hks(hp_ctx *ctx, size_t logn, size_t L, size_
         ProfScope ps(ctx, "tensor");
         if ((rc = chk(ctx, hp_launch_tensor(plan->d_limbs, (u32)L, 0, (u32)L, (u32)n, (u32)batch, ct1, ct2, quad, ctx->stream), "tensor")))
             return rc;
+    }
+    if (fused_drop_ok(ctx, logn) && !ctx->hks_two_step) {
+        // ModDown and the rescale in ONE transform per remaining limb.  With c = the coefficients of the relinearised limb L-1,
+        //   ((ks_i - NTT(rem_i)) P^-1 + quad_i - NTT(centre_i(c))) q_last^-1 = ((ks_i - NTT(rem_i + P centre_i(c))) P^-1 + quad_i) q_last^-1
+        // so: ModDown of limb L-1 alone -> its coefficients -> rem_i += P centre_i(c) -> one fused transform over limbs 0..L-2.
+        // The same residues as the two-step composition below (another lazy representative of them).
+        const size_t P2 = 2 * batch, E = L + k;
+        u64 *ks, *rem;
+        if ((rc = hks_front(ctx, plan, hc, logn, L, k, alpha, batch, quad + 2 * L * n, 3 * L, key, moduli_ext, &ks, &rem, cv))) return rc;
+        u64 *r_last = cv.take(P2 * n), *c_last = cv.take(P2 * n);
+        HpDropArgs da;
+        {
+            HpNttJob fj = batch_job(plan, logn, 1, P2, rem + (L - 1) * n, nullptr, L, 0, 0, 0);
+            fj.limbs = plan->d_limbs + (L - 1);
+            memset(&da, 0, sizeof(da));
+            da.raw_input = 1;
+            da.dc.inv[0] = hc_host_pinv(ctx, moduli_ext, L, k, L - 1, &da.dc.inv_h[0]);
+            da.x = ks + (L - 1) * n; da.L = (u32)E; da.addend = quad + (L - 1) * n; da.add_poly_stride = (u32)L;
+            da.add_ct_stride = (u32)(3 * L); da.add_mask = 3u; da.out = r_last; da.out_stride = 1;
+            ProfScope ps(ctx, "ntt_drop");
+            if ((rc = chk(ctx, hp_launch_ntt_fast_drop(fj, da, ctx->stream), "hks ModDown of the last limb"))) return rc;
+        }
+        {
+            HpNttJob lj = batch_job(plan, logn, 1, P2, r_last, c_last, 1, 1, 1, 1);
+            lj.limbs = plan->d_limbs + (L - 1);
+            if ((rc = run_ntt(ctx, lj))) return rc;
+        }
+        const bool in_loads = getenv("HP_HKS_COMBINE_KERNEL") == nullptr;   // tuning switch: the combination as its own kernel
+        if (!in_loads) {
+            ProfScope ps(ctx, "hks_combine");
+            if ((rc = chk(ctx, hp_launch_hks_combine(plan->d_limbs, hc, (u32)L, (u32)n, (u32)P2, c_last, rem, ctx->stream), "hks_combine")))
+                return rc;
+        }
+        HpNttJob fj = batch_job(plan, logn, L - 1, P2, rem, nullptr, L, 0, 0, 0);
+        memset(&da, 0, sizeof(da));
+        da.raw_input = 1;
+        da.fin_on = 1;
+        const u64 q_last = moduli_ext[L - 1];
+        if (in_loads) { da.comb = c_last; da.comb_half = q_last / 2; }
+        for (size_t i = 0; i + 1 < L; i++) {
+            u64 pm = 1 % moduli_ext[i];
+            for (size_t j = 0; j < k; j++) pm = (u64)((unsigned __int128)pm * (moduli_ext[L + j] % moduli_ext[i]) % moduli_ext[i]);
+            da.comb_mul[i] = pm; da.comb_mul_h[i] = hp::harvey_quotient(pm, moduli_ext[i]); da.comb_r[i] = q_last % moduli_ext[i];
+            da.dc.inv[i] = hc_host_pinv(ctx, moduli_ext, L, k, i, &da.dc.inv_h[i]);
+            da.fin[i] = hp::inverse_mod_prime(q_last % moduli_ext[i], moduli_ext[i]) % moduli_ext[i];
+            da.fin_h[i] = hp::harvey_quotient(da.fin[i], moduli_ext[i]);
+        }
+        da.x = ks; da.L = (u32)E; da.addend = quad; da.add_poly_stride = (u32)L; da.add_ct_stride = (u32)(3 * L); da.add_mask = 3u;
+        da.out = out; da.out_stride = (u32)(L - 1);
+        ProfScope ps(ctx, "ntt_drop");
+        return chk(ctx, hp_launch_ntt_fast_drop(fj, da, ctx->stream), "hks fused ModDown + rescale");
     }
     if ((rc = hks_switch(ctx, plan, hc, logn, L, k, alpha, batch, quad + 2 * L * n, 3 * L, key, quad, L, 3 * L, 3, moduli_ext, lin, cv)))
         return rc;

@@ -232,6 +232,40 @@ hipError_t hp_launch_hks_moddown(const HpLimb *limbs, const HpHksConsts *hc, u32
     return hipGetLastError();
 }
 
+// merged ModDown + rescale: the remainder of the division by q_{L-1} joins the ModDown remainder before the transform.
+// In the coefficient domain, limb i < L-1:  rem_i <- rem_i + (P mod q_i) * centre_{q_i}(c), c the strict coefficient of the
+// relinearised limb L-1 modulo q_last (centred like rescaling.cpp:54-69: c >= q_last/2 means c - q_last)
+__global__ void __launch_bounds__(HKS_THREADS) k_hks_combine(const HpLimb *__restrict__ limbs, const HpHksConsts *__restrict__ hc,
+                                                            u32 n, u32 chunks, const u64 *__restrict__ clast,
+                                                            u64 *__restrict__ rem) {
+    const u32 L = hc->L, Lm1 = L - 1;
+    const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;   // row = p2*(L-1) + i
+    const u32 p2 = row / Lm1, k = row % Lm1;
+    const u64 q = limbs[k].q, bc = limbs[k].barrett_c, two_q = limbs[k].two_q;
+    const u64 q_last = limbs[Lm1].q, half = q_last / 2;
+    const u64 bump = q - hp_strict(hp_barrett_lazy(q_last, q, bc), q);   // q_i - (q_last mod q_i)
+    const u64 pm = hc->p_mod_q[k], pmh = hc->p_mod_q_h[k];
+    const u64 *c = clast + (size_t)p2 * n;
+    u64 *r = rem + ((size_t)p2 * L + k) * n;
+    const u32 end = min(n, (chunk + 1) * HKS_CHUNK);
+    for (u32 i = chunk * HKS_CHUNK + threadIdx.x; i < end; i += HKS_THREADS) {
+        const u64 cv = c[i];
+        u64 v = hp_strict(hp_barrett_lazy(cv, q, bc), q);
+        if (cv >= half) v += bump;                         // < 2 q_i
+        v = hp_harvey_lazy(v, pm, pmh, q);                 // * (P mod q_i), lazy
+        r[i] = hp_add_lazy(r[i], v, two_q);
+    }
+}
+
+hipError_t hp_launch_hks_combine(const HpLimb *limbs, const HpHksConsts *hc, u32 L, u32 n, u32 P2, const u64 *clast, u64 *rem,
+                                 hipStream_t stream) {
+    if (L < 2) return hipSuccess;
+    u32 chunks; dim3 grid;
+    hks_grid(n, P2 * (L - 1), chunks, grid);
+    k_hks_combine<<<grid, HKS_THREADS, 0, stream>>>(limbs, hc, n, chunks, clast, rem);
+    return hipGetLastError();
+}
+
 // ModDown epilogue: out[p2][i] = ((x[p2][i] - rem[p2][i]) * P^-1 mod q_i) [+ addend]; x rows have E limbs, rem / out rows L
 __global__ void __launch_bounds__(HKS_THREADS) k_hks_down_fin(const HpLimb *__restrict__ limbs, const HpHksConsts *__restrict__ hc,
                                                              u32 n, u32 chunks, const u64 *__restrict__ x,

@@ -109,6 +109,10 @@ struct HpDropArgs {
     int raw_input;         // 1: the transform's input rows already are the per-limb remainders (hybrid key switch): no
                            //    Barrett / centring prologue
     u32 out_stride;        // limbs between consecutive polynomials of out (L - 1 for a plain drop)
+    int fin_on;            // 1: one more per-limb multiplication AFTER the addend (hybrid key switch: merged rescale)
+    u64 fin[HP_MAX_LIMBS], fin_h[HP_MAX_LIMBS];
+    const u64 *comb;       // non-NULL (with raw_input): input = src + comb_mul[k] * centre_k(comb[p2]), comb [P2][N] strict modulo 2*comb_half+1
+    u64 comb_half, comb_r[HP_MAX_LIMBS], comb_mul[HP_MAX_LIMBS], comb_mul_h[HP_MAX_LIMBS];
     const u64 *x;          // [P2][L][n]: polynomial p2 at x + p2*L*n, limb k at + k*n
     u32 L;                 // limbs of x (the last one is being dropped)
     const u64 *addend;     // optional [.][.][n]: row (p2>>1)*add_ct_stride + (p2&1)*add_poly_stride + k
@@ -172,7 +176,7 @@ struct HpHksConsts {   // device memory, built by the engine per (moduli, k, alp
     u64 pg_inv[HP_HKS_MAX_ALPHA][HP_HKS_MAX_ALPHA], pg_inv_h[HP_HKS_MAX_ALPHA][HP_HKS_MAX_ALPHA];
     u64 p_half[HP_HKS_MAX_ALPHA];
     u64 p_pref[HP_MAX_LIMBS][HP_HKS_MAX_ALPHA], p_pref_h[HP_MAX_LIMBS][HP_HKS_MAX_ALPHA];
-    u64 p_mod_q[HP_MAX_LIMBS];
+    u64 p_mod_q[HP_MAX_LIMBS], p_mod_q_h[HP_MAX_LIMBS];
 };
 // yp [P2][k][n] (strict coefficients of the special-prime part) -> rem [P2][L][n]: the exact centred value in every q_i
 hipError_t hp_launch_hks_moddown(const HpLimb *limbs, const HpHksConsts *hc, u32 k, u32 n, u32 P2, const u64 *yp, u64 *rem,
@@ -181,6 +185,10 @@ hipError_t hp_launch_hks_modup(const HpLimb *limbs, const HpHksConsts *hc, u32 a
                                u64 *lifted, hipStream_t stream);
 hipError_t hp_launch_hks_inner(const HpLimb *limbs, u32 L, u32 E, u32 nd, u32 alpha, u32 n, u32 P, const u64 *lifted, const u64 *pt,
                                u32 pt_pstride, const u64 *key, u64 *out, hipStream_t stream);
+// merged ModDown + rescale (hp_engine.cpp: hks_mult): rem[p2][i] += (P mod q_i) * centre(c_last[p2]) for i < L-1, in the
+// coefficient domain; c_last = strict coefficients modulo q_{L-1} of the relinearised limb L-1
+hipError_t hp_launch_hks_combine(const HpLimb *limbs, const HpHksConsts *hc, u32 L, u32 n, u32 P2, const u64 *clast, u64 *rem,
+                                 hipStream_t stream);
 hipError_t hp_launch_hks_down_fin(const HpLimb *limbs, const HpHksConsts *hc, u32 L, u32 n, u32 P2, const u64 *x, const u64 *rem,
                                   const u64 *addend, u32 add_poly_stride, u32 add_ct_stride, u32 add_mask, u64 *out,
                                   hipStream_t stream);

@@ -368,6 +368,40 @@ __device__ u64 g_trace[2 * 2048 * 16 * HP_TRACE_SLOTS];
 #endif
 
 // ---- forward kernel ----------------------------------------------------------------------------
+// load, layout A: thread reads 2^PB consecutive coefficients at 2^A places 1024 apart
+template <int LOGN>
+HP_DEV void load_flight(const u64 *src, u32 tid, u64 (&x)[32]) {
+    using G = Geo<LOGN>;
+    const u64 *s = src + ((size_t)tid << G::PB);
+    if (G::PB == 0) {
+        // N = 32768: a thread owns one column (tid) of 32 rows 1024 apart.  Two neighbouring lanes
+        // fetch 16 bytes (both their columns) of alternate rows and trade halves with one DPP swap,
+        // so every HBM instruction still moves 16 bytes per lane.
+        const bool odd = (tid & 1u) != 0;
+        const u64 *sp = src + (tid & ~1u);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const V2 v = ld_stream(sp + ((size_t)(2 * p + (odd ? 1 : 0)) << 10));
+            const u64 keep = odd ? v.y : v.x, send = odd ? v.x : v.y;
+            const u64 recv = from_pair_lane(send);
+            x[2 * p] = odd ? recv : keep;
+            x[2 * p + 1] = odd ? keep : recv;
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < (G::PB == 0 ? 0 : (1 << G::A)); ++kk) {
+        if (G::PB == 0) {
+        } else {
+#pragma unroll
+            for (int pp = 0; pp < (1 << G::PB); pp += 2) {
+                const V2 v = ld_stream(s + ((size_t)kk << 10) + pp);
+                x[(kk << G::PB) | pp] = v.x;
+                x[(kk << G::PB) | pp | 1] = v.y;
+            }
+        }
+    }
+}
+
 template <int LOGN, bool DROP>
 HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
     using G = Geo<LOGN>;
@@ -400,37 +434,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
     TRACE_DECL
     TRACE_MARK();
     u64 x[32];
-    // load, layout A: thread reads 2^PB consecutive coefficients at 2^A places 1024 apart
-    {
-        const u64 *s = it.src + ((size_t)tid << G::PB);
-        if (G::PB == 0) {
-            // N = 32768: a thread owns one column (tid) of 32 rows 1024 apart.  Two neighbouring lanes
-            // fetch 16 bytes (both their columns) of alternate rows and trade halves with one DPP swap,
-            // so every HBM instruction still moves 16 bytes per lane.
-            const bool odd = (tid & 1u) != 0;
-            const u64 *sp = it.src + (tid & ~1u);
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const V2 v = ld_stream(sp + ((size_t)(2 * p + (odd ? 1 : 0)) << 10));
-                const u64 keep = odd ? v.y : v.x, send = odd ? v.x : v.y;
-                const u64 recv = from_pair_lane(send);
-                x[2 * p] = odd ? recv : keep;
-                x[2 * p + 1] = odd ? keep : recv;
-            }
-        }
-#pragma unroll
-        for (int kk = 0; kk < (G::PB == 0 ? 0 : (1 << G::A)); ++kk) {
-            if (G::PB == 0) {
-            } else {
-#pragma unroll
-                for (int pp = 0; pp < (1 << G::PB); pp += 2) {
-                    const V2 v = ld_stream(s + ((size_t)kk << 10) + pp);
-                    x[(kk << G::PB) | pp] = v.x;
-                    x[(kk << G::PB) | pp | 1] = v.y;
-                }
-            }
-        }
-    }
+    load_flight<LOGN>(it.src, tid, x);
     if (tid < 31u * (1u << G::A)) lds_tw[tid] = stg;
     if (DROP) {
         // rescaling.cpp:54-69 / mod_switch.cpp:52-70 while the coefficients are still in flight order:
@@ -447,6 +451,19 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
                 if (c >= half) v += bump;
                 if (bgv) v = hp_harvey_lazy_nq(v, tk, tkh, (u32)nq, (u32)(nq >> 32));
                 x[r] = v;
+            }
+        }
+        if (da->comb) {
+            // hybrid key switch, ModDown merged with the rescale: x = rem_k + (P mod q_k) * centre_k(c), c = the strict
+            // coefficients modulo q_last of the relinearised last limb (one row per polynomial, read by every limb)
+            u64 c[32];
+            load_flight<LOGN>(da->comb + (size_t)(w % job.P) * G::N, tid, c);
+            const u64 pm = da->comb_mul[k], pmh = da->comb_mul_h[k], cbump = q - da->comb_r[k], chalf = da->comb_half;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                u64 v = hp_strict(hp_barrett_lazy(c[r], q, bc), q);
+                if (c[r] >= chalf) v += cbump;
+                x[r] = hp_add_lazy(x[r], hp_harvey_lazy_nq(v, pm, pmh, (u32)nq, (u32)(nq >> 32)), two_q);
             }
         }
     }
@@ -500,7 +517,8 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
                             ? da->addend + ((size_t)(p2 >> 1) * da->add_ct_stride + (size_t)(p2 & 1) * da->add_poly_stride + k) * G::N + off : nullptr;
         u64 *d = da->out + ((size_t)p2 * da->out_stride + k) * G::N + off;
         const u64 inv = da->dc.inv[k], invh = da->dc.inv_h[k], ql = da->dc.qlt[k], qlh = da->dc.qlt_h[k];
-        const bool bgv = da->dc.bgv != 0;
+        const bool bgv = da->dc.bgv != 0, fin_on = da->fin_on != 0;
+        const u64 fin = da->fin[k], finh = da->fin_h[k];
         const u32 n0 = (u32)nq, n1 = (u32)(nq >> 32);
         // The 16 rows are software-pipelined by hand: the operand loads run EPI_DEPTH rows ahead of their use (ring in
         // registers, the twiddle ring is dead by now), otherwise every row waits for its own two loads with
@@ -532,6 +550,10 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
             if (as) {
                 v0 = hp_add_lazy(v0, av.x, two_q);
                 v1 = hp_add_lazy(v1, av.y, two_q);
+            }
+            if (fin_on) {
+                v0 = hp_harvey_lazy_nq(v0, fin, finh, n0, n1);
+                v1 = hp_harvey_lazy_nq(v1, fin, finh, n0, n1);
             }
             V2 v{v0, v1};
             st_stream(d + ((size_t)s << 7), v);

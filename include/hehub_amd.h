@@ -262,7 +262,10 @@ int hp_dev_ckks_rotate_hks(hp_ctx *ctx, size_t logn, size_t L, size_t k, size_t 
                            size_t batch, size_t step, const uint64_t *d_ct, const uint64_t *d_rot_key, uint64_t *d_out);
 int hp_dev_ckks_conjugate_hks(hp_ctx *ctx, size_t logn, size_t L, size_t k, size_t alpha, const uint64_t *moduli_ext,
                               size_t batch, const uint64_t *d_ct, const uint64_t *d_conj_key, uint64_t *d_out);
-/* ckks::mult_low_level + relinearisation with a hybrid key + rescale by q_{L-1}: out u64[batch][2][L-1][N] */
+/* ckks::mult_low_level + relinearisation with a hybrid key + rescale by q_{L-1}: out u64[batch][2][L-1][N].
+ * For N = 2^11 .. 2^15 ModDown and the rescale share one transform per limb: the residues of hp_dev_hks_switch followed by
+ * hp_dev_ckks_rescale, in a lazy representative (< 2q) of their own; HP_HKS_TWO_STEP=1 in the environment at hp_ctx_create
+ * runs the two steps separately and reproduces those words. */
 int hp_dev_ckks_mult_relin_rescale_hks(hp_ctx *ctx, size_t logn, size_t L, size_t k, size_t alpha,
                                        const uint64_t *moduli_ext, size_t batch, const uint64_t *d_ct1,
                                        const uint64_t *d_ct2, const uint64_t *d_key, uint64_t *d_out);
