@@ -75,6 +75,7 @@ SIGNATURES = {
     "hp_dev_drop_apply_range": (INT, [P, szt, szt, P, u64, szt, szt, szt, P, P, P, szt, szt, C.c_uint, P]),
     "hp_dev_ckks_mult_relin_rescale": (INT, [P, szt, szt, P, szt, P, P, P, P]),
     "hp_dev_bgv_mult_relin_modswitch": (INT, [P, szt, szt, P, u64, szt, P, P, P, P]),
+    "hp_dev_bgv_mult_relin_modswitch_t": (INT, [P, szt, szt, P, u64, szt, P, P, P, P]),
     "hp_dev_ext_prod_montgomery_at": (INT, [P, szt, szt, szt, P, szt, P, P, P]),
     "hp_dev_ckks_relinearize_at": (INT, [P, szt, szt, szt, P, szt, P, P, P]),
     "hp_dev_ckks_rotate_at": (INT, [P, szt, szt, szt, P, szt, szt, P, P, P]),

@@ -945,7 +945,7 @@ static int dev_ckks_automorphism(hp_ctx *ctx, size_t logn, size_t L, size_t key_
 
 // mult_low_level + relinearize + drop q_last, processed in sub-batches so the working set
 // (dominated by the L(L+1) digit limbs per ciphertext) stays small
-static int dev_mult(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, bool bgv, u64 t, size_t batch,
+static int dev_mult(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, bool bgv, u64 t, u64 inner_t, size_t batch,
                     const uint64_t *ct1, const uint64_t *ct2, const uint64_t *key, uint64_t *out) {
     Guard g(ctx);
     HP_REQUIRE(ctx, moduli_ext, ct1, ct2, key, out);
@@ -992,8 +992,8 @@ static int dev_mult(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uin
             rc = chk(ctx, hp_launch_tensor(plan->d_limbs, (u32)L, 0, (u32)L, (u32)n, (u32)P, ct1 + b0 * 2 * L * n,
                                            ct2 + b0 * 2 * L * n, quad, ctx->stream), "tensor");
         }
-        // the reference's bgv::relinearize runs its inner mod switch with plain_modulus == 1 (bgv.h:32)
-        if (!rc) rc = relin_core(ctx, plan, logn, L, P, bgv, 1, quad, key, key_L0, lin, cv);
+        // the reference's bgv::relinearize runs its inner mod switch with plain_modulus == 1 (bgv.h:32): inner_t = 1
+        if (!rc) rc = relin_core(ctx, plan, logn, L, P, bgv, inner_t, quad, key, key_L0, lin, cv);
         if (!rc) rc = drop_last(ctx, plan, logn, L, 2 * P, bgv, t, lin, nullptr, 0, 0, 0, out + b0 * 2 * (L - 1) * n, cv);
         if (rc) break;
     }
@@ -1024,17 +1024,22 @@ int hp_dev_ckks_conjugate_at(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, 
 }
 int hp_dev_ckks_mult_relin_rescale(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch,
                                    const uint64_t *ct1, const uint64_t *ct2, const uint64_t *key, uint64_t *out) {
-    return dev_mult(ctx, logn, L, L, moduli_ext, false, 0, batch, ct1, ct2, key, out);
+    return dev_mult(ctx, logn, L, L, moduli_ext, false, 0, 1, batch, ct1, ct2, key, out);
 }
 int hp_dev_ckks_mult_relin_rescale_at(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext,
                                       size_t batch, const uint64_t *ct1, const uint64_t *ct2, const uint64_t *key,
                                       uint64_t *out) {
-    return dev_mult(ctx, logn, L, key_L0, moduli_ext, false, 0, batch, ct1, ct2, key, out);
+    return dev_mult(ctx, logn, L, key_L0, moduli_ext, false, 0, 1, batch, ct1, ct2, key, out);
 }
 int hp_dev_bgv_mult_relin_modswitch(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, uint64_t t,
                                     size_t batch, const uint64_t *ct1, const uint64_t *ct2, const uint64_t *key,
                                     uint64_t *out) {
-    return dev_mult(ctx, logn, L, L, moduli_ext, true, t, batch, ct1, ct2, key, out);
+    return dev_mult(ctx, logn, L, L, moduli_ext, true, t, 1, batch, ct1, ct2, key, out);
+}
+int hp_dev_bgv_mult_relin_modswitch_t(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, uint64_t t,
+                                      size_t batch, const uint64_t *ct1, const uint64_t *ct2, const uint64_t *key,
+                                      uint64_t *out) {
+    return dev_mult(ctx, logn, L, L, moduli_ext, true, t, t, batch, ct1, ct2, key, out);
 }
 
 // ---- profiling ------------------------------------------------------------------------------

@@ -378,10 +378,12 @@ class Engine:
                                                           self._ptr(out)))
         return out
 
-    def bgv_mult(self, moduli_ext, t, ct1, ct2, key, out=None):
+    def bgv_mult(self, moduli_ext, t, ct1, ct2, key, out=None, inner_t: bool = False):
+        """inner_t: the extension that keeps the key-switched term (hp_dev_bgv_mult_relin_modswitch_t)"""
         B, two, L, n = ct1.shape
         out = self.empty((B, 2, L - 1, n)) if out is None else out
-        self._chk(self.lib.hp_dev_bgv_mult_relin_modswitch(self.h, n.bit_length() - 1, L, _u64arr(moduli_ext), t, B,
+        fn = self.lib.hp_dev_bgv_mult_relin_modswitch_t if inner_t else self.lib.hp_dev_bgv_mult_relin_modswitch
+        self._chk(fn(self.h, n.bit_length() - 1, L, _u64arr(moduli_ext), t, B,
                                                            self._ptr(ct1), self._ptr(ct2), self._ptr(key),
                                                            self._ptr(out)))
         return out

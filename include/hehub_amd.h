@@ -162,6 +162,14 @@ int hp_dev_ckks_mult_relin_rescale(hp_ctx *ctx, size_t logn, size_t L, const uin
 int hp_dev_bgv_mult_relin_modswitch(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext,
                                     uint64_t plain_modulus, size_t batch, const uint64_t *d_ct1,
                                     const uint64_t *d_ct2, const uint64_t *d_key, uint64_t *d_out);
+/* Extension (SURVEY.md 8c caveat 1): the same pipeline with the inner switch of bgv::relinearize run with the plain modulus t
+ * instead of hehub's 1, so that the key-switched term survives and the product decrypts.  The key must be made for it: row j
+ * encrypts (p mod q_j) * ((p mod t)^-1 mod q_j) * s^2 in limb j with noise lifted by t (tests/test_extensions.py has the
+ * recipe); with hehub's own keys use the parity entry point above.  Equals hp_dev_bgv_relinearize(inner_plain_modulus = t)
+ * between hp_dev_mult_low_level and hp_dev_bgv_mod_switch, word for word. */
+int hp_dev_bgv_mult_relin_modswitch_t(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext,
+                                      uint64_t plain_modulus, size_t batch, const uint64_t *d_ct1,
+                                      const uint64_t *d_ct2, const uint64_t *d_key, uint64_t *d_out);
 
 /* ---- either side of the path: what a pipeline needs to keep ciphertexts on the device ---- */
 /* rlwe.cpp:57-72 encrypt_core with the samples of get_rlwe_sample supplied by the caller (sampling stays on the host):
