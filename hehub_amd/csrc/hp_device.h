@@ -109,19 +109,21 @@ HP_DEV void hp_butterfly2_nq(u64 &lo_a, u64 &hi_a, u64 &lo_b, u64 &hi_b, u64 wa,
     const u64 bA = (u64)bx1 * bp0 + (u64)__umulhi(bx0, bp0);
     u64 aB, aG, aE, bB, bG, bE, sd;
     u32 ac, bc;
+    // The low-product chains G start from the other butterfly input instead of 0 (wrapping u64, like the reference's
+    // x[l] + t): lo + t costs nothing, and hi = lo + 2q - t becomes (2 lo + 2q) - (lo + t).
     asm("v_mad_u64_u32 %0, vcc, %9, %10, %11\n\t"     // aB = ax0*ap1 + aA, carry -> vcc
-        "v_mad_u64_u32 %1, %8, %9, %12, 0\n\t"        // aG = ax0*aw0
+        "v_mad_u64_u32 %1, %8, %9, %12, %21\n\t"      // aG = ax0*aw0 + lo_a
         "v_mad_u64_u32 %2, %8, %9, %13, 0\n\t"        // aE = ax0*aw1
         "v_addc_co_u32_e64 %3, vcc, 0, 0, vcc\n\t"    // ac
         "v_mad_u64_u32 %4, vcc, %15, %18, %16\n\t"    // bB = bx0*bp1 + bA, carry -> vcc
         "v_mad_u64_u32 %2, %8, %14, %12, %2\n\t"      // aE += ax1*aw0
-        "v_mad_u64_u32 %5, %8, %15, %19, 0\n\t"       // bG = bx0*bw0
+        "v_mad_u64_u32 %5, %8, %15, %19, %22\n\t"     // bG = bx0*bw0 + lo_b
         "v_addc_co_u32_e64 %7, vcc, 0, 0, vcc\n\t"    // bc
         "v_mad_u64_u32 %6, %8, %15, %20, 0\n\t"       // bE = bx0*bw1
         "v_mad_u64_u32 %6, %8, %17, %19, %6"            // bE += bx1*bw0
         : "=&v"(aB), "=&v"(aG), "=&v"(aE), "=&v"(ac), "=&v"(bB), "=&v"(bG), "=&v"(bE), "=&v"(bc), "=&s"(sd)
         : "v"(ax0), "v"(ap1), "v"(aA), "v"(aw0), "v"(aw1), "v"(ax1), "v"(bx0), "v"(bA), "v"(bx1), "v"(bp1), "v"(bw0),
-          "v"(bw1)
+          "v"(bw1), "v"(lo_a), "v"(lo_b)
         : "vcc");
     const u64 aU = ((u64)ac << 32) | (aB >> 32), bU = ((u64)bc << 32) | (bB >> 32);
     const u64 aQ = (u64)ax1 * ap1 + aU, bQ = (u64)bx1 * bp1 + bU;
@@ -137,11 +139,11 @@ HP_DEV void hp_butterfly2_nq(u64 &lo_a, u64 &hi_a, u64 &lo_b, u64 &hi_b, u64 wa,
     u32 ath, bth;
     asm("v_add_u32 %0, %1, %2" : "=v"(ath) : "v"((u32)(aG >> 32)), "v"((u32)aE));
     asm("v_add_u32 %0, %1, %2" : "=v"(bth) : "v"((u32)(bG >> 32)), "v"((u32)bE));
-    const u64 at = ((u64)ath << 32) | (u32)aG, bt = ((u64)bth << 32) | (u32)bG;
-    hi_a = lo_a + two_q - at;
-    lo_a = lo_a + at;
-    hi_b = lo_b + two_q - bt;
-    lo_b = lo_b + bt;
+    const u64 as = ((u64)ath << 32) | (u32)aG, bs = ((u64)bth << 32) | (u32)bG;   // lo + t
+    hi_a = ((lo_a << 1) + two_q) - as;
+    lo_a = as;
+    hi_b = ((lo_b << 1) + two_q) - bs;
+    lo_b = bs;
 }
 
 // ntt.cpp:171-175
