@@ -62,6 +62,7 @@ struct hp_ctx {
     hipStream_t aux[2] = {nullptr, nullptr};
     hipEvent_t ev_start = nullptr, ev_done[2] = {nullptr, nullptr};
     // tuning / A-B knobs, read from the environment once when the context is created
+    int spread_group = 2;         // HP_SPREAD_GROUP=G: digit-spread launch numbered by groups of G moduli (0: modulus-major)
     bool hks_two_step = false;    // HP_HKS_TWO_STEP: hybrid mult = switch, then a separate rescale (instead of the merged transform)
     bool no_fused_drop = false;   // HP_NO_FUSED_DROP: separate drop_rem / NTT / drop_fin launches
     int mult_streams = 1;         // HP_MULT_STREAMS=2: software-pipeline two sub-batches in dev_mult
@@ -345,6 +346,8 @@ int ks_digits_inner(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t
     // items: (L-1)*P per modulus k < L (the diagonal digit is not transformed), L*P for the special prime k = L
     const size_t n_lo = (k1 < L ? k1 : L) - (k0 < L ? k0 : L);
     sj.k_first = (u32)k0; sj.W = (u32)(n_lo * (L - 1) * P + (k1 > L ? L * P : 0)); sj.mode = HP_NTT_SPREAD;
+    sj.pair_moduli = (k0 == 0 && k1 == L + 1 && L >= 2) ? (u32)ctx->spread_group : 0u;
+    if (sj.pair_moduli > L) sj.pair_moduli = (u32)L;
     if ((rc = run_ntt(ctx, sj))) return rc;
     // (iii) u128 inner product + Montgomery                         rgsw.cpp:121-153
     {
@@ -539,6 +542,7 @@ int hp_ctx_create(int device, hp_ctx **out) {
     c->stream = c->own_stream;
     c->no_fused_drop = getenv("HP_NO_FUSED_DROP") != nullptr;
     c->hks_two_step = getenv("HP_HKS_TWO_STEP") != nullptr;
+    if (const char *e = getenv("HP_SPREAD_GROUP")) c->spread_group = atoi(e) > 0 ? atoi(e) : 0;   // measured: 2..6 alike, -2 % on the launch
     if (const char *e = getenv("HP_MULT_STREAMS")) c->mult_streams = atoi(e) >= 2 ? 2 : 1;
     if (const char *e = getenv("HP_MULT_CHUNK")) c->mult_chunk = (size_t)atol(e);
     *out = c;

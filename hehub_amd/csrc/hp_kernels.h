@@ -14,7 +14,7 @@ enum HpNttMode : int {
     HP_NTT_HKS = 2,     // hybrid key switch (extension): in-place transforms of the lifted digits [P][nd][E][N]; one item per
                         //   (modulus m, digit d, polynomial p) with m outside digit d, modulus-major, hole-free
     HP_NTT_SPREAD = 1,  // digit spread (rgsw.cpp:108-119): one item per (k, j != k, p), k in [0,L], numbered modulus-major
-                        //   then digit then polynomial without holes (hp_ntt_job.h): src = coef row p*L + j,
+                        //   then digit then polynomial without holes, or by groups of moduli (pair_moduli, hp_ntt_job.h): src = coef row p*L + j,
                         //   dst = digit row (p*L + j)*(L+1) + k, limb k; a launch may cover only the moduli
                         //   k_first .. k_first + kc - 1 (W = their item count)
 };
@@ -31,6 +31,8 @@ struct HpNttJob {
     u32 src_kstride;  // HP_NTT_BATCH: rows between consecutive limbs of src (1; 0 = every limb reads the same row)
     u32 W;          // work items
     u32 k_first;    // HP_NTT_SPREAD: first output modulus of the launch
+    u32 pair_moduli;  // HP_NTT_SPREAD, whole launches only: G > 0 numbers the items by groups of G consecutive moduli so that
+                      // the G transforms of one source row run in neighbouring workgroups (the row is re-read from L2)
     u32 hks_nd, hks_E, hks_alpha;   // HP_NTT_HKS: digits, moduli of the extended chain, limbs per digit (L = ciphertext moduli)
     int mode;
     int inverse;

@@ -27,7 +27,25 @@ HP_DEV bool hp_decode_item(const HpNttJob &job, u32 w, HpItem &it) {
         const u32 per = (job.L - 1) * job.P;
         const u32 g = job.k_first * per + w;
         u32 k, j, p;
-        if (g < job.L * per) {
+        if (job.pair_moduli) {
+            // groups of G consecutive moduli, items of a group ordered (digit j, polynomial p, modulus k): the G workgroups
+            // that transform one source row under the group's moduli are neighbours, the row comes from HBM once per group.
+            // Full groups [aG, aG+G) below L hold G(L-1)P items (the digit that is a member has G-1 targets); the last
+            // group is what is left of the ciphertext moduli plus the special prime L (which is never a digit).
+            const u32 L = job.L, P = job.P, G = job.pair_moduli, nfull = L / G, perg = G * (L - 1) * P;
+            u32 a, m, ain, r;
+            if (w < nfull * perg) { a = (w / perg) * G; r = w % perg; m = G; ain = G; }
+            else { a = nfull * G; r = w - nfull * perg; m = L + 1 - a; ain = m - 1; }
+            const u32 r1 = P * m * a, r2 = r1 + P * (m - 1) * ain;
+            if (r < r1) { j = r / (P * m); const u32 rem = r % (P * m); p = rem / m; k = a + rem % m; }
+            else if (r < r2) {
+                const u32 rr = r - r1, pm = P * (m - 1);
+                j = a + rr / pm;
+                const u32 rem = rr % pm, t = a + rem % (m - 1);
+                p = rem / (m - 1);
+                k = t + (t >= j ? 1u : 0u);
+            } else { const u32 rr = r - r2; j = a + ain + rr / (P * m); const u32 rem = rr % (P * m); p = rem / m; k = a + rem % m; }
+        } else if (g < job.L * per) {
             k = g / per;
             const u32 r = g % per, jj = r / job.P;
             p = r % job.P;
