@@ -356,7 +356,10 @@ def main():
         # FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, tools/prof_pmc.sh); null when no measurement exists
         try:
             with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-                tr = json.load(f).get(f"k_ntt_fwd_logn{logn}") if family == "ntt" else None
+                trs = json.load(f)
+                tr = None
+                if family == "ntt":   # the digit-spread launch has its own measurement where one exists
+                    tr = (trs.get(f"k_ntt_fwd_logn{logn}_spread") if wl in ("ckks", "bgv", "rotate") else None) or trs.get(f"k_ntt_fwd_logn{logn}")
             if tr:
                 limbs_per_launch = bytes_per_launch / (16.0 * n)
                 res["roofline"]["traffic"] = tr["bytes_per_limb"] * limbs_per_launch
