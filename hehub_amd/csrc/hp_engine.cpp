@@ -434,6 +434,7 @@ int drop_apply(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, 
         HpNttJob fj = batch_job(plan, logn, kc, P2, clast, nullptr, 1, 0, 0, 0);
         fj.limbs = limbs;
         fj.src_kstride = 0;
+        fj.pair_moduli = ctx->spread_group ? 1u : 0u;
         HpDropArgs da;
         memset(&da, 0, sizeof(da));
         da.dc = dc; da.x = x; da.L = (u32)L; da.addend = addend; da.add_poly_stride = (u32)add_poly_stride;

@@ -457,7 +457,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
             // hybrid key switch, ModDown merged with the rescale: x = rem_k + (P mod q_k) * centre_k(c), c = the strict
             // coefficients modulo q_last of the relinearised last limb (one row per polynomial, read by every limb)
             u64 c[32];
-            load_flight<LOGN>(da->comb + (size_t)(w % job.P) * G::N, tid, c);
+            load_flight<LOGN>(da->comb + (size_t)it.poly * G::N, tid, c);
             const u64 pm = da->comb_mul[k], pmh = da->comb_mul_h[k], cbump = q - da->comb_r[k], chalf = da->comb_half;
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
@@ -510,7 +510,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
     } else {
         // rescaling.cpp:72-74 / mod_switch.cpp:72-76 (+ the += of relinearize, ckks/arith.cpp:70-71):
         // out = ((x - NTT(rem)) * inv) [* (q_last mod t)] [+ addend], all in the lazy representation
-        const u32 k = it.limb, p2 = w % job.P;
+        const u32 k = it.limb, p2 = it.poly;
         const size_t off = (((size_t)(tid >> 6)) << 11) + ((tid & 63u) << 1);
         const u64 *xs = da->x + ((size_t)p2 * da->L + k) * G::N + off;
         const u64 *as = (da->addend && ((da->add_mask >> (p2 & 1)) & 1u))

@@ -6,6 +6,7 @@ struct HpItem {
     const u64 *src;
     u64 *dst;
     u32 limb;
+    u32 poly;   // HP_NTT_BATCH: the polynomial of the item
 };
 
 // (digit spread: the diagonal digit k == j is never an item -- it is the untouched NTT-form input limb,
@@ -13,10 +14,16 @@ struct HpItem {
 HP_DEV bool hp_decode_item(const HpNttJob &job, u32 w, HpItem &it) {
     const size_t n = (size_t)1 << job.logn;
     if (job.mode == HP_NTT_BATCH) {
-        const u32 k = w / job.P, p = w % job.P;
+        u32 k = w / job.P, p = w % job.P;
+        if (job.pair_moduli) {   // every limb reads the same row (src_kstride 0): pairs of moduli side by side, as in the digit spread
+            const u32 full = (job.L >> 1) * 2 * job.P;
+            if (w < full) { k = 2 * (w / (2 * job.P)) + (w & 1u); p = (w % (2 * job.P)) >> 1; }
+            else { k = job.L - 1; p = w - full; }
+        }
         it.src = job.src + ((size_t)p * job.src_pstride + (size_t)k * job.src_kstride) * n;
         it.dst = job.dst + ((size_t)p * job.dst_pstride + k) * n;
         it.limb = k;
+        it.poly = p;
         return true;
     }
     if (job.mode == HP_NTT_SPREAD) {
