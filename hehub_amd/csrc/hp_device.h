@@ -161,6 +161,46 @@ HP_DEV void hp_mul128(u64 a, u64 b, u64 &lo, u64 &hi) {
     hi = hp_mulhi(a, b);
 }
 
+// ---- 128-bit multiply-accumulate in carry-save columns ------------------------------------------
+// sum_j x_j * y_j mod 2^128 (the u128 accumulators of rgsw.cpp:126-149) as three 64-bit columns
+//     p00 = sum x0*y0,   px = sum (x0*y1 + x1*y0)  (weight 2^32),   p11 = sum x1*y1  (weight 2^64)
+// plus the counts c00 / cx of the carries out of p00 / px; what p11 loses has weight 2^128.  One term costs the four
+// v_mad_u64_u32 and three v_addc_co (7 VALU instructions; the compiler's u128 += u64*u64 is ~20).  Exact for any u64 words.
+struct HpAcc {
+    u64 p00, px, p11;
+    u32 c00, cx;
+};
+HP_DEV void hp_acc_zero(HpAcc &a) { a.p00 = a.px = a.p11 = 0; a.c00 = a.cx = 0; }
+// two independent accumulators in one block: the carry of a mad (an SGPR pair) is consumed four instructions later
+HP_DEV void hp_mac2(HpAcc &a, u64 ax, u64 ay, HpAcc &b, u64 bx, u64 by) {
+    const u32 ax0 = (u32)ax, ax1 = (u32)(ax >> 32), ay0 = (u32)ay, ay1 = (u32)(ay >> 32);
+    const u32 bx0 = (u32)bx, bx1 = (u32)(bx >> 32), by0 = (u32)by, by1 = (u32)(by >> 32);
+    u64 s0, s1, s2, s3, sd;
+    asm("v_mad_u64_u32 %0, %10, %15, %17, %0\n\t"     // a.p00 += ax0*ay0      carry -> s0
+        "v_mad_u64_u32 %1, %11, %15, %18, %1\n\t"     // a.px  += ax0*ay1      carry -> s1
+        "v_mad_u64_u32 %5, %12, %19, %21, %5\n\t"     // b.p00 += bx0*by0      carry -> s2
+        "v_mad_u64_u32 %6, %13, %19, %22, %6\n\t"     // b.px  += bx0*by1      carry -> s3
+        "v_addc_co_u32_e64 %3, %14, %3, 0, %10\n\t"   // a.c00 += s0
+        "v_addc_co_u32_e64 %4, %14, %4, 0, %11\n\t"   // a.cx  += s1
+        "v_addc_co_u32_e64 %8, %14, %8, 0, %12\n\t"   // b.c00 += s2
+        "v_addc_co_u32_e64 %9, %14, %9, 0, %13\n\t"   // b.cx  += s3
+        "v_mad_u64_u32 %1, %11, %16, %17, %1\n\t"     // a.px  += ax1*ay0      carry -> s1
+        "v_mad_u64_u32 %6, %13, %20, %21, %6\n\t"     // b.px  += bx1*by0      carry -> s3
+        "v_mad_u64_u32 %2, %14, %16, %18, %2\n\t"     // a.p11 += ax1*ay1
+        "v_mad_u64_u32 %7, %14, %20, %22, %7\n\t"     // b.p11 += bx1*by1
+        "v_addc_co_u32_e64 %4, %14, %4, 0, %11\n\t"   // a.cx  += s1
+        "v_addc_co_u32_e64 %9, %14, %9, 0, %13"          // b.cx  += s3
+        : "+v"(a.p00), "+v"(a.px), "+v"(a.p11), "+v"(a.c00), "+v"(a.cx), "+v"(b.p00), "+v"(b.px), "+v"(b.p11), "+v"(b.c00),
+          "+v"(b.cx), "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3), "=&s"(sd)
+        : "v"(ax0), "v"(ax1), "v"(ay0), "v"(ay1), "v"(bx0), "v"(bx1), "v"(by0), "v"(by1));
+}
+// the accumulated value: lo = p00 + (px << 32), hi = c00 + (px >> 32) + (cx << 32) + p11 + carry(lo)
+HP_DEV void hp_acc_value(const HpAcc &a, u64 &lo, u64 &hi) {
+    const u64 sh = a.px << 32;
+    lo = a.p00 + sh;
+    hi = (u64)a.c00 + (a.px >> 32) + ((u64)a.cx << 32) + a.p11 + (lo < sh ? 1ull : 0ull);
+}
+
 // mod_arith.cpp:113-134: (acc + ((acc.lo * m) mod 2^64) * q) >> 64
 HP_DEV u64 hp_montgomery128_lazy(u64 lo, u64 hi, u64 q, u64 mqinv) {
     u64 u = lo * mqinv;

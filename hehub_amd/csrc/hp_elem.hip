@@ -308,21 +308,12 @@ HP_DEV void ks_load(KsRow<PT> &r, u32 j, u32 k, u32 L, u32 Le, u32 key_Le, u32 k
     }
 }
 
-template <int PT> HP_DEV void ks_mac(const KsRow<PT> &r, u64 (&al)[PT][2][2], u64 (&ah)[PT][2][2]) {
+template <int PT> HP_DEV void ks_mac(const KsRow<PT> &r, HpAcc (&acc)[PT][2][2]) {
     const u64 kw[2][2] = {{r.g0.x, r.g0.y}, {r.g1.x, r.g1.y}};
 #pragma unroll
-    for (int c = 0; c < PT; c++) {
-        const u64 dv[2] = {r.d[c].x, r.d[c].y};
+    for (int c = 0; c < PT; c++)
 #pragma unroll
-        for (int h = 0; h < 2; h++)
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                u64 lo, hi;
-                hp_mul128(dv[e], kw[h][e], lo, hi);
-                al[c][h][e] += lo;
-                ah[c][h][e] += hi + (al[c][h][e] < lo ? 1ull : 0ull);
-            }
-    }
+        for (int h = 0; h < 2; h++) hp_mac2(acc[c][h][0], r.d[c].x, kw[h][0], acc[c][h][1], r.d[c].y, kw[h][1]);
 }
 
 template <int PT>
@@ -341,28 +332,31 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner_blk(const HpLimb *__r
     for (int c = 0; c < PT; c++) pc[c] = min(p0 + c, P - 1);
     const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
     for (u32 i = chunk * ELEM_CHUNK + threadIdx.x * 2; i < end; i += ELEM_THREADS * 2) {
-        u64 al[PT][2][2], ah[PT][2][2];   // [ciphertext][half][word]
+        HpAcc acc[PT][2][2];   // [ciphertext][half][word]
 #pragma unroll
         for (int c = 0; c < PT; c++)
 #pragma unroll
-            for (int h = 0; h < 2; h++) al[c][h][0] = al[c][h][1] = ah[c][h][0] = ah[c][h][1] = 0;
+            for (int h = 0; h < 2; h++) { hp_acc_zero(acc[c][h][0]); hp_acc_zero(acc[c][h][1]); }
         KsRow<PT> ra, rb;
         ks_load<PT>(ra, 0, k, L, Le, key_Le, kcol, n, i, pc, digits, pt, pt_pstride, key);
         u32 j = 0;
         for (; j + 2 <= L; j += 2) {
             ks_load<PT>(rb, j + 1, k, L, Le, key_Le, kcol, n, i, pc, digits, pt, pt_pstride, key);
-            ks_mac<PT>(ra, al, ah);
+            ks_mac<PT>(ra, acc);
             ks_load<PT>(ra, min(j + 2, L - 1), k, L, Le, key_Le, kcol, n, i, pc, digits, pt, pt_pstride, key);   // last: harmless re-read
-            ks_mac<PT>(rb, al, ah);
+            ks_mac<PT>(rb, acc);
         }
-        if (j < L) ks_mac<PT>(ra, al, ah);
+        if (j < L) ks_mac<PT>(ra, acc);
 #pragma unroll
         for (int c = 0; c < PT; c++) {
             const u32 p = p0 + c;
             if (p < P) {
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    U2 v{hp_montgomery128_lazy(al[c][h][0], ah[c][h][0], q, mqinv), hp_montgomery128_lazy(al[c][h][1], ah[c][h][1], q, mqinv)};
+                    u64 l0, h0, l1, h1;
+                    hp_acc_value(acc[c][h][0], l0, h0);
+                    hp_acc_value(acc[c][h][1], l1, h1);
+                    U2 v{hp_montgomery128_lazy(l0, h0, q, mqinv), hp_montgomery128_lazy(l1, h1, q, mqinv)};
                     *reinterpret_cast<U2 *>(out + (((size_t)p * 2 + h) * Le + k) * n + i) = v;
                 }
             }

@@ -13,6 +13,7 @@
 //   ModDown  the P-part of the result, centred exactly (hp_elem.hip: k_base_to_single_crt), is subtracted and the rest
 //            multiplied by P^-1:  out = (x - NTT(rem)) * P^-1 [+ addend]
 #include "hp_kernels.h"
+#include <cstdlib>
 
 struct alignas(16) U2 {
     u64 x, y;
@@ -114,11 +115,11 @@ __global__ void __launch_bounds__(HKS_THREADS) k_hks_inner(const HpLimb *__restr
     const u32 own = (m < L) ? m / alpha : nd;   // the digit this modulus belongs to (none for the special primes)
     const u32 end = min(n, (chunk + 1) * HKS_CHUNK);
     for (u32 i = chunk * HKS_CHUNK + threadIdx.x * 2; i < end; i += HKS_THREADS * 2) {
-        u64 al[PT][2][2], ah[PT][2][2];
+        HpAcc acc[PT][2][2];   // carry-save columns (hp_device.h)
 #pragma unroll
         for (int c = 0; c < PT; c++)
 #pragma unroll
-            for (int h = 0; h < 2; h++) al[c][h][0] = al[c][h][1] = ah[c][h][0] = ah[c][h][1] = 0;
+            for (int h = 0; h < 2; h++) { hp_acc_zero(acc[c][h][0]); hp_acc_zero(acc[c][h][1]); }
         for (u32 d = 0; d < nd; d++) {
             const U2 g0 = *reinterpret_cast<const U2 *>(key + (((size_t)d * 2 + 0) * E + m) * n + i);
             const U2 g1 = *reinterpret_cast<const U2 *>(key + (((size_t)d * 2 + 1) * E + m) * n + i);
@@ -128,16 +129,8 @@ __global__ void __launch_bounds__(HKS_THREADS) k_hks_inner(const HpLimb *__restr
                 const u32 p = min(p0 + c, P - 1);
                 const u64 *src = (d == own) ? pt + ((size_t)p * pt_pstride + m) * n : lifted + (((size_t)p * nd + d) * E + m) * n;
                 const vv t = __builtin_nontemporal_load(reinterpret_cast<const vv *>(src + i));
-                const u64 dv[2] = {t.x, t.y};
 #pragma unroll
-                for (int h = 0; h < 2; h++)
-#pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        u64 lo, hi;
-                        hp_mul128(dv[e], kw[h][e], lo, hi);
-                        al[c][h][e] += lo;
-                        ah[c][h][e] += hi + (al[c][h][e] < lo ? 1ull : 0ull);
-                    }
+                for (int h = 0; h < 2; h++) hp_mac2(acc[c][h][0], t.x, kw[h][0], acc[c][h][1], t.y, kw[h][1]);
             }
         }
 #pragma unroll
@@ -146,7 +139,10 @@ __global__ void __launch_bounds__(HKS_THREADS) k_hks_inner(const HpLimb *__restr
             if (p < P) {
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    U2 v{hp_montgomery128_lazy(al[c][h][0], ah[c][h][0], q, mqinv), hp_montgomery128_lazy(al[c][h][1], ah[c][h][1], q, mqinv)};
+                    u64 l0, h0, l1, h1;
+                    hp_acc_value(acc[c][h][0], l0, h0);
+                    hp_acc_value(acc[c][h][1], l1, h1);
+                    U2 v{hp_montgomery128_lazy(l0, h0, q, mqinv), hp_montgomery128_lazy(l1, h1, q, mqinv)};
                     *reinterpret_cast<U2 *>(out + (((size_t)p * 2 + h) * E + m) * n + i) = v;
                 }
             }
@@ -157,9 +153,13 @@ __global__ void __launch_bounds__(HKS_THREADS) k_hks_inner(const HpLimb *__restr
 hipError_t hp_launch_hks_inner(const HpLimb *limbs, u32 L, u32 E, u32 nd, u32 alpha, u32 n, u32 P, const u64 *lifted, const u64 *pt,
                                u32 pt_pstride, const u64 *key, u64 *out, hipStream_t stream) {
     u32 chunks; dim3 grid;
-    if (P >= 2) {
+    static const int pt_env = getenv("HP_HKS_PT") ? atoi(getenv("HP_HKS_PT")) : 2;   // ciphertexts per thread (4: the column accumulators halve the occupancy, -5 %)
+    if (P >= 2 && pt_env >= 4) {
         hks_grid(n, ((P + 3) / 4) * E, chunks, grid);
         k_hks_inner<4><<<grid, HKS_THREADS, 0, stream>>>(limbs, L, E, nd, alpha, P, n, chunks, lifted, pt, pt_pstride, key, out);
+    } else if (P >= 2) {
+        hks_grid(n, ((P + 1) / 2) * E, chunks, grid);
+        k_hks_inner<2><<<grid, HKS_THREADS, 0, stream>>>(limbs, L, E, nd, alpha, P, n, chunks, lifted, pt, pt_pstride, key, out);
     } else {
         hks_grid(n, P * E, chunks, grid);
         k_hks_inner<1><<<grid, HKS_THREADS, 0, stream>>>(limbs, L, E, nd, alpha, P, n, chunks, lifted, pt, pt_pstride, key, out);

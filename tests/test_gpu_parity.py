@@ -337,3 +337,20 @@ def test_maximum_number_of_moduli(eng, orc, logn):
 
     with pytest.raises(InvalidArgument):      # one more modulus does not fit
         eng.ckks_rotate(mext + _ntt_primes(L + 2, logn)[-1:], eng.empty((1, 2, L + 1, n)), eng.empty((L + 1, 2, L + 2, n)), 1)
+
+
+@pytest.mark.parametrize("logn,L,B", [(4, 3, 3), (11, 4, 5), (12, 10, 2), (11, 31, 2)])
+def test_ext_prod_with_arbitrary_words(eng, orc, logn, L, B):
+    """rgsw.cpp:121-153 accumulates in wrapping u128 and never looks at the size of a word: inputs and key words that use
+    all 64 bits (no valid ciphertext has them) must still give the reference's words -- this is what drives every carry
+    path of the column accumulators (hp_device.h: hp_mac2), including the one 50-bit moduli never reach."""
+    mext = _ntt_primes(L + 1, logn) if L + 1 > len(P.P40) else P.P40[:L] + [P.P50[0]]
+    n = 1 << logn
+    rng = SplitMix(4242 + logn + L)
+    pt = rng.words(B * L * n).reshape(B, L, n)
+    key = rng.words(L * 2 * (L + 1) * n).reshape(L, 2, L + 1, n)
+    key[:, :, :, ::3] = np.uint64(0xFFFFFFFFFFFFFFFF)      # runs of maximal words: the carries pile up
+    pt[:, :, 1::3] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    got = eng.to_host(eng.ext_prod(mext, eng.to_device(pt), eng.to_device(key)))
+    for i in range(B):
+        assert np.array_equal(got[i], orc.ext_prod(mext, pt[i], key)), i

@@ -153,6 +153,21 @@ def test_key_switch_and_scheme_level(orc, ref, logn, mext):
     assert (orc.bgv_mult(mext, 65537, ct1, ct2, key) == ref.bgv_mult(mext, 65537, ct1, ct2, key)).all()
 
 
+@pytest.mark.parametrize("logn,mext", SCHEME_CASES[:2])
+def test_key_switch_with_arbitrary_words(orc, ref, logn, mext):
+    """ext_prod_montgomery never looks at the size of a word (wrapping u64 / u128 throughout): the restatement must agree
+    with the reference on words that use all 64 bits too -- the GPU's carry paths are pinned against exactly this."""
+    import numpy as np
+
+    n, L = 1 << logn, len(mext) - 1
+    rng = SplitMix(4242 + logn)
+    pt = rng.words(L * n).reshape(L, n)
+    key = rng.words(L * 2 * (L + 1) * n).reshape(L, 2, L + 1, n)
+    key[:, :, :, ::3] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    pt[:, 1::3] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    assert (orc.ext_prod(mext, pt, key) == ref.ext_prod(mext, pt, key)).all()
+
+
 def test_bgv_relinearize_quirk(orc, ref):
     """SURVEY.md 8c(1): the reference's bgv::relinearize returns (quad[0], quad[1])
     as residues because its inner mod switch runs with plain_modulus == 1."""
