@@ -62,7 +62,10 @@ void hp_ctx_destroy(hp_ctx *ctx);
 const char *hp_last_error(hp_ctx *ctx);
 const char *hp_version(void);
 /* enqueue on an existing hipStream_t (e.g. torch's current stream); NULL = the HIP default stream.
- * A fresh ctx uses a private non-blocking stream; hp_ctx_reset_stream goes back to it. */
+ * A fresh ctx uses a private non-blocking stream; hp_ctx_reset_stream goes back to it.
+ * HIP graphs: the first hp_dev_* call with a new (ring degree, moduli, shape) builds tables / constants and may grow the
+ * workspace (allocations and host-to-device copies); every later call with the same parameters only enqueues kernels on the
+ * ctx stream, so it can be recorded with hipStreamBeginCapture on that stream and replayed (tests/test_gpu_parity.py). */
 int hp_ctx_set_stream(hp_ctx *ctx, void *hip_stream);
 int hp_ctx_reset_stream(hp_ctx *ctx);
 void *hp_ctx_get_stream(hp_ctx *ctx);

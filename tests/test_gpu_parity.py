@@ -354,3 +354,39 @@ def test_ext_prod_with_arbitrary_words(eng, orc, logn, L, B):
     got = eng.to_host(eng.ext_prod(mext, eng.to_device(pt), eng.to_device(key)))
     for i in range(B):
         assert np.array_equal(got[i], orc.ext_prod(mext, pt[i], key)), i
+
+
+def test_pipeline_is_capturable_in_a_hip_graph(eng, orc):
+    """After one warm-up call (tables, constants and workspace exist) an entry point only enqueues kernels on the
+    context's stream: it can be captured into a HIP graph and replayed on new inputs (include/hehub_amd.h, hp_ctx_set_stream)."""
+    import torch
+
+    logn, L = 11, 3
+    mext = P.P40[:L] + [P.P50[0]]
+    n, B = 1 << logn, 3
+    rng = SplitMix(777)
+    ct1 = np.stack([rng.poly((2, L, n), mext[:L]) for _ in range(B)]); ct2 = np.stack([rng.poly((2, L, n), mext[:L]) for _ in range(B)])
+    key = rng.poly((L, 2, L + 1, n), mext)
+    d1, d2, dk = eng.to_device(ct1), eng.to_device(ct2), eng.to_device(key)
+    out = eng.empty((B, 2, L - 1, n))
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    try:
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            eng.use_stream(side)
+            eng.ckks_mult(mext, d1, d2, dk, out=out)            # warm-up on the capture stream
+            side.synchronize()
+            with torch.cuda.graph(g, stream=side):
+                eng.ckks_mult(mext, d1, d2, dk, out=out)
+        torch.cuda.current_stream().wait_stream(side)
+        exp = lambda a, b: np.stack([orc.ckks_mult(mext, a[i], b[i], key) for i in range(B)])
+        out.zero_()
+        g.replay(); torch.cuda.synchronize()
+        assert np.array_equal(eng.to_host(out), exp(ct1, ct2))
+        d1.copy_(eng.to_device(ct2)); d2.copy_(eng.to_device(ct1))   # new inputs in the captured buffers
+        out.zero_()
+        g.replay(); torch.cuda.synchronize()
+        assert np.array_equal(eng.to_host(out), exp(ct2, ct1))
+    finally:
+        eng.use_stream(torch.cuda.current_stream())
