@@ -216,3 +216,35 @@ def test_rotate_and_conjugate_with_a_hybrid_key(eng, orc, logn, L, k, alpha):
         exp = np.stack([orc.poly_add(q, sw[0], moved[0]), sw[1]])
         got = eng.ckks_conjugate_hks(mext, k, alpha, d_ct, d_key) if conj else eng.ckks_rotate_hks(mext, k, alpha, d_ct, d_key, 3)
         assert np.array_equal(eng.to_host(got)[0], exp), conj
+
+
+def test_merged_and_two_step_hybrid_mult_agree_on_random_shapes(eng, orc, monkeypatch):
+    """The merged ModDown + rescale (one transform per limb) against the two-step composition -- itself held to the exact
+    model word for word above -- on random tiled shapes: same strict residues everywhere, lazy words below 2q."""
+    from hehub_amd.engine import Engine
+
+    monkeypatch.setenv("HP_HKS_TWO_STEP", "1")
+    two = Engine(0)
+    monkeypatch.delenv("HP_HKS_TWO_STEP")
+    try:
+        rng = SplitMix(20260928)
+        pool = P.P40 + P.P50
+        for case in range(24):
+            logn = 11 + int(rng.words(1, 3)[0])                       # 11..13
+            L = 2 + int(rng.words(1, 9)[0])                           # 2..10
+            k = 1 + int(rng.words(1, 4)[0])                           # 1..4
+            alpha = 1 + int(rng.words(1, min(L, 8))[0])
+            B = 1 + int(rng.words(1, 3)[0])
+            order = np.argsort(rng.words(len(pool)))                   # a random chain of distinct primes
+            mext = [pool[i] for i in order[:L + k]]
+            n, q = 1 << logn, mext[:L]
+            nd = (L + alpha - 1) // alpha
+            ct1 = np.stack([rng.poly((2, L, n), q) for _ in range(B)]); ct2 = np.stack([rng.poly((2, L, n), q) for _ in range(B)])
+            key = rng.poly((nd, 2, L + k, n), mext)
+            a = eng.to_host(eng.ckks_mult_hks(mext, k, alpha, eng.to_device(ct1), eng.to_device(ct2), eng.to_device(key)))
+            b = two.to_host(two.ckks_mult_hks(mext, k, alpha, two.to_device(ct1), two.to_device(ct2), two.to_device(key)))
+            qa = np.array(q[:-1], dtype=U)[None, None, :, None]
+            assert (a < 2 * qa).all() and (b < 2 * qa).all(), (case, logn, L, k, alpha)
+            assert np.array_equal(a % qa, b % qa), (case, logn, L, k, alpha, B)
+    finally:
+        two.close()
