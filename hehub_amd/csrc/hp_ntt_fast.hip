@@ -92,6 +92,7 @@ struct GTab {
 // STab: wave-uniform entries of a global table (the first pass of a transform): constant address space, so the
 //       loads are scalar (s_load_dwordx4 through the scalar cache) and take no vector-memory slots.
 typedef const u64v2 __attribute__((address_space(4))) * cptr_u64x2;
+typedef const HpLimb __attribute__((address_space(4))) * cptr_limb;
 #ifndef STAB_DEPTH
 #define STAB_DEPTH 4
 #endif
@@ -120,7 +121,20 @@ template <bool FWD> constexpr int slot_bit(int s) { return 1 << (FWD ? 4 - ilog2
 
 // One slot (or, in the last stage of a pass where every butterfly has its own twiddle, two slots) of a pass;
 // recursion over the slot number keeps every register index a compile-time constant.
-template <bool FWD, int S, int S0, int S1, int D, class Tab>
+// LZ (first pass of the N = 32768 forward kernel): registers still hold the 16-byte loads as they arrived; the lane-pair
+// swap that sorts them into columns (load_flight) is done here, right before the first butterfly that touches a register,
+// so that the first stage runs while the later loads are still in flight instead of after all sixteen.
+HP_DEV u64 from_pair_lane(u64 v);
+HP_DEV void lazy_swap(u64 (&x)[32], int r) {
+    const bool odd = (threadIdx.x & 1u) != 0;
+    const u64 vx = x[r], vy = x[r + 1];
+    const u64 keep = odd ? vy : vx, send = odd ? vx : vy;
+    const u64 recv = from_pair_lane(send);
+    x[r] = odd ? recv : keep;
+    x[r + 1] = odd ? keep : recv;
+}
+
+template <bool FWD, int S, int S0, int S1, int D, class Tab, bool LZ = false>
 HP_DEV void pass_slots(u64 (&x)[32], u64x2 (&ring)[D], const Tab &tbl, u32 ncls, u32 cls, u64 two_q, u32 n0, u32 n1) {
     if constexpr (S < S1) {
         constexpr int cnt = 1 << (4 - ilog2c(S + 1));   // butterflies that use this slot's twiddle
@@ -131,6 +145,11 @@ HP_DEV void pass_slots(u64 (&x)[32], u64x2 (&ring)[D], const Tab &tbl, u32 ncls,
 #pragma unroll
             for (int o = 0; o < cnt; o += 2) {
                 const int ra = slot_reg<FWD>(S, o), rb = slot_reg<FWD>(S, o + 1);
+                if constexpr (LZ && S == 0) {
+                    static_assert(!LZ || (FWD && S0 == 0), "lazy swap: first slot of a forward pass");
+                    lazy_swap(x, ra);          // rb == ra + 1: one 16-byte load
+                    lazy_swap(x, ra | bit);
+                }
 #ifdef HP_SINGLE_BFLY   // tuning experiment: one butterfly at a time
                 hp_butterfly_nq(x[ra], x[ra | bit], tw.x, tw.y, two_q, n0, n1);
                 hp_butterfly_nq(x[rb], x[rb | bit], tw.x, tw.y, two_q, n0, n1);
@@ -140,7 +159,7 @@ HP_DEV void pass_slots(u64 (&x)[32], u64x2 (&ring)[D], const Tab &tbl, u32 ncls,
                 if (o & 2) __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (cnt == 2) { if constexpr (S & 1) __builtin_amdgcn_sched_barrier(0); }
-            pass_slots<FWD, S + 1, S0, S1, D>(x, ring, tbl, ncls, cls, two_q, n0, n1);
+            pass_slots<FWD, S + 1, S0, S1, D, Tab, LZ>(x, ring, tbl, ncls, cls, two_q, n0, n1);
         } else {
             static_assert(S + 1 < S1, "single-butterfly slots come in pairs");
             const u64x2 tw2 = ring[(S + 1 - S0) % D];
@@ -158,7 +177,7 @@ HP_DEV void pass_slots(u64 (&x)[32], u64x2 (&ring)[D], const Tab &tbl, u32 ncls,
     }
 }
 
-template <bool FWD, int S0, int S1, int D, class Tab>
+template <bool FWD, int S0, int S1, int D, class Tab, bool LZ = false>
 HP_DEV void run_pass(u64 (&x)[32], const Tab tbl, u32 ncls, u32 cls, u64 nq, u64 two_q) {
 #ifdef HP_ABLATE_PASS   // tuning experiment only (wrong results): no butterflies
     return;
@@ -176,14 +195,14 @@ HP_DEV void run_pass(u64 (&x)[32], const Tab tbl, u32 ncls, u32 cls, u64 nq, u64
 #pragma unroll
     for (int s = S0; s < S0 + D; ++s)
         if (s < S1) ring[(s - S0) % D] = tbl((u32)s * ncls + cls);
-    pass_slots<FWD, S0, S0, S1, D>(x, ring, tbl, ncls, cls, two_q, (u32)nq, (u32)(nq >> 32));
+    pass_slots<FWD, S0, S0, S1, D, Tab, LZ>(x, ring, tbl, ncls, cls, two_q, (u32)nq, (u32)(nq >> 32));
 }
 
 // forward: stages on register bits BHI..BLO (descending)
-template <int BHI, int BLO, class Tab>
+template <int BHI, int BLO, class Tab, bool LZ = false>
 HP_DEV void fwd_pass(u64 (&x)[32], const Tab tbl, u32 ncls, u32 cls, u64 nq, u64 two_q) {
     static_assert(BHI == 4, "forward passes start at register bit 4");
-    run_pass<true, 0, (1 << (5 - BLO)) - 1, Tab::depth>(x, tbl, ncls, cls, nq, two_q);
+    run_pass<true, 0, (1 << (5 - BLO)) - 1, Tab::depth, Tab, LZ>(x, tbl, ncls, cls, nq, two_q);
 }
 
 // inverse: stages on register bits BLO..BHI (ascending)
@@ -368,8 +387,13 @@ __device__ u64 g_trace[2 * 2048 * 16 * HP_TRACE_SLOTS];
 #endif
 
 // ---- forward kernel ----------------------------------------------------------------------------
+#ifdef HP_LOAD_SEQUENTIAL   // A/B switch: loads in row order
+#define HP_LOAD_ORDER(t) (t)
+#else
+#define HP_LOAD_ORDER(t) (((t) >> 1) | (((t) & 1) << 3))
+#endif
 // load, layout A: thread reads 2^PB consecutive coefficients at 2^A places 1024 apart
-template <int LOGN>
+template <int LOGN, bool LZ = false>
 HP_DEV void load_flight(const u64 *src, u32 tid, u64 (&x)[32]) {
     using G = Geo<LOGN>;
     const u64 *s = src + ((size_t)tid << G::PB);
@@ -379,9 +403,13 @@ HP_DEV void load_flight(const u64 *src, u32 tid, u64 (&x)[32]) {
         // so every HBM instruction still moves 16 bytes per lane.
         const bool odd = (tid & 1u) != 0;
         const u64 *sp = src + (tid & ~1u);
+        // issue order 0, 8, 1, 9, ...: the first stage pairs register r with r + 16, i.e. load p with load p + 8, so its
+        // butterflies can start as soon as the first two loads are back instead of after nine
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
+        for (int t = 0; t < 16; ++t) {
+            const int p = HP_LOAD_ORDER(t);
             const V2 v = ld_stream(sp + ((size_t)(2 * p + (odd ? 1 : 0)) << 10));
+            if (LZ) { x[2 * p] = v.x; x[2 * p + 1] = v.y; continue; }   // sorted by lazy_swap in the first pass
             const u64 keep = odd ? v.y : v.x, send = odd ? v.x : v.y;
             const u64 recv = from_pair_lane(send);
             x[2 * p] = odd ? recv : keep;
@@ -389,7 +417,13 @@ HP_DEV void load_flight(const u64 *src, u32 tid, u64 (&x)[32]) {
         }
     }
 #pragma unroll
-    for (int kk = 0; kk < (G::PB == 0 ? 0 : (1 << G::A)); ++kk) {
+    for (int tk = 0; tk < (G::PB == 0 ? 0 : (1 << G::A)); ++tk) {
+        // same idea as above: the first stage pairs place kk with kk + 2^(A-1)
+#ifdef HP_LOAD_SEQUENTIAL
+        const int kk = tk;
+#else
+        const int kk = (tk >> 1) | ((tk & 1) << (G::A - 1));
+#endif
         if (G::PB == 0) {
         } else {
 #pragma unroll
@@ -421,7 +455,9 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
     default: __builtin_amdgcn_s_setprio(HP_PRIO_SKEW == 2 ? 3 : 0); break;
     }
 #endif
-    const HpLimb *lp = job.limbs + it.limb;
+    // the limb's constants and table pointers through the scalar cache (constant address space): as vector loads they would
+    // queue behind the coefficient loads and the first pass could not start before nearly all of those are back
+    const cptr_limb lp = (cptr_limb)(job.limbs + __builtin_amdgcn_readfirstlane(it.limb));
     const u64 q = lp->q, two_q = lp->two_q, nq = lp->neg_q;
     const u32 tid = threadIdx.x;
     Addr<LOGN> ad;
@@ -434,7 +470,12 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
     TRACE_DECL
     TRACE_MARK();
     u64 x[32];
-    load_flight<LOGN>(it.src, tid, x);
+#ifdef HP_EAGER_SWAP   // A/B switch
+    constexpr bool LZ = false;
+#else
+    constexpr bool LZ = !DROP && G::PB == 0;
+#endif
+    load_flight<LOGN, LZ>(it.src, tid, x);
     if (tid < 31u * (1u << G::A)) lds_tw[tid] = stg;
     if (DROP) {
         // rescaling.cpp:54-69 / mod_switch.cpp:52-70 while the coefficients are still in flight order:
@@ -472,7 +513,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
 #endif
     TRACE_MARK();   // 1: coefficients have arrived
     // pass A: global stages 1..A, wave-uniform twiddles seq[1 .. 2^A - 1]
-    fwd_pass<4, G::PB>(x, STab(lp->fwd_ref + 1), 1u, 0u, nq, two_q);
+    fwd_pass<4, G::PB, STab, LZ>(x, STab(lp->fwd_ref + 1), 1u, 0u, nq, two_q);
     TRACE_MARK();   // 2
     exchange<LOGN, LAY_A, LAY_B, true>(x, lds, ad);
     TRACE_MARK();   // 3
@@ -594,7 +635,9 @@ __global__ void HP_NTT_VGPR_ATTR __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW
     default: __builtin_amdgcn_s_setprio(HP_PRIO_SKEW == 2 ? 3 : 0); break;
     }
 #endif
-    const HpLimb *lp = job.limbs + it.limb;
+    // the limb's constants and table pointers through the scalar cache (constant address space): as vector loads they would
+    // queue behind the coefficient loads and the first pass could not start before nearly all of those are back
+    const cptr_limb lp = (cptr_limb)(job.limbs + __builtin_amdgcn_readfirstlane(it.limb));
     const u64 q = lp->q, two_q = lp->two_q, nq = lp->neg_q;
     const u32 tid = threadIdx.x;
     Addr<LOGN> ad;
