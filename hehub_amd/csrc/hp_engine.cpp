@@ -62,6 +62,7 @@ struct hp_ctx {
     hipStream_t aux[2] = {nullptr, nullptr};
     hipEvent_t ev_start = nullptr, ev_done[2] = {nullptr, nullptr};
     // tuning / A-B knobs, read from the environment once when the context is created
+    int drop_group = 2;           // HP_DROP_GROUP=G: the same numbering for the fused drop launch (every limb reads one coefficient row)
     int spread_group = 2;         // HP_SPREAD_GROUP=G: digit-spread launch numbered by groups of G moduli (0: modulus-major)
     bool hks_two_step = false;    // HP_HKS_TWO_STEP: hybrid mult = switch, then a separate rescale (instead of the merged transform)
     bool no_fused_drop = false;   // HP_NO_FUSED_DROP: separate drop_rem / NTT / drop_fin launches
@@ -434,7 +435,8 @@ int drop_apply(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, 
         HpNttJob fj = batch_job(plan, logn, kc, P2, clast, nullptr, 1, 0, 0, 0);
         fj.limbs = limbs;
         fj.src_kstride = 0;
-        fj.pair_moduli = ctx->spread_group ? 1u : 0u;
+        fj.pair_moduli = (u32)ctx->drop_group;
+        if (fj.pair_moduli > kc) fj.pair_moduli = (u32)kc;
         HpDropArgs da;
         memset(&da, 0, sizeof(da));
         da.dc = dc; da.x = x; da.L = (u32)L; da.addend = addend; da.add_poly_stride = (u32)add_poly_stride;
@@ -543,6 +545,7 @@ int hp_ctx_create(int device, hp_ctx **out) {
     c->stream = c->own_stream;
     c->no_fused_drop = getenv("HP_NO_FUSED_DROP") != nullptr;
     c->hks_two_step = getenv("HP_HKS_TWO_STEP") != nullptr;
+    if (const char *e = getenv("HP_DROP_GROUP")) c->drop_group = atoi(e) > 0 ? atoi(e) : 0;
     if (const char *e = getenv("HP_SPREAD_GROUP")) c->spread_group = atoi(e) > 0 ? atoi(e) : 0;   // measured: 2..6 alike, -2 % on the launch
     if (const char *e = getenv("HP_MULT_STREAMS")) c->mult_streams = atoi(e) >= 2 ? 2 : 1;
     if (const char *e = getenv("HP_MULT_CHUNK")) c->mult_chunk = (size_t)atol(e);

@@ -497,14 +497,51 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
         if (da->comb) {
             // hybrid key switch, ModDown merged with the rescale: x = rem_k + (P mod q_k) * centre_k(c), c = the strict
             // coefficients modulo q_last of the relinearised last limb (one row per polynomial, read by every limb)
-            u64 c[32];
-            load_flight<LOGN>(da->comb + (size_t)it.poly * G::N, tid, c);
+            // Eight registers (four 16-byte loads) at a time with the next four loads in flight.  The loads are inline asm: left
+            // to itself the compiler, short of registers beside x, issues the sixteen loads one by one with a full wait after
+            // each.  It does not count asm loads, so the waits are explicit (vector loads return in order: "at most four
+            // outstanding" means the current four are back); each wait is tied to the registers it guards.
+            typedef u64 __attribute__((ext_vector_type(2))) vv;
+            const u64 *crow = da->comb + (size_t)it.poly * G::N;
             const u64 pm = da->comb_mul[k], pmh = da->comb_mul_h[k], cbump = q - da->comb_r[k], chalf = da->comb_half;
+            const bool odd = (tid & 1u) != 0;
+            vv ca[4], cb[4];
+            auto issue = [&](vv (&d)[4], int ch) {
 #pragma unroll
-            for (int r = 0; r < 32; ++r) {
-                u64 v = hp_strict(hp_barrett_lazy(c[r], q, bc), q);
-                if (c[r] >= chalf) v += cbump;
-                x[r] = hp_add_lazy(x[r], hp_harvey_lazy_nq(v, pm, pmh, (u32)nq, (u32)(nq >> 32)), two_q);
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 8 * ch + 2 * i;
+                    const u64 *a = (G::PB == 0) ? crow + (tid & ~1u) + ((size_t)(r + (odd ? 1 : 0)) << 10)
+                                                : crow + ((size_t)tid << G::PB) + ((size_t)(r >> G::PB) << 10) + (r & ((1 << G::PB) - 1));
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(d[i]) : "v"(a) : "memory");
+                }
+            };
+            issue(ca, 0);
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                vv(&cur)[4] = (ch & 1) ? cb : ca;
+                vv(&nxt)[4] = (ch & 1) ? ca : cb;
+                if (ch + 1 < 4) {
+                    issue(nxt, ch + 1);
+                    asm volatile("s_waitcnt vmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]) : : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]) : : "memory");
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    u64 c0 = cur[i].x, c1 = cur[i].y;
+                    if (G::PB == 0) {   // lane-pair swap as in load_flight
+                        const u64 keep = odd ? c1 : c0, send = odd ? c0 : c1;
+                        const u64 recv = from_pair_lane(send);
+                        c0 = odd ? recv : keep;
+                        c1 = odd ? keep : recv;
+                    }
+                    const int r = 8 * ch + 2 * i;
+                    u64 v0 = hp_strict(hp_barrett_lazy(c0, q, bc), q), v1 = hp_strict(hp_barrett_lazy(c1, q, bc), q);
+                    if (c0 >= chalf) v0 += cbump;
+                    if (c1 >= chalf) v1 += cbump;
+                    x[r] = hp_add_lazy(x[r], hp_harvey_lazy_nq(v0, pm, pmh, (u32)nq, (u32)(nq >> 32)), two_q);
+                    x[r + 1] = hp_add_lazy(x[r + 1], hp_harvey_lazy_nq(v1, pm, pmh, (u32)nq, (u32)(nq >> 32)), two_q);
+                }
             }
         }
     }

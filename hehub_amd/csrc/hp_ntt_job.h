@@ -15,10 +15,10 @@ HP_DEV bool hp_decode_item(const HpNttJob &job, u32 w, HpItem &it) {
     const size_t n = (size_t)1 << job.logn;
     if (job.mode == HP_NTT_BATCH) {
         u32 k = w / job.P, p = w % job.P;
-        if (job.pair_moduli) {   // every limb reads the same row (src_kstride 0): pairs of moduli side by side, as in the digit spread
-            const u32 full = (job.L >> 1) * 2 * job.P;
-            if (w < full) { k = 2 * (w / (2 * job.P)) + (w & 1u); p = (w % (2 * job.P)) >> 1; }
-            else { k = job.L - 1; p = w - full; }
+        if (job.pair_moduli) {   // every limb reads the same row (src_kstride 0): groups of G moduli side by side, as in the digit spread
+            const u32 G = job.pair_moduli, ng = job.L / G, full = ng * G * job.P;
+            if (w < full) { k = G * (w / (G * job.P)) + (w % G); p = (w % (G * job.P)) / G; }
+            else { const u32 r = job.L - ng * G, v = w - full; k = ng * G + v % r; p = v / r; }
         }
         it.src = job.src + ((size_t)p * job.src_pstride + (size_t)k * job.src_kstride) * n;
         it.dst = job.dst + ((size_t)p * job.dst_pstride + k) * n;
