@@ -436,7 +436,10 @@ HP_DEV void load_flight(const u64 *src, u32 tid, u64 (&x)[32]) {
     }
 }
 
-template <int LOGN, bool DROP>
+// FLAV (fused drop only): 0 = every option decided at run time; 1..4 = the shapes of the CKKS / BGV pipelines with the options
+// fixed at compile time (Barrett prologue, no final multiplication; 1: CKKS, no addend; 2: CKKS, addend on both polynomials;
+// 3 / 4: the same with the BGV factors), which takes ~100 uniform branches out of the prologue and the store loop
+template <int LOGN, bool DROP, int FLAV = 0>
 HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
     using G = Geo<LOGN>;
     __shared__ u32 lds[G::N];
@@ -483,8 +486,8 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
         const u32 k = it.limb;
         const u64 bc = lp->barrett_c, bump = q - da->dc.r[k], half = da->dc.half_q_last;
         const u64 tk = da->dc.t[k], tkh = da->dc.t_h[k];
-        const bool bgv = da->dc.bgv != 0;
-        if (!da->raw_input) {
+        const bool bgv = FLAV ? (FLAV >= 3) : da->dc.bgv != 0;
+        if (FLAV || !da->raw_input) {
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
                 const u64 c = x[r];
@@ -494,7 +497,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
                 x[r] = v;
             }
         }
-        if (da->comb) {
+        if (!FLAV && da->comb) {
             // hybrid key switch, ModDown merged with the rescale: x = rem_k + (P mod q_k) * centre_k(c), c = the strict
             // coefficients modulo q_last of the relinearised last limb (one row per polynomial, read by every limb)
             // Eight registers (four 16-byte loads) at a time with the next four loads in flight.  The loads are inline asm: left
@@ -591,11 +594,11 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
         const u32 k = it.limb, p2 = it.poly;
         const size_t off = (((size_t)(tid >> 6)) << 11) + ((tid & 63u) << 1);
         const u64 *xs = da->x + ((size_t)p2 * da->L + k) * G::N + off;
-        const u64 *as = (da->addend && ((da->add_mask >> (p2 & 1)) & 1u))
+        const u64 *as = (FLAV == 2 || FLAV == 4 || (FLAV == 0 && da->addend && ((da->add_mask >> (p2 & 1)) & 1u)))
                             ? da->addend + ((size_t)(p2 >> 1) * da->add_ct_stride + (size_t)(p2 & 1) * da->add_poly_stride + k) * G::N + off : nullptr;
         u64 *d = da->out + ((size_t)p2 * da->out_stride + k) * G::N + off;
         const u64 inv = da->dc.inv[k], invh = da->dc.inv_h[k], ql = da->dc.qlt[k], qlh = da->dc.qlt_h[k];
-        const bool bgv = da->dc.bgv != 0, fin_on = da->fin_on != 0;
+        const bool bgv = FLAV ? (FLAV >= 3) : da->dc.bgv != 0, fin_on = FLAV ? false : da->fin_on != 0;
         const u64 fin = da->fin[k], finh = da->fin_h[k];
         const u32 n0 = (u32)nq, n1 = (u32)(nq >> 32);
         // The 16 rows are software-pipelined by hand: the operand loads run EPI_DEPTH rows ahead of their use (ring in
@@ -647,9 +650,9 @@ __global__ void HP_NTT_VGPR_ATTR __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW
 }
 
 // forward NTT with the drop-last-prime prologue/epilogue fused in (HpDropArgs in kernel-argument memory)
-template <int LOGN>
+template <int LOGN, int FLAV>
 __global__ void HP_NTT_VGPR_ATTR __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd_drop(HpNttJob job, HpDropArgs da) {
-    ntt_fwd_body<LOGN, true>(job, &da);
+    ntt_fwd_body<LOGN, true, FLAV>(job, &da);
 }
 
 // ---- inverse kernel ----------------------------------------------------------------------------
@@ -798,17 +801,33 @@ extern "C" int hp_debug_trace(u64 *out, size_t words) {
 }
 #endif
 
+template <int LOGN>
+static hipError_t launch_drop(const HpNttJob &job, const HpDropArgs &da, hipStream_t stream) {
+    static const bool generic_only = getenv("HP_DROP_GENERIC") != nullptr;   // A/B switch
+    int flav = 0;
+    if (!generic_only && !da.fin_on && !da.raw_input && !da.comb) {
+        if (!da.addend || da.add_mask == 0) flav = 1;
+        else if (da.add_mask == 3u) flav = 2;
+        if (flav && da.dc.bgv) flav += 2;
+    }
+    if (flav == 1) k_ntt_fwd_drop<LOGN, 1><<<job.W, Geo<LOGN>::T, 0, stream>>>(job, da);
+    else if (flav == 2) k_ntt_fwd_drop<LOGN, 2><<<job.W, Geo<LOGN>::T, 0, stream>>>(job, da);
+    else if (flav == 3) k_ntt_fwd_drop<LOGN, 3><<<job.W, Geo<LOGN>::T, 0, stream>>>(job, da);
+    else if (flav == 4) k_ntt_fwd_drop<LOGN, 4><<<job.W, Geo<LOGN>::T, 0, stream>>>(job, da);
+    else k_ntt_fwd_drop<LOGN, 0><<<job.W, Geo<LOGN>::T, 0, stream>>>(job, da);
+    return hipGetLastError();
+}
+
 hipError_t hp_launch_ntt_fast_drop(const HpNttJob &job, const HpDropArgs &da, hipStream_t stream) {
     if (job.W == 0) return hipSuccess;
     switch (job.logn) {
-    case 11: k_ntt_fwd_drop<11><<<job.W, Geo<11>::T, 0, stream>>>(job, da); break;
-    case 12: k_ntt_fwd_drop<12><<<job.W, Geo<12>::T, 0, stream>>>(job, da); break;
-    case 13: k_ntt_fwd_drop<13><<<job.W, Geo<13>::T, 0, stream>>>(job, da); break;
-    case 14: k_ntt_fwd_drop<14><<<job.W, Geo<14>::T, 0, stream>>>(job, da); break;
-    case 15: k_ntt_fwd_drop<15><<<job.W, Geo<15>::T, 0, stream>>>(job, da); break;
+    case 11: return launch_drop<11>(job, da, stream);
+    case 12: return launch_drop<12>(job, da, stream);
+    case 13: return launch_drop<13>(job, da, stream);
+    case 14: return launch_drop<14>(job, da, stream);
+    case 15: return launch_drop<15>(job, da, stream);
     default: return hipErrorNotSupported;
     }
-    return hipGetLastError();
 }
 
 hipError_t hp_launch_ntt_fast(const HpNttJob &job, hipStream_t stream) {
