@@ -53,7 +53,7 @@ HP_DEV void hp_butterfly(u64 &lo, u64 &hi, u64 w, u64 wh, u64 q, u64 two_q) {
 }
 
 // The same product, hand-scheduled for gfx950 (17 VALU instructions per butterfly instead of the
-// compiler's 23).  nq = 2^64 - q is wave-uniform (SGPRs), so x*w - qhat*q becomes the wrapping sum
+// compiler's 23; 16 in hp_butterfly2_nq, where the low chain also absorbs the addition of the other input).  nq = 2^64 - q is wave-uniform (SGPRs), so x*w - qhat*q becomes the wrapping sum
 // x*w + qhat*nq and both low products chain through v_mad_u64_u32 accumulators:
 //   qhat = floor(x*wh / 2^64), exactly:   A = x1*p0 + hi32(x0*p0)
 //                                          B = x0*p1 + A           (carry c from the mad's carry-out)
