@@ -733,8 +733,13 @@ __global__ void HP_NTT_VGPR_ATTR __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = r0 + e;
+#ifdef HP_INV_C_HARVEY   // A/B switch: the compiler's multiplication
                 u64 v = hp_harvey_lazy(hp_shift_fold(x[r], q, k, fix), f[e].x, f[e].y, q);
                 if (PSCAL) v = hp_harvey_lazy(v, psc, psh, q);
+#else
+                u64 v = hp_harvey_lazy_nq(hp_shift_fold(x[r], q, k, fix), f[e].x, f[e].y, (u32)nq, (u32)(nq >> 32));
+                if (PSCAL) v = hp_harvey_lazy_nq(v, psc, psh, (u32)nq, (u32)(nq >> 32));
+#endif
                 if (STRICT) v = hp_strict(v, q);
                 x[r] = v;
             }
