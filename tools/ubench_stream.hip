@@ -9,7 +9,7 @@ typedef u64 __attribute__((ext_vector_type(2))) vv;
 #define N 32768u
 #define CHUNK 2048u
 
-template <int S, int W, int PT>
+template <int S, int W, int PT, bool STRIDED = false>
 __global__ void __launch_bounds__(256) k_stream(const u64 *__restrict__ in, u64 *__restrict__ out, unsigned groups, unsigned rows_in) {
     const unsigned chunks = N / CHUNK, g = blockIdx.x / chunks, chunk = blockIdx.x % chunks;   // g: group of PT "ciphertexts"
     for (unsigned i = chunk * CHUNK + threadIdx.x * 2; i < (chunk + 1) * CHUNK; i += 512) {
@@ -22,7 +22,10 @@ __global__ void __launch_bounds__(256) k_stream(const u64 *__restrict__ in, u64 
         for (int s = 0; s < S; s++)
 #pragma unroll
             for (int c = 0; c < PT; c++) {
-                const size_t row = ((size_t)(g * PT + c) * S + s) % rows_in;
+                // STRIDED: the engine's digit layout [p][j][k]: item = (k, p) modulus-major, its S rows are (S+1) rows apart
+                const unsigned item = g * PT + c, P = 256;
+                const size_t row = STRIDED ? (((size_t)(item % P) * S + s) * (S + 1) + (item / P) % (S + 1)) % rows_in
+                                           : ((size_t)item * S + s) % rows_in;
                 const vv t = __builtin_nontemporal_load(reinterpret_cast<const vv *>(in + row * N + i));
 #pragma unroll
                 for (int w = 0; w < W; w++) acc[c][w] ^= t + (u64)w;
@@ -34,13 +37,13 @@ __global__ void __launch_bounds__(256) k_stream(const u64 *__restrict__ in, u64 
     }
 }
 
-template <int S, int W, int PT> void run(const char *name, const u64 *in, u64 *out, unsigned cts, unsigned rows_in) {
+template <int S, int W, int PT, bool STRIDED = false> void run(const char *name, const u64 *in, u64 *out, unsigned cts, unsigned rows_in) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const unsigned groups = cts / PT, blocks = groups * (N / CHUNK);
-    k_stream<S, W, PT><<<blocks, 256>>>(in, out, groups, rows_in);
+    k_stream<S, W, PT, STRIDED><<<blocks, 256>>>(in, out, groups, rows_in);
     (void)hipEventRecord(e0);
     const int reps = 5;
-    for (int r = 0; r < reps; r++) k_stream<S, W, PT><<<blocks, 256>>>(in, out, groups, rows_in);
+    for (int r = 0; r < reps; r++) k_stream<S, W, PT, STRIDED><<<blocks, 256>>>(in, out, groups, rows_in);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= reps;
     const double bytes = (double)cts * (S + W) * N * 8;
@@ -54,6 +57,8 @@ int main() {
     (void)hipMemset(in, 1, (size_t)rows_in * N * 8);
     run<10, 2, 1>("10 streams in, 2 out, 1 item per thread", in, out, cts, rows_in);
     run<10, 2, 4>("10 streams in, 2 out, 4 items per thread", in, out, cts, rows_in);
+    run<10, 2, 4, true>("the same, rows strided like [p][j][k]", in, out, cts, rows_in);
+    run<10, 2, 1, true>("strided rows, 1 item per thread", in, out, cts, rows_in);
     run<10, 0, 4>("10 streams in, nothing out (4 items)", in, out, cts, rows_in);
     run<1, 1, 4>("copy: 1 in, 1 out (4 items)", in, out, cts * 5, rows_in);
     run<2, 1, 4>("2 in, 1 out (4 items)", in, out, cts * 3, rows_in);
