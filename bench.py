@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Headline benchmark of the MI355X ring-arithmetic engine.
 
-    python bench.py --gpus 1 --steps K --warmup W [--workload ckks|ntt|ntt15|intt|intt15|bgv|rotate] [--batch B]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ckks|ntt|ntt15|intt|intt15|bgv|rotate|...] [--batch B]
 
-A "step" is one pass of the hot path over one batch of synthetic ciphertexts that is already
-resident in HBM:
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment launches its own N ranks
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>`),
+after checking that N devices exist; under an external `torch.distributed.run` it is one of the ranks.
+
+A "step" is one pass of the hot path over one batch of synthetic ciphertexts that is already resident in HBM:
 
   ckks (default, BASELINE config 3/4): ckks::mult + relinearize + rescale_inplace on `batch`
         ciphertext pairs, N = 32768, L = 10 moduli {50,40x9} bits + 50-bit special prime
@@ -13,15 +15,29 @@ resident in HBM:
   bgv  (BASELINE config 5 shape): bgv mult + relinearize + mod_switch, N = 8192, L = 6
 
 One process per GPU; ciphertext batches are sharded across ranks with no data-path collective
-(SURVEY.md section 8e), so per-GPU work is fixed: weak scaling.  Rank 0 prints ONE JSON line.
+(SURVEY.md section 8e), so per-GPU work is fixed: weak scaling.  Rank 0 prints ONE JSON line:
 
-The oracle / compiled reference is used only for the `cpu_baseline` leg (rank 0, N = 1).
+  value / ms_per_step   whole-job throughput of the timed region (barrier + synchronize on both sides, max over ranks)
+  roofline              dominant kernel (digit-spread k_ntt_fwd launch), HIP events recorded by the library on its stream
+  verified              every output of the timed buffers compared with the CPU checker AFTER the timed region: the batch
+                        is periodic (ciphertext i = class i mod 3 of three distinct random inputs, --input-period), so
+                        three checker evaluations cover all of them; a mismatch makes the run fail (exit code 1)
+  ntt / coeffwise       (default ckks line) the other half of BASELINE's metric: forward / inverse limb-NTT/s at N = 32768
+                        and across N = 4096..32768, coefficient-wise multiply / add, each with achieved GB/s and the
+                        fraction of HBM peak; timed outside the hom-mult region
+  cpu_baseline          the compiled reference (or the C restatement) on ONE core of this host; cpu_baseline_node: the
+                        same as P independent processes (P stated)
+  --roofline-only       drops everything after the timed region (for clean rocprofv3 summaries of the default command)
+
+The oracle / compiled reference is used only after the timed region, as the checker and as the CPU baseline.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,32 +49,101 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")   # PMC measurements per kernel shape (tools/prof_pmc.sh)
+WORKLOADS = ["ckks", "ntt", "ntt15", "intt", "intt15", "bgv", "rotate", "ckks-limb", "encdec", "mul", "add", "ckks-hks"]
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="ckks", choices=["ckks", "ntt", "ntt15", "intt", "intt15", "bgv", "rotate", "ckks-limb", "encdec", "mul", "add", "ckks-hks"])
+    ap.add_argument("--workload", default="ckks", choices=WORKLOADS)
     ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (0 = BASELINE config value)")
     ap.add_argument("--logn", type=int, default=0,
                     help="override log2 of the ring degree for the ntt/intt/ckks/rotate workloads (same moduli); "
                          "0 = the BASELINE config's N")
-    ap.add_argument("--ntt-rates", action="store_true",
-                    help="ckks workload: also time forward / inverse limb transforms of the same batch (outside the timed "
-                         "region) and report them under \"ntt\".  Off by default so that a rocprofv3 summary of the default "
-                         "command shows k_ntt_fwd in its digit-spread launches only, as the roofline object does")
+    ap.add_argument("--input-period", type=int, default=3,
+                    help="the batch repeats this many distinct random inputs (item i = class i mod period) so that EVERY "
+                         "output can be checked against the CPU checker; 0 = all items distinct (then --verify samples)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the output check after the timed region")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="only the timed region and its roofline: no transform / coefficient-wise rates, no verification, no "
+                         "CPU legs -- a rocprofv3 summary of this command shows k_ntt_fwd in its digit-spread launches only")
+    ap.add_argument("--no-rates", action="store_true", help="ckks workload: skip the \"ntt\" / \"coeffwise\" sections")
     ap.add_argument("--hks-alpha", type=int, default=2, help="ckks-hks: ciphertext moduli per key-switch digit")
     ap.add_argument("--hks-k", type=int, default=2, help="ckks-hks: number of (50-bit) special primes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")
-    ap.add_argument("--cpu-procs", type=int, default=1,
-                    help="cpu_baseline as this many independent processes at once (the reference has process-global "
-                         "unsynchronised caches, so processes, not threads); the rates are summed, cores = this number")
-    return ap.parse_args()
+    ap.add_argument("--cpu-procs", type=int, default=-1,
+                    help="cpu_baseline_node: this many independent processes at once (the reference has process-global "
+                         "unsynchronised caches, so processes, not threads); -1 = the cores this process may run on "
+                         "(at most 64), 0 = skip")
+    ap.add_argument("--cpu-node-seconds", type=float, default=6.0, help="CPU budget per process of cpu_baseline_node")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="exercise only the launcher / rendezvous / timing fences with the gloo backend and a dummy step "
+                         "(no engine, no GPU); the line says so and carries no throughput claim")
+    return ap.parse_args(argv)
 
 
+# =====================================================================================================================
+# launcher
+# =====================================================================================================================
+def self_launch(args) -> int:
+    """--gpus N > 1 without a torch.distributed environment: become the launcher of N ranks on this node."""
+    n = args.gpus
+    if not args.launcher_selftest:
+        import torch
+
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            print(f"bench.py: --gpus {n} requested but only {have} HIP device(s) are visible; refusing to run on fewer",
+                  file=sys.stderr)
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+
+
+def launcher_selftest(args) -> int:
+    """The code around the timed region (rendezvous, barrier, max over ranks, one JSON line from rank 0) with gloo on CPU
+    and a dummy step.  Exists so that `bench.py --gpus 2` can be exercised end to end where there is no GPU."""
+    import torch.distributed as dist
+
+    from hehub_amd import dist as hd
+
+    world, rank, _ = hd.env_world()
+    hd.init("gloo")
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    step = lambda: time.sleep(0.002)
+    for _ in range(args.warmup):
+        step()
+    hd.barrier(sync_device=False)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    elapsed = hd.max_over_ranks(time.perf_counter() - t0)
+    hd.barrier(sync_device=False)
+    ranks = dist.get_world_size() if dist.is_initialized() else 1
+    if rank == 0:
+        print(json.dumps({"metric": "launcher_selftest", "value": world * args.steps / elapsed, "unit": "dummy-step/s",
+                          "n_gpus": world, "rccl_ranks": ranks, "backend": "gloo", "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "none (launcher self-test: no engine work, no claim)",
+                          "config": {"workload": "launcher self-test"}}))
+    hd.finalize()
+    return 0
+
+
+# =====================================================================================================================
+# inputs
+# =====================================================================================================================
 def rand_words(torch, shape, moduli, device, seed):
     """uniform words in [0, q_k) per limb (limb axis = -2), generated on the device"""
     g = torch.Generator(device=device)
@@ -70,18 +155,63 @@ def rand_words(torch, shape, moduli, device, seed):
     return out
 
 
+class Batch:
+    """A batch of B items that repeats `period` distinct random classes (item i = class i mod period); period 0: all
+    items distinct.  `base` keeps the classes (device), `full` is the batch the kernels see."""
+
+    def __init__(self, torch, B, item_shape, moduli, device, seed, period):
+        self.period = period if 0 < period < B else 0
+        if self.period:
+            self.base = rand_words(torch, (self.period,) + tuple(item_shape), moduli, device, seed)
+            idx = torch.arange(B, device=device) % self.period
+            self.full = self.base.index_select(0, idx).contiguous()
+        else:
+            self.full = rand_words(torch, (B,) + tuple(item_shape), moduli, device, seed)
+            self.base = None
+        self.B = B
+
+    def classes(self, sample=(0,)):
+        """(indices of the items that stand for all others, their host copies as uint64)"""
+        import numpy as np
+
+        if self.period:
+            return list(range(self.period)), self.base.cpu().numpy().view(np.uint64)
+        idx = sorted({i % self.B for i in sample})
+        return idx, self.full[idx].cpu().numpy().view(np.uint64)
+
+
+def compare_classes(torch, out, expected_host, period, idx):
+    """every item of `out` against its class (period > 0) or the sampled items against theirs; returns (ok, compared)"""
+    import numpy as np
+
+    exp = torch.from_numpy(np.ascontiguousarray(expected_host).view(np.int64)).to(out.device)
+    if period:
+        ok = all(bool(torch.equal(out[c::period], exp[c].expand_as(out[c::period]))) for c in range(period))
+        return ok, out.shape[0]
+    ok = all(bool(torch.equal(out[i], exp[j])) for j, i in enumerate(idx))
+    return ok, len(idx)
+
+
+def checker():
+    from oracle.pyoracle import Oracle, build, have_ref
+
+    build(ref=False)
+    kind = "reference" if have_ref() else "port"
+    return Oracle("ref" if kind == "reference" else "orc"), kind
+
+
+# =====================================================================================================================
+# CPU baseline (after the timed region; the checker, never the product)
+# =====================================================================================================================
 LOGN_OVERRIDE = 0   # set from --logn so that the CPU leg times the same ring degree
 
 
 def cpu_baseline(workload, P, budget_s):
     """Time the CPU path on this host: the compiled reference when oracle/_ref travelled with the
     snapshot ("reference"), else the C restatement ("port").  Single thread, bounded sample."""
-    import numpy as np
-    from oracle.pyoracle import Oracle, SplitMix, have_ref, build
+    from oracle.pyoracle import SplitMix
 
-    build(ref=False)
-    kind = "reference" if have_ref() else "port"
-    lib = Oracle("ref" if kind == "reference" else "orc")
+    lib, kind = checker()
     rng = SplitMix(3)
     if workload in ("mul", "add"):
         q, n = P.C2_MODULI[0], 1 << P.C2_LOGN
@@ -169,11 +299,127 @@ def _cpu_baseline_worker(workload, budget_s, logn_override=0):
     return cpu_baseline(workload, P, budget_s)
 
 
-def main():
+def cpu_baseline_node(workload, procs, budget_s, logn_override):
+    """The same sample as P independent processes at once: rates summed, P stated."""
+    import multiprocessing as mp
+
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if procs < 0:
+        procs = max(1, min(visible, 64))
+    with mp.get_context("spawn").Pool(procs) as pool:
+        parts = pool.starmap(_cpu_baseline_worker, [(workload, budget_s, logn_override)] * procs)
+    return dict(parts[0], value=sum(p["value"] for p in parts), cores=procs, cores_visible=visible,
+                per_process_min=min(p["value"] for p in parts), per_process_max=max(p["value"] for p in parts),
+                sample=f"{procs} concurrent single-threaded processes ({visible} hardware threads visible to this process), each: "
+                       + parts[0]["sample"])
+
+
+# =====================================================================================================================
+# the other half of the metric: limb-transform and coefficient-wise rates (outside the hom-mult region)
+# =====================================================================================================================
+def timed_launches(torch, hd, eng, fn, family, steps, dev):
+    """`steps` calls of fn between fences; returns (wall seconds max over ranks, launches, kernel ms from the library's
+    HIP events on its stream)"""
+    fn()
+    hd.barrier()
+    eng.prof_begin(family)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    launches, kern_ms = eng.prof_end()
+    dt = hd.max_over_ranks(t1 - t0, device=dev)
+    hd.barrier()
+    return dt, launches, kern_ms
+
+
+def rate_entry(units_per_launch, bytes_per_unit, steps, world, dt, launches, kern_ms):
+    """units/s over the wall clock of the region (whole job) and the achieved GB/s of the kernel itself (events)"""
+    e = {"per_s": units_per_launch * world * steps / dt,
+         "wall_GBps_per_gpu": units_per_launch * bytes_per_unit * steps / dt / 1e9}
+    if launches:
+        gbps = units_per_launch * bytes_per_unit * steps / (kern_ms * 1e-3) / 1e9
+        e.update({"avg_launch_ms": kern_ms / launches, "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS})
+    return e
+
+
+def transform_rates(torch, hd, eng, P, args, world, dev, rank):
+    """forward / inverse limb transforms at N = 4096 .. 32768 (north star: "NTT/INTT ... at N in {4096..32768}"), the C3
+    moduli (2^16 | q - 1 for all of them), 512 MiB per pass; every launch checked against the checker on a periodic
+    batch afterwards"""
+    import numpy as np
+
+    moduli = P.C3_MODULI_EXT
+    L = len(moduli)
+    out = {}
+    lib = None if args.no_verify else checker()[0]
+    for logn in (12, 13, 14, 15):
+        n = 1 << logn
+        B = (512 << 20) // (8 * n * L)          # polynomials of L limbs: 512 MiB in place
+        xb = Batch(torch, B, (L, n), moduli, dev, 40 + logn + 100 * rank, 3)
+        x = xb.full
+        ent = {"N": n, "limbs_per_launch": B * L}
+        for name, fam, fn in (("forward", "ntt", lambda: eng.ntt_(moduli, x)), ("inverse", "intt", lambda: eng.intt_(moduli, x))):
+            dt, launches, kern_ms = timed_launches(torch, hd, eng, fn, fam, args.steps, dev)
+            ent[name] = rate_entry(B * L, 16.0 * n, args.steps, world, dt, launches, kern_ms)
+            ent[name]["unit"] = "limb-NTT/s"
+        if lib is not None:
+            idx, host = xb.classes()
+            y = xb.base.index_select(0, torch.arange(B, device=dev) % xb.period).contiguous()   # fresh copy of the inputs
+            eng.ntt_(moduli, y)
+            fwd = np.stack([lib.poly_ntt(moduli, host[c]) for c in range(len(idx))])
+            ok1, cnt = compare_classes(torch, y, fwd, xb.period, idx)
+            eng.intt_(moduli, y)
+            inv = np.stack([lib.poly_intt(moduli, fwd[c]) for c in range(len(idx))])
+            ok2, _ = compare_classes(torch, y, inv, xb.period, idx)
+            ent["verified"] = bool(ok1 and ok2)
+            ent["verified_polynomials"] = cnt
+        out[str(n)] = ent
+        del x, xb
+    return out
+
+
+def coeffwise_rates(torch, hd, eng, P, args, world, dev, rank):
+    """RnsPolynomial operator* (hybrid Montgomery + Harvey product, rns.cpp:120-140) and operator+= (rns.cpp:58-87) at the
+    C3 limb shape: 24*N algorithmic bytes per limb; 3 x 512 MiB touched per launch"""
+    import numpy as np
+
+    moduli = P.C3_Q
+    L, n = len(moduli), 1 << P.C3_LOGN
+    B = (512 << 20) // (8 * n * L)
+    a = Batch(torch, B, (L, n), moduli, dev, 61 + 100 * rank, 3)
+    b = Batch(torch, B, (L, n), moduli, dev, 62 + 100 * rank, 3)
+    o = eng.empty((B, L, n))
+    out = {"N": n, "limbs_per_launch": B * L}
+    lib = None if args.no_verify else checker()[0]
+    for name, fn, ref in (("mul", lambda: eng.poly_mul(moduli, a.full, b.full, out=o), "poly_mul"),
+                          ("add", lambda: eng.poly_add(moduli, a.full, b.full, out=o), "poly_add")):
+        dt, launches, kern_ms = timed_launches(torch, hd, eng, fn, "elem", args.steps, dev)
+        out[name] = rate_entry(B * L, 24.0 * n, args.steps, world, dt, launches, kern_ms)
+        out[name]["unit"] = "limb-op/s"
+        if lib is not None:
+            idx, ha = a.classes()
+            _, hb = b.classes()
+            exp = np.stack([getattr(lib, ref)(moduli, ha[c], hb[c]) for c in range(len(idx))])
+            ok, cnt = compare_classes(torch, o, exp, a.period, idx)
+            out[name]["verified"] = bool(ok)
+            out[name]["verified_polynomials"] = cnt
+    return out
+
+
+# =====================================================================================================================
+def main() -> int:
     global LOGN_OVERRIDE
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
+    if args.launcher_selftest:
+        return launcher_selftest(args)
     LOGN_OVERRIDE = args.logn
+    import numpy as np
     import torch
+    import torch.distributed as dist
 
     import params as P
     from hehub_amd.engine import Engine
@@ -181,13 +427,25 @@ def main():
     from hehub_amd import dist as hd
 
     world, rank, local = hd.env_world()
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a number for the wrong job size",
+              file=sys.stderr)
+        return 2
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
+        print(f"bench.py: rank {rank} needs HIP device {local}, {torch.cuda.device_count() if torch.cuda.is_available() else 0} "
+              f"visible (no CPU fallback)", file=sys.stderr)
+        return 2
     torch.cuda.set_device(local)
     hd.init("nccl", device=torch.device(f"cuda:{local}"))   # "nccl" is RCCL on ROCm; rendezvous + timing fences only
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    rccl_ranks = dist.get_world_size() if dist.is_initialized() else 1
     dev = f"cuda:{local}"
     eng = Engine(local)
+    period = args.input_period
+    verify = None          # callable -> (ok, compared, classes) run after the timed region
+    extras = not args.roofline_only
 
     wl = args.workload
+    scaling = "weak"
     if wl in ("ntt", "ntt15", "intt", "intt15"):
         inverse = wl.startswith("intt")
         if wl.endswith("15"):   # the transform shape inside the C3 pipeline: N=32768, 10 moduli + special prime
@@ -198,32 +456,52 @@ def main():
             B = args.batch or P.C2_BATCH
         logn = args.logn or logn
         n, L = 1 << logn, len(moduli)
-        x = rand_words(torch, (B, L, n), moduli, dev, 2 + rank)
+        xb = Batch(torch, B, (L, n), moduli, dev, 2 + rank, period)
+        x = xb.full
         units_per_step = B * L
         step = (lambda: eng.intt_(moduli, x)) if inverse else (lambda: eng.ntt_(moduli, x))
         family = "intt" if inverse else "ntt"
         alg_bytes_per_step = 16.0 * n * B * L
-        launches_per_step = 1
         metric, unit = "limb_ntt_per_s", "limb-NTT/s"
         cfg = {"workload": f"{'C2' if (logn == 14 and L == 4) else 'C3-shape' if logn == 15 else 'custom'}: batched {'inverse' if inverse else 'forward'} negacyclic NTT, N={n}, {L} RNS limbs, batch={B} polynomials per GPU",
                "N": n, "limbs": L, "batch_per_gpu": B}
+
+        def verify():
+            # the timed buffer has been transformed in place steps+warmup times; check one fresh application of the same call
+            lib, kind = checker()
+            idx, host = xb.classes((0, B // 2, B - 1))
+            y = (xb.base.index_select(0, torch.arange(B, device=dev) % xb.period).contiguous() if xb.period else
+                 rand_words(torch, (B, L, n), moduli, dev, 2 + rank))
+            (eng.intt_ if inverse else eng.ntt_)(moduli, y)
+            exp = np.stack([(lib.poly_intt if inverse else lib.poly_ntt)(moduli, host[c]) for c in range(len(idx))])
+            ok, cnt = compare_classes(torch, y, exp, xb.period, idx)
+            return ok, cnt, len(idx), kind
     elif wl in ("mul", "add"):
         # coefficient-wise kernels at the C2 shape: RnsPolynomial operator* (hybrid Montgomery+Harvey product,
         # rns.cpp:120-140) / operator+= (rns.cpp:58-87); 24*N algorithmic bytes per limb
         logn, moduli = P.C2_LOGN, P.C2_MODULI
         B = args.batch or P.C2_BATCH
         n, L = 1 << logn, len(moduli)
-        a = rand_words(torch, (B, L, n), moduli, dev, 21 + rank)
-        b = rand_words(torch, (B, L, n), moduli, dev, 22 + rank)
+        ab = Batch(torch, B, (L, n), moduli, dev, 21 + rank, period)
+        bb = Batch(torch, B, (L, n), moduli, dev, 22 + rank, period)
+        a, b = ab.full, bb.full
         out = eng.empty((B, L, n))
         units_per_step = B * L
         step = (lambda: eng.poly_mul(moduli, a, b, out=out)) if wl == "mul" else (lambda: eng.poly_add(moduli, a, b, out=out))
         family = "elem"
         alg_bytes_per_step = 24.0 * n * B * L
-        launches_per_step = 1
         metric, unit = f"limb_{wl}_per_s", "limb-op/s"
         cfg = {"workload": f"C2 shape: coefficient-wise modular {'multiply' if wl == 'mul' else 'add'}, N={n}, {L} RNS limbs, batch={B} polynomials per GPU",
                "N": n, "limbs": L, "batch_per_gpu": B}
+
+        def verify():
+            lib, kind = checker()
+            idx, ha = ab.classes((0, B // 2, B - 1))
+            _, hb = bb.classes((0, B // 2, B - 1))
+            f = lib.poly_mul if wl == "mul" else lib.poly_add
+            exp = np.stack([f(moduli, ha[c], hb[c]) for c in range(len(idx))])
+            ok, cnt = compare_classes(torch, out, exp, ab.period, idx)
+            return ok, cnt, len(idx), kind
     elif wl == "ckks-hks":
         # EXTENSION, not comparable with the reference: the C3 ciphertext chain with a hybrid key switch (digits of
         # --hks-alpha moduli, --hks-k special primes); keys in the hybrid format, results differ from hehub's by design
@@ -241,7 +519,6 @@ def main():
         family = "ntt"
         fwd = nd * (L + k) - L                       # lifted-digit transforms per ciphertext: the one k_ntt_fwd launch per step
         alg_bytes_per_step = 16.0 * n * fwd * B      # (ModDown and rescale transforms are k_ntt_fwd_drop launches, family "ntt_drop")
-        launches_per_step = 1
         metric, unit = "ckks_hks_hom_mult_per_s", "hom-mult/s"
         cfg = {"workload": f"EXTENSION (not hehub-compatible keys): ckks mult + hybrid-key relinearisation (digits of {alpha} moduli, "
                            f"{k} special primes) + rescale, N={n}, L={L}, batch={B} ciphertext pairs per GPU",
@@ -260,7 +537,6 @@ def main():
         step = lambda: eng.rlwe_decrypt_core(moduli, eng.rlwe_encrypt_core(moduli, noise, c1, pt, sk), sk)
         family = "ntt"
         alg_bytes_per_step = 16.0 * n * 2 * L * B      # the two forward transforms per ciphertext (noise, plaintext)
-        launches_per_step = 2
         metric, unit = "rlwe_encrypt_decrypt_per_s", "ciphertext/s"
         cfg = {"workload": f"C3 shape: rlwe encrypt_core (given samples) + decrypt_core, N={n}, L={L}, batch={B} ciphertexts per GPU",
                "N": n, "L": L, "batch_per_gpu": B, "A_step_bytes_per_op": (15 * L + 1) * 8 * n}
@@ -273,8 +549,10 @@ def main():
         if wl in ("ckks", "rotate"):
             logn = args.logn or logn
         n, L = 1 << logn, len(mext) - 1
-        ct1 = rand_words(torch, (B, 2, L, n), mext[:L], dev, 3 + rank)
-        ct2 = rand_words(torch, (B, 2, L, n), mext[:L], dev, 1003 + rank)
+        shared = wl == "ckks-limb"            # the limb-sharded mode works on the SAME batch on every rank
+        b1 = Batch(torch, B, (2, L, n), mext[:L], dev, 3 + (0 if shared else rank), period)
+        b2 = Batch(torch, B, (2, L, n), mext[:L], dev, 1003 + (0 if shared else rank), period)
+        ct1, ct2 = b1.full, b2.full
         key = rand_words(torch, (L, 2, L + 1, n), mext, dev, 7)
         out = eng.empty((B, 2, L - 1, n))
         units_per_step = B
@@ -285,40 +563,61 @@ def main():
         # ciphertext, one launch per step; the fused drop-last-prime launches are a different kernel (k_ntt_fwd_drop,
         # profiling family "ntt_drop") and are not mixed into this roofline
         fwd_per_ct = L * L
-        scaling = "weak"
+        result = {"t": out}
         if wl == "ckks-limb":
             # latency mode (hehub_amd/sharded.py): the SAME small batch on every rank, cut by output modulus, with
             # the all-gather of the key-switch digits over RCCL; total work is fixed as N grows -> strong scaling
             from hehub_amd.sharded import Comm, ShardedMult
 
             comm, sm = Comm(), ShardedMult(eng, mext, world)
-            ct1 = rand_words(torch, (B, 2, L, n), mext[:L], dev, 3)
-            ct2 = rand_words(torch, (B, 2, L, n), mext[:L], dev, 1003)
             bufs = sm.buffers(B, n)
-            step = lambda: sm.run(comm, ct1, ct2, key, bufs)
+
+            def step():
+                result["t"] = sm.run(comm, ct1, ct2, key, bufs)
             metric, unit = "ckks_hom_mult_per_s", "hom-mult/s"
             name = "C3 shape, limb-sharded latency mode: ckks::mult + relinearize + rescale_inplace"
             scaling = "strong"
             units_per_step = B / world   # `value` multiplies by world below: the batch is shared, not replicated work
+            check = lambda lib, c1, c2, k: lib.ckks_mult(mext, c1, c2, k)
         elif wl == "rotate":
-            step = lambda: eng.ckks_rotate(mext, ct1, key, 1)
+            rot = eng.empty((B, 2, L, n))
+            result["t"] = rot
+
+            def step():
+                result["t"] = eng.ckks_rotate(mext, ct1, key, 1)
             metric, unit = "ckks_rotation_per_s", "rotation/s"
             name = "C3 shape: ckks::rotate (gather + key switch + drop of the special prime)"
             a_limbs = 5 * L * L + 22 * L + 6
+            check = lambda lib, c1, c2, k: lib.ckks_rotate(mext, c1, k, 1)
         elif wl == "ckks":
             step = lambda: eng.ckks_mult(mext, ct1, ct2, key, out=out)
             metric, unit = "ckks_hom_mult_per_s", "hom-mult/s"
             name = "C3: ckks::mult + relinearize + rescale_inplace"
+            check = lambda lib, c1, c2, k: lib.ckks_mult(mext, c1, c2, k)
         else:
             step = lambda: eng.bgv_mult(mext, t, ct1, ct2, key, out=out)
             metric, unit = "bgv_hom_mult_per_s", "hom-mult/s"
             name = "C5 shape: bgv mult_low_level + relinearize + mod_switch_inplace"
+            check = lambda lib, c1, c2, k: lib.bgv_mult(mext, t, c1, c2, k)
         family = "ntt"
         alg_bytes_per_step = 16.0 * n * fwd_per_ct * B
-        launches_per_step = None
         cfg = {"workload": f"{name}, N={n}, L={L} moduli + special prime, batch={B} ciphertext pairs per GPU",
                "N": n, "L": L, "batch_per_gpu": B, "sub_batch": int(os.environ.get("HP_MULT_CHUNK", "0")) or B,
-               "A_step_bytes_per_op": a_limbs * 8 * n}
+               "input_period": b1.period, "A_step_bytes_per_op": a_limbs * 8 * n}
+
+        def verify():
+            # the buffer the LAST timed step wrote, every ciphertext of it
+            lib, kind = checker()
+            sample = (0, 1, B // 2, B - 1)
+            idx, h1 = b1.classes(sample)
+            _, h2 = b2.classes(sample)
+            hk = key.cpu().numpy().view(np.uint64)
+            exp = np.stack([check(lib, h1[c], h2[c], hk) for c in range(len(idx))])
+            res = result["t"]
+            if res.shape[0] != B:
+                return False, 0, len(idx), kind
+            ok, cnt = compare_classes(torch, res, exp, b1.period, idx)
+            return ok, cnt, len(idx), kind
 
     for _ in range(args.warmup):
         step()
@@ -335,10 +634,25 @@ def main():
 
     value = units_per_step * world * args.steps / elapsed
     res = {
-        "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling if wl == "ckks-limb" else "weak", "vs_baseline": None,
-        "dtype": "u64", "data": "synthetic", "config": cfg,
+        "metric": metric, "value": value, "unit": unit, "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic", "config": cfg,
     }
+    # ---- output check on the timed buffers (every rank checks its own; the verdict is the AND over ranks) ----------
+    failed = False
+    if extras and not args.no_verify and verify is not None:
+        try:
+            ok, compared, classes, kind = verify()
+        except Exception as e:   # a missing checker must not look like a pass
+            ok, compared, classes, kind = False, 0, 0, f"error: {e!r}"
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        if dist.is_initialized():
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        res["verified"] = bool(flag.item())
+        res["verify"] = {"outputs_compared_per_gpu": compared, "checker_evaluations": classes, "checker": kind,
+                         "what": "raw u64 words of the buffers the timed region wrote (in-place transforms: one fresh call on "
+                                 "the same inputs), bit for bit"}
+        failed = not res["verified"]
     # roofline of the dominant kernel family (forward NTT), from HIP events recorded by the library on the
     # launch stream around every launch of that family inside the timed region (rank-local)
     if launches:
@@ -352,19 +666,24 @@ def main():
                            "traffic": None, "launches": launches, "avg_launch_ms": kern_ms / launches,
                            "algorithmic_bytes_per_launch": bytes_per_launch,
                            "share_of_step_time": kern_ms * 1e-3 / elapsed}
-        # HBM traffic per launch from the committed PMC measurement of this kernel shape (rocprofv3 --pmc
+        # HBM traffic per launch and VALUBusy from the committed PMC measurement of this kernel shape (rocprofv3 --pmc
         # FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, tools/prof_pmc.sh); null when no measurement exists
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            with open(TRAFFIC_FILE) as f:
                 trs = json.load(f)
-                tr = None
-                if family == "ntt":   # the digit-spread launch has its own measurement where one exists
-                    tr = (trs.get(f"k_ntt_fwd_logn{logn}_spread") if wl in ("ckks", "bgv", "rotate") else None) or trs.get(f"k_ntt_fwd_logn{logn}")
+            tr = None
+            if family == "ntt":   # the digit-spread launch has its own measurement where one exists
+                tr = (trs.get(f"k_ntt_fwd_logn{logn}_spread") if wl in ("ckks", "bgv", "rotate") else None) or trs.get(f"k_ntt_fwd_logn{logn}")
+            elif family == "intt":
+                tr = trs.get(f"k_ntt_inv_logn{logn}")
             if tr:
                 limbs_per_launch = bytes_per_launch / (16.0 * n)
                 res["roofline"]["traffic"] = tr["bytes_per_limb"] * limbs_per_launch
-                res["roofline"]["traffic_source"] = "rocprofv3 PMC per-limb measurement x limbs per launch (profiles/r01_traffic.json)"
-        except (OSError, ValueError):
+                res["roofline"]["traffic_source"] = ("rocprofv3 PMC per-limb measurement x limbs per launch "
+                                                     f"(profiles/traffic.json: {tr.get('source', 'see _comment')})")
+                if "valu_busy" in tr:
+                    res["roofline"]["valu_busy"] = tr["valu_busy"]
+        except (OSError, ValueError, KeyError):
             pass
     if wl in ("ckks", "bgv", "rotate", "ckks-limb"):
         a_step = a_limbs * 8 * n
@@ -375,45 +694,39 @@ def main():
             a_min = (6 * L - 2) * 8 * n + 2 * L * (L + 1) * 8 * n / B
             res["pipeline_roofline"].update({"A_prim_frac_of_hbm_peak": value / world * a_prim / 1e9 / HBM_PEAK_GBS,
                                              "A_min_frac_of_hbm_peak": value / world * a_min / 1e9 / HBM_PEAK_GBS})
-    if wl == "ckks" and args.ntt_rates:
-        # BASELINE.json's metric names both rates ("NTT/s and CKKS hom-mult/s ... N=32768"): the line also carries the
-        # limb-transform rates at the same ring degree (all limbs of the same batch of ciphertexts, forward and inverse
-        # timed separately, same fences; outside the timed region of `value`)
-        xq = ct1.view(B * 2, L, n)
-        rates = {}
-        for name, fn in (("forward", lambda: eng.ntt_(mext[:L], xq)), ("inverse", lambda: eng.intt_(mext[:L], xq))):
-            fn()
-            hd.barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                fn()
-            torch.cuda.synchronize()
-            dt = hd.max_over_ranks(time.perf_counter() - t0, device=dev)
-            hd.barrier()
-            rates[name] = B * 2 * L * world * args.steps / dt
-        res["ntt"] = {"N": n, "limbs_per_launch": B * 2 * L, "forward_limb_ntt_per_s": rates["forward"],
-                      "inverse_limb_ntt_per_s": rates["inverse"],
-                      "forward_frac_of_hbm_peak": rates["forward"] / world * 16.0 * n / 1e9 / HBM_PEAK_GBS,
-                      "inverse_frac_of_hbm_peak": rates["inverse"] / world * 16.0 * n / 1e9 / HBM_PEAK_GBS}
+    if wl == "ckks" and extras and not args.no_rates and not args.logn and not args.batch:
+        # BASELINE.json's metric names both rates ("NTT/s and CKKS hom-mult/s ... N=32768") and the north star the
+        # coefficient-wise kernels: the default line carries them too (timed after the hom-mult region, same fences)
+        by_n = transform_rates(torch, hd, eng, P, args, world, dev, rank)
+        top = by_n[str(1 << P.C3_LOGN)]
+        res["ntt"] = {"N": top["N"], "limbs_per_launch": top["limbs_per_launch"],
+                      "forward_limb_ntt_per_s": top["forward"]["per_s"], "inverse_limb_ntt_per_s": top["inverse"]["per_s"],
+                      "forward": top["forward"], "inverse": top["inverse"], "verified": top.get("verified"),
+                      "by_N": by_n}
+        res["coeffwise"] = coeffwise_rates(torch, hd, eng, P, args, world, dev, rank)
+        for sect in list(by_n.values()) + [res["coeffwise"]["mul"], res["coeffwise"]["add"]]:
+            if sect.get("verified") is False:
+                failed = True
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and extras and not args.no_cpu_baseline:
+            cwl = "ckks" if wl in ("ckks-limb", "ckks-hks") else wl
             try:
-                cwl = "ckks" if wl in ("ckks-limb", "ckks-hks") else wl
-                if args.cpu_procs > 1:
-                    import multiprocessing as mp
-
-                    with mp.get_context("spawn").Pool(args.cpu_procs) as pool:
-                        parts = pool.starmap(_cpu_baseline_worker, [(cwl, args.cpu_seconds, args.logn)] * args.cpu_procs)
-                    res["cpu_baseline"] = dict(parts[0], value=sum(p["value"] for p in parts), cores=args.cpu_procs,
-                                               sample=f"{args.cpu_procs} concurrent processes, each: " + parts[0]["sample"])
-                else:
-                    res["cpu_baseline"] = cpu_baseline(cwl, P, args.cpu_seconds)
+                res["cpu_baseline"] = cpu_baseline(cwl, P, args.cpu_seconds)
             except Exception as e:  # the checker is optional infrastructure; the GPU number stands on its own
                 res["cpu_baseline"] = {"error": repr(e)}
+            if args.cpu_procs != 0:
+                try:
+                    res["cpu_baseline_node"] = cpu_baseline_node(cwl, args.cpu_procs, args.cpu_node_seconds, args.logn)
+                except Exception as e:
+                    res["cpu_baseline_node"] = {"error": repr(e)}
         print(json.dumps(res))
     hd.finalize()
     eng.close()
+    if failed:
+        print("bench.py: OUTPUT CHECK FAILED -- the numbers above are void", file=sys.stderr)
+        return 1
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -87,6 +87,7 @@ SIGNATURES = {
     "hp_dev_ckks_conjugate_hks": (INT, [P, szt, szt, szt, szt, P, szt, P, P, P]),
     "hp_dev_ckks_mult_relin_rescale_hks": (INT, [P, szt, szt, szt, szt, P, szt, P, P, P, P]),
     "hp_dev_ckks_rescale_n": (INT, [P, szt, szt, P, szt, szt, P, P, P]),
+    "hp_wire_fnv1a64": (u64, [P, szt]),
     "hp_wire_payload_words": (szt, [P]),
     "hp_wire_bytes": (szt, [P]),
     "hp_wire_pack": (INT, [P, P, P, P, szt]),

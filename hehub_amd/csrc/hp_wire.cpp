@@ -50,6 +50,8 @@ bool desc_ok(const hp_wire_desc *d) {
 
 extern "C" {
 
+uint64_t hp_wire_fnv1a64(const void *data, size_t bytes) { return data ? fnv1a64((const unsigned char *)data, bytes) : 0; }
+
 size_t hp_wire_payload_words(const hp_wire_desc *d) {
     return desc_ok(d) ? (size_t)d->polys * d->limbs * ((size_t)1 << d->log_dimension) : 0;
 }

@@ -76,6 +76,12 @@ class Engine:
     def sync(self):
         self._chk(self.lib.hp_sync(self.h))
 
+    def workspace_bytes(self) -> int:
+        return int(self.lib.hp_ctx_workspace_bytes(self.h))
+
+    def release_workspace(self):
+        self._chk(self.lib.hp_ctx_release_workspace(self.h))
+
     def force_generic(self, on: bool):
         self._chk(self.lib.hp_ctx_set_force_generic(self.h, int(on)))
 

@@ -296,6 +296,8 @@ typedef struct {
     uint32_t rep_form;       /* 0 coefficient, 1 NTT value */
     uint64_t scheme_scalar;  /* IEEE-754 bits of the CKKS scaling factor / BGV plain modulus / 0 */
 } hp_wire_desc;
+/* the format's checksum: FNV-1a-64 over `bytes` bytes (little-endian words as they lie in memory) */
+uint64_t hp_wire_fnv1a64(const void *data, size_t bytes);
 size_t hp_wire_payload_words(const hp_wire_desc *d);   /* 0 for an invalid descriptor */
 size_t hp_wire_bytes(const hp_wire_desc *d);
 /* host words -> buffer, and back (payload_offset: where the words start inside buf) */

@@ -1,10 +1,15 @@
 """Case list shared by the golden-vector generator and the golden test.
 
-`run_cases(lib)` evaluates every case with one checker library (the compiled
-reference when generating, the C oracle when testing) on inputs derived from
+`run_cases(lib)` evaluates every case with one implementation (the compiled
+reference when generating, the C oracle in the CPU tier, the HIP engine behind
+tests/test_gpu_golden.py's adapter in the GPU tier) on inputs derived from
 fixed splitmix64 seeds, and returns {case name: summary}.  A summary holds the
 FNV-1a-64 digest of the raw little-endian output words, the first and last 8
-words, and the full output when it is small.
+words, and the full output when it is small.  `fnv` is the digest function
+(bytes of a contiguous array -> int); the default is the oracle library's, the
+engine test passes the product's own (hp_wire_fnv1a64) so that no checker
+library is loaded there.  Cases an implementation has no entry point for
+(the scalar known answers) are skipped when the method is absent.
 """
 import os
 import sys
@@ -13,30 +18,52 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import params as P  # noqa: E402
-from oracle.pyoracle import Oracle, SplitMix  # noqa: E402
+from splitmix import SplitMix  # noqa: E402
 
 U = np.uint64
-_FNV = Oracle("orc")  # digest helper only (fnv1a64 is not reference code)
+_fnv = None
+
+
+def _default_fnv(flat):
+    global _fnv
+    if _fnv is None:
+        from oracle.pyoracle import Oracle
+
+        _fnv = Oracle("orc").fnv  # digest helper only (fnv1a64 is not reference code)
+    return _fnv(flat)
 
 
 def summary(a: np.ndarray) -> dict:
     flat = np.ascontiguousarray(a).reshape(-1)
-    s = {"n": int(flat.size), "fnv": f"{_FNV.fnv(flat):016x}",
+    s = {"n": int(flat.size), "fnv": f"{(_digest or _default_fnv)(flat):016x}",
          "head": [int(x) for x in flat[:8]], "tail": [int(x) for x in flat[-8:]]}
     if flat.size <= 256:
         s["full"] = [int(x) for x in flat]
     return s
 
 
-def run_cases(lib, big: bool = True) -> dict:
+_digest = None
+
+
+def run_cases(lib, big: bool = True, fnv=None) -> dict:
+    global _digest
+    _digest = fnv
+    try:
+        return _run_cases(lib, big)
+    finally:
+        _digest = None
+
+
+def _run_cases(lib, big: bool) -> dict:
     out = {}
     # ---- scalar known answers -------------------------------------------------
     q40 = P.P40[0]
-    out["harvey_scalar"] = {"value": lib.mul_mod_harvey_lazy(q40, 123456789012345678, 987654321,
-                                                             (987654321 << 64) // q40)}
-    out["inverse_65537_mod_q40"] = {"value": lib.inverse_mod_prime(65537, q40)}
-    for q, logn in ((P.C1_Q, 12), (q40, 14), (65537, 4), (P.P50[0], 15)):
-        out[f"psi_q{q}_logn{logn}"] = {"value": lib.unity_root(q, 1 << logn)}
+    if hasattr(lib, "mul_mod_harvey_lazy"):
+        out["harvey_scalar"] = {"value": lib.mul_mod_harvey_lazy(q40, 123456789012345678, 987654321,
+                                                                 (987654321 << 64) // q40)}
+        out["inverse_65537_mod_q40"] = {"value": lib.inverse_mod_prime(65537, q40)}
+        for q, logn in ((P.C1_Q, 12), (q40, 14), (65537, 4), (P.P50[0], 15)):
+            out[f"psi_q{q}_logn{logn}"] = {"value": lib.unity_root(q, 1 << logn)}
 
     # ---- batched modular arithmetic (tests/mod_arith_t.cpp moduli + list primes)
     for q in P.BARRETT_TEST_Q + [P.P40[0], P.P50[0], P.C1_Q]:

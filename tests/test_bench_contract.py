@@ -15,7 +15,7 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 @pytest.mark.parametrize("workload", ["ckks", "ntt"])
 def test_bench_line_has_the_contract_fields(workload):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--batch", "8", "--steps", "2",
-                          "--warmup", "1", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=900)
+                          "--warmup", "1", "--cpu-seconds", "1", "--cpu-procs", "0"], capture_output=True, text=True, timeout=900)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, (out.stdout[-2000:], out.stderr[-2000:])
     r = json.loads(lines[0])
@@ -28,3 +28,52 @@ def test_bench_line_has_the_contract_fields(workload):
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and 0 < roof["frac"] < 1
     cpu = r["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cpu) and cpu["kind"] in ("reference", "port") and cpu["cores"] == 1
+    # every output of the timed buffers was compared with the CPU checker (periodic batch: 3 checker evaluations)
+    assert r["verified"] is True and r["verify"]["outputs_compared_per_gpu"] == 8 and r["verify"]["checker_evaluations"] == 3
+    assert r["rccl_ranks"] == 1
+
+
+@pytest.mark.gpu
+def test_default_line_carries_both_halves_of_the_metric():
+    """The default command (C3, batch 256) with a short CPU budget: hom-mult/s with roofline + verification, the limb-transform
+    rates at N = 4096..32768, the coefficient-wise rates, one-core and P-process CPU baselines."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-seconds", "1",
+                          "--cpu-procs", "2", "--cpu-node-seconds", "1"], capture_output=True, text=True, timeout=1800)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.stdout[-2000:], out.stderr[-2000:])
+    r = json.loads(lines[0])
+    assert REQUIRED <= set(r) and r["metric"] == "ckks_hom_mult_per_s" and r["config"]["batch_per_gpu"] == 256
+    assert r["verified"] is True and r["verify"]["outputs_compared_per_gpu"] == 256
+    ntt = r["ntt"]
+    assert ntt["N"] == 32768 and ntt["verified"] is True and set(ntt["by_N"]) == {"4096", "8192", "16384", "32768"}
+    for ent in ntt["by_N"].values():
+        assert ent["verified"] is True
+        for d in ("forward", "inverse"):
+            assert ent[d]["per_s"] > 0 and 0.05 < ent[d]["frac_of_hbm_peak"] < 1 and ent[d]["achieved_GBps"] > 0
+    cw = r["coeffwise"]
+    for op in ("mul", "add"):
+        assert cw[op]["verified"] is True and 0.2 < cw[op]["frac_of_hbm_peak"] < 1
+    node = r["cpu_baseline_node"]
+    assert node["cores"] == 2 and node["value"] > r["cpu_baseline"]["value"] * 0.8 and "cores_visible" in node
+
+
+@pytest.mark.gpu
+def test_roofline_only_line_has_no_side_legs():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "8", "--steps", "2", "--warmup", "1",
+                          "--roofline-only"], capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.stdout[-2000:], out.stderr[-2000:])
+    r = json.loads(lines[0])
+    assert "roofline" in r and not ({"ntt", "coeffwise", "cpu_baseline", "cpu_baseline_node", "verified"} & set(r))
+
+
+@pytest.mark.gpu
+def test_bench_refuses_two_gpus_on_a_one_gpu_box():
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("more than one GPU here")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 2 and "refusing" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -5,7 +5,7 @@ REPS=$1; VAR=$2; shift 2
 for i in $(seq $REPS); do
   for v in "$@"; do
     if [ "$v" = "-" ]; then unset $VAR; else export $VAR=$v; fi
-    python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; print('$VAR=$v', 'ckks', round(json.loads(sys.stdin.read())['value']))"
+    python $R/bench.py --steps 10 --warmup 2 --roofline-only 2>/dev/null | python -c "import sys,json; print('$VAR=$v', 'ckks', round(json.loads(sys.stdin.read())['value']))"
     python - <<'PY'
 import os,sys
 R=os.environ.get("GRAFT_REPO_ROOT",".")

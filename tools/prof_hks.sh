@@ -7,7 +7,7 @@ for a in 2 3 4 5; do
 done
 cd /tmp && export TMPDIR=/tmp
 for a in 2 5; do
-  rocprofv3 --kernel-trace --stats -d $R/gpurun_out/hks_kt_$a -o p -- python $R/bench.py --workload ckks-hks --hks-alpha $a --hks-k $a --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats -d $R/gpurun_out/hks_kt_$a -o p -- python $R/bench.py --workload ckks-hks --hks-alpha $a --hks-k $a --steps 3 --warmup 1 --roofline-only > /dev/null 2>&1
   python $R/tools/rocpd_summary.py $R/gpurun_out/hks_kt_$a/p_results.db > $R/gpurun_out/${TAG}_hks_kernel_stats_alpha$a.txt 2>&1
   rm -rf $R/gpurun_out/hks_kt_$a
 done
