@@ -16,7 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libhehub_amd.so")
-SOURCES = ["hp_engine.cpp", "hp_tables.cpp", "hp_wire.cpp", "hp_elem.hip", "hp_hks.hip", "hp_ntt_generic.hip", "hp_ntt_fast.hip"]
+SOURCES = ["hp_ctx.cpp", "hp_prof.cpp", "hp_api_poly.cpp", "hp_api_scheme.cpp", "hp_api_hks.cpp", "hp_tables.cpp", "hp_wire.cpp",
+           "hp_elem.hip", "hp_hks.hip", "hp_ntt_generic.hip", "hp_ntt_fast.hip"]
 ARCH = "gfx950"
 
 

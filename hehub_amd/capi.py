@@ -31,6 +31,7 @@ SIGNATURES = {
     "hp_ctx_get_stream": (P, [P]),
     "hp_sync": (INT, [P]),
     "hp_ctx_workspace_bytes": (szt, [P]),
+    "hp_ctx_workspace_generation": (C.c_ulong, [P]),
     "hp_ctx_release_workspace": (INT, [P]),
     "hp_dev_alloc": (INT, [P, szt, C.POINTER(P)]),
     "hp_dev_free": (INT, [P, P]),

@@ -1,0 +1,377 @@
+// hp_ctx.cpp -- engine context: life cycle, stream selection, scratch workspace, device memory helpers, and the
+// caches of twiddle tables / per-limb constants / gather maps / CRT constants (include/hehub_amd.h, "engine").
+#include "hp_ctx.h"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace hpi {
+
+namespace {
+// last failure of the calling thread: (context, message)
+thread_local const hp_ctx *tl_err_ctx = nullptr;
+thread_local std::string tl_err_msg;
+} // namespace
+
+int fail(hp_ctx *ctx, int code, const std::string &msg) {
+    ctx->err = msg;        // under the context lock (every caller holds it)
+    tl_err_ctx = ctx;
+    tl_err_msg = msg;
+    return code;
+}
+
+int chk(hp_ctx *ctx, hipError_t e, const char *what) {
+    if (e != hipSuccess) return fail(ctx, HP_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+    return HP_OK;
+}
+
+int upload(hp_ctx *ctx, const void *host, size_t bytes, void **dptr) {
+    HIP_TRY(ctx, hipMalloc(dptr, bytes));
+    HIP_TRY(ctx, hipMemcpy(*dptr, host, bytes, hipMemcpyHostToDevice));
+    return HP_OK;
+}
+
+// twiddle tables of one (modulus, logn), built on first use (the reference fills global maps
+// lazily in the same way, ntt.cpp:117-143)
+static int get_tables_impl(hp_ctx *ctx, u64 q, size_t logn, DevTables &out) {
+    auto key = std::make_pair(q, logn);
+    auto it = ctx->tables.find(key);
+    if (it != ctx->tables.end()) {
+        out = it->second;
+        return HP_OK;
+    }
+    std::string why = hp::check_ntt_modulus(q, logn);
+    if (!why.empty()) return fail(ctx, HP_EINVAL, why);
+    std::vector<hp::Pair> fwd, inv, fk, ik;
+    hp::build_fwd_ref(q, logn, fwd);
+    hp::build_inv_ref(q, logn, inv);
+    DevTables t;
+    int rc;
+    if ((rc = upload(ctx, fwd.data(), fwd.size() * sizeof(hp::Pair), (void **)&t.fwd_ref))) return rc;
+    if ((rc = upload(ctx, inv.data(), inv.size() * sizeof(hp::Pair), (void **)&t.inv_ref))) return rc;
+    if (logn >= 11 && logn <= 15) {
+        hp::build_fwd_fast(fwd, logn, fk);
+        hp::build_inv_fast(inv, logn, ik);
+        if ((rc = upload(ctx, fk.data(), fk.size() * sizeof(hp::Pair), (void **)&t.fwd_k))) return rc;
+        if ((rc = upload(ctx, ik.data(), ik.size() * sizeof(hp::Pair), (void **)&t.inv_k))) return rc;
+    }
+    ctx->tables[key] = t;
+    out = t;
+    return HP_OK;
+}
+int get_tables(hp_ctx *ctx, u64 q, size_t logn, DevTables &out) {
+    return contained(ctx, [&] { return get_tables_impl(ctx, q, logn, out); });
+}
+
+static int get_plan_impl(hp_ctx *ctx, size_t logn, const uint64_t *moduli, size_t count, bool with_ntt, const Plan **out) {
+    if (count == 0 || count > HP_MAX_LIMBS) return fail(ctx, HP_EINVAL, "unsupported number of RNS components");
+    std::vector<u64> mv(moduli, moduli + count);
+    for (u64 q : mv)
+        if (q < 2) return fail(ctx, HP_EINVAL, "modulus must be >= 2");
+    auto key = std::make_pair(with_ntt ? logn : (size_t)0, mv);
+    auto it = ctx->plans.find(key);
+    if (it != ctx->plans.end()) {
+        *out = &it->second;
+        return HP_OK;
+    }
+    Plan plan;
+    std::vector<HpLimb> limbs(count);
+    for (size_t k = 0; k < count; k++) {
+        hp::ModConsts c = hp::make_consts(mv[k]);
+        plan.consts.push_back(c);
+        HpLimb &l = limbs[k];
+        memset(&l, 0, sizeof(l));
+        l.q = c.q; l.two_q = c.two_q; l.neg_q = c.neg_q; l.mqinv = c.mqinv; l.r64 = c.r64; l.r64h = c.r64h;
+        l.barrett_c = c.barrett_c; l.k = c.k; l.fix = c.fix;
+        if (with_ntt) {
+            DevTables t;
+            int rc = get_tables(ctx, mv[k], logn, t);
+            if (rc) return rc;
+            l.fwd_ref = t.fwd_ref; l.inv_ref = t.inv_ref; l.fwd_k = t.fwd_k; l.inv_k = t.inv_k;
+        }
+    }
+    int rc = upload(ctx, limbs.data(), limbs.size() * sizeof(HpLimb), (void **)&plan.d_limbs);
+    if (rc) return rc;
+    auto ins = ctx->plans.emplace(key, std::move(plan));
+    *out = &ins.first->second;
+    return HP_OK;
+}
+int get_plan(hp_ctx *ctx, size_t logn, const uint64_t *moduli, size_t count, bool with_ntt, const Plan **out) {
+    return contained(ctx, [&] { return get_plan_impl(ctx, logn, moduli, count, with_ntt, out); });
+}
+
+// A bounded cache of small device objects that is full gets emptied: kernels that may still read the entries are
+// drained first.  (Rotation-heavy workloads with thousands of distinct steps would otherwise grow without bound.)
+template <class Map> static int make_room(hp_ctx *ctx, Map &m, size_t cap) {
+    if (m.size() < cap) return HP_OK;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    for (auto &kv : m) (void)hipFree((void *)kv.second);
+    m.clear();
+    return HP_OK;
+}
+
+static int get_cycle_perm_impl(hp_ctx *ctx, size_t logn, size_t step, const u32 **out) {
+    const size_t n = (size_t)1 << logn;
+    // 3 has order N/2 modulo 2N (N >= 4): steps s and s + N/2 are the same permutation
+    const size_t period = logn >= 2 ? n / 2 : 2;
+    step %= period;
+    auto key = std::make_pair(logn, step);
+    auto it = ctx->perms.find(key);
+    if (it == ctx->perms.end()) {
+        int rc = make_room(ctx, ctx->perms, MAX_PERMS);
+        if (rc) return rc;
+        std::vector<u32> perm(n);
+        for (size_t i = 0; i < n; i++) perm[i] = (u32)i;
+        const u32 mask = (u32)((1u << (logn + 1)) - 1);
+        u32 factor = 1;
+        for (size_t s = 0; s < step; s++) factor *= 3u;
+        factor &= mask;
+        u32 pw = 1;
+        for (size_t i = 0; i < n / 2; i++, pw *= 3u) {
+            const u32 old_idx = pw & mask;
+            const u32 from = hp::bit_rev((old_idx - 1) / 2, (int)logn);
+            const u32 to = hp::bit_rev((((old_idx * factor) & mask) - 1) / 2, (int)logn);
+            perm[to] = from;
+            perm[n - 1 - to] = (u32)(n - 1 - from);
+        }
+        u32 *d = nullptr;
+        rc = upload(ctx, perm.data(), n * sizeof(u32), (void **)&d);
+        if (rc) return rc;
+        it = ctx->perms.emplace(key, d).first;
+    }
+    *out = it->second;
+    return HP_OK;
+}
+int get_cycle_perm(hp_ctx *ctx, size_t logn, size_t step, const u32 **out) {
+    return contained(ctx, [&] { return get_cycle_perm_impl(ctx, logn, step, out); });
+}
+
+// constants of the CRT branch of the many -> one base transform (rns_transform.cpp:86-104), cached per (moduli, t)
+int get_crt_consts(hp_ctx *ctx, const uint64_t *moduli, size_t L, u64 t, const HpCrtConsts **out) {
+    return contained(ctx, [&] {
+        auto key = std::make_pair(std::vector<u64>(moduli, moduli + L), t);
+        auto it = ctx->crt.find(key);
+        if (it == ctx->crt.end()) {
+            int rc = make_room(ctx, ctx->crt, MAX_CRT);
+            if (rc) return rc;
+            HpCrtConsts c;
+            memset(&c, 0, sizeof(c));
+            c.t = t;
+            typedef unsigned __int128 u128;
+            u64 prod_t = 1 % t;
+            for (size_t a = 0; a < L; a++) {
+                c.pref[a] = prod_t;
+                c.pref_h[a] = hp::harvey_quotient(prod_t, t);
+                prod_t = (u64)((u128)prod_t * (moduli[a] % t) % t);
+                for (size_t b = 0; b < a; b++) {
+                    if (moduli[b] % moduli[a] == 0) return fail(ctx, HP_EINVAL, "moduli are not pairwise coprime");
+                    c.inv[b][a] = hp::inverse_mod_prime(moduli[b] % moduli[a], moduli[a]) % moduli[a];
+                    c.inv_h[b][a] = hp::harvey_quotient(c.inv[b][a], moduli[a]);
+                }
+            }
+            c.q_mod_t = prod_t;
+            // floor(Q/2) = (Q-1)/2 has the residues (q_a - 1)/2; its mixed-radix digits by the same recurrence
+            for (size_t a = 0; a < L; a++) {
+                const u64 qa = moduli[a];
+                u64 u = (qa - 1) / 2;
+                for (size_t b = 0; b < a; b++) {
+                    const u64 vb = c.half[b] % qa;
+                    u = (u64)((u128)((u + qa - vb) % qa) * c.inv[b][a] % qa);
+                }
+                c.half[a] = u;
+            }
+            HpCrtConsts *d = nullptr;
+            rc = upload(ctx, &c, sizeof(c), (void **)&d);
+            if (rc) return rc;
+            it = ctx->crt.emplace(key, d).first;
+        }
+        *out = it->second;
+        return (int)HP_OK;
+    });
+}
+
+// The workspace only grows.  Replacing it frees memory that kernels enqueued earlier -- on ANY stream this context was
+// pointed at -- may still use, so the whole device is drained first (growth is rare: once per new largest shape).
+// A HIP graph captured earlier holds the old pointers: ws_generation tells the caller that it went stale.
+int ws_reserve(hp_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return HP_OK;
+    if (ctx->ws) {
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        HIP_TRY(ctx, hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    ctx->ws_generation++;
+    hipError_t e = hipMalloc(&ctx->ws, bytes);
+    if (e != hipSuccess) {
+        ctx->ws = nullptr;
+        fail(ctx, HP_ENOMEM, std::string("workspace hipMalloc: ") + hipGetErrorString(e));
+        return HP_ENOMEM;
+    }
+    ctx->ws_bytes = bytes;
+    return HP_OK;
+}
+
+int run_ntt(hp_ctx *ctx, const HpNttJob &job) {
+    if (job.W == 0) return HP_OK;
+    hipError_t e;
+    {
+        ProfScope ps(ctx, job.inverse ? "intt" : "ntt");
+        if (tiled_ok(ctx, job.logn)) e = hp_launch_ntt_fast(job, ctx->stream);
+        else e = hp_launch_ntt_generic(job, ctx->stream);
+    }
+    if (e != hipSuccess) return fail(ctx, HP_EHIP, std::string("transform launch: ") + hipGetErrorString(e));
+    return HP_OK;
+}
+
+HpNttJob batch_job(const Plan *plan, size_t logn, size_t L, size_t P, const u64 *src, u64 *dst, size_t src_ps,
+                   size_t dst_ps, int inverse, int strict) {
+    HpNttJob j;
+    memset(&j, 0, sizeof(j));
+    j.limbs = plan->d_limbs; j.src = src; j.dst = dst; j.logn = (u32)logn; j.L = (u32)L; j.P = (u32)P;
+    j.src_pstride = (u32)src_ps; j.dst_pstride = (u32)dst_ps; j.src_kstride = 1; j.W = (u32)(L * P); j.mode = HP_NTT_BATCH;
+    j.inverse = inverse; j.strict = strict;
+    return j;
+}
+
+// Point the context at another stream.  Scratch buffers and cached tables are shared by everything the context
+// enqueues, so work enqueued from now on must not overtake what is already queued on the previous stream: one event
+// recorded there, waited for here (no host synchronisation).
+static int switch_stream(hp_ctx *ctx, hipStream_t to) {
+    if (to == ctx->stream) return HP_OK;
+    if (!ctx->ev_switch) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_switch, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_switch, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(to, ctx->ev_switch, 0));
+    ctx->stream = to;
+    return HP_OK;
+}
+
+} // namespace hpi
+
+using namespace hpi;
+
+extern "C" {
+
+const char *hp_version(void) { return "hehub_amd 0.2 (gfx950)"; }
+
+int hp_ctx_create(int device, hp_ctx **out) {
+    if (!out) return HP_EINVAL;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return HP_EHIP;
+    if (hipSetDevice(device) != hipSuccess) return HP_EHIP;
+    hp_ctx *c = new (std::nothrow) hp_ctx();
+    if (!c) return HP_ENOMEM;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return HP_EHIP;
+    }
+    c->stream = c->own_stream;
+    c->no_fused_drop = getenv("HP_NO_FUSED_DROP") != nullptr;
+    c->hks_two_step = getenv("HP_HKS_TWO_STEP") != nullptr;
+    c->hks_combine_kernel = getenv("HP_HKS_COMBINE_KERNEL") != nullptr;
+    if (const char *e = getenv("HP_DROP_GROUP")) c->drop_group = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char *e = getenv("HP_SPREAD_GROUP")) c->spread_group = atoi(e) > 0 ? atoi(e) : 0;   // measured: 2..6 alike, -2 % on the launch
+    if (const char *e = getenv("HP_MULT_STREAMS")) c->mult_streams = atoi(e) >= 2 ? 2 : 1;
+    if (const char *e = getenv("HP_MULT_CHUNK")) c->mult_chunk = (size_t)atol(e);
+    *out = c;
+    return HP_OK;
+}
+
+void hp_ctx_destroy(hp_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto &kv : ctx->tables) {
+        (void)hipFree(kv.second.fwd_ref); (void)hipFree(kv.second.inv_ref);
+        (void)hipFree(kv.second.fwd_k); (void)hipFree(kv.second.inv_k);
+    }
+    for (auto &kv : ctx->plans) (void)hipFree(kv.second.d_limbs);
+    for (auto &kv : ctx->perms) (void)hipFree(kv.second);
+    for (auto &kv : ctx->crt) (void)hipFree(kv.second);
+    for (auto &kv : ctx->hks) (void)hipFree(kv.second);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    for (auto &ev : ctx->prof_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]);
+        if (ctx->ev_done[i]) (void)hipEventDestroy(ctx->ev_done[i]);
+    }
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_switch) (void)hipEventDestroy(ctx->ev_switch);
+    (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+// The calling thread's last failure on this context if it had one, else the context's last failure.  The pointer
+// stays valid until the calling thread's next hp_* call on any context.
+const char *hp_last_error(hp_ctx *ctx) {
+    if (!ctx) return "null context";
+    if (tl_err_ctx == ctx) return tl_err_msg.c_str();
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    tl_err_msg = ctx->err;
+    tl_err_ctx = ctx;
+    return tl_err_msg.c_str();
+}
+
+int hp_ctx_set_stream(hp_ctx *ctx, void *s) {
+    HP_ENTER(ctx);
+    return switch_stream(ctx, (hipStream_t)s);   // NULL is the HIP default (null) stream, e.g. torch's default stream
+}
+int hp_ctx_reset_stream(hp_ctx *ctx) {
+    HP_ENTER(ctx);
+    return switch_stream(ctx, ctx->own_stream);
+}
+void *hp_ctx_get_stream(hp_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+// The scratch workspace only grows (the largest call so far defines it: 10+ GiB for a C3 batch of 256); this gives it back.
+int hp_ctx_release_workspace(hp_ctx *ctx) {
+    HP_ENTER(ctx);
+    HIP_TRY(ctx, hipDeviceSynchronize());   // every stream that may have used it, not only the current one
+    if (ctx->ws) HIP_TRY(ctx, hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+    ctx->ws_generation++;
+    return HP_OK;
+}
+size_t hp_ctx_workspace_bytes(hp_ctx *ctx) { return ctx ? ctx->ws_bytes : 0; }
+unsigned long hp_ctx_workspace_generation(hp_ctx *ctx) { return ctx ? ctx->ws_generation : 0; }
+
+int hp_sync(hp_ctx *ctx) {
+    HP_ENTER(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HP_OK;
+}
+
+int hp_dev_alloc(hp_ctx *ctx, size_t bytes, void **dptr) {
+    HP_ENTER(ctx);
+    HP_REQUIRE(ctx, dptr);
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e != hipSuccess) return fail(ctx, HP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return HP_OK;
+}
+int hp_dev_free(hp_ctx *ctx, void *dptr) {
+    HP_ENTER(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(dptr));
+    return HP_OK;
+}
+int hp_memcpy_h2d(hp_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    HP_ENTER(ctx);
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HP_OK;
+}
+int hp_memcpy_d2h(hp_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    HP_ENTER(ctx);
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HP_OK;
+}
+int hp_ctx_set_force_generic(hp_ctx *ctx, int on) {
+    HP_ENTER(ctx);
+    ctx->force_generic = on != 0;
+    return HP_OK;
+}
+
+} // extern "C"

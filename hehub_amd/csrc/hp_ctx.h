@@ -1,0 +1,182 @@
+// hp_ctx.h -- engine-internal declarations shared by the C-ABI translation units:
+//   hp_ctx.cpp         context life cycle, streams, workspace, table / plan / gather-map caches, error strings
+//   hp_prof.cpp        in-library kernel timing (HIP events on the launch stream)
+//   hp_api_poly.cpp    drop-in host entry points, device-resident polynomial batches, encrypt / decrypt cores, base conversions
+//   hp_api_scheme.cpp  key switch, drop-last-prime, relinearisation, rotations, the mult pipelines, limb-range stages
+//   hp_api_hks.cpp     hybrid key switch (extension)
+//   hp_node.cpp        several contexts (GPUs) behind one handle: batch slices and the limb-sharded exchange
+// There is NO CPU fallback anywhere: every entry point launches HIP kernels or fails.
+#pragma once
+#include "../../include/hehub_amd.h"
+
+#include "hp_kernels.h"
+#include "hp_tables.h"
+
+#include <hip/hip_runtime.h>
+
+#include <initializer_list>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace hpi {
+
+struct DevTables {
+    u64x2 *fwd_ref = nullptr, *inv_ref = nullptr, *fwd_k = nullptr, *inv_k = nullptr;
+};
+
+struct Plan {
+    HpLimb *d_limbs = nullptr;
+    std::vector<hp::ModConsts> consts;
+};
+
+struct ProfEvent {
+    hipEvent_t a, b;
+};
+
+// caches of small device objects are bounded: when one is full it is emptied (after a device synchronise), not grown
+constexpr size_t MAX_PERMS = 64, MAX_CRT = 128, MAX_HKS = 16;
+
+} // namespace hpi
+
+struct hp_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_switch = nullptr;   // orders a newly selected stream after the work already enqueued on the previous one
+    std::mutex mu;
+    std::string err;
+    bool force_generic = false;
+    std::map<std::pair<u64, size_t>, hpi::DevTables> tables;          // (q, logn)
+    std::map<std::pair<size_t, std::vector<u64>>, hpi::Plan> plans;   // (logn, moduli); logn == 0: no transforms needed
+    std::map<std::pair<size_t, size_t>, u32 *> perms;                 // (logn, step mod N/2) -> gather map
+    std::map<std::pair<std::vector<u64>, u64>, HpCrtConsts *> crt;    // (old moduli, new modulus) -> CRT-branch constants
+    std::map<std::pair<std::vector<u64>, std::pair<size_t, size_t>>, HpHksConsts *> hks;   // (extended moduli, (k, alpha))
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    unsigned long ws_generation = 0;   // bumped whenever the workspace is reallocated or released (captured graphs go stale)
+    // profiling
+    std::string prof_family;
+    bool prof_on = false;
+    std::vector<hpi::ProfEvent> prof_events;
+    std::vector<hipEvent_t> event_pool;
+    // two auxiliary streams for software-pipelined sub-batches (dev_mult)
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t ev_start = nullptr, ev_done[2] = {nullptr, nullptr};
+    // knobs, read from the environment once when the context is created (all default to the measured-best setting)
+    int drop_group = 2;           // HP_DROP_GROUP=G: the same numbering for the fused drop launch (every limb reads one coefficient row)
+    int spread_group = 2;         // HP_SPREAD_GROUP=G: digit-spread launch numbered by groups of G moduli (0: modulus-major)
+    bool hks_two_step = false;    // HP_HKS_TWO_STEP: hybrid mult = switch, then a separate rescale (instead of the merged transform)
+    bool hks_combine_kernel = false;   // HP_HKS_COMBINE_KERNEL: the merged ModDown + rescale combination as its own kernel
+    bool no_fused_drop = false;   // HP_NO_FUSED_DROP: separate drop_rem / NTT / drop_fin launches
+    int mult_streams = 1;         // HP_MULT_STREAMS=2: software-pipeline two sub-batches in dev_mult
+    size_t mult_chunk = 0;        // HP_MULT_CHUNK: sub-batch size of dev_mult (0 = whole batch, or half with 2 streams)
+};
+
+namespace hpi {
+
+// ---- errors -----------------------------------------------------------------------------------------------
+// The message goes to the context AND to a per-thread slot, so that hp_last_error() on the failing thread returns the
+// message of ITS call even when another thread fails on the same context in between.
+int fail(hp_ctx *ctx, int code, const std::string &msg);
+
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess) return hpi::fail((ctx), HP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+// Host-side containers (table / plan / gather-map caches, profiling lists) may throw; nothing may cross the C ABI.
+template <class F> int contained(hp_ctx *ctx, F &&f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, HP_ENOMEM, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(ctx, HP_ELOGIC, e.what());
+    }
+}
+
+// a NULL operand would fault on the device and take the process down: reject it at the boundary
+inline bool any_null(std::initializer_list<const void *> ptrs) {
+    for (const void *p : ptrs)
+        if (!p) return true;
+    return false;
+}
+#define HP_REQUIRE(ctx, ...) \
+    if (hpi::any_null({__VA_ARGS__})) return hpi::fail(ctx, HP_EINVAL, "NULL pointer argument")
+// the kernels move 16 bytes per lane: device operands must be 16-byte aligned (every allocator's blocks are)
+inline bool any_misaligned(std::initializer_list<const void *> ptrs) {
+    for (const void *p : ptrs)
+        if ((uintptr_t)p & 15u) return true;
+    return false;
+}
+#define HP_ALIGNED(ctx, ...) \
+    if (hpi::any_misaligned({__VA_ARGS__})) return hpi::fail(ctx, HP_EINVAL, "device pointers must be 16-byte aligned")
+
+struct Guard {
+    hp_ctx *ctx;
+    std::unique_lock<std::mutex> lk;
+    explicit Guard(hp_ctx *c) : ctx(c), lk(c->mu) { (void)hipSetDevice(c->device); }
+};
+// first statement of every entry point: a NULL context is an argument error, not a crash; then the context lock
+#define HP_ENTER(ctx)                 \
+    if (!(ctx)) return HP_EINVAL;     \
+    hpi::Guard guard__(ctx)
+
+int chk(hp_ctx *ctx, hipError_t e, const char *what);
+int upload(hp_ctx *ctx, const void *host, size_t bytes, void **dptr);
+
+// ---- caches -----------------------------------------------------------------------------------------------
+int get_tables(hp_ctx *ctx, u64 q, size_t logn, DevTables &out);
+// device array of per-limb constants for a modulus chain; with_ntt == false skips the twiddles
+int get_plan(hp_ctx *ctx, size_t logn, const uint64_t *moduli, size_t count, bool with_ntt, const Plan **out);
+// gather map of cycle(poly, step) (permutation.cpp:39-53): out[to] = in[perm[to]]
+int get_cycle_perm(hp_ctx *ctx, size_t logn, size_t step, const u32 **out);
+int get_crt_consts(hp_ctx *ctx, const uint64_t *moduli, size_t L, u64 t, const HpCrtConsts **out);
+
+// ---- workspace --------------------------------------------------------------------------------------------
+// grow-only scratch; stream order makes reuse across calls safe (hp_ctx_set_stream orders streams, see hp_ctx.cpp)
+int ws_reserve(hp_ctx *ctx, size_t bytes);
+inline size_t padded(size_t words) { return (words * 8 + 255) & ~(size_t)255; }
+struct Carver {
+    char *base;
+    size_t off = 0;
+    explicit Carver(void *b) : base((char *)b) {}
+    u64 *take(size_t words) {
+        u64 *p = (u64 *)(base + off);
+        off += padded(words);
+        return p;
+    }
+};
+
+// ---- profiling brackets (hp_prof.cpp) -----------------------------------------------------------------------
+struct ProfScope {
+    hp_ctx *ctx;
+    bool on;
+    ProfEvent ev;
+    ProfScope(hp_ctx *c, const char *family);
+    ~ProfScope();
+};
+
+// ---- transforms -------------------------------------------------------------------------------------------
+inline bool logn_ok(size_t logn) { return logn >= 1 && logn <= 15; }
+inline bool tiled_ok(const hp_ctx *ctx, size_t logn) { return !ctx->force_generic && logn >= 11 && logn <= 15; }
+inline bool fused_drop_ok(const hp_ctx *ctx, size_t logn) { return tiled_ok(ctx, logn) && !ctx->no_fused_drop; }
+#define HP_LOGN_MSG "ring degrees 2^1 .. 2^15 are supported"
+int run_ntt(hp_ctx *ctx, const HpNttJob &job);
+HpNttJob batch_job(const Plan *plan, size_t logn, size_t L, size_t P, const u64 *src, u64 *dst, size_t src_ps, size_t dst_ps,
+                   int inverse, int strict);
+
+// ---- building blocks of the scheme-level pipelines (hp_api_scheme.cpp), also used by the hybrid key switch ----
+size_t ext_prod_ws_words(size_t n, size_t L, size_t P);
+size_t drop_ws_words(size_t n, size_t L, size_t P2);
+int ks_coef(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P, size_t j0, size_t j1, const u64 *pt, size_t pt_pstride,
+            u64 *coef);
+int drop_last(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, bool bgv, u64 t, const u64 *x, const u64 *addend,
+              size_t add_poly_stride, size_t add_ct_stride, u32 add_mask, u64 *out, Carver &cv);
+
+} // namespace hpi

@@ -234,9 +234,6 @@ HP_DEV u64 hp_sub_lazy(u64 a, u64 b, u64 two_q) {
 // items are numbered so that neighbours share a modulus (twiddle table); this
 // map hands XCD x the contiguous slice [x*W/8, (x+1)*W/8).
 HP_DEV u32 hp_xcd_remap(u32 b, u32 W) {
-#ifdef HP_NO_XCD_REMAP
-    return b;   // experiment: hardware round-robin, every XCD walks the whole item list with stride 8
-#endif
     const u32 per = W >> 3;
     if (b >= (per << 3)) return b; // tail that does not divide evenly
     return (b & 7u) * per + (b >> 3);

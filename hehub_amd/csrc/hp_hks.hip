@@ -153,11 +153,8 @@ __global__ void __launch_bounds__(HKS_THREADS) k_hks_inner(const HpLimb *__restr
 hipError_t hp_launch_hks_inner(const HpLimb *limbs, u32 L, u32 E, u32 nd, u32 alpha, u32 n, u32 P, const u64 *lifted, const u64 *pt,
                                u32 pt_pstride, const u64 *key, u64 *out, hipStream_t stream) {
     u32 chunks; dim3 grid;
-    static const int pt_env = getenv("HP_HKS_PT") ? atoi(getenv("HP_HKS_PT")) : 2;   // ciphertexts per thread (4: the column accumulators halve the occupancy, -5 %)
-    if (P >= 2 && pt_env >= 4) {
-        hks_grid(n, ((P + 3) / 4) * E, chunks, grid);
-        k_hks_inner<4><<<grid, HKS_THREADS, 0, stream>>>(limbs, L, E, nd, alpha, P, n, chunks, lifted, pt, pt_pstride, key, out);
-    } else if (P >= 2) {
+    // two ciphertexts per thread (four: the column accumulators halve the occupancy, measured -5 %)
+    if (P >= 2) {
         hks_grid(n, ((P + 1) / 2) * E, chunks, grid);
         k_hks_inner<2><<<grid, HKS_THREADS, 0, stream>>>(limbs, L, E, nd, alpha, P, n, chunks, lifted, pt, pt_pstride, key, out);
     } else {

@@ -41,11 +41,6 @@ struct HpNttJob {
     // multiplication BEFORE the strict reduction (mod_switch.cpp:49-50); s_h == 0 and s == 0 -> off
     u64 post_scalar, post_scalar_h;
     int use_post_scalar;
-    // Phase staggering of the first dispatch wave (tiled kernels): workgroup b < stagger_first sleeps
-    // ((b >> 3) % stagger_phases) * stagger_ticks before it starts.  All workgroups take the same
-    // time, so without this every CU would load, compute and store in lockstep and HBM would sit
-    // idle while the whole chip multiplies, then saturate while the whole chip loads.
-    u32 stagger_first, stagger_phases, stagger_ticks;
 };
 
 hipError_t hp_launch_ntt_generic(const HpNttJob &job, hipStream_t stream);

@@ -30,17 +30,8 @@
 #include "hp_kernels.h"
 #include "hp_ntt_job.h"
 
-#include <cstdlib>
-
 namespace {
 
-// Cap the kernels' VGPR allocation below the 128 of "4 waves per SIMD" to leave room in the register file for
-// waves of other (HBM-bound, low-register) kernels running next to a transform workgroup on the same CU.
-#ifdef HP_NTT_NUM_VGPR
-#define HP_NTT_VGPR_ATTR __attribute__((amdgpu_num_vgpr(HP_NTT_NUM_VGPR)))
-#else
-#define HP_NTT_VGPR_ATTR
-#endif
 
 template <int LOGN> struct Geo {
     static constexpr int A = LOGN - 10;          // stages of pass A (1..5)
@@ -63,9 +54,7 @@ HP_DEV u64 mk64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 // Twiddle loads run TW_DEPTH slots ahead of their use through a small register ring; scheduling
 // barriers keep the compiler from hoisting all 31 loads (124 VGPRs) to the top of the pass, which
 // would push the kernel past the 128-VGPR budget of 4 waves per SIMD.
-#ifndef TW_DEPTH
-#define TW_DEPTH 4
-#endif
+constexpr int TW_DEPTH = 4;     // deeper rings spill (measured)
 
 typedef u64 __attribute__((ext_vector_type(2))) u64v2;
 typedef const u64v2 __attribute__((address_space(1))) * gptr_u64x2;
@@ -93,9 +82,7 @@ struct GTab {
 //       loads are scalar (s_load_dwordx4 through the scalar cache) and take no vector-memory slots.
 typedef const u64v2 __attribute__((address_space(4))) * cptr_u64x2;
 typedef const HpLimb __attribute__((address_space(4))) * cptr_limb;
-#ifndef STAB_DEPTH
-#define STAB_DEPTH 4
-#endif
+constexpr int STAB_DEPTH = 4;   // 2 / 8 / 16 measured the same or worse
 struct STab {
     static constexpr int depth = STAB_DEPTH;   // held in SGPRs; SMEM returns out of order, so every use waits for all of them
     cptr_u64x2 p;
@@ -150,12 +137,7 @@ HP_DEV void pass_slots(u64 (&x)[32], u64x2 (&ring)[D], const Tab &tbl, u32 ncls,
                     lazy_swap(x, ra);          // rb == ra + 1: one 16-byte load
                     lazy_swap(x, ra | bit);
                 }
-#ifdef HP_SINGLE_BFLY   // tuning experiment: one butterfly at a time
-                hp_butterfly_nq(x[ra], x[ra | bit], tw.x, tw.y, two_q, n0, n1);
-                hp_butterfly_nq(x[rb], x[rb | bit], tw.x, tw.y, two_q, n0, n1);
-#else
                 hp_butterfly2_nq(x[ra], x[ra | bit], x[rb], x[rb | bit], tw.x, tw.y, tw.x, tw.y, two_q, n0, n1);
-#endif
                 if (o & 2) __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (cnt == 2) { if constexpr (S & 1) __builtin_amdgcn_sched_barrier(0); }
@@ -165,12 +147,7 @@ HP_DEV void pass_slots(u64 (&x)[32], u64x2 (&ring)[D], const Tab &tbl, u32 ncls,
             const u64x2 tw2 = ring[(S + 1 - S0) % D];
             if constexpr (S + 1 + D < S1) ring[(S + 1 - S0) % D] = tbl((u32)(S + 1 + D) * ncls + cls);
             constexpr int ra = slot_reg<FWD>(S, 0), rb = slot_reg<FWD>(S + 1, 0);
-#ifdef HP_SINGLE_BFLY
-            hp_butterfly_nq(x[ra], x[ra | bit], tw.x, tw.y, two_q, n0, n1);
-            hp_butterfly_nq(x[rb], x[rb | bit], tw2.x, tw2.y, two_q, n0, n1);
-#else
             hp_butterfly2_nq(x[ra], x[ra | bit], x[rb], x[rb | bit], tw.x, tw.y, tw2.x, tw2.y, two_q, n0, n1);
-#endif
             if constexpr (((S - 15) & 2) != 0) __builtin_amdgcn_sched_barrier(0);
             pass_slots<FWD, S + 2, S0, S1, D>(x, ring, tbl, ncls, cls, two_q, n0, n1);
         }
@@ -179,18 +156,6 @@ HP_DEV void pass_slots(u64 (&x)[32], u64x2 (&ring)[D], const Tab &tbl, u32 ncls,
 
 template <bool FWD, int S0, int S1, int D, class Tab, bool LZ = false>
 HP_DEV void run_pass(u64 (&x)[32], const Tab tbl, u32 ncls, u32 cls, u64 nq, u64 two_q) {
-#ifdef HP_ABLATE_PASS   // tuning experiment only (wrong results): no butterflies
-    return;
-#endif
-#ifdef HP_ABLATE_TW     // tuning experiment only (wrong results): one twiddle for the whole pass
-    ncls = 0; cls = 0;
-#endif
-#ifdef HP_ABLATE_TW_GLOBAL   // tuning experiment only (wrong results): no per-thread global twiddle traffic
-    if (Tab::depth != 2 && ncls > 32) { ncls = 0; cls = 0; }
-#endif
-#ifdef HP_ABLATE_TW_LDS      // tuning experiment only (wrong results): no LDS twiddle reads
-    if (Tab::depth == 2) { ncls = 0; cls = 0; }
-#endif
     u64x2 ring[D];
 #pragma unroll
     for (int s = S0; s < S0 + D; ++s)
@@ -284,9 +249,6 @@ HP_DEV u32 &lds_w(u32 *lds, u32 byte_off) { return *reinterpret_cast<u32 *>(rein
 // confined to the wave's own 2048-word region and relies on in-order LDS execution per wave.
 template <int LOGN, int FROM, int TO, bool WG>
 HP_DEV void exchange(u64 (&x)[32], u32 *lds, const Addr<LOGN> &ad) {
-#ifdef HP_ABLATE_EXCH   // tuning experiment only (wrong results): no LDS transposition
-    return;
-#endif
     u32 keep[32];
     {
         const u32 fb = opaque(lay_base<LOGN, FROM>(ad));
@@ -317,44 +279,23 @@ HP_DEV void exchange(u64 (&x)[32], u32 *lds, const Addr<LOGN> &ad) {
     }
 }
 
-#ifndef HP_EPI_DEPTH
-#define HP_EPI_DEPTH 4   // rows of the fused drop epilogue whose operand loads are in flight
-#endif
+constexpr int HP_EPI_DEPTH = 4;   // rows of the fused drop epilogue whose operand loads are in flight
 
 struct alignas(16) V2 {
     u64 x, y;
 };
 
-HP_DEV void stagger_start(const HpNttJob &job) {
-    if (blockIdx.x < job.stagger_first && job.stagger_phases > 1) {
-        // stagger_phases >= 0x100: experiment, offset the workgroups that share a CU (dispatch fills the 32 CUs of an
-        // XCD once before it doubles up) instead of neighbouring CUs
-        const u32 phase = (job.stagger_phases >= 0x100) ? ((blockIdx.x >> 3) / 32u) % (job.stagger_phases & 0xffu)
-                                                        : (blockIdx.x >> 3) % job.stagger_phases;
-        const u64 until = __builtin_amdgcn_s_memtime() + (u64)phase * job.stagger_ticks;
-        while (__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(32);
-    }
-}
-
 // Streaming accesses to coefficient data are marked non-temporal so that the once-read, once-written
 // limbs do not push the twiddle tables (re-read by every workgroup) out of L2: +3.5..5 % on every
 // transform shape (HP_TEMPORAL_DATA restores plain accesses for A/B runs).
 HP_DEV V2 ld_stream(const u64 *p) {
-#ifndef HP_TEMPORAL_DATA
     typedef u64 __attribute__((ext_vector_type(2))) vv;
     const vv v = __builtin_nontemporal_load(reinterpret_cast<const vv *>(p));
     return V2{v.x, v.y};
-#else
-    return *reinterpret_cast<const V2 *>(p);
-#endif
 }
 HP_DEV void st_stream(u64 *p, const V2 &v) {
-#ifndef HP_TEMPORAL_DATA
     typedef u64 __attribute__((ext_vector_type(2))) vv;
     __builtin_nontemporal_store(vv{v.x, v.y}, reinterpret_cast<vv *>(p));
-#else
-    *reinterpret_cast<V2 *>(p) = v;
-#endif
 }
 
 // value held by the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2], no LDS involved
@@ -387,11 +328,7 @@ __device__ u64 g_trace[2 * 2048 * 16 * HP_TRACE_SLOTS];
 #endif
 
 // ---- forward kernel ----------------------------------------------------------------------------
-#ifdef HP_LOAD_SEQUENTIAL   // A/B switch: loads in row order
-#define HP_LOAD_ORDER(t) (t)
-#else
 #define HP_LOAD_ORDER(t) (((t) >> 1) | (((t) & 1) << 3))
-#endif
 // load, layout A: thread reads 2^PB consecutive coefficients at 2^A places 1024 apart
 template <int LOGN, bool LZ = false>
 HP_DEV void load_flight(const u64 *src, u32 tid, u64 (&x)[32]) {
@@ -419,11 +356,7 @@ HP_DEV void load_flight(const u64 *src, u32 tid, u64 (&x)[32]) {
 #pragma unroll
     for (int tk = 0; tk < (G::PB == 0 ? 0 : (1 << G::A)); ++tk) {
         // same idea as above: the first stage pairs place kk with kk + 2^(A-1)
-#ifdef HP_LOAD_SEQUENTIAL
-        const int kk = tk;
-#else
         const int kk = (tk >> 1) | ((tk & 1) << (G::A - 1));
-#endif
         if (G::PB == 0) {
         } else {
 #pragma unroll
@@ -447,17 +380,6 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
     const u32 w = hp_xcd_remap(blockIdx.x, job.W);
     HpItem it;
     if (!hp_decode_item(job, w, it)) return;
-    stagger_start(job);
-#ifdef HP_PRIO_SKEW
-    // experiment: the four waves that share a SIMD get different issue priorities so that they drift apart after
-    // the one workgroup-wide exchange and overlap each other's LDS / memory phases with integer multiplies
-    switch ((threadIdx.x >> 8) & 3u) {
-    case 0: __builtin_amdgcn_s_setprio(HP_PRIO_SKEW == 2 ? 0 : 3); break;
-    case 1: __builtin_amdgcn_s_setprio(HP_PRIO_SKEW == 2 ? 3 : 2); break;
-    case 2: __builtin_amdgcn_s_setprio(HP_PRIO_SKEW == 2 ? 0 : 1); break;
-    default: __builtin_amdgcn_s_setprio(HP_PRIO_SKEW == 2 ? 3 : 0); break;
-    }
-#endif
     // the limb's constants and table pointers through the scalar cache (constant address space): as vector loads they would
     // queue behind the coefficient loads and the first pass could not start before nearly all of those are back
     const cptr_limb lp = (cptr_limb)(job.limbs + __builtin_amdgcn_readfirstlane(it.limb));
@@ -473,11 +395,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
     TRACE_DECL
     TRACE_MARK();
     u64 x[32];
-#ifdef HP_EAGER_SWAP   // A/B switch
-    constexpr bool LZ = false;
-#else
     constexpr bool LZ = !DROP && G::PB == 0;
-#endif
     load_flight<LOGN, LZ>(it.src, tid, x);
     if (tid < 31u * (1u << G::A)) lds_tw[tid] = stg;
     if (DROP) {
@@ -558,13 +476,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
     exchange<LOGN, LAY_A, LAY_B, true>(x, lds, ad);
     TRACE_MARK();   // 3
     // pass B: global stages A+1..A+5, twiddles depend on the 1024-block
-#if defined(HP_EXP_B_CLS0)      // tuning experiment (wrong results): every half-wave reads block 0's twiddles
-    fwd_pass<4, 0>(x, LTab(lds_tw), 1u << G::A, 0u, nq, two_q);
-#elif defined(HP_EXP_B_GLOBAL)  // tuning experiment: middle-pass twiddles straight from global memory
-    fwd_pass<4, 0>(x, GTab(lp->fwd_k), 1u << G::A, tid >> 5, nq, two_q);
-#else
     fwd_pass<4, 0>(x, LTab(lds_tw), 1u << G::A, tid >> 5, nq, two_q);
-#endif
     TRACE_MARK();   // 4
     exchange<LOGN, LAY_B, LAY_C, false>(x, lds, ad);
     TRACE_MARK();   // 5
@@ -645,36 +557,25 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
 }
 
 template <int LOGN>
-__global__ void HP_NTT_VGPR_ATTR __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd(HpNttJob job) {
+__global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd(HpNttJob job) {
     ntt_fwd_body<LOGN, false>(job, nullptr);
 }
 
 // forward NTT with the drop-last-prime prologue/epilogue fused in (HpDropArgs in kernel-argument memory)
 template <int LOGN, int FLAV>
-__global__ void HP_NTT_VGPR_ATTR __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd_drop(HpNttJob job, HpDropArgs da) {
+__global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd_drop(HpNttJob job, HpDropArgs da) {
     ntt_fwd_body<LOGN, true, FLAV>(job, &da);
 }
 
 // ---- inverse kernel ----------------------------------------------------------------------------
 template <int LOGN, bool STRICT, bool PSCAL>
-__global__ void HP_NTT_VGPR_ATTR __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_inv(HpNttJob job) {
+__global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_inv(HpNttJob job) {
     using G = Geo<LOGN>;
     __shared__ u32 lds[G::N];
     __shared__ u64v2 lds_tw[31 * 32];
     const u32 w = hp_xcd_remap(blockIdx.x, job.W);
     HpItem it;
     if (!hp_decode_item(job, w, it)) return;
-    stagger_start(job);
-#ifdef HP_PRIO_SKEW
-    // experiment: the four waves that share a SIMD get different issue priorities so that they drift apart after
-    // the one workgroup-wide exchange and overlap each other's LDS / memory phases with integer multiplies
-    switch ((threadIdx.x >> 8) & 3u) {
-    case 0: __builtin_amdgcn_s_setprio(HP_PRIO_SKEW == 2 ? 0 : 3); break;
-    case 1: __builtin_amdgcn_s_setprio(HP_PRIO_SKEW == 2 ? 3 : 2); break;
-    case 2: __builtin_amdgcn_s_setprio(HP_PRIO_SKEW == 2 ? 0 : 1); break;
-    default: __builtin_amdgcn_s_setprio(HP_PRIO_SKEW == 2 ? 3 : 0); break;
-    }
-#endif
     // the limb's constants and table pointers through the scalar cache (constant address space): as vector loads they would
     // queue behind the coefficient loads and the first pass could not start before nearly all of those are back
     const cptr_limb lp = (cptr_limb)(job.limbs + __builtin_amdgcn_readfirstlane(it.limb));
@@ -733,13 +634,8 @@ __global__ void HP_NTT_VGPR_ATTR __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = r0 + e;
-#ifdef HP_INV_C_HARVEY   // A/B switch: the compiler's multiplication
-                u64 v = hp_harvey_lazy(hp_shift_fold(x[r], q, k, fix), f[e].x, f[e].y, q);
-                if (PSCAL) v = hp_harvey_lazy(v, psc, psh, q);
-#else
                 u64 v = hp_harvey_lazy_nq(hp_shift_fold(x[r], q, k, fix), f[e].x, f[e].y, (u32)nq, (u32)(nq >> 32));
                 if (PSCAL) v = hp_harvey_lazy_nq(v, psc, psh, (u32)nq, (u32)(nq >> 32));
-#endif
                 if (STRICT) v = hp_strict(v, q);
                 x[r] = v;
             }
@@ -771,25 +667,7 @@ __global__ void HP_NTT_VGPR_ATTR __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW
     }
 }
 
-template <int LOGN> hipError_t launch(const HpNttJob &job_in, hipStream_t stream) {
-    HpNttJob job = job_in;
-    {
-        // first dispatch wave = CUs x resident workgroups per CU (LDS- and VGPR-limited)
-        static int cus = 0;
-        if (!cus) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-            else cus = 256;
-        }
-        const u32 per_cu = (u32)(1024 / Geo<LOGN>::T);
-        static const char *e_ph = getenv("HP_STAGGER_PHASES"), *e_tk = getenv("HP_STAGGER_TICKS");
-        const u32 phases = e_ph ? (u32)atoi(e_ph) : 1u;   // off by default: measured no gain (profiles/)
-        const u32 ticks = e_tk ? (u32)atoi(e_tk) : (u32)(10000u >> (15 - LOGN));
-        job.stagger_first = (job.W > 2u * cus * per_cu) ? cus * per_cu : 0u;   // only worth it for long launches
-        job.stagger_phases = phases;
-        job.stagger_ticks = ticks;
-    }
+template <int LOGN> hipError_t launch(const HpNttJob &job, hipStream_t stream) {
     if (!job.inverse) k_ntt_fwd<LOGN><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
     else if (job.use_post_scalar && job.strict) k_ntt_inv<LOGN, true, true><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
     else if (job.use_post_scalar) return hipErrorNotSupported;
@@ -808,9 +686,8 @@ extern "C" int hp_debug_trace(u64 *out, size_t words) {
 
 template <int LOGN>
 static hipError_t launch_drop(const HpNttJob &job, const HpDropArgs &da, hipStream_t stream) {
-    static const bool generic_only = getenv("HP_DROP_GENERIC") != nullptr;   // A/B switch
     int flav = 0;
-    if (!generic_only && !da.fin_on && !da.raw_input && !da.comb) {
+    if (!da.fin_on && !da.raw_input && !da.comb) {
         if (!da.addend || da.add_mask == 0) flav = 1;
         else if (da.add_mask == 3u) flav = 2;
         if (flav && da.dc.bgv) flav += 2;

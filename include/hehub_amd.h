@@ -14,8 +14,9 @@
  *
  * Conventions
  *   - plain C: pointers, sizes, integers.  No torch / STL types.
- *   - every function returns an hp_status; nothing throws across the ABI.
- *     hp_last_error(ctx) gives the message for the last failure on that ctx.
+ *   - every function returns an hp_status; nothing throws across the ABI; a NULL
+ *     ctx is HP_EINVAL.  hp_last_error(ctx) gives the message of the calling
+ *     thread's last failure on that ctx (valid until its next hp_* call).
  *   - one hp_ctx per GPU; calls on one ctx are serialised by an internal
  *     mutex; different ctxs are independent.
  *   - "host" entry points take caller-owned host pointers, are synchronous and
@@ -62,16 +63,22 @@ void hp_ctx_destroy(hp_ctx *ctx);
 const char *hp_last_error(hp_ctx *ctx);
 const char *hp_version(void);
 /* enqueue on an existing hipStream_t (e.g. torch's current stream); NULL = the HIP default stream.
- * A fresh ctx uses a private non-blocking stream; hp_ctx_reset_stream goes back to it.
+ * A fresh ctx uses a private non-blocking stream; hp_ctx_reset_stream goes back to it.  Switching streams keeps device
+ * order: the new stream first waits (event, no host synchronisation) for everything the ctx enqueued on the previous one,
+ * because the scratch workspace and the cached tables are shared by all calls of a ctx.
  * HIP graphs: the first hp_dev_* call with a new (ring degree, moduli, shape) builds tables / constants and may grow the
  * workspace (allocations and host-to-device copies); every later call with the same parameters only enqueues kernels on the
- * ctx stream, so it can be recorded with hipStreamBeginCapture on that stream and replayed (tests/test_gpu_parity.py). */
+ * ctx stream, so it can be recorded with hipStreamBeginCapture on that stream and replayed (tests/test_gpu_parity.py).
+ * A later call that needs a LARGER workspace drains the device, frees the old block and allocates a new one: graphs captured
+ * before that hold stale scratch pointers and must be re-captured -- hp_ctx_workspace_generation() changes whenever that
+ * happened (also on hp_ctx_release_workspace).  Warm up with the largest shape first to avoid it. */
 int hp_ctx_set_stream(hp_ctx *ctx, void *hip_stream);
 int hp_ctx_reset_stream(hp_ctx *ctx);
 void *hp_ctx_get_stream(hp_ctx *ctx);
 int hp_sync(hp_ctx *ctx);
 /* the engine's scratch workspace grows to the largest call so far and is reused; these report / release it */
 size_t hp_ctx_workspace_bytes(hp_ctx *ctx);
+unsigned long hp_ctx_workspace_generation(hp_ctx *ctx);
 int hp_ctx_release_workspace(hp_ctx *ctx);
 int hp_dev_alloc(hp_ctx *ctx, size_t bytes, void **dptr);
 int hp_dev_free(hp_ctx *ctx, void *dptr);
