@@ -103,6 +103,7 @@ int hp_wire_unpack(const void *buf, size_t len, hp_wire_desc *d, uint64_t *modul
 }
 
 int hp_dev_wire_load(hp_ctx *ctx, const void *buf, size_t len, uint64_t *d_words) {
+    if (!ctx || !buf || !d_words) return HP_EINVAL;
     hp_wire_desc d;
     size_t off = 0;
     int rc = hp_wire_unpack(buf, len, &d, nullptr, 0, &off);
@@ -113,6 +114,7 @@ int hp_dev_wire_load(hp_ctx *ctx, const void *buf, size_t len, uint64_t *d_words
 
 int hp_dev_wire_store(hp_ctx *ctx, const hp_wire_desc *d, const uint64_t *moduli, const uint64_t *d_words, void *buf,
                       size_t cap) {
+    if (!ctx || !d || !d_words) return HP_EINVAL;
     const size_t total = hp_wire_bytes(d);
     if (total == 0 || !moduli || !buf || cap < total) return HP_EINVAL;
     unsigned char *b = (unsigned char *)buf;

@@ -69,7 +69,7 @@ struct CallCounter {
 void check(int rc) {
     g_calls.n++;
     if (rc == HP_OK) return;
-    std::string msg = hp_last_error(amd::engine());
+    std::string msg = hp_last_error(amd::engine());   // the calling thread's own last failure (hp_ctx.cpp)
     if (rc == HP_EINVAL) throw std::invalid_argument(msg);
     if (rc == HP_ELOGIC) throw std::logic_error(msg);
     throw std::runtime_error("hehub_amd: " + msg);
@@ -206,8 +206,12 @@ public:
                     const u64 *w = rgsw[j][h][(int)k].data();
                     sig.insert(sig.end(), {w[0], w[n / 3], w[(2 * n) / 3], w[n - 1]});
                 }
-        static std::mutex mu;
-        static std::vector<std::pair<std::vector<u64>, std::shared_ptr<DevBuf>>> cache;   // most recently used last
+        // Heap-allocated and never destroyed on purpose: a static object's destructor would run hipFree during static
+        // destruction at process exit, when the HIP runtime may already be gone (crash or hang at exit).  The cached
+        // device blocks go back with the process.
+        typedef std::vector<std::pair<std::vector<u64>, std::shared_ptr<DevBuf>>> Cache;   // most recently used last
+        static std::mutex &mu = *new std::mutex;
+        static Cache &cache = *new Cache;
         std::lock_guard<std::mutex> lock(mu);
         for (size_t i = 0; i < cache.size(); i++)
             if (cache[i].first == sig) {

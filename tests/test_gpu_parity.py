@@ -390,3 +390,65 @@ def test_pipeline_is_capturable_in_a_hip_graph(eng, orc):
         assert np.array_equal(eng.to_host(out), exp(ct2, ct1))
     finally:
         eng.use_stream(torch.cuda.current_stream())
+
+
+def test_stream_switches_keep_device_order(eng, orc):
+    """all calls of a context share one scratch workspace, so switching the context to another stream must
+    not let new work overtake what is queued on the previous one.  Calls alternate between two side streams with no
+    host synchronisation in between; every result must equal the oracle's."""
+    import torch
+
+    logn, L = 13, 4
+    mext = P.P40[:L] + [P.P50[0]]
+    n, B, rounds = 1 << logn, 24, 6
+    rng = SplitMix(4242)
+    base1 = rng.poly((3, 2, L, n), mext[:L]); base2 = rng.poly((3, 2, L, n), mext[:L])
+    key = rng.poly((L, 2, L + 1, n), mext)
+    idx = torch.arange(B, device="cuda:0") % 3
+    d1 = eng.to_device(base1).index_select(0, idx).contiguous(); d2 = eng.to_device(base2).index_select(0, idx).contiguous()
+    dk = eng.to_device(key)
+    exp = [np.stack([orc.ckks_mult(mext, base1[c], base2[c], key) for c in range(3)]),
+           np.stack([orc.ckks_mult(mext, base2[c], base2[c], key) for c in range(3)])]
+    outs = [eng.empty((B, 2, L - 1, n)) for _ in range(rounds)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    try:
+        for r in range(rounds):
+            eng.use_stream(streams[r & 1])
+            eng.ckks_mult(mext, d1 if r % 2 == 0 else d2, d2, dk, out=outs[r])
+        torch.cuda.synchronize()
+    finally:
+        eng.use_stream(torch.cuda.current_stream())
+    for r in range(rounds):
+        got = eng.to_host(outs[r])
+        for i in range(B):
+            assert np.array_equal(got[i], exp[r % 2][i % 3]), (r, i)
+
+
+def test_workspace_generation_and_per_thread_errors(eng):
+    """the workspace generation counter moves when the scratch block is replaced (captured graphs go stale); an error
+    message belongs to the thread whose call failed"""
+    import threading
+
+    from hehub_amd.engine import InvalidArgument
+
+    eng.release_workspace()
+    g0 = eng.lib.hp_ctx_workspace_generation(eng.h)
+    eng.ckks_rescale(P.P40[:3], eng.empty((1, 2, 3, 2048)))
+    g1 = eng.lib.hp_ctx_workspace_generation(eng.h)
+    eng.ckks_rescale(P.P40[:3], eng.empty((1, 2, 3, 2048)))          # same shape: no reallocation
+    assert g1 > g0 and eng.lib.hp_ctx_workspace_generation(eng.h) == g1
+    eng.ckks_rescale(P.P40[:3], eng.empty((4, 2, 3, 2048)))          # larger: replaced
+    assert eng.lib.hp_ctx_workspace_generation(eng.h) > g1
+    msgs = {}
+
+    def worker(name, fn):
+        try:
+            fn()
+        except InvalidArgument as e:
+            msgs[name] = e.msg
+
+    t1 = threading.Thread(target=worker, args=("drop", lambda: eng.ckks_rescale([P.P40[0]], eng.empty((1, 2, 1, 8)))))
+    t2 = threading.Thread(target=worker, args=("ntt", lambda: eng.ntt_([12289], eng.empty((1, 1, 1 << 15)))))
+    t1.start(); t2.start(); t1.join(); t2.join()
+    assert "Unable to drop the only one prime" in msgs["drop"] and "2N doesn't divide" in msgs["ntt"]
