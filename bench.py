@@ -346,17 +346,17 @@ def rate_entry(units_per_launch, bytes_per_unit, steps, world, dt, launches, ker
 
 def transform_rates(torch, hd, eng, P, args, world, dev, rank):
     """forward / inverse limb transforms at N = 4096 .. 32768 (north star: "NTT/INTT ... at N in {4096..32768}"), the C3
-    moduli (2^16 | q - 1 for all of them), 512 MiB per pass; every launch checked against the checker on a periodic
-    batch afterwards"""
+    ciphertext moduli (2^16 | q - 1 for all of them), 2.5 GiB in place per launch = the limbs of the C3 ciphertext batch (5120 at
+    N = 32768, 20 per CU); one application of each transform checked against the checker on the periodic batch afterwards"""
     import numpy as np
 
-    moduli = P.C3_MODULI_EXT
+    moduli = P.C3_Q
     L = len(moduli)
     out = {}
     lib = None if args.no_verify else checker()[0]
     for logn in (12, 13, 14, 15):
         n = 1 << logn
-        B = (512 << 20) // (8 * n * L)          # polynomials of L limbs: 512 MiB in place
+        B = (512 << 15) // n                    # the bytes of the C3 ciphertext batch (256 x 2 polynomials of 10 limbs at N = 32768)
         xb = Batch(torch, B, (L, n), moduli, dev, 40 + logn + 100 * rank, 3)
         x = xb.full
         ent = {"N": n, "limbs_per_launch": B * L}

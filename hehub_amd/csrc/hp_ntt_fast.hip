@@ -568,27 +568,54 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd_drop(
 }
 
 // ---- inverse kernel ----------------------------------------------------------------------------
+// The middle pass of the inverse stages 31 x 32 twiddle pairs (15.5 KiB) in LDS whatever N is.  With one limb per workgroup
+// that stage caps the occupancy of the small sizes (N = 4096: 16 + 15.5 KiB per two waves -> 5 workgroups = 2.5 waves per
+// SIMD, VALUBusy 42 %).  So for N <= 8192 a workgroup transforms LPW limbs OF ONE MODULUS side by side and shares the stage:
+// 512 threads, 4 N LPW + 15.5 KiB = 80 KiB of LDS, two workgroups = four waves per SIMD on a CU.
+template <int LOGN> struct InvGeo {
+    static constexpr int LPW = LOGN >= 14 ? 1 : (512 >> (LOGN - 5));   // limbs per workgroup: 2^11 -> 8, 2^12 -> 4, 2^13 -> 2
+    static constexpr int TT = Geo<LOGN>::T * LPW;                      // threads per workgroup
+    static constexpr bool STREAM_EPILOGUE = LOGN <= 13;                // see the end of k_ntt_inv
+};
+
 template <int LOGN, bool STRICT, bool PSCAL>
-__global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_inv(HpNttJob job) {
+__global__ void __launch_bounds__(InvGeo<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv(HpNttJob job) {
     using G = Geo<LOGN>;
-    __shared__ u32 lds[G::N];
+    constexpr int LPW = InvGeo<LOGN>::LPW, TT = InvGeo<LOGN>::TT;
+    __shared__ u32 lds_all[G::N * LPW];
     __shared__ u64v2 lds_tw[31 * 32];
-    const u32 w = hp_xcd_remap(blockIdx.x, job.W);
+    const u32 sub = threadIdx.x / G::T, tid = threadIdx.x % G::T;   // limb of the workgroup, thread within the limb
+    u32 *lds = lds_all + sub * G::N;
     HpItem it;
-    if (!hp_decode_item(job, w, it)) return;
+    bool active = true;
+    if (LPW == 1) {
+        const u32 w = hp_xcd_remap(blockIdx.x, job.W);
+        if (!hp_decode_item(job, w, it)) return;
+    } else {
+        // HP_NTT_BATCH only (every inverse launch is one): ceil(P / LPW) workgroups per modulus, modulus-major like the item
+        // numbering; a group past the last polynomial re-reads the last one and stores nothing
+        const u32 bpm = (job.P + LPW - 1) / LPW;
+        const u32 wb = hp_xcd_remap(blockIdx.x, job.L * bpm);
+        const u32 k = wb / bpm, p0 = (wb % bpm) * LPW + sub;
+        active = p0 < job.P;
+        const u32 p = active ? p0 : job.P - 1;
+        it.src = job.src + ((size_t)p * job.src_pstride + (size_t)k * job.src_kstride) * G::N;
+        it.dst = job.dst + ((size_t)p * job.dst_pstride + k) * G::N;
+        it.limb = k;
+        it.poly = p;
+    }
     // the limb's constants and table pointers through the scalar cache (constant address space): as vector loads they would
     // queue behind the coefficient loads and the first pass could not start before nearly all of those are back
     const cptr_limb lp = (cptr_limb)(job.limbs + __builtin_amdgcn_readfirstlane(it.limb));
     const u64 q = lp->q, two_q = lp->two_q, nq = lp->neg_q;
-    const u32 tid = threadIdx.x;
     Addr<LOGN> ad;
     ad.init(tid);
-    // stage the middle pass's twiddles (31 x 32 pairs; a few per thread when T < 992)
-    constexpr int NSTG = (31 * 32 + G::T - 1) / G::T;
+    // stage the middle pass's twiddles (31 x 32 pairs; a few per thread when the workgroup has fewer than 992 threads)
+    constexpr int NSTG = (31 * 32 + TT - 1) / TT;
     u64v2 stg[NSTG];
 #pragma unroll
     for (int i = 0; i < NSTG; ++i) {
-        const u32 e = tid + (u32)i * G::T;
+        const u32 e = threadIdx.x + (u32)i * TT;
         stg[i] = (e < 31u * 32u) ? ((gptr_u64x2)(lp->inv_k + 31))[e] : u64v2{0, 0};
     }
 
@@ -604,7 +631,7 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_inv(HpNtt
     }
 #pragma unroll
     for (int i = 0; i < NSTG; ++i) {
-        const u32 e = tid + (u32)i * G::T;
+        const u32 e = threadIdx.x + (u32)i * TT;
         if (e < 31u * 32u) lds_tw[e] = stg[i];
     }
     __syncthreads();   // the staged twiddles are read by other waves in pass B' (the exchanges before it are wave-local)
@@ -617,6 +644,39 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_inv(HpNtt
     exchange<LOGN, LAY_B, LAY_A, true>(x, lds, ad);
     // pass C': levels 10..logN-1, per-thread twiddles
     inv_pass<G::PB, 4>(x, GTab(lp->inv_k + 31 + 31 * 32), (u32)G::T, tid, nq, two_q);
+    if constexpr (InvGeo<LOGN>::STREAM_EPILOGUE) {
+        // N <= 8192: in layout A a thread owns 2^PB >= 4 consecutive coefficients, so a 16-byte store instruction would write
+        // a quarter or half of every cache line it touches: measured 1.9 x the algorithmic write traffic at N = 4096
+        // (WRITE_SIZE, rocprofv3).  Fold in place, transpose once more (layout S, as the forward kernel stores), then the
+        // psi^-i N^-1 pairs are read and the words written 16 contiguous bytes per lane, 1 KiB per wave instruction.
+        const u32 k = lp->k, fix = lp->fix;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) x[r] = hp_shift_fold(x[r], q, k, fix);
+        exchange<LOGN, LAY_A, LAY_S, true>(x, lds, ad);
+        if (!active) return;   // (after the last barrier of the kernel)
+        const size_t off = (((size_t)(tid >> 6)) << 11) + ((tid & 63u) << 1);
+        const gptr_u64x2 sc = (gptr_u64x2)(lp->inv_ref + G::N + off);
+        u64 *d = it.dst + off;
+        const u64 psc = job.post_scalar, psh = job.post_scalar_h;
+#pragma unroll
+        for (int s0 = 0; s0 < 16; s0 += 2) {
+            u64x2 f[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[e] = gload(sc, ((size_t)(s0 + (e >> 1)) << 7) + (e & 1));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 2 * s0 + e;
+                u64 v = hp_harvey_lazy_nq(x[r], f[e].x, f[e].y, (u32)nq, (u32)(nq >> 32));
+                if (PSCAL) v = hp_harvey_lazy_nq(v, psc, psh, (u32)nq, (u32)(nq >> 32));
+                if (STRICT) v = hp_strict(v, q);
+                x[r] = v;
+            }
+            st_stream(d + ((size_t)s0 << 7), V2{x[2 * s0], x[2 * s0 + 1]});
+            st_stream(d + ((size_t)(s0 + 1) << 7), V2{x[2 * s0 + 2], x[2 * s0 + 3]});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
     // fold, multiply by psi^-i * N^-1 (ntt.cpp:214-222), optional scalar + strict reduction, store (layout A)
     {
         const u32 k = lp->k, fix = lp->fix;
@@ -641,6 +701,7 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_inv(HpNtt
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (!active) return;   // (after the last barrier of the kernel)
         if (G::PB == 0) {   // mirror of the forward load: lane pairs assemble 16-byte stores
             const bool odd = (tid & 1u) != 0;
             u64 *dp = it.dst + (tid & ~1u);
@@ -668,11 +729,17 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_inv(HpNtt
 }
 
 template <int LOGN> hipError_t launch(const HpNttJob &job, hipStream_t stream) {
-    if (!job.inverse) k_ntt_fwd<LOGN><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
-    else if (job.use_post_scalar && job.strict) k_ntt_inv<LOGN, true, true><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
+    if (!job.inverse) {
+        k_ntt_fwd<LOGN><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
+        return hipGetLastError();
+    }
+    constexpr int LPW = InvGeo<LOGN>::LPW, TT = InvGeo<LOGN>::TT;
+    if (LPW > 1 && job.mode != HP_NTT_BATCH) return hipErrorNotSupported;
+    const u32 grid = LPW == 1 ? job.W : job.L * ((job.P + LPW - 1) / LPW);
+    if (job.use_post_scalar && job.strict) k_ntt_inv<LOGN, true, true><<<grid, TT, 0, stream>>>(job);
     else if (job.use_post_scalar) return hipErrorNotSupported;
-    else if (job.strict) k_ntt_inv<LOGN, true, false><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
-    else k_ntt_inv<LOGN, false, false><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
+    else if (job.strict) k_ntt_inv<LOGN, true, false><<<grid, TT, 0, stream>>>(job);
+    else k_ntt_inv<LOGN, false, false><<<grid, TT, 0, stream>>>(job);
     return hipGetLastError();
 }
 

@@ -1,0 +1,15 @@
+#!/bin/bash
+# quick GPU check after a kernel change: transform / pipeline parity tests, then the default bench line -> gpurun_out/<tag>_*
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+TAG=${1:-quick}
+cd $R; mkdir -p gpurun_out
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py tests/test_gpu_full_batch.py tests/test_hks.py tests/test_extensions.py tests/test_sharded.py -m gpu -x -q > gpurun_out/${TAG}_pytest.txt 2>&1
+tail -3 gpurun_out/${TAG}_pytest.txt
+python bench.py --steps 10 --warmup 2 --cpu-seconds 2 --cpu-procs 0 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+python - <<PY
+import json
+r=json.load(open('gpurun_out/${TAG}_bench.json'))
+print('hom-mult/s', round(r['value']), 'verified', r.get('verified'), 'spread ms', round(r['roofline']['avg_launch_ms'],3), 'frac', round(r['roofline']['frac'],3))
+for n,e in r['ntt']['by_N'].items():
+    print(n, 'fwd', round(e['forward']['frac_of_hbm_peak'],3), 'inv', round(e['inverse']['frac_of_hbm_peak'],3), e.get('verified'))
+PY
