@@ -108,9 +108,11 @@ template <bool FWD> constexpr int slot_bit(int s) { return 1 << (FWD ? 4 - ilog2
 
 // One slot (or, in the last stage of a pass where every butterfly has its own twiddle, two slots) of a pass;
 // recursion over the slot number keeps every register index a compile-time constant.
-// LZ (first pass of the N = 32768 forward kernel): registers still hold the 16-byte loads as they arrived; the lane-pair
-// swap that sorts them into columns (load_flight) is done here, right before the first butterfly that touches a register,
-// so that the first stage runs while the later loads are still in flight instead of after all sixteen.
+// Pre (first pass of a forward kernel): work that belongs to the LOADS is done here, per register pair (r, r + 1) = one 16-byte
+// load, right before the first butterfly that touches it -- so the first stage runs while the later loads are still in flight
+// instead of after all sixteen:
+//   SwapPre  N = 32768: registers still hold the loads as they arrived; the lane-pair swap sorts them into columns (load_flight)
+//   DropPre  fused drop-last-prime: that swap, then the Barrett / centring / [* t] prologue of rescaling.cpp:54-69, mod_switch.cpp:52-70
 HP_DEV u64 from_pair_lane(u64 v);
 HP_DEV void lazy_swap(u64 (&x)[32], int r) {
     const bool odd = (threadIdx.x & 1u) != 0;
@@ -120,9 +122,33 @@ HP_DEV void lazy_swap(u64 (&x)[32], int r) {
     x[r] = odd ? recv : keep;
     x[r + 1] = odd ? keep : recv;
 }
+struct NoPre {
+    static constexpr bool on = false;
+    HP_DEV void operator()(u64 (&)[32], int) const {}
+};
+struct SwapPre {
+    static constexpr bool on = true;
+    HP_DEV void operator()(u64 (&x)[32], int r) const { lazy_swap(x, r); }
+};
+template <bool SWAP, bool BGV> struct DropPre {
+    static constexpr bool on = true;
+    u64 q, bc, bump, half, tk, tkh;
+    u32 n0, n1;
+    HP_DEV void operator()(u64 (&x)[32], int r) const {
+        if (SWAP) lazy_swap(x, r);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const u64 c = x[r + e];
+            u64 v = hp_strict(hp_barrett_lazy(c, q, bc), q);
+            if (c >= half) v += bump;
+            if (BGV) v = hp_harvey_lazy_nq(v, tk, tkh, n0, n1);
+            x[r + e] = v;
+        }
+    }
+};
 
-template <bool FWD, int S, int S0, int S1, int D, class Tab, bool LZ = false>
-HP_DEV void pass_slots(u64 (&x)[32], u64x2 (&ring)[D], const Tab &tbl, u32 ncls, u32 cls, u64 two_q, u32 n0, u32 n1) {
+template <bool FWD, int S, int S0, int S1, int D, class Tab, class Pre = NoPre>
+HP_DEV void pass_slots(u64 (&x)[32], u64x2 (&ring)[D], const Tab &tbl, u32 ncls, u32 cls, u64 two_q, u32 n0, u32 n1, const Pre &pre = Pre()) {
     if constexpr (S < S1) {
         constexpr int cnt = 1 << (4 - ilog2c(S + 1));   // butterflies that use this slot's twiddle
         constexpr int bit = slot_bit<FWD>(S);
@@ -132,16 +158,16 @@ HP_DEV void pass_slots(u64 (&x)[32], u64x2 (&ring)[D], const Tab &tbl, u32 ncls,
 #pragma unroll
             for (int o = 0; o < cnt; o += 2) {
                 const int ra = slot_reg<FWD>(S, o), rb = slot_reg<FWD>(S, o + 1);
-                if constexpr (LZ && S == 0) {
-                    static_assert(!LZ || (FWD && S0 == 0), "lazy swap: first slot of a forward pass");
-                    lazy_swap(x, ra);          // rb == ra + 1: one 16-byte load
-                    lazy_swap(x, ra | bit);
+                if constexpr (Pre::on && S == 0) {
+                    static_assert(!Pre::on || (FWD && S0 == 0), "load-side work: first slot of a forward pass");
+                    pre(x, ra);          // rb == ra + 1: one 16-byte load
+                    pre(x, ra | bit);
                 }
                 hp_butterfly2_nq(x[ra], x[ra | bit], x[rb], x[rb | bit], tw.x, tw.y, tw.x, tw.y, two_q, n0, n1);
                 if (o & 2) __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (cnt == 2) { if constexpr (S & 1) __builtin_amdgcn_sched_barrier(0); }
-            pass_slots<FWD, S + 1, S0, S1, D, Tab, LZ>(x, ring, tbl, ncls, cls, two_q, n0, n1);
+            pass_slots<FWD, S + 1, S0, S1, D, Tab, Pre>(x, ring, tbl, ncls, cls, two_q, n0, n1, pre);
         } else {
             static_assert(S + 1 < S1, "single-butterfly slots come in pairs");
             const u64x2 tw2 = ring[(S + 1 - S0) % D];
@@ -154,20 +180,20 @@ HP_DEV void pass_slots(u64 (&x)[32], u64x2 (&ring)[D], const Tab &tbl, u32 ncls,
     }
 }
 
-template <bool FWD, int S0, int S1, int D, class Tab, bool LZ = false>
-HP_DEV void run_pass(u64 (&x)[32], const Tab tbl, u32 ncls, u32 cls, u64 nq, u64 two_q) {
+template <bool FWD, int S0, int S1, int D, class Tab, class Pre = NoPre>
+HP_DEV void run_pass(u64 (&x)[32], const Tab tbl, u32 ncls, u32 cls, u64 nq, u64 two_q, const Pre &pre = Pre()) {
     u64x2 ring[D];
 #pragma unroll
     for (int s = S0; s < S0 + D; ++s)
         if (s < S1) ring[(s - S0) % D] = tbl((u32)s * ncls + cls);
-    pass_slots<FWD, S0, S0, S1, D, Tab, LZ>(x, ring, tbl, ncls, cls, two_q, (u32)nq, (u32)(nq >> 32));
+    pass_slots<FWD, S0, S0, S1, D, Tab, Pre>(x, ring, tbl, ncls, cls, two_q, (u32)nq, (u32)(nq >> 32), pre);
 }
 
 // forward: stages on register bits BHI..BLO (descending)
-template <int BHI, int BLO, class Tab, bool LZ = false>
-HP_DEV void fwd_pass(u64 (&x)[32], const Tab tbl, u32 ncls, u32 cls, u64 nq, u64 two_q) {
+template <int BHI, int BLO, class Tab, class Pre = NoPre>
+HP_DEV void fwd_pass(u64 (&x)[32], const Tab tbl, u32 ncls, u32 cls, u64 nq, u64 two_q, const Pre &pre = Pre()) {
     static_assert(BHI == 4, "forward passes start at register bit 4");
-    run_pass<true, 0, (1 << (5 - BLO)) - 1, Tab::depth, Tab, LZ>(x, tbl, ncls, cls, nq, two_q);
+    run_pass<true, 0, (1 << (5 - BLO)) - 1, Tab::depth, Tab, Pre>(x, tbl, ncls, cls, nq, two_q, pre);
 }
 
 // inverse: stages on register bits BLO..BHI (ascending)
@@ -395,7 +421,11 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
     TRACE_DECL
     TRACE_MARK();
     u64 x[32];
-    constexpr bool LZ = !DROP && G::PB == 0;
+    // load-side work deferred into the first stage: the plain N = 32768 kernel (lane-pair swap) and the compile-time flavours of
+    // the fused drop (swap + Barrett / centring prologue); the run-time flavour 0 (hybrid key switch inputs) keeps the eager form
+    // (N = 32768 only: -2 % on the launch there, +2 % at N = 8192 where two workgroups per CU hide the load phase anyway)
+    constexpr bool LZ_DROP = DROP && FLAV != 0 && G::PB == 0;
+    constexpr bool LZ = (!DROP && G::PB == 0) || LZ_DROP;   // registers left as loaded
     load_flight<LOGN, LZ>(it.src, tid, x);
     if (tid < 31u * (1u << G::A)) lds_tw[tid] = stg;
     if (DROP) {
@@ -405,7 +435,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
         const u64 bc = lp->barrett_c, bump = q - da->dc.r[k], half = da->dc.half_q_last;
         const u64 tk = da->dc.t[k], tkh = da->dc.t_h[k];
         const bool bgv = FLAV ? (FLAV >= 3) : da->dc.bgv != 0;
-        if (FLAV || !da->raw_input) {
+        if (!LZ_DROP && (FLAV || !da->raw_input)) {
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
                 const u64 c = x[r];
@@ -471,7 +501,16 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
 #endif
     TRACE_MARK();   // 1: coefficients have arrived
     // pass A: global stages 1..A, wave-uniform twiddles seq[1 .. 2^A - 1]
-    fwd_pass<4, G::PB, STab, LZ>(x, STab(lp->fwd_ref + 1), 1u, 0u, nq, two_q);
+    if constexpr (LZ_DROP) {
+        const u32 k = it.limb;
+        const DropPre<G::PB == 0, (FLAV >= 3)> pre{q, lp->barrett_c, q - da->dc.r[k], da->dc.half_q_last, da->dc.t[k], da->dc.t_h[k],
+                                                    (u32)nq, (u32)(nq >> 32)};
+        fwd_pass<4, G::PB, STab>(x, STab(lp->fwd_ref + 1), 1u, 0u, nq, two_q, pre);
+    } else if constexpr (LZ) {
+        fwd_pass<4, G::PB, STab>(x, STab(lp->fwd_ref + 1), 1u, 0u, nq, two_q, SwapPre());
+    } else {
+        fwd_pass<4, G::PB, STab>(x, STab(lp->fwd_ref + 1), 1u, 0u, nq, two_q);
+    }
     TRACE_MARK();   // 2
     exchange<LOGN, LAY_A, LAY_B, true>(x, lds, ad);
     TRACE_MARK();   // 3
