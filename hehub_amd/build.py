@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libhehub_amd.so")
-SOURCES = ["hp_ctx.cpp", "hp_prof.cpp", "hp_api_poly.cpp", "hp_api_scheme.cpp", "hp_api_hks.cpp", "hp_tables.cpp", "hp_wire.cpp",
+SOURCES = ["hp_ctx.cpp", "hp_prof.cpp", "hp_api_poly.cpp", "hp_api_scheme.cpp", "hp_api_hks.cpp", "hp_node.cpp", "hp_tables.cpp", "hp_wire.cpp",
            "hp_elem.hip", "hp_hks.hip", "hp_ntt_generic.hip", "hp_ntt_fast.hip"]
 ARCH = "gfx950"
 
@@ -51,7 +51,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True)
     if force or _stale(LIB, objs):
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib"]
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)

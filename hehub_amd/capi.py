@@ -74,6 +74,25 @@ SIGNATURES = {
     "hp_dev_ks_inner_range": (INT, [P, szt, szt, P, szt, szt, szt, P, P, szt, P, P]),
     "hp_dev_drop_coeffs": (INT, [P, szt, szt, P, u64, szt, P, P]),
     "hp_dev_drop_apply_range": (INT, [P, szt, szt, P, u64, szt, szt, szt, P, P, P, szt, szt, C.c_uint, P]),
+    "hp_node_create": (INT, [P, szt, C.POINTER(P)]),
+    "hp_node_destroy": (None, [P]),
+    "hp_node_size": (szt, [P]),
+    "hp_node_ctx": (P, [P, szt]),
+    "hp_node_last_error": (C.c_char_p, [P]),
+    "hp_node_slice": (INT, [P, szt, szt, C.POINTER(szt), C.POINTER(szt)]),
+    "hp_node_sync": (INT, [P]),
+    "hp_node_replicate": (INT, [P, P, szt, P]),
+    "hp_node_free_replicas": (INT, [P, P]),
+    "hp_node_ckks_mult_relin_rescale": (INT, [P, szt, szt, P, szt, P, P, P, P]),
+    "hp_node_bgv_mult_relin_modswitch": (INT, [P, szt, szt, P, u64, szt, P, P, P, P]),
+    "hp_node_ntt": (INT, [P, szt, szt, P, szt, P, INT, INT]),
+    "hp_node_dev_ckks_mult_relin_rescale": (INT, [P, szt, szt, P, P, P, P, P, P]),
+    "hp_node_dev_bgv_mult_relin_modswitch": (INT, [P, szt, szt, P, u64, P, P, P, P, P]),
+    "hp_node_sharded_create": (INT, [P, szt, szt, P, u64, szt, C.POINTER(P)]),
+    "hp_node_sharded_destroy": (None, [P]),
+    "hp_node_sharded_range": (INT, [P, szt, C.POINTER(szt), C.POINTER(szt)]),
+    "hp_node_sharded_mult": (INT, [P, P, P, P, P]),
+    "hp_node_sharded_mult_dev": (INT, [P, P, P, P, P]),
     "hp_dev_ckks_mult_relin_rescale": (INT, [P, szt, szt, P, szt, P, P, P, P]),
     "hp_dev_bgv_mult_relin_modswitch": (INT, [P, szt, szt, P, u64, szt, P, P, P, P]),
     "hp_dev_bgv_mult_relin_modswitch_t": (INT, [P, szt, szt, P, u64, szt, P, P, P, P]),

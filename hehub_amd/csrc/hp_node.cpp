@@ -1,0 +1,551 @@
+// hp_node.cpp -- several GPUs of one node behind one handle (include/hehub_amd.h, "node").
+//
+// hehub itself is single-threaded and knows nothing about devices; a host application that holds a batch of
+// ciphertexts uses all GPUs of a node through this layer without Python or torch.distributed:
+//
+//   * batch-sharded mode (the throughput mode): the batch is cut into contiguous per-rank slices
+//     (hp_node_slice), every rank runs the SAME single-GPU entry point on its slice, keys and tables are replicated,
+//     no data-path exchange.  One worker thread per rank feeds its own hp_ctx (own stream), so the ranks' host-side
+//     copies and launches overlap.
+//   * limb-sharded mode (the "latency" mode; north star: "all-gather ... only for the key-switch accumulation"): ONE
+//     batch is processed by all ranks, cut by OUTPUT MODULUS; rank r owns a contiguous range of q_0..q_{L-1}, p.  Every
+//     sum over the digits for an output modulus is formed on one GPU in the reference's order (rgsw.cpp:126-149), so
+//     results stay bit-identical.  The exchanges are DIRECT PEER WRITES: the owner of a limb copies it straight into
+//     every peer's buffer (hipMemcpy2DAsync between devices with peer access enabled -- each shard crosses exactly one
+//     xGMI link, no ring, no padding, no staging), ordered by HIP events; buffers are allocated once per plan.
+//
+// Ranks may share a device (devices = {0, 0, 0}): that is how the tests run every code path of this file on a one-GPU box.
+#include "hp_ctx.h"
+
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <thread>
+
+using namespace hpi;
+
+namespace {
+
+// a reusable barrier for the worker threads (hipStreamWaitEvent only orders against events that have ALREADY been recorded
+// on the host side, so "everybody has recorded" is a host-side rendezvous)
+class HostBarrier {
+public:
+    explicit HostBarrier(size_t n) : n_(n) {}
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu_);
+        const size_t gen = gen_;
+        if (++count_ == n_) {
+            count_ = 0;
+            gen_++;
+            cv_.notify_all();
+        } else {
+            cv_.wait(lk, [&] { return gen_ != gen; });
+        }
+    }
+
+private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    size_t n_, count_ = 0, gen_ = 0;
+};
+
+// per-rank staging of a host-resident batch: device buffers grow on demand and are kept with the node
+struct Staging {
+    void *d[3] = {nullptr, nullptr, nullptr};
+    size_t bytes[3] = {0, 0, 0};
+};
+
+struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> task;
+    bool has_task = false, done = false, quit = false;
+    int rc = HP_OK;
+};
+
+} // namespace
+
+struct hp_node {
+    std::vector<int> devices;
+    std::vector<hp_ctx *> ctx;
+    std::vector<std::unique_ptr<Worker>> workers;
+    std::unique_ptr<HostBarrier> barrier;
+    std::vector<Staging> staging;
+    std::mutex mu;        // one node-level call at a time
+    std::string err;
+};
+
+namespace {
+
+void worker_loop(Worker *w) {
+    for (;;) {
+        std::function<int()> task;
+        {
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [&] { return w->has_task || w->quit; });
+            if (w->quit) return;
+            task = std::move(w->task);
+            w->has_task = false;
+        }
+        int rc;
+        try {
+            rc = task();
+        } catch (...) {
+            rc = HP_ELOGIC;
+        }
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->rc = rc;
+            w->done = true;
+        }
+        w->cv.notify_all();
+    }
+}
+
+// run fn(rank) on every rank's worker thread at once; the first non-zero status (lowest rank) is returned and its message kept
+int run_all(hp_node *node, const std::function<int(size_t)> &fn) {
+    const size_t n = node->ctx.size();
+    for (size_t r = 0; r < n; r++) {
+        Worker *w = node->workers[r].get();
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->task = [&fn, r] { return fn(r); };
+            w->has_task = true;
+            w->done = false;
+        }
+        w->cv.notify_all();
+    }
+    int first = HP_OK;
+    for (size_t r = 0; r < n; r++) {
+        Worker *w = node->workers[r].get();
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->cv.wait(lk, [&] { return w->done; });
+        if (w->rc != HP_OK && first == HP_OK) {
+            first = w->rc;
+            node->err = "rank " + std::to_string(r) + ": " + hp_last_error(node->ctx[r]);
+        }
+    }
+    return first;
+}
+
+int node_fail(hp_node *node, int code, const std::string &msg) {
+    node->err = msg;
+    return code;
+}
+
+void slice_of(size_t total, size_t world, size_t rank, size_t *lo, size_t *hi) {
+    const size_t base = total / world, extra = total % world;
+    *lo = rank * base + (rank < extra ? rank : extra);
+    *hi = *lo + base + (rank < extra ? 1 : 0);
+}
+
+} // namespace
+
+namespace {
+
+int stage_reserve(hp_ctx *ctx, Staging &s, int slot, size_t bytes) {
+    if (bytes <= s.bytes[slot]) return HP_OK;
+    if (s.d[slot]) {
+        int rc = hp_dev_free(ctx, s.d[slot]);
+        if (rc) return rc;
+        s.d[slot] = nullptr;
+        s.bytes[slot] = 0;
+    }
+    int rc = hp_dev_alloc(ctx, bytes, &s.d[slot]);
+    if (rc) return rc;
+    s.bytes[slot] = bytes;
+    return HP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int hp_node_create(const int *devices, size_t count, hp_node **out) {
+    if (!devices || !out || count == 0 || count > 64) return HP_EINVAL;
+    hp_node *node = new (std::nothrow) hp_node();
+    if (!node) return HP_ENOMEM;
+    node->devices.assign(devices, devices + count);
+    for (size_t r = 0; r < count; r++) {
+        hp_ctx *c = nullptr;
+        int rc = hp_ctx_create(devices[r], &c);
+        if (rc != HP_OK) {
+            for (hp_ctx *p : node->ctx) hp_ctx_destroy(p);
+            delete node;
+            return rc;
+        }
+        node->ctx.push_back(c);
+    }
+    // peer access between every pair of distinct devices (direct writes over xGMI in the limb-sharded mode)
+    for (size_t a = 0; a < count; a++)
+        for (size_t b = 0; b < count; b++) {
+            if (devices[a] == devices[b]) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can) {
+                (void)hipSetDevice(devices[a]);
+                hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { /* copies fall back to staged transfers inside the runtime */ }
+                (void)hipGetLastError();
+            }
+        }
+    node->staging.resize(count);
+    node->barrier.reset(new HostBarrier(count));
+    for (size_t r = 0; r < count; r++) {
+        node->workers.emplace_back(new Worker());
+        Worker *w = node->workers.back().get();
+        w->th = std::thread(worker_loop, w);
+    }
+    *out = node;
+    return HP_OK;
+}
+
+void hp_node_destroy(hp_node *node) {
+    if (!node) return;
+    for (auto &w : node->workers) {
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->quit = true;
+        }
+        w->cv.notify_all();
+        w->th.join();
+    }
+    for (size_t r = 0; r < node->staging.size(); r++)
+        for (int s = 0; s < 3; s++)
+            if (node->staging[r].d[s]) (void)hp_dev_free(node->ctx[r], node->staging[r].d[s]);
+    for (hp_ctx *c : node->ctx) hp_ctx_destroy(c);
+    delete node;
+}
+
+size_t hp_node_size(const hp_node *node) { return node ? node->ctx.size() : 0; }
+hp_ctx *hp_node_ctx(hp_node *node, size_t rank) { return (node && rank < node->ctx.size()) ? node->ctx[rank] : nullptr; }
+const char *hp_node_last_error(hp_node *node) { return node ? node->err.c_str() : "null node"; }
+
+int hp_node_slice(const hp_node *node, size_t total, size_t rank, size_t *lo, size_t *hi) {
+    if (!node || !lo || !hi || rank >= node->ctx.size()) return HP_EINVAL;
+    slice_of(total, node->ctx.size(), rank, lo, hi);
+    return HP_OK;
+}
+
+int hp_node_sync(hp_node *node) {
+    if (!node) return HP_EINVAL;
+    std::lock_guard<std::mutex> lk(node->mu);
+    return run_all(node, [&](size_t r) { return hp_sync(node->ctx[r]); });
+}
+
+int hp_node_replicate(hp_node *node, const uint64_t *h_words, size_t words, uint64_t **d_copies) {
+    if (!node || !h_words || !d_copies || words == 0) return HP_EINVAL;
+    std::lock_guard<std::mutex> lk(node->mu);
+    for (size_t r = 0; r < node->ctx.size(); r++) d_copies[r] = nullptr;
+    return run_all(node, [&](size_t r) {
+        int rc = hp_dev_alloc(node->ctx[r], words * 8, (void **)&d_copies[r]);
+        if (rc) return rc;
+        return hp_memcpy_h2d(node->ctx[r], d_copies[r], h_words, words * 8);
+    });
+}
+
+int hp_node_free_replicas(hp_node *node, uint64_t **d_copies) {
+    if (!node || !d_copies) return HP_EINVAL;
+    std::lock_guard<std::mutex> lk(node->mu);
+    return run_all(node, [&](size_t r) {
+        if (!d_copies[r]) return (int)HP_OK;
+        int rc = hp_dev_free(node->ctx[r], d_copies[r]);
+        d_copies[r] = nullptr;
+        return rc;
+    });
+}
+
+// ---- batch-sharded mode ---------------------------------------------------------------------------------------
+// device-resident operands: rank r works on counts[r] items behind its own pointers
+static int node_dev_mult(hp_node *node, bool bgv, size_t logn, size_t L, const uint64_t *mext, uint64_t t, const size_t *counts,
+                         const uint64_t *const *d_ct1, const uint64_t *const *d_ct2, uint64_t *const *d_key, uint64_t *const *d_out) {
+    if (!node || !mext || !counts || !d_ct1 || !d_ct2 || !d_key || !d_out) return HP_EINVAL;
+    std::lock_guard<std::mutex> lk(node->mu);
+    return run_all(node, [&](size_t r) {
+        if (counts[r] == 0) return (int)HP_OK;
+        hp_ctx *c = node->ctx[r];
+        return bgv ? hp_dev_bgv_mult_relin_modswitch(c, logn, L, mext, t, counts[r], d_ct1[r], d_ct2[r], d_key[r], d_out[r])
+                   : hp_dev_ckks_mult_relin_rescale(c, logn, L, mext, counts[r], d_ct1[r], d_ct2[r], d_key[r], d_out[r]);
+    });
+}
+int hp_node_dev_ckks_mult_relin_rescale(hp_node *node, size_t logn, size_t L, const uint64_t *moduli_ext, const size_t *counts,
+                                        const uint64_t *const *d_ct1, const uint64_t *const *d_ct2, uint64_t *const *d_key,
+                                        uint64_t *const *d_out) {
+    return node_dev_mult(node, false, logn, L, moduli_ext, 0, counts, d_ct1, d_ct2, d_key, d_out);
+}
+int hp_node_dev_bgv_mult_relin_modswitch(hp_node *node, size_t logn, size_t L, const uint64_t *moduli_ext, uint64_t plain_modulus,
+                                         const size_t *counts, const uint64_t *const *d_ct1, const uint64_t *const *d_ct2,
+                                         uint64_t *const *d_key, uint64_t *const *d_out) {
+    return node_dev_mult(node, true, logn, L, moduli_ext, plain_modulus, counts, d_ct1, d_ct2, d_key, d_out);
+}
+
+// host-resident operands (what a hehub application holds): every rank stages its slice in, computes, stages it out
+static int node_host_mult(hp_node *node, bool bgv, size_t logn, size_t L, const uint64_t *mext, uint64_t t, size_t batch,
+                          const uint64_t *h_ct1, const uint64_t *h_ct2, uint64_t *const *d_key, uint64_t *h_out) {
+    if (!node || !mext || !h_ct1 || !h_ct2 || !d_key || !h_out) return HP_EINVAL;
+    if (logn < 1 || logn > 15 || L < 2) return node_fail(node, HP_EINVAL, "invalid shape");
+    std::lock_guard<std::mutex> lk(node->mu);
+    std::vector<Staging> &st = node->staging;
+    const size_t n = (size_t)1 << logn, in_words = 2 * L * n, out_words = 2 * (L - 1) * n;
+    return run_all(node, [&](size_t r) {
+        size_t lo, hi;
+        slice_of(batch, node->ctx.size(), r, &lo, &hi);
+        const size_t cnt = hi - lo;
+        if (cnt == 0) return (int)HP_OK;
+        hp_ctx *c = node->ctx[r];
+        int rc;
+        if ((rc = stage_reserve(c, st[r], 0, cnt * in_words * 8))) return rc;
+        if ((rc = stage_reserve(c, st[r], 1, cnt * in_words * 8))) return rc;
+        if ((rc = stage_reserve(c, st[r], 2, cnt * out_words * 8))) return rc;
+        uint64_t *a = (uint64_t *)st[r].d[0], *b = (uint64_t *)st[r].d[1], *o = (uint64_t *)st[r].d[2];
+        if ((rc = hp_memcpy_h2d(c, a, h_ct1 + lo * in_words, cnt * in_words * 8))) return rc;
+        if ((rc = hp_memcpy_h2d(c, b, h_ct2 + lo * in_words, cnt * in_words * 8))) return rc;
+        rc = bgv ? hp_dev_bgv_mult_relin_modswitch(c, logn, L, mext, t, cnt, a, b, d_key[r], o)
+                 : hp_dev_ckks_mult_relin_rescale(c, logn, L, mext, cnt, a, b, d_key[r], o);
+        if (rc) return rc;
+        return hp_memcpy_d2h(c, h_out + lo * out_words, o, cnt * out_words * 8);
+    });
+}
+int hp_node_ckks_mult_relin_rescale(hp_node *node, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch,
+                                    const uint64_t *h_ct1, const uint64_t *h_ct2, uint64_t *const *d_key, uint64_t *h_out) {
+    return node_host_mult(node, false, logn, L, moduli_ext, 0, batch, h_ct1, h_ct2, d_key, h_out);
+}
+int hp_node_bgv_mult_relin_modswitch(hp_node *node, size_t logn, size_t L, const uint64_t *moduli_ext, uint64_t plain_modulus,
+                                     size_t batch, const uint64_t *h_ct1, const uint64_t *h_ct2, uint64_t *const *d_key,
+                                     uint64_t *h_out) {
+    return node_host_mult(node, true, logn, L, moduli_ext, plain_modulus, batch, h_ct1, h_ct2, d_key, h_out);
+}
+
+// ntt.h:41-51 / :72-92 on a host-resident batch u64[batch][L][N], in place, sliced over the ranks
+int hp_node_ntt(hp_node *node, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *h_x, int inverse, int strict) {
+    if (!node || !moduli || !h_x) return HP_EINVAL;
+    if (logn < 1 || logn > 15 || L < 1) return node_fail(node, HP_EINVAL, "invalid shape");
+    std::lock_guard<std::mutex> lk(node->mu);
+    std::vector<Staging> &st = node->staging;
+    const size_t words = L * ((size_t)1 << logn);
+    return run_all(node, [&](size_t r) {
+        size_t lo, hi;
+        slice_of(batch, node->ctx.size(), r, &lo, &hi);
+        const size_t cnt = hi - lo;
+        if (cnt == 0) return (int)HP_OK;
+        hp_ctx *c = node->ctx[r];
+        int rc;
+        if ((rc = stage_reserve(c, st[r], 0, cnt * words * 8))) return rc;
+        uint64_t *d = (uint64_t *)st[r].d[0];
+        if ((rc = hp_memcpy_h2d(c, d, h_x + lo * words, cnt * words * 8))) return rc;
+        rc = inverse ? hp_dev_intt(c, logn, L, moduli, cnt, d, strict) : hp_dev_ntt(c, logn, L, moduli, cnt, d);
+        if (rc) return rc;
+        return hp_memcpy_d2h(c, h_x + lo * words, d, cnt * words * 8);
+    });
+}
+
+} // extern "C"
+
+// ---- limb-sharded mode ------------------------------------------------------------------------------------------
+struct hp_node_sharded {
+    hp_node *node = nullptr;
+    size_t logn = 0, L = 0, batch = 0;
+    uint64_t t = 0;                        // 0: CKKS, else the BGV plain modulus
+    std::vector<uint64_t> mext;
+    std::vector<std::pair<size_t, size_t>> own;   // [k0, k1) of the L+1 extended moduli per rank
+    struct Rank {
+        uint64_t *ct1 = nullptr, *ct2 = nullptr, *quad = nullptr, *coef = nullptr, *ks = nullptr, *c_p = nullptr, *relin = nullptr,
+                 *c_q = nullptr, *out = nullptr;
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // coef sent, c_p sent, c_q sent, result sent
+    };
+    std::vector<Rank> rk;
+};
+
+namespace {
+
+size_t owner_of(const hp_node_sharded *p, size_t k) {
+    for (size_t r = 0; r < p->own.size(); r++)
+        if (p->own[r].first <= k && k < p->own[r].second) return r;
+    return 0;
+}
+
+// rows x (limbs lo..hi of a row of `row_limbs` limbs) from this rank's buffer into the same place of a peer's buffer
+int copy_limbs(hp_ctx *ctx, hipStream_t s, uint64_t *dst, const uint64_t *src, size_t rows, size_t row_limbs, size_t lo, size_t hi,
+               size_t n) {
+    if (hi <= lo || rows == 0) return HP_OK;
+    const size_t pitch = row_limbs * n * 8, width = (hi - lo) * n * 8;
+    hipError_t e = hipMemcpy2DAsync((char *)dst + lo * n * 8, pitch, (const char *)src + lo * n * 8, pitch, width, rows,
+                                    hipMemcpyDeviceToDevice, s);
+    return chk(ctx, e, "peer copy of owned limbs");
+}
+
+void free_plan(hp_node_sharded *p) {
+    if (!p) return;
+    for (size_t r = 0; r < p->rk.size(); r++) {
+        hp_ctx *c = p->node->ctx[r];
+        auto &R = p->rk[r];
+        for (uint64_t *b : {R.ct1, R.ct2, R.quad, R.coef, R.ks, R.c_p, R.relin, R.c_q, R.out})
+            if (b) (void)hp_dev_free(c, b);
+        (void)hipSetDevice(p->node->devices[r]);
+        for (hipEvent_t e : R.ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+    delete p;
+}
+
+// One multiplication, every rank in lockstep on its worker thread.  d_in != nullptr: inputs are already on the devices.
+int sharded_run(hp_node_sharded *p, const uint64_t *h_ct1, const uint64_t *h_ct2, const uint64_t *const *d_ct1,
+                const uint64_t *const *d_ct2, uint64_t *const *d_key, uint64_t *h_out, uint64_t *const *d_out) {
+    hp_node *node = p->node;
+    const size_t W = node->ctx.size(), L = p->L, B = p->batch, logn = p->logn, n = (size_t)1 << logn;
+    const uint64_t *mext = p->mext.data();
+    const uint64_t inner_t = p->t ? 1 : 0;   // bgv.h:32: relinearize's inner mod switch sees plain_modulus == 1
+    const size_t own_p = owner_of(p, L), own_q = owner_of(p, L - 1);
+    std::unique_ptr<std::atomic<int>[]> status(new std::atomic<int>[W]);
+    for (size_t r = 0; r < W; r++) status[r] = HP_OK;
+    auto all_ok = [&] {
+        for (size_t r = 0; r < W; r++)
+            if (status[r].load()) return false;
+        return true;
+    };
+    return run_all(node, [&](size_t r) {
+        hp_ctx *c = node->ctx[r];
+        auto &R = p->rk[r];
+        hipStream_t s = (hipStream_t)hp_ctx_get_stream(c);
+        (void)hipSetDevice(node->devices[r]);
+        const size_t k0 = p->own[r].first, k1 = p->own[r].second;
+        const size_t a0 = std::min(k0, L), a1 = std::min(k1, L);             // owned ciphertext limbs
+        const size_t b0 = std::min(k0, L - 1), b1 = std::min(k1, L - 1);     // ... that survive the final drop
+        int rc = HP_OK;
+        auto step = [&](int code) {
+            if (!rc && code) {
+                rc = code;
+                status[r] = code;
+            }
+        };
+        // a rank that failed keeps meeting the others at the barriers (with nothing enqueued)
+        const uint64_t *ct1 = d_ct1 ? d_ct1[r] : R.ct1, *ct2 = d_ct2 ? d_ct2[r] : R.ct2;
+        if (!d_ct1) {
+            step(hp_memcpy_h2d(c, R.ct1, h_ct1, B * 2 * L * n * 8));
+            step(hp_memcpy_h2d(c, R.ct2, h_ct2, B * 2 * L * n * 8));
+        }
+        const uint64_t *d2 = R.quad + 2 * L * n;   // polynomial 2 of each quadratic ciphertext: stride 3L limbs
+        // stage 1: tensor product and strict coefficients of the owned digits              ckks/arith.cpp:55-62, rgsw.cpp:103-105
+        if (!rc) step(hp_dev_mult_low_level_range(c, logn, L, mext, B, a0, a1, ct1, ct2, R.quad));
+        if (!rc) step(hp_dev_ks_coef_range(c, logn, L, mext, B, a0, a1, d2, 3 * L, R.coef));
+        // exchange 1: owned coefficient limbs straight into every peer's coef buffer
+        for (size_t d = 0; d < W && !rc; d++)
+            if (d != r) step(copy_limbs(c, s, p->rk[d].coef, R.coef, B, L, a0, a1, n));
+        if (!rc) step(chk(c, hipEventRecord(R.ev[0], s), "event"));
+        node->barrier->wait();
+        if (all_ok())
+            for (size_t d = 0; d < W && !rc; d++)
+                if (d != r) step(chk(c, hipStreamWaitEvent(s, p->rk[d].ev[0], 0), "wait"));
+        // stage 2: digits + inner product for the owned output moduli; the owner of p prepares the coefficients of its limb
+        if (!rc && all_ok()) step(hp_dev_ks_inner_range(c, logn, L, mext, B, k0, k1, R.coef, d2, 3 * L, d_key[r], R.ks));
+        if (!rc && all_ok() && r == own_p) {
+            step(hp_dev_drop_coeffs(c, logn, L + 1, mext, inner_t, 2 * B, R.ks, R.c_p));
+            for (size_t d = 0; d < W && !rc; d++)
+                if (d != r) step(chk(c, hipMemcpyAsync(p->rk[d].c_p, R.c_p, 2 * B * n * 8, hipMemcpyDeviceToDevice, s), "peer copy c_p"));
+        }
+        if (!rc) step(chk(c, hipEventRecord(R.ev[1], s), "event"));
+        node->barrier->wait();
+        if (all_ok() && !rc && r != own_p) step(chk(c, hipStreamWaitEvent(s, p->rk[own_p].ev[1], 0), "wait"));
+        // stage 3: drop p on the owned limbs (+= d0, d1); the owner of q_{L-1} prepares that limb's coefficients
+        if (!rc && all_ok())
+            step(hp_dev_drop_apply_range(c, logn, L + 1, mext, inner_t, 2 * B, a0, a1, R.ks, R.c_p, R.quad, L, 3 * L, 3, R.relin));
+        if (!rc && all_ok() && r == own_q) {
+            step(hp_dev_drop_coeffs(c, logn, L, mext, p->t, 2 * B, R.relin, R.c_q));
+            for (size_t d = 0; d < W && !rc; d++)
+                if (d != r) step(chk(c, hipMemcpyAsync(p->rk[d].c_q, R.c_q, 2 * B * n * 8, hipMemcpyDeviceToDevice, s), "peer copy c_q"));
+        }
+        if (!rc) step(chk(c, hipEventRecord(R.ev[2], s), "event"));
+        node->barrier->wait();
+        if (all_ok() && !rc && r != own_q) step(chk(c, hipStreamWaitEvent(s, p->rk[own_q].ev[2], 0), "wait"));
+        // stage 4: drop q_{L-1} on the owned limbs; result limbs go to rank 0 (and to the caller's per-rank buffers)
+        uint64_t *out = d_out ? d_out[r] : R.out;
+        if (!rc && all_ok()) step(hp_dev_drop_apply_range(c, logn, L, mext, p->t, 2 * B, b0, b1, R.relin, R.c_q, nullptr, 0, 0, 0, out));
+        if (d_out) {   // every rank ends up with the whole result
+            for (size_t d = 0; d < W && !rc && all_ok(); d++)
+                if (d != r) step(copy_limbs(c, s, d_out[d], out, 2 * B, L - 1, b0, b1, n));
+        } else if (r != 0 && !rc && all_ok()) {
+            step(copy_limbs(c, s, p->rk[0].out, out, 2 * B, L - 1, b0, b1, n));
+        }
+        if (!rc) step(chk(c, hipEventRecord(R.ev[3], s), "event"));
+        node->barrier->wait();
+        if (all_ok() && !rc && (d_out || r == 0))
+            for (size_t d = 0; d < W && !rc; d++)
+                if (d != r) step(chk(c, hipStreamWaitEvent(s, p->rk[d].ev[3], 0), "wait"));
+        if (!rc && all_ok() && !d_out && r == 0) step(hp_memcpy_d2h(c, h_out, R.out, B * 2 * (L - 1) * n * 8));
+        // the call returns with every stream drained: the next call may overwrite peers' buffers at once
+        step(hp_sync(c));
+        node->barrier->wait();
+        if (!rc && !all_ok()) rc = HP_ELOGIC;   // another rank failed: this rank's result is not valid either
+        return rc;
+    });
+}
+
+} // namespace
+
+extern "C" {
+
+void hp_node_sharded_destroy(hp_node_sharded *plan) { free_plan(plan); }
+
+int hp_node_sharded_create(hp_node *node, size_t logn, size_t L, const uint64_t *moduli_ext, uint64_t plain_modulus, size_t batch,
+                           hp_node_sharded **out) {
+    if (!node || !moduli_ext || !out) return HP_EINVAL;
+    if (logn < 1 || logn > 15 || L < 2 || L + 1 > HP_MAX_LIMBS || batch == 0) return node_fail(node, HP_EINVAL, "invalid shape");
+    std::lock_guard<std::mutex> lk(node->mu);
+    hp_node_sharded *p = new (std::nothrow) hp_node_sharded();
+    if (!p) return HP_ENOMEM;
+    p->node = node; p->logn = logn; p->L = L; p->batch = batch; p->t = plain_modulus;
+    p->mext.assign(moduli_ext, moduli_ext + L + 1);
+    const size_t W = node->ctx.size(), n = (size_t)1 << logn;
+    // contiguous ownership ranges of the L+1 extended moduli, sizes differing by at most one, the LARGER ranges first: the
+    // special prime (the most expensive output modulus: L digit transforms per polynomial instead of L-1) is the last
+    // modulus and therefore sits in a smallest range.  With more ranks than moduli the tail ranks own nothing.
+    p->own.resize(W);
+    for (size_t r = 0; r < W; r++) slice_of(L + 1, W, r, &p->own[r].first, &p->own[r].second);
+    p->rk.resize(W);
+    int rc = run_all(node, [&](size_t r) {
+        hp_ctx *c = node->ctx[r];
+        auto &R = p->rk[r];
+        struct { uint64_t **ptr; size_t words; } bufs[] = {
+            {&R.ct1, batch * 2 * L * n}, {&R.ct2, batch * 2 * L * n}, {&R.quad, batch * 3 * L * n}, {&R.coef, batch * L * n},
+            {&R.ks, batch * 2 * (L + 1) * n}, {&R.c_p, 2 * batch * n}, {&R.relin, batch * 2 * L * n}, {&R.c_q, 2 * batch * n},
+            {&R.out, batch * 2 * (L - 1) * n}};
+        for (auto &b : bufs) {
+            int rc2 = hp_dev_alloc(c, b.words * 8, (void **)b.ptr);
+            if (rc2) return rc2;
+        }
+        (void)hipSetDevice(node->devices[r]);
+        for (auto &e : R.ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return (int)HP_EHIP;
+        return (int)HP_OK;
+    });
+    if (rc) {
+        free_plan(p);
+        return rc;
+    }
+    *out = p;
+    return HP_OK;
+}
+
+int hp_node_sharded_range(const hp_node_sharded *plan, size_t rank, size_t *k0, size_t *k1) {
+    if (!plan || !k0 || !k1 || rank >= plan->own.size()) return HP_EINVAL;
+    *k0 = plan->own[rank].first;
+    *k1 = plan->own[rank].second;
+    return HP_OK;
+}
+
+int hp_node_sharded_mult(hp_node_sharded *plan, const uint64_t *h_ct1, const uint64_t *h_ct2, uint64_t *const *d_key, uint64_t *h_out) {
+    if (!plan || !h_ct1 || !h_ct2 || !d_key || !h_out) return HP_EINVAL;
+    std::lock_guard<std::mutex> lk(plan->node->mu);
+    return sharded_run(plan, h_ct1, h_ct2, nullptr, nullptr, d_key, h_out, nullptr);
+}
+
+int hp_node_sharded_mult_dev(hp_node_sharded *plan, const uint64_t *const *d_ct1, const uint64_t *const *d_ct2, uint64_t *const *d_key,
+                             uint64_t *const *d_out) {
+    if (!plan || !d_ct1 || !d_ct2 || !d_key || !d_out) return HP_EINVAL;
+    std::lock_guard<std::mutex> lk(plan->node->mu);
+    return sharded_run(plan, nullptr, nullptr, d_ct1, d_ct2, d_key, nullptr, d_out);
+}
+
+} // extern "C"

@@ -1,0 +1,116 @@
+"""ctypes front-end of the node layer (include/hehub_amd.h, "node"; hehub_amd/csrc/hp_node.cpp): several GPUs of one
+node behind one handle, driven from ONE process through the C ABI -- the layer a C/C++ hehub application uses.
+Host-resident numpy batches in, numpy out; nothing is computed here.  (The other way to use several GPUs, one process
+per GPU over torch.distributed, is hehub_amd/dist.py and hehub_amd/sharded.py.)"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+
+from . import capi
+from .engine import HpError, InvalidArgument, _u64arr
+
+
+class Node:
+    def __init__(self, devices: Sequence[int]):
+        import torch  # noqa: F401  (loads the HIP runtime the library binds to)
+
+        if not torch.cuda.is_available():
+            raise capi.EngineMissing("no HIP device visible: the node layer needs MI355X GPUs (no CPU fallback)")
+        self.lib = capi.load()
+        self.devices = [int(d) for d in devices]
+        self.world = len(self.devices)
+        h = capi.P()
+        rc = self.lib.hp_node_create((C.c_int * self.world)(*self.devices), self.world, C.byref(h))
+        if rc != capi.HP_OK:
+            raise HpError(rc, "hp_node_create failed")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hp_node_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int):
+        if rc == capi.HP_OK:
+            return
+        msg = self.lib.hp_node_last_error(self.h).decode()
+        raise (InvalidArgument if rc == capi.HP_EINVAL else HpError)(rc, msg)
+
+    def slice(self, total: int, rank: int):
+        lo, hi = capi.szt(0), capi.szt(0)
+        self._chk(self.lib.hp_node_slice(self.h, total, rank, C.byref(lo), C.byref(hi)))
+        return int(lo.value), int(hi.value)
+
+    def replicate(self, words: np.ndarray):
+        """host words -> one device copy per rank; returns the pointer array to pass as `key`"""
+        words = np.ascontiguousarray(words)
+        copies = (capi.P * self.world)()
+        self._chk(self.lib.hp_node_replicate(self.h, words.ctypes.data_as(capi.P), words.size, copies))
+        return copies
+
+    def free_replicas(self, copies):
+        self._chk(self.lib.hp_node_free_replicas(self.h, copies))
+
+    def ckks_mult(self, moduli_ext, ct1: np.ndarray, ct2: np.ndarray, key):
+        B, _, L, n = ct1.shape
+        out = np.empty((B, 2, L - 1, n), dtype=np.uint64)
+        self._chk(self.lib.hp_node_ckks_mult_relin_rescale(self.h, n.bit_length() - 1, L, _u64arr(moduli_ext), B,
+                                                           np.ascontiguousarray(ct1).ctypes.data_as(capi.P),
+                                                           np.ascontiguousarray(ct2).ctypes.data_as(capi.P), key,
+                                                           out.ctypes.data_as(capi.P)))
+        return out
+
+    def bgv_mult(self, moduli_ext, t: int, ct1: np.ndarray, ct2: np.ndarray, key):
+        B, _, L, n = ct1.shape
+        out = np.empty((B, 2, L - 1, n), dtype=np.uint64)
+        self._chk(self.lib.hp_node_bgv_mult_relin_modswitch(self.h, n.bit_length() - 1, L, _u64arr(moduli_ext), t, B,
+                                                            np.ascontiguousarray(ct1).ctypes.data_as(capi.P),
+                                                            np.ascontiguousarray(ct2).ctypes.data_as(capi.P), key,
+                                                            out.ctypes.data_as(capi.P)))
+        return out
+
+    def ntt_(self, moduli, x: np.ndarray, inverse: bool = False, strict: bool = False):
+        B, L, n = x.shape
+        assert x.flags["C_CONTIGUOUS"] and x.dtype == np.uint64
+        self._chk(self.lib.hp_node_ntt(self.h, n.bit_length() - 1, L, _u64arr(moduli), B, x.ctypes.data_as(capi.P), int(inverse),
+                                       int(strict)))
+        return x
+
+
+class ShardedPlan:
+    """limb-sharded multiplication of one batch across the ranks of a node (hp_node_sharded_*)"""
+
+    def __init__(self, node: Node, logn: int, moduli_ext, batch: int, plain_modulus: int = 0):
+        self.node, self.logn, self.mext, self.batch = node, logn, [int(q) for q in moduli_ext], batch
+        self.L = len(self.mext) - 1
+        h = capi.P()
+        node._chk(node.lib.hp_node_sharded_create(node.h, logn, self.L, _u64arr(self.mext), plain_modulus, batch, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.node.lib.hp_node_sharded_destroy(self.h)
+            self.h = None
+
+    def range(self, rank: int):
+        k0, k1 = capi.szt(0), capi.szt(0)
+        self.node._chk(self.node.lib.hp_node_sharded_range(self.h, rank, C.byref(k0), C.byref(k1)))
+        return int(k0.value), int(k1.value)
+
+    def mult(self, ct1: np.ndarray, ct2: np.ndarray, key):
+        B, _, L, n = ct1.shape
+        assert B == self.batch and L == self.L and n == 1 << self.logn
+        out = np.empty((B, 2, L - 1, n), dtype=np.uint64)
+        self.node._chk(self.node.lib.hp_node_sharded_mult(self.h, np.ascontiguousarray(ct1).ctypes.data_as(capi.P),
+                                                          np.ascontiguousarray(ct2).ctypes.data_as(capi.P), key,
+                                                          out.ctypes.data_as(capi.P)))
+        return out

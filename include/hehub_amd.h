@@ -240,6 +240,60 @@ int hp_dev_drop_apply_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *
                             const uint64_t *d_addend, size_t add_poly_stride, size_t add_ct_stride, unsigned add_mask,
                             uint64_t *d_out);
 
+/* ---- node: several GPUs behind one handle (hehub_amd/csrc/hp_node.cpp) ------------------------------------------
+ * hehub is a single-threaded CPU library; an application that holds a BATCH of ciphertexts uses all GPUs of a node through
+ * this layer, from C, without Python.  A node owns one hp_ctx (own stream) and one worker thread per rank; ranks may share
+ * a device (devices = {0, 0}: how the one-GPU tests exercise it).  Calls on a node are serialised.
+ *
+ * Batch-sharded mode (the throughput mode): item i of the batch belongs to the rank whose contiguous slice
+ * [lo, hi) holds i (hp_node_slice; sizes differ by at most one); every rank runs the single-GPU entry point on its
+ * slice; keys are replicated once (hp_node_replicate); there is NO exchange on the data path. */
+typedef struct hp_node hp_node;
+int hp_node_create(const int *devices, size_t count, hp_node **out);
+void hp_node_destroy(hp_node *node);
+size_t hp_node_size(const hp_node *node);
+hp_ctx *hp_node_ctx(hp_node *node, size_t rank);      /* the rank's engine context, for the hp_dev_* entry points */
+const char *hp_node_last_error(hp_node *node);
+int hp_node_slice(const hp_node *node, size_t total, size_t rank, size_t *lo, size_t *hi);
+int hp_node_sync(hp_node *node);
+/* copy a read-only host object (a key-switching key) to every rank: d_copies[rank] receives the device pointers */
+int hp_node_replicate(hp_node *node, const uint64_t *h_words, size_t words, uint64_t **d_copies);
+int hp_node_free_replicas(hp_node *node, uint64_t **d_copies);
+/* host-resident batches (what a hehub application holds): each rank stages its slice in, computes, stages it out
+ * ckks.h:270 mult + ckks.h:313 rescale_inplace / bgv mult_low_level + relinearize + mod_switch_inplace:
+ * h_ct1, h_ct2 u64[batch][2][L][N] -> h_out u64[batch][2][L-1][N]; d_key[rank] from hp_node_replicate */
+int hp_node_ckks_mult_relin_rescale(hp_node *node, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch,
+                                    const uint64_t *h_ct1, const uint64_t *h_ct2, uint64_t *const *d_key, uint64_t *h_out);
+int hp_node_bgv_mult_relin_modswitch(hp_node *node, size_t logn, size_t L, const uint64_t *moduli_ext, uint64_t plain_modulus,
+                                     size_t batch, const uint64_t *h_ct1, const uint64_t *h_ct2, uint64_t *const *d_key,
+                                     uint64_t *h_out);
+/* ntt.h:41-51 / :72-92 on a host-resident batch u64[batch][L][N], in place */
+int hp_node_ntt(hp_node *node, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *h_x, int inverse,
+                int strict);
+/* device-resident slices: rank r works on counts[r] items behind d_*[r] (allocated on hp_node_ctx(node, r)) */
+int hp_node_dev_ckks_mult_relin_rescale(hp_node *node, size_t logn, size_t L, const uint64_t *moduli_ext, const size_t *counts,
+                                        const uint64_t *const *d_ct1, const uint64_t *const *d_ct2, uint64_t *const *d_key,
+                                        uint64_t *const *d_out);
+int hp_node_dev_bgv_mult_relin_modswitch(hp_node *node, size_t logn, size_t L, const uint64_t *moduli_ext, uint64_t plain_modulus,
+                                         const size_t *counts, const uint64_t *const *d_ct1, const uint64_t *const *d_ct2,
+                                         uint64_t *const *d_key, uint64_t *const *d_out);
+/* Limb-sharded ("latency") mode: ONE batch processed by all ranks, cut by output modulus (the limb-range stages above);
+ * rank r owns a contiguous range of q_0..q_{L-1}, p (hp_node_sharded_range; sizes differ by at most one, the special prime
+ * in a smallest range).  Exchanges are direct peer writes: the owner copies its limbs into every peer's buffer (one xGMI link
+ * per shard, no ring, no padding), ordered by HIP events; all buffers belong to the plan.  With L+1 moduli over W ranks the
+ * speed-up is bounded by (L+1) / ceil((L+1)/W): 11 moduli over 8 GPUs -> 5.5 x.  plain_modulus 0: CKKS pipeline. */
+typedef struct hp_node_sharded hp_node_sharded;
+int hp_node_sharded_create(hp_node *node, size_t logn, size_t L, const uint64_t *moduli_ext, uint64_t plain_modulus, size_t batch,
+                           hp_node_sharded **out);
+void hp_node_sharded_destroy(hp_node_sharded *plan);
+int hp_node_sharded_range(const hp_node_sharded *plan, size_t rank, size_t *k0, size_t *k1);
+/* host operands (copied to every rank), result gathered on rank 0 and copied back */
+int hp_node_sharded_mult(hp_node_sharded *plan, const uint64_t *h_ct1, const uint64_t *h_ct2, uint64_t *const *d_key,
+                         uint64_t *h_out);
+/* operands already replicated on every rank; every rank ends up with the whole result in d_out[rank] */
+int hp_node_sharded_mult_dev(hp_node_sharded *plan, const uint64_t *const *d_ct1, const uint64_t *const *d_ct2,
+                             uint64_t *const *d_key, uint64_t *const *d_out);
+
 /* ---- extensions beyond the reference ---------------------------------------------------
  * hehub throws for both cases; these entry points are additions, not replacements, and are pinned by equivalence to
  * the reference-parity entry points (tests/test_extensions.py):

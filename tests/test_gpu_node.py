@@ -1,0 +1,118 @@
+"""The node layer of the C ABI (include/hehub_amd.h "node", hehub_amd/csrc/hp_node.cpp): several ranks behind one handle,
+driven from one process.  The test box has one GPU, so the ranks share device 0 (devices = [0, 0, ...]): every code path --
+worker threads, per-rank contexts and streams, slicing, staging, the direct peer writes and event ordering of the limb-sharded
+mode -- runs as it would on distinct devices, and every result must equal the oracle's words.
+Reference: ckks/arith.cpp:55-73, bgv/arith.cpp:59-79, rgsw.cpp:57-156, rescaling.cpp:14-78, mod_switch.cpp:13-78."""
+import numpy as np
+import pytest
+
+import params as P
+from oracle.pyoracle import SplitMix
+
+pytestmark = pytest.mark.gpu
+
+
+def make_node(world):
+    from hehub_amd.node import Node
+
+    return Node([0] * world)
+
+
+def case(logn, mext, B, seed):
+    n, L = 1 << logn, len(mext) - 1
+    rng = SplitMix(seed)
+    ct1 = rng.poly((B, 2, L, n), mext[:L])
+    ct2 = rng.poly((B, 2, L, n), mext[:L])
+    key = rng.poly((L, 2, L + 1, n), mext)
+    return ct1, ct2, key
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_batch_sharded_host_batches(orc, world):
+    """hp_node_ckks_mult_relin_rescale / bgv / ntt on host-resident batches: slices of unequal size, more ranks than items"""
+    node = make_node(world)
+    try:
+        for logn, mext, B in ((12, P.P40[:3] + [P.P50[0]], 7), (7, [P.P40[0], P.P40[1], P.P50[0]], 2)):
+            ct1, ct2, key = case(logn, mext, B, 900 + world)
+            dk = node.replicate(key)
+            cuts = [node.slice(B, r) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == B and all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            out = node.ckks_mult(mext, ct1, ct2, dk)
+            for i in range(B):
+                assert np.array_equal(out[i], orc.ckks_mult(mext, ct1[i], ct2[i], key)), (world, logn, i)
+            out = node.bgv_mult(mext, P.C5_T, ct1, ct2, dk)
+            for i in range(B):
+                assert np.array_equal(out[i], orc.bgv_mult(mext, P.C5_T, ct1[i], ct2[i], key)), (world, logn, i)
+            x = ct1[:, 0].copy()
+            node.ntt_(mext[:-1], x)
+            for i in range(B):
+                assert np.array_equal(x[i], orc.poly_ntt(mext[:-1], ct1[i, 0]))
+            node.ntt_(mext[:-1], x, inverse=True, strict=True)
+            assert np.array_equal(x, ct1[:, 0])
+            node.free_replicas(dk)
+    finally:
+        node.close()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("logn,mext,B", [(12, [P.P50[1]] + P.P40[:4] + [P.P50[0]], 3), (7, [P.P40[0], P.P40[1], P.P50[0]], 2)])
+def test_limb_sharded_matches_the_oracle(orc, world, logn, mext, B):
+    """hp_node_sharded_mult: one batch cut by output modulus over `world` ranks (more ranks than moduli included), direct
+    peer writes between the ranks' buffers; CKKS and BGV (plain_modulus == 1 quirk of bgv::relinearize included); the
+    same plan run twice (buffers are reused) with different inputs"""
+    from hehub_amd.node import ShardedPlan
+
+    node = make_node(world)
+    try:
+        for t in (0, P.C5_T):
+            plan = ShardedPlan(node, logn, mext, B, plain_modulus=t)
+            owned = [plan.range(r) for r in range(world)]
+            assert owned[0][0] == 0 and owned[-1][1] == len(mext) and max(b - a for a, b in owned) - min(b - a for a, b in owned) <= 1
+            for rep in range(2):
+                ct1, ct2, key = case(logn, mext, B, 70 * world + rep)
+                dk = node.replicate(key)
+                out = plan.mult(ct1, ct2, dk)
+                for i in range(B):
+                    exp = orc.bgv_mult(mext, t, ct1[i], ct2[i], key) if t else orc.ckks_mult(mext, ct1[i], ct2[i], key)
+                    assert np.array_equal(out[i], exp), (world, t, rep, i)
+                node.free_replicas(dk)
+            plan.close()
+    finally:
+        node.close()
+
+
+def test_limb_sharded_c3_shape(orc):
+    """the C3 shape (N = 32768, L = 10: 11 extended moduli over 8 ranks = 2,2,2,1,1,1,1,1) on two ciphertext pairs"""
+    from hehub_amd.node import ShardedPlan
+
+    node = make_node(8)
+    try:
+        mext = P.C3_MODULI_EXT
+        plan = ShardedPlan(node, P.C3_LOGN, mext, 2)
+        sizes = [plan.range(r)[1] - plan.range(r)[0] for r in range(8)]
+        assert sizes == [2, 2, 2, 1, 1, 1, 1, 1] and plan.range(7) == (10, 11)   # the special prime alone on the last rank
+        ct1, ct2, key = case(P.C3_LOGN, mext, 2, 33)
+        dk = node.replicate(key)
+        out = plan.mult(ct1, ct2, dk)
+        for i in range(2):
+            assert np.array_equal(out[i], orc.ckks_mult(mext, ct1[i], ct2[i], key))
+        plan.close()
+    finally:
+        node.close()
+
+
+def test_node_errors_are_reported_not_thrown():
+    from hehub_amd import capi
+    from hehub_amd.engine import HpError
+    from hehub_amd.node import Node
+
+    lib = capi.load()
+    h = capi.P()
+    assert lib.hp_node_create((capi.INT * 1)(99), 1, __import__("ctypes").byref(h)) != capi.HP_OK   # no such device
+    node = make_node(2)
+    try:
+        ct = np.zeros((1, 2, 1, 8), dtype=np.uint64)
+        with pytest.raises(HpError):
+            node.ckks_mult([P.P40[0], P.P50[0]], ct, ct, node.replicate(np.zeros(8, dtype=np.uint64)))   # L = 1: nothing to drop
+    finally:
+        node.close()

@@ -117,3 +117,30 @@ def test_contexts_are_independent_across_threads():
     out = subprocess.run([build_multi(), "4", "1", "12", "3", "2"], capture_output=True, text=True, timeout=600)
     print(out.stdout, out.stderr)
     assert out.returncode == 0 and "digest" in out.stdout and "everywhere" in out.stdout
+
+
+NODE_SRC = os.path.join(ROOT, "examples", "node_batch.c")
+NODE_BIN = os.path.join(ROOT, "examples", "node_batch")
+
+
+def build_node_example():
+    from hehub_amd.build import LIBDIR, build_lib
+
+    build_lib(verbose=False)
+    subprocess.run(["gcc", "-O2", "-std=c99", "-Wall", "-Wextra", "-Werror", NODE_SRC, f"-I{ROOT}/include", f"-L{LIBDIR}", "-lhehub_amd",
+                    f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-o", NODE_BIN], check=True)
+    return NODE_BIN
+
+
+def test_node_example_builds():
+    assert os.path.exists(build_node_example())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 5])
+def test_node_example_drives_several_contexts_from_c(ranks):
+    """examples/node_batch.c (C99, the C ABI alone): a host batch through the node API -- batch-sharded and limb-sharded over
+    `ranks` contexts -- equals the single-context result word for word"""
+    out = subprocess.run([build_node_example(), str(ranks), "1", "12", "6"], capture_output=True, text=True, timeout=600)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0 and "single context: yes" in out.stdout
