@@ -21,6 +21,12 @@ Per multiplication (ckks::mult_low_level + relinearize + rescale_inplace, or the
 torch.distributed is the transport (backend "nccl" = RCCL over xGMI on the GPUs; "gloo" is staged through
 host memory and exists for tests).  The stages themselves are C-ABI calls (include/hehub_amd.h, "limb-range
 stages"); nothing is computed by torch.
+
+Ownership: contiguous ranges of the L+1 extended moduli, sizes differing by at most one, larger ranges first -- the
+special prime (L digit transforms per polynomial instead of L-1, the most expensive output modulus) is the last
+modulus and so always sits in a smallest range.  The speed-up over one GPU is bounded by (L+1) / ceil((L+1)/W):
+11 moduli over 8 GPUs = 2,2,2,1,1,1,1,1 -> at most 5.5 x (stated in DESIGN.md section 6; the throughput mode is the
+batch-sharded one).
 """
 from __future__ import annotations
 
@@ -53,54 +59,74 @@ def clip(ranges, limit):
 
 
 class Comm:
-    """The two exchanges of the mode over torch.distributed."""
+    """The two exchanges of the mode over torch.distributed, one process per GPU.
+
+    All-gather of owned limbs = every rank SENDS its slice to every peer and RECEIVES theirs (batched isend / irecv: with
+    the "nccl" backend = RCCL each transfer goes straight over the xGMI link between the two GPUs -- no ring, so a shard
+    crosses exactly one link), exact sizes (no padding to the largest slice), through staging tensors that are allocated
+    once per buffer shape and kept.  "gloo" (tests) stages through host memory.  (In ONE process the same exchange is
+    done with direct peer writes by the C node layer, hehub_amd/csrc/hp_node.cpp.)"""
 
     def __init__(self, group=None):
         import torch.distributed as dist
 
         self.dist = dist
         self.group = group
+        self._stage = {}
         if not dist.is_initialized():       # single process: both exchanges are the identity
             self.world, self.rank, self.staged = 1, 0, False
             return
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.staged = dist.get_backend(group) != "nccl"   # gloo has no device all_gather: go through host memory
+        self.staged = dist.get_backend(group) != "nccl"   # gloo has no device transfers: go through host memory
+
+    def _buffers(self, buf, ranges):
+        """persistent contiguous staging per (buffer, ownership): [rows][owned limbs][n] to send, one per peer to receive"""
+        import torch
+
+        key = (buf.data_ptr(), tuple(buf.shape), tuple(ranges), self.staged)
+        st = self._stage.get(key)
+        if st is None:
+            rows, _, n = buf.shape
+            dev = "cpu" if self.staged else buf.device
+            st = {r: torch.empty((rows, hi - lo, n), dtype=buf.dtype, device=dev) for r, (lo, hi) in enumerate(ranges) if hi > lo}
+            if len(self._stage) > 16:
+                self._stage.clear()
+            self._stage[key] = st
+        return st
 
     def all_gather_limbs(self, buf, ranges):
         """buf: [rows][limbs][n]; rank r holds valid data in buf[:, ranges[r][0]:ranges[r][1]] and ends up with all."""
-        import torch
-
-        kmax = max(hi - lo for lo, hi in ranges)
-        if kmax == 0 or self.world == 1:
+        if self.world == 1 or max(hi - lo for lo, hi in ranges) == 0:
             return
-        rows, _, n = buf.shape
+        dist = self.dist
+        st = self._buffers(buf, ranges)
         lo, hi = ranges[self.rank]
-        send = torch.zeros((rows, kmax, n), dtype=buf.dtype, device=buf.device)
-        send[:, : hi - lo] = buf[:, lo:hi]
-        if self.staged:
-            send_h = send.cpu()
-            recv_h = [torch.empty_like(send_h) for _ in range(self.world)]
-            self.dist.all_gather(recv_h, send_h, group=self.group)
-            recv = [t.to(buf.device) for t in recv_h]
-        else:
-            flat = torch.empty((self.world,) + tuple(send.shape), dtype=buf.dtype, device=buf.device)
-            self.dist.all_gather_into_tensor(flat, send, group=self.group)
-            recv = [flat[r] for r in range(self.world)]
+        ops = []
+        if hi > lo:
+            st[self.rank].copy_(buf[:, lo:hi])                      # contiguous copy of the owned slice
+            ops += [dist.P2POp(dist.isend, st[self.rank], self._peer(d), self.group) for d in range(self.world) if d != self.rank]
+        ops += [dist.P2POp(dist.irecv, st[r], self._peer(r), self.group) for r in st if r != self.rank]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
         for r, (a, b) in enumerate(ranges):
             if r != self.rank and b > a:
-                buf[:, a:b] = recv[r][:, : b - a]
+                buf[:, a:b].copy_(st[r])
+
+    def _peer(self, r):
+        return r if self.group is None else self.dist.get_global_rank(self.group, r)
 
     def broadcast(self, t, src: int):
         if self.world == 1:
             return
         if self.staged:
             h = t.cpu()
-            self.dist.broadcast(h, src=src, group=self.group)
+            self.dist.broadcast(h, src=self._peer(src), group=self.group)
             if self.rank != src:
                 t.copy_(h)
         else:
-            self.dist.broadcast(t, src=src, group=self.group)
+            self.dist.broadcast(t, src=self._peer(src), group=self.group)
 
 
 class ShardedMult:
