@@ -1,16 +1,30 @@
 #!/bin/bash
-# Round profile: kernel-trace stats for the bench workloads + PMC passes for the NTT shapes.
-# usage (GPU box): tools/prof_round.sh <tag>      outputs under gpurun_out/<tag>_*
+# Round profile (GPU box): tools/prof_round.sh <tag>      outputs under gpurun_out/<tag>_*; copy what is to be judged into profiles/
+#   1. the DEFAULT command twice: as the driver runs it (-> <tag>_bench_default.json) and under rocprofv3 --kernel-trace --stats
+#      with --roofline-only (k_ntt_fwd<15> then appears in its digit-spread launches only, as the roofline object counts it)
+#   2. the full default command under rocprofv3 (its "ntt" / "coeffwise" legs: k_ntt_fwd / k_ntt_inv at N = 4096..32768, k_poly_binary)
+#   3. every other workload under rocprofv3 --kernel-trace --stats
+#   4. PMC passes (own runs, --kernel-trace only) for the transform shapes and the C3 pipeline
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=$1
+cd $R && python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
 cd /tmp && export TMPDIR=/tmp
-for wl in ckks ntt intt ntt15 intt15 bgv rotate mul encdec; do
-  rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_kt_$wl -o p -- python $R/bench.py --workload $wl --steps 3 --warmup 1 --roofline-only > $R/gpurun_out/${TAG}_kt_$wl.log 2>&1
-  python $R/tools/rocpd_summary.py $R/gpurun_out/${TAG}_kt_$wl/p_results.db > $R/gpurun_out/${TAG}_kernel_stats_$wl.txt 2>&1
-  grep '^{"metric"' $R/gpurun_out/${TAG}_kt_$wl.log >> $R/gpurun_out/${TAG}_bench_lines_under_rocprof.jsonl
-  rm -rf $R/gpurun_out/${TAG}_kt_$wl $R/gpurun_out/${TAG}_kt_$wl.log
-done
+kt() {   # kt <name> <bench args...>
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_kt_$name -o p -- python $R/bench.py "$@" > $R/gpurun_out/${TAG}_kt_$name.log 2>&1
+  python $R/tools/rocpd_summary.py $R/gpurun_out/${TAG}_kt_$name/p_results.db > $R/gpurun_out/${TAG}_kernel_stats_$name.txt 2>&1
+  grep '^{"metric"' $R/gpurun_out/${TAG}_kt_$name.log >> $R/gpurun_out/${TAG}_bench_lines_under_rocprof.jsonl
+  rm -rf $R/gpurun_out/${TAG}_kt_$name $R/gpurun_out/${TAG}_kt_$name.log
+}
+kt default --roofline-only
+kt default_full --cpu-seconds 1 --cpu-procs 0
+for wl in ntt intt ntt15 intt15 bgv rotate mul add encdec; do kt $wl --workload $wl --steps 3 --warmup 1 --roofline-only; done
 cd $R
 tools/prof_pmc.sh ${TAG}_ntt --workload ntt --steps 3 --warmup 1
+tools/prof_pmc.sh ${TAG}_intt --workload intt --steps 3 --warmup 1
 tools/prof_pmc.sh ${TAG}_ntt15 --workload ntt15 --steps 3 --warmup 1
+tools/prof_pmc.sh ${TAG}_intt15 --workload intt15 --steps 3 --warmup 1
+tools/prof_pmc.sh ${TAG}_ntt12 --workload ntt15 --logn 12 --batch 3724 --steps 3 --warmup 1
+tools/prof_pmc.sh ${TAG}_intt12 --workload intt15 --logn 12 --batch 3724 --steps 3 --warmup 1
+tools/prof_pmc.sh ${TAG}_mul --workload mul --steps 3 --warmup 1
 tools/prof_pmc.sh ${TAG}_ckks --workload ckks --steps 2 --warmup 1 --batch 64
