@@ -33,7 +33,7 @@ while time.time() - t0 < budget:
     logn = int(rs.choice([1, 2, 3, 5, 8, 10, 11, 12, 13, 14, 15], p=[.04, .04, .05, .07, .1, .1, .15, .15, .12, .1, .08]))
     n = 1 << logn
     L = int(rs.randint(1, 7)) if logn < 14 else int(rs.randint(1, 4))
-    B = int(rs.randint(1, 5)) if logn < 13 else int(rs.randint(1, 3))
+    B = int(rs.randint(1, 12)) if logn < 13 else int(rs.randint(1, 4))   # up to 11: ragged last groups of the multi-limb inverse workgroups
     idx = rs.choice(len(pool), L + 1, replace=False)
     mext = [pool[i] for i in idx]
     q = mext[:L]
