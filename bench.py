@@ -354,12 +354,15 @@ def transform_rates(torch, hd, eng, P, args, world, dev, rank):
     L = len(moduli)
     out = {}
     lib = None if args.no_verify else checker()[0]
-    for logn in (12, 13, 14, 15):
+    # (key, log2 N, polynomials): by-N entries at the bytes of the C3 ciphertext batch (256 x 2 polynomials of 10 limbs at
+    # N = 32768 = 2.5 GiB), plus "steady": as many limb transforms per launch as the digit-spread launch of the C3 step (25 600 =
+    # 100 per CU; a launch's first and last rounds cost about one and a half items, which 20 rounds do not amortise)
+    shapes = [(str(1 << logn), logn, (512 << 15) >> logn) for logn in (12, 13, 14, 15)] + [("steady_32768", 15, 2560)]
+    for key, logn, B in shapes:
         n = 1 << logn
-        B = (512 << 15) // n                    # the bytes of the C3 ciphertext batch (256 x 2 polynomials of 10 limbs at N = 32768)
         xb = Batch(torch, B, (L, n), moduli, dev, 40 + logn + 100 * rank, 3)
         x = xb.full
-        ent = {"N": n, "limbs_per_launch": B * L}
+        ent = {"N": n, "limbs_per_launch": B * L, "bytes_in_place": B * L * n * 8}
         for name, fam, fn in (("forward", "ntt", lambda: eng.ntt_(moduli, x)), ("inverse", "intt", lambda: eng.intt_(moduli, x))):
             dt, launches, kern_ms = timed_launches(torch, hd, eng, fn, fam, args.steps, dev)
             ent[name] = rate_entry(B * L, 16.0 * n, args.steps, world, dt, launches, kern_ms)
@@ -375,7 +378,7 @@ def transform_rates(torch, hd, eng, P, args, world, dev, rank):
             ok2, _ = compare_classes(torch, y, inv, xb.period, idx)
             ent["verified"] = bool(ok1 and ok2)
             ent["verified_polynomials"] = cnt
-        out[str(n)] = ent
+        out[key] = ent
         del x, xb
     return out
 
@@ -699,12 +702,13 @@ def main() -> int:
         # coefficient-wise kernels: the default line carries them too (timed after the hom-mult region, same fences)
         by_n = transform_rates(torch, hd, eng, P, args, world, dev, rank)
         top = by_n[str(1 << P.C3_LOGN)]
+        steady = by_n.pop("steady_32768")
         res["ntt"] = {"N": top["N"], "limbs_per_launch": top["limbs_per_launch"],
                       "forward_limb_ntt_per_s": top["forward"]["per_s"], "inverse_limb_ntt_per_s": top["inverse"]["per_s"],
                       "forward": top["forward"], "inverse": top["inverse"], "verified": top.get("verified"),
-                      "by_N": by_n}
+                      "steady_state": steady, "by_N": by_n}
         res["coeffwise"] = coeffwise_rates(torch, hd, eng, P, args, world, dev, rank)
-        for sect in list(by_n.values()) + [res["coeffwise"]["mul"], res["coeffwise"]["add"]]:
+        for sect in list(by_n.values()) + [steady, res["coeffwise"]["mul"], res["coeffwise"]["add"]]:
             if sect.get("verified") is False:
                 failed = True
     if rank == 0:

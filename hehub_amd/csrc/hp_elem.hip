@@ -292,12 +292,26 @@ template <int PT> struct KsRow {
     U2 d[PT];
 };
 
+// packed: the digit rows of this output modulus are in the HP_PACK48 format (hp_device.h); the diagonal j == k is the
+// caller's NTT-form limb and always plain u64
 template <int PT>
 HP_DEV void ks_load(KsRow<PT> &r, u32 j, u32 k, u32 L, u32 Le, u32 key_Le, u32 kcol, u32 n, u32 i, const u32 (&pc)[PT],
-                    const u64 *digits, const u64 *pt, u32 pt_pstride, const u64 *key) {
+                    const u64 *digits, const u64 *pt, u32 pt_pstride, const u64 *key, bool packed) {
     typedef u64 __attribute__((ext_vector_type(2))) vv;
+    typedef u32 __attribute__((ext_vector_type(2))) v2u;
     r.g0 = *reinterpret_cast<const U2 *>(key + (((size_t)j * 2 + 0) * key_Le + kcol) * n + i);
     r.g1 = *reinterpret_cast<const U2 *>(key + (((size_t)j * 2 + 1) * key_Le + kcol) * n + i);
+    if (packed && j != k) {
+#pragma unroll
+        for (int c = 0; c < PT; c++) {
+            const u32 *row = reinterpret_cast<const u32 *>(digits + (((size_t)pc[c] * L + j) * Le + k) * n);
+            const v2u lo = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(row + i));
+            const u32 hi = __builtin_nontemporal_load(row + n + (i >> 1));
+            r.d[c].x = lo.x | ((u64)(hi & 0xffffu) << 32);
+            r.d[c].y = lo.y | ((u64)(hi >> 16) << 32);
+        }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < PT; c++) {
         const u64 *d = (j == k) ? pt + ((size_t)pc[c] * pt_pstride + j) * n : digits + (((size_t)pc[c] * L + j) * Le + k) * n;
@@ -320,13 +334,14 @@ template <int PT>
 __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner_blk(const HpLimb *__restrict__ limbs, u32 L, u32 k_first, u32 P,
                                                               u32 key_Le, u32 n, u32 chunks, const u64 *__restrict__ digits,
                                                               const u64 *__restrict__ pt, u32 pt_pstride,
-                                                              const u64 *__restrict__ key, u64 *__restrict__ out) {
+                                                              const u64 *__restrict__ key, u64 *__restrict__ out, u32 pack_mask) {
     const u32 Le = L + 1;
     const u32 PG = (P + PT - 1) / PT;
     const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
     const u32 k = k_first + row / PG, p0 = (row % PG) * PT;
     const u64 q = limbs[k].q, mqinv = limbs[k].mqinv;
     const u32 kcol = (k == L) ? key_Le - 1 : k;   // key made for more moduli (extension): special prime = its last column
+    const bool packed = ((pack_mask >> k) & 1u) != 0;
     u32 pc[PT];
 #pragma unroll
     for (int c = 0; c < PT; c++) pc[c] = min(p0 + c, P - 1);
@@ -338,12 +353,12 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner_blk(const HpLimb *__r
 #pragma unroll
             for (int h = 0; h < 2; h++) { hp_acc_zero(acc[c][h][0]); hp_acc_zero(acc[c][h][1]); }
         KsRow<PT> ra, rb;
-        ks_load<PT>(ra, 0, k, L, Le, key_Le, kcol, n, i, pc, digits, pt, pt_pstride, key);
+        ks_load<PT>(ra, 0, k, L, Le, key_Le, kcol, n, i, pc, digits, pt, pt_pstride, key, packed);
         u32 j = 0;
         for (; j + 2 <= L; j += 2) {
-            ks_load<PT>(rb, j + 1, k, L, Le, key_Le, kcol, n, i, pc, digits, pt, pt_pstride, key);
+            ks_load<PT>(rb, j + 1, k, L, Le, key_Le, kcol, n, i, pc, digits, pt, pt_pstride, key, packed);
             ks_mac<PT>(ra, acc);
-            ks_load<PT>(ra, min(j + 2, L - 1), k, L, Le, key_Le, kcol, n, i, pc, digits, pt, pt_pstride, key);   // last: harmless re-read
+            ks_load<PT>(ra, min(j + 2, L - 1), k, L, Le, key_Le, kcol, n, i, pc, digits, pt, pt_pstride, key, packed);   // last: harmless re-read
             ks_mac<PT>(rb, acc);
         }
         if (j < L) ks_mac<PT>(ra, acc);
@@ -365,17 +380,18 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner_blk(const HpLimb *__r
 }
 
 hipError_t hp_launch_ks_inner(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32 key_Le, u32 n, u32 P, const u64 *digits,
-                              const u64 *pt, u32 pt_pstride, const u64 *key, u64 *out, hipStream_t stream) {
+                              const u64 *pt, u32 pt_pstride, const u64 *key, u64 *out, u32 pack_mask, hipStream_t stream) {
     if (kc == 0) return hipSuccess;
+    if (pack_mask && !(n >= 2 && P >= 2)) return hipErrorInvalidValue;   // the one-ciphertext kernel reads plain rows only
     u32 chunks; dim3 grid;
     // ciphertexts per thread: four share every key word in registers (1 or 2 measured 1.5 % slower at the C3 shape)
     const int PT = (n >= 2 && P >= 4) ? 4 : (n >= 2 && P >= 2) ? 2 : 1;
     if (PT >= 4) {
         elem_grid(n, ((P + 3) / 4) * kc, chunks, grid);
-        k_ks_inner_blk<4><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, key_Le, n, chunks, digits, pt, pt_pstride, key, out);
+        k_ks_inner_blk<4><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, key_Le, n, chunks, digits, pt, pt_pstride, key, out, pack_mask);
     } else if (PT >= 2) {
         elem_grid(n, ((P + 1) / 2) * kc, chunks, grid);
-        k_ks_inner_blk<2><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, key_Le, n, chunks, digits, pt, pt_pstride, key, out);
+        k_ks_inner_blk<2><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, key_Le, n, chunks, digits, pt, pt_pstride, key, out, pack_mask);
     } else {
         elem_grid(n, P * kc, chunks, grid);
         k_ks_inner<<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, key_Le, n, chunks, digits, pt, pt_pstride, key, out);

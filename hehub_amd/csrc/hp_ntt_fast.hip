@@ -533,11 +533,24 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
     TRACE_MARK();   // 8
     // store, layout S: 16 bytes per lane, a wave writes 1 KiB of consecutive words per instruction
     if (!DROP) {
-        u64 *d = it.dst + (((size_t)(tid >> 6)) << 11) + ((tid & 63u) << 1);
+        const size_t off = (((size_t)(tid >> 6)) << 11) + ((tid & 63u) << 1);
+        if (job.mode == HP_NTT_SPREAD && ((job.pack_mask >> it.limb) & 1u)) {
+            // HP_PACK48 (hp_device.h): low words as 8 bytes per lane, high 16 bits of the two words as 4 bytes per lane
+            typedef u32 __attribute__((ext_vector_type(2))) v2u;
+            u32 *lo = reinterpret_cast<u32 *>(it.dst) + off;
+            u32 *hi = reinterpret_cast<u32 *>(it.dst) + G::N + (off >> 1);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            V2 v{x[2 * s], x[2 * s + 1]};
-            st_stream(d + ((size_t)s << 7), v);
+            for (int s = 0; s < 16; ++s) {
+                __builtin_nontemporal_store(v2u{lo32(x[2 * s]), lo32(x[2 * s + 1])}, reinterpret_cast<v2u *>(lo + ((size_t)s << 7)));
+                __builtin_nontemporal_store((hi32(x[2 * s]) & 0xffffu) | (hi32(x[2 * s + 1]) << 16), hi + ((size_t)s << 6));
+            }
+        } else {
+            u64 *d = it.dst + off;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                V2 v{x[2 * s], x[2 * s + 1]};
+                st_stream(d + ((size_t)s << 7), v);
+            }
         }
     } else {
         // rescaling.cpp:72-74 / mod_switch.cpp:72-76 (+ the += of relinearize, ckks/arith.cpp:70-71):

@@ -46,6 +46,8 @@ def test_default_line_carries_both_halves_of_the_metric():
     assert r["verified"] is True and r["verify"]["outputs_compared_per_gpu"] == 256
     ntt = r["ntt"]
     assert ntt["N"] == 32768 and ntt["verified"] is True and set(ntt["by_N"]) == {"4096", "8192", "16384", "32768"}
+    assert ntt["steady_state"]["limbs_per_launch"] == 25600 and ntt["steady_state"]["verified"] is True
+    assert ntt["steady_state"]["forward"]["frac_of_hbm_peak"] >= ntt["forward"]["frac_of_hbm_peak"] * 0.95
     for ent in ntt["by_N"].values():
         assert ent["verified"] is True
         for d in ("forward", "inverse"):

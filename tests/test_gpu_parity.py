@@ -452,3 +452,36 @@ def test_workspace_generation_and_per_thread_errors(eng):
     t2 = threading.Thread(target=worker, args=("ntt", lambda: eng.ntt_([12289], eng.empty((1, 1, 1 << 15)))))
     t1.start(); t2.start(); t1.join(); t2.join()
     assert "Unable to drop the only one prime" in msgs["drop"] and "2N doesn't divide" in msgs["ntt"]
+
+
+def test_digit_workspace_packing_is_invisible(eng, orc):
+    """At N = 32768 the digit rows of output moduli whose folded words are provably below 2^48 cross HBM as 6 bytes per word
+    (HP_PACK48, hp_device.h) -- an internal workspace format.  Mixed chain: 40-bit list primes (packed), a 50-bit prime and a
+    prime far from a power of two, 1.37 * 2^40, whose fold wraps exactly as the reference's does (both must stay plain rows);
+    the results equal the oracle's and those of a context created with HP_NO_PACK48."""
+    import os
+
+    from hehub_amd.engine import Engine
+
+    far = 1506330935297                      # = 1 (mod 2^16), prime, 37 % above 2^40
+    logn, B = 15, 3
+    for mext in ([P.P40[0], far, P.P50[1], P.P40[1], P.P50[0]], [P.P40[2], P.P40[3], far]):
+        n, L = 1 << logn, len(mext) - 1
+        rng = SplitMix(4848 + L)
+        pt = rng.poly((B, L, n), mext[:L])
+        ct1 = rng.poly((B, 2, L, n), mext[:L]); ct2 = rng.poly((B, 2, L, n), mext[:L])
+        key = rng.poly((L, 2, L + 1, n), mext)
+        exp_ext = np.stack([orc.ext_prod(mext, pt[i], key) for i in range(B)])
+        exp_mul = np.stack([orc.ckks_mult(mext, ct1[i], ct2[i], key) for i in range(B)])
+        os.environ["HP_NO_PACK48"] = "1"
+        try:
+            plain = Engine(0)
+        finally:
+            del os.environ["HP_NO_PACK48"]
+        try:
+            for e in (eng, plain):
+                dk = e.to_device(key)
+                assert np.array_equal(e.to_host(e.ext_prod(mext, e.to_device(pt), dk)), exp_ext)
+                assert np.array_equal(e.to_host(e.ckks_mult(mext, e.to_device(ct1), e.to_device(ct2), dk)), exp_mul)
+        finally:
+            plain.close()
