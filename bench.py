@@ -192,10 +192,28 @@ def compare_classes(torch, out, expected_host, period, idx):
     return ok, len(idx)
 
 
-def checker():
-    from oracle.pyoracle import Oracle, build, have_ref
+_CHECKER_BUILT = False
 
-    build(ref=False)
+
+def build_checker_once(hd=None, rank=0):
+    """compile the C restatement if its .so is missing or stale: rank 0 only (N ranks running make in one directory would
+    race), the others wait at a barrier.  Building the checker is not using it."""
+    global _CHECKER_BUILT
+    if _CHECKER_BUILT:
+        return
+    from oracle.pyoracle import build
+
+    if rank == 0:
+        build(ref=False)
+    if hd is not None:
+        hd.barrier()
+    _CHECKER_BUILT = True
+
+
+def checker():
+    from oracle.pyoracle import Oracle, have_ref
+
+    build_checker_once()
     kind = "reference" if have_ref() else "port"
     return Oracle("ref" if kind == "reference" else "orc"), kind
 
@@ -643,6 +661,8 @@ def main() -> int:
     }
     # ---- output check on the timed buffers (every rank checks its own; the verdict is the AND over ranks) ----------
     failed = False
+    if extras:
+        build_checker_once(hd, rank)
     if extras and not args.no_verify and verify is not None:
         try:
             ok, compared, classes, kind = verify()
