@@ -139,7 +139,7 @@ template <bool SWAP, bool BGV> struct DropPre {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const u64 c = x[r + e];
-            u64 v = hp_strict(hp_barrett_lazy(c, q, bc), q);
+            u64 v = hp_strict(hp_barrett_lazy_nq(c, bc, n0, n1), q);
             if (c >= half) v += bump;
             if (BGV) v = hp_harvey_lazy_nq(v, tk, tkh, n0, n1);
             x[r + e] = v;
@@ -439,7 +439,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
                 const u64 c = x[r];
-                u64 v = hp_strict(hp_barrett_lazy(c, q, bc), q);
+                u64 v = hp_strict(hp_barrett_lazy_nq(c, bc, (u32)nq, (u32)(nq >> 32)), q);
                 if (c >= half) v += bump;
                 if (bgv) v = hp_harvey_lazy_nq(v, tk, tkh, (u32)nq, (u32)(nq >> 32));
                 x[r] = v;
@@ -487,7 +487,8 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
                         c1 = odd ? keep : recv;
                     }
                     const int r = 8 * ch + 2 * i;
-                    u64 v0 = hp_strict(hp_barrett_lazy(c0, q, bc), q), v1 = hp_strict(hp_barrett_lazy(c1, q, bc), q);
+                    u64 v0 = hp_strict(hp_barrett_lazy_nq(c0, bc, (u32)nq, (u32)(nq >> 32)), q);
+                    u64 v1 = hp_strict(hp_barrett_lazy_nq(c1, bc, (u32)nq, (u32)(nq >> 32)), q);
                     if (c0 >= chalf) v0 += cbump;
                     if (c1 >= chalf) v1 += cbump;
                     x[r] = hp_add_lazy(x[r], hp_harvey_lazy_nq(v0, pm, pmh, (u32)nq, (u32)(nq >> 32)), two_q);
