@@ -9,7 +9,7 @@ logn,mods=15,P.C3_MODULI_EXT
 n=1<<logn; L=len(mods)-1
 lib=capi.load()
 lib.hp_debug_trace.argtypes=[C.c_void_p,C.c_size_t]; lib.hp_debug_trace.restype=C.c_int
-names=["load","passA","exch1","passB","exch2","passC","fold","exch3","store"]
+names=os.environ.get("TRACE_NAMES","load,passA,exch1,passB,exch2,passC,fold,exch3,store").split(",")
 def dump(W,label):
     nrec=((W+15)//16)*2
     buf=np.zeros(4096*12,dtype=np.uint64)
