@@ -306,29 +306,28 @@ void drop_last_prime(RlweCt &ct, bool bgv, u64 t) {
 // rns.h / rns.cpp
 // =====================================================================================================
 #ifndef HEHUB_AMD_BIND_REFERENCE
-RnsIntVec::RnsIntVec(const size_t dimension, const size_t components, const std::vector<u64> &moduli)
-    : log_dimension_((size_t)(std::log2((double)dimension) + 0.5)), dimension_(dimension), components_(components) {
-    if (dimension_ != (size_t)1 << log_dimension_) throw std::invalid_argument("dimension should be a 2-power.");
-    if (moduli.size() < component_count())
-        throw std::invalid_argument("No matching number of moduli provided to create RnsIntVec.");
-    moduli_.assign(moduli.begin(), moduli.begin() + component_count());
-    for (auto &c : components_) c = ComponentData(dimension_);
+RnsIntVec::RnsIntVec(size_t dimension, size_t components, const std::vector<u64> &moduli) {
+    size_t lg = 0;
+    while (((size_t)1 << lg) < dimension) lg++;
+    if (dimension == 0 || dimension != (size_t)1 << lg) throw std::invalid_argument("dimension should be a 2-power.");   // rns.cpp:17-22
+    if (moduli.size() < components) throw std::invalid_argument("No matching number of moduli provided to create RnsIntVec.");
+    logn_ = lg;
+    q_.assign(moduli.begin(), moduli.begin() + components);
+    limbs_.assign(components, ComponentData(dimension));
 }
 
 RnsIntVec::RnsIntVec(const RnsIntVec::Params &p) : RnsIntVec(p.dimension, p.component_count, p.moduli) {}
 
 void RnsIntVec::add_components(const std::vector<u64> &new_moduli, size_t adding) {
     if (new_moduli.size() < adding) throw std::invalid_argument("No matching number of moduli provided to add components.");
-    auto orig = components_.size();
-    moduli_.insert(moduli_.end(), new_moduli.begin(), new_moduli.end());   // rns.cpp:41 (appends all supplied moduli)
-    components_.resize(orig + adding);
-    for (size_t i = orig; i < components_.size(); i++) components_[i] = ComponentData(dimension_);
+    q_.insert(q_.end(), new_moduli.begin(), new_moduli.end());   // rns.cpp:41: every supplied modulus is appended, `adding` limbs are
+    limbs_.insert(limbs_.end(), adding, ComponentData(dimension()));
 }
 
 void RnsIntVec::remove_components(size_t removing) {
     if (component_count() < removing) throw std::invalid_argument("Trying to remove components more than existing.");
-    moduli_.erase(moduli_.end() - removing, moduli_.end());
-    components_.erase(components_.end() - removing, components_.end());
+    q_.resize(q_.size() - removing);
+    limbs_.resize(limbs_.size() - removing);
 }
 #endif
 

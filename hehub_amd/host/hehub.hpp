@@ -39,48 +39,50 @@ namespace amd {
 hp_ctx *engine();
 } // namespace amd
 
+// Stand-alone mirror of hehub's RNS vector (rns.h:15-115): the public names a caller of hehub uses, over plain
+// std::vector limbs (hehub pools SmartArray blocks).  Only built when hehub's own headers are not (the real binding
+// compiles against those: -DHEHUB_AMD_BIND_REFERENCE).
 class RnsIntVec {
 public:
+    using ComponentData = std::vector<u64>;   // one limb: N words modulo modulus_at(k)
     struct Params {
         size_t dimension = 0;
         size_t component_count;
         std::vector<u64> moduli;
     };
-    using ComponentData = std::vector<u64>;
 
-    RnsIntVec() {}
-    RnsIntVec(const size_t dimension, const size_t components, const std::vector<u64> &moduli);
+    RnsIntVec() = default;
+    RnsIntVec(size_t dimension, size_t components, const std::vector<u64> &moduli);
     RnsIntVec(const Params &params);
 
-    inline bool operator==(const RnsIntVec &o) const {
-        return log_dimension_ == o.log_dimension_ && dimension_ == o.dimension_ && moduli_ == o.moduli_ &&
-               components_ == o.components_;
-    }
-    inline Params params() const { return Params{dimension_, components_.size(), moduli_}; }
-    inline size_t component_count() const { return components_.size(); }
-    inline size_t log_dimension() const { return log_dimension_; }
-    inline size_t dimension() const { return dimension_; }
-    inline std::vector<ComponentData> &components() { return components_; }
-    inline const std::vector<ComponentData> &components() const { return components_; }
-    inline auto begin() { return components_.begin(); }
-    inline auto begin() const { return components_.cbegin(); }
-    inline auto end() { return components_.end(); }
-    inline auto end() const { return components_.cend(); }
-    inline auto last() { return components_.end() - 1; }
-    inline auto last() const { return components_.cend() - 1; }
-    inline u64 modulus_at(int i) const { return moduli_[i]; }
-    inline const std::vector<u64> &modulus_vec() const { return moduli_; }
-    inline ComponentData &operator[](int i) { return components_[i]; }
-    inline const ComponentData &operator[](int i) const { return components_[i]; }
+    // shape
+    size_t log_dimension() const { return logn_; }
+    size_t dimension() const { return limbs_.empty() && !logn_ ? 0 : (size_t)1 << logn_; }
+    size_t component_count() const { return limbs_.size(); }
+    Params params() const { return Params{dimension(), limbs_.size(), q_}; }
+    u64 modulus_at(int k) const { return q_[k]; }
+    const std::vector<u64> &modulus_vec() const { return q_; }
+    bool operator==(const RnsIntVec &o) const { return logn_ == o.logn_ && q_ == o.q_ && limbs_ == o.limbs_; }
+
+    // limbs
+    ComponentData &operator[](int k) { return limbs_[k]; }
+    const ComponentData &operator[](int k) const { return limbs_[k]; }
+    std::vector<ComponentData> &components() { return limbs_; }
+    const std::vector<ComponentData> &components() const { return limbs_; }
+    auto begin() { return limbs_.begin(); }
+    auto end() { return limbs_.end(); }
+    auto last() { return limbs_.end() - 1; }
+    auto begin() const { return limbs_.cbegin(); }
+    auto end() const { return limbs_.cend(); }
+    auto last() const { return limbs_.cend() - 1; }
 
     void add_components(const std::vector<u64> &new_moduli, size_t adding = 1);
     void remove_components(size_t removing = 1);
 
 private:
-    size_t log_dimension_ = 0;
-    size_t dimension_ = 0;
-    std::vector<ComponentData> components_;
-    std::vector<u64> moduli_;
+    size_t logn_ = 0;
+    std::vector<u64> q_;
+    std::vector<ComponentData> limbs_;
 };
 
 class RnsPolynomial : public RnsIntVec {
