@@ -35,6 +35,8 @@ SIGNATURES = {
     "hp_ctx_release_workspace": (INT, [P]),
     "hp_dev_alloc": (INT, [P, szt, C.POINTER(P)]),
     "hp_dev_free": (INT, [P, P]),
+    "hp_host_alloc": (INT, [P, szt, C.POINTER(P)]),
+    "hp_host_free": (INT, [P, P]),
     "hp_memcpy_h2d": (INT, [P, P, P, szt]),
     "hp_memcpy_d2h": (INT, [P, P, P, szt]),
     "hp_ctx_set_force_generic": (INT, [P, INT]),

@@ -357,6 +357,19 @@ int hp_dev_free(hp_ctx *ctx, void *dptr) {
     HIP_TRY(ctx, hipFree(dptr));
     return HP_OK;
 }
+int hp_host_alloc(hp_ctx *ctx, size_t bytes, void **hptr) {
+    HP_ENTER(ctx);
+    HP_REQUIRE(ctx, hptr);
+    hipError_t e = hipHostMalloc(hptr, bytes, hipHostMallocPortable);
+    if (e != hipSuccess) return fail(ctx, HP_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    return HP_OK;
+}
+int hp_host_free(hp_ctx *ctx, void *hptr) {
+    HP_ENTER(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipHostFree(hptr));
+    return HP_OK;
+}
 int hp_memcpy_h2d(hp_ctx *ctx, void *dst, const void *src, size_t bytes) {
     HP_ENTER(ctx);
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));

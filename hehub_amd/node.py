@@ -45,6 +45,24 @@ class Node:
         msg = self.lib.hp_node_last_error(self.h).decode()
         raise (InvalidArgument if rc == capi.HP_EINVAL else HpError)(rc, msg)
 
+    def pinned(self, shape) -> np.ndarray:
+        """uint64 array in page-locked host memory (hp_host_alloc on rank 0's context); free with unpin()"""
+        words = int(np.prod(shape))
+        ptr = capi.P()
+        ctx = self.lib.hp_node_ctx(self.h, 0)
+        rc = self.lib.hp_host_alloc(ctx, words * 8, C.byref(ptr))
+        if rc != capi.HP_OK:
+            raise HpError(rc, "hp_host_alloc failed")
+        buf = (C.c_uint64 * words).from_address(ptr.value)
+        a = np.frombuffer(buf, dtype=np.uint64).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = ptr
+        return a
+
+    def unpin(self, a: np.ndarray):
+        ptr = self._pinned.pop(a.ctypes.data)
+        self.lib.hp_host_free(self.lib.hp_node_ctx(self.h, 0), ptr)
+
     def slice(self, total: int, rank: int):
         lo, hi = capi.szt(0), capi.szt(0)
         self._chk(self.lib.hp_node_slice(self.h, total, rank, C.byref(lo), C.byref(hi)))
@@ -60,9 +78,9 @@ class Node:
     def free_replicas(self, copies):
         self._chk(self.lib.hp_node_free_replicas(self.h, copies))
 
-    def ckks_mult(self, moduli_ext, ct1: np.ndarray, ct2: np.ndarray, key):
+    def ckks_mult(self, moduli_ext, ct1: np.ndarray, ct2: np.ndarray, key, out: np.ndarray = None):
         B, _, L, n = ct1.shape
-        out = np.empty((B, 2, L - 1, n), dtype=np.uint64)
+        out = np.empty((B, 2, L - 1, n), dtype=np.uint64) if out is None else out
         self._chk(self.lib.hp_node_ckks_mult_relin_rescale(self.h, n.bit_length() - 1, L, _u64arr(moduli_ext), B,
                                                            np.ascontiguousarray(ct1).ctypes.data_as(capi.P),
                                                            np.ascontiguousarray(ct2).ctypes.data_as(capi.P), key,

@@ -40,6 +40,13 @@ def test_batch_sharded_host_batches(orc, world):
             out = node.ckks_mult(mext, ct1, ct2, dk)
             for i in range(B):
                 assert np.array_equal(out[i], orc.ckks_mult(mext, ct1[i], ct2[i], key)), (world, logn, i)
+            # the same through page-locked host buffers (hp_host_alloc)
+            p1, p2, po = node.pinned(ct1.shape), node.pinned(ct2.shape), node.pinned(out.shape)
+            p1[...] = ct1; p2[...] = ct2; po[...] = 0
+            node.ckks_mult(mext, p1, p2, dk, out=po)
+            assert np.array_equal(po, out)
+            for a in (p1, p2, po):
+                node.unpin(a)
             out = node.bgv_mult(mext, P.C5_T, ct1, ct2, dk)
             for i in range(B):
                 assert np.array_equal(out[i], orc.bgv_mult(mext, P.C5_T, ct1[i], ct2[i], key)), (world, logn, i)
