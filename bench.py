@@ -25,6 +25,7 @@ One process per GPU; ciphertext batches are sharded across ranks with no data-pa
   ntt / coeffwise       (default ckks line) the other half of BASELINE's metric: forward / inverse limb-NTT/s at N = 32768
                         and across N = 4096..32768, coefficient-wise multiply / add, each with achieved GB/s and the
                         fraction of HBM peak; timed outside the hom-mult region
+  ckks_by_N             (default ckks line) hom-mult/s at N = 4096 .. 32768 (same chain, batch 256), each verified
   cpu_baseline          the compiled reference (or the C restatement) on ONE core of this host; cpu_baseline_node: the
                         same as P independent processes (P stated)
   --roofline-only       drops everything after the timed region (for clean rocprofv3 summaries of the default command)
@@ -429,6 +430,37 @@ def coeffwise_rates(torch, hd, eng, P, args, world, dev, rank):
     return out
 
 
+def ckks_rates(torch, hd, eng, P, args, world, dev, rank):
+    """ckks::mult + relinearize + rescale_inplace at the smaller ring degrees the north star names (N = 4096, 8192, 16384; the C3
+    moduli chain, L = 10, batch 256 per GPU), timed like the headline and every output checked against the checker"""
+    import numpy as np
+
+    mext = P.C3_MODULI_EXT
+    L, B = len(mext) - 1, P.C3_BATCH
+    out = {}
+    lib = None if args.no_verify else checker()[0]
+    for logn in (12, 13, 14):
+        n = 1 << logn
+        b1 = Batch(torch, B, (2, L, n), mext[:L], dev, 300 + logn + 100 * rank, 3)
+        b2 = Batch(torch, B, (2, L, n), mext[:L], dev, 400 + logn + 100 * rank, 3)
+        key = rand_words(torch, (L, 2, L + 1, n), mext, dev, 7 + logn)
+        res = eng.empty((B, 2, L - 1, n))
+        dt, _, _ = timed_launches(torch, hd, eng, lambda: eng.ckks_mult(mext, b1.full, b2.full, key, out=res), "none", args.steps, dev)
+        a_step = (5 * L * L + 36 * L) * 8 * n
+        ent = {"N": n, "L": L, "batch_per_gpu": B, "per_s": B * world * args.steps / dt, "unit": "hom-mult/s",
+               "A_step_frac_of_hbm_peak": B * args.steps / dt * a_step / 1e9 / HBM_PEAK_GBS}
+        if lib is not None:
+            idx, h1 = b1.classes()
+            _, h2 = b2.classes()
+            hk = key.cpu().numpy().view(np.uint64)
+            exp = np.stack([lib.ckks_mult(mext, h1[c], h2[c], hk) for c in range(len(idx))])
+            ok, cnt = compare_classes(torch, res, exp, b1.period, idx)
+            ent["verified"] = bool(ok)
+            ent["verified_outputs"] = cnt
+        out[str(n)] = ent
+    return out
+
+
 # =====================================================================================================================
 def main() -> int:
     global LOGN_OVERRIDE
@@ -728,7 +760,11 @@ def main() -> int:
                       "forward": top["forward"], "inverse": top["inverse"], "verified": top.get("verified"),
                       "steady_state": steady, "by_N": by_n}
         res["coeffwise"] = coeffwise_rates(torch, hd, eng, P, args, world, dev, rank)
-        for sect in list(by_n.values()) + [steady, res["coeffwise"]["mul"], res["coeffwise"]["add"]]:
+        res["ckks_by_N"] = ckks_rates(torch, hd, eng, P, args, world, dev, rank)
+        res["ckks_by_N"][str(n)] = {"N": n, "L": L, "batch_per_gpu": B, "per_s": value, "unit": "hom-mult/s",
+                                    "A_step_frac_of_hbm_peak": res["pipeline_roofline"]["frac_of_hbm_peak"],
+                                    "verified": res.get("verified"), "verified_outputs": B}
+        for sect in list(by_n.values()) + list(res["ckks_by_N"].values()) + [steady, res["coeffwise"]["mul"], res["coeffwise"]["add"]]:
             if sect.get("verified") is False:
                 failed = True
     if rank == 0:

@@ -52,6 +52,10 @@ def test_default_line_carries_both_halves_of_the_metric():
         assert ent["verified"] is True
         for d in ("forward", "inverse"):
             assert ent[d]["per_s"] > 0 and 0.05 < ent[d]["frac_of_hbm_peak"] < 1 and ent[d]["achieved_GBps"] > 0
+    assert set(r["ckks_by_N"]) == {"4096", "8192", "16384", "32768"}
+    for ent in r["ckks_by_N"].values():
+        assert ent["verified"] is True and ent["per_s"] > 0 and 0.3 < ent["A_step_frac_of_hbm_peak"] < 1
+    assert r["ckks_by_N"]["4096"]["per_s"] > 4 * r["ckks_by_N"]["32768"]["per_s"]
     cw = r["coeffwise"]
     for op in ("mul", "add"):
         assert cw[op]["verified"] is True and 0.2 < cw[op]["frac_of_hbm_peak"] < 1

@@ -12,4 +12,6 @@ r=json.load(open('gpurun_out/${TAG}_bench.json'))
 print('hom-mult/s', round(r['value']), 'verified', r.get('verified'), 'spread ms', round(r['roofline']['avg_launch_ms'],3), 'frac', round(r['roofline']['frac'],3))
 for n,e in r['ntt']['by_N'].items():
     print(n, 'fwd', round(e['forward']['frac_of_hbm_peak'],3), 'inv', round(e['inverse']['frac_of_hbm_peak'],3), e.get('verified'))
+for n,e in r.get('ckks_by_N',{}).items():
+    print('ckks', n, round(e['per_s']), round(e['A_step_frac_of_hbm_peak'],3), e.get('verified'))
 PY
