@@ -132,3 +132,28 @@ class ShardedPlan:
                                                           np.ascontiguousarray(ct2).ctypes.data_as(capi.P), key,
                                                           out.ctypes.data_as(capi.P)))
         return out
+
+    def mult_dev(self, d_ct1, d_ct2, key, d_out):
+        """operands already on the devices: per-rank lists of int64 torch tensors (device of the rank), result replicated into
+        every rank's d_out tensor (hp_node_sharded_mult_dev)"""
+        W = self.node.world
+        arr = lambda ts: (capi.P * W)(*[C.c_void_p(t.data_ptr()) for t in ts])
+        self.node._chk(self.node.lib.hp_node_sharded_mult_dev(self.h, arr(d_ct1), arr(d_ct2), key, arr(d_out)))
+        return d_out
+
+
+def dev_mult(node: Node, moduli_ext, d_ct1, d_ct2, key, d_out, plain_modulus: int = 0):
+    """batch-sharded, device-resident: rank r multiplies the ciphertext pairs behind d_ct1[r] / d_ct2[r] (torch tensors
+    [count_r][2][L][n] on the rank's device) into d_out[r] (hp_node_dev_ckks_mult_relin_rescale / _bgv_...)"""
+    W = node.world
+    counts = (capi.szt * W)(*[int(t.shape[0]) for t in d_ct1])
+    L, n = int(d_ct1[0].shape[2]), int(d_ct1[0].shape[3])
+    arr = lambda ts: (capi.P * W)(*[C.c_void_p(t.data_ptr()) for t in ts])
+    if plain_modulus:
+        rc = node.lib.hp_node_dev_bgv_mult_relin_modswitch(node.h, n.bit_length() - 1, L, _u64arr(moduli_ext), plain_modulus, counts,
+                                                           arr(d_ct1), arr(d_ct2), key, arr(d_out))
+    else:
+        rc = node.lib.hp_node_dev_ckks_mult_relin_rescale(node.h, n.bit_length() - 1, L, _u64arr(moduli_ext), counts, arr(d_ct1),
+                                                          arr(d_ct2), key, arr(d_out))
+    node._chk(rc)
+    return d_out

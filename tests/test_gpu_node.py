@@ -123,3 +123,42 @@ def test_node_errors_are_reported_not_thrown():
             node.ckks_mult([P.P40[0], P.P50[0]], ct, ct, node.replicate(np.zeros(8, dtype=np.uint64)))   # L = 1: nothing to drop
     finally:
         node.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_device_resident_entry_points(orc, world):
+    """hp_node_dev_* (per-rank device slices, unequal counts) and hp_node_sharded_mult_dev (operands replicated on the ranks, the
+    whole result left on every rank)"""
+    import torch
+
+    from hehub_amd.node import ShardedPlan, dev_mult
+
+    node = make_node(world)
+    try:
+        logn, mext, B = 12, [P.P50[1]] + P.P40[:3] + [P.P50[0]], 5
+        n, L = 1 << logn, len(mext) - 1
+        ct1, ct2, key = case(logn, mext, B, 4100 + world)
+        dk = node.replicate(key)
+        tdev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to("cuda:0")
+        host = lambda t: t.cpu().numpy().view(np.uint64)
+        cuts = [node.slice(B, r) for r in range(world)]
+        d1 = [tdev(ct1[lo:hi]) for lo, hi in cuts]; d2 = [tdev(ct2[lo:hi]) for lo, hi in cuts]
+        for t in (0, P.C5_T):
+            do = [torch.full((hi - lo, 2, L - 1, n), -1, dtype=torch.int64, device="cuda:0") for lo, hi in cuts]
+            dev_mult(node, mext, d1, d2, dk, do, plain_modulus=t)
+            torch.cuda.synchronize()
+            got = np.concatenate([host(x) for x in do])
+            for i in range(B):
+                exp = orc.bgv_mult(mext, t, ct1[i], ct2[i], key) if t else orc.ckks_mult(mext, ct1[i], ct2[i], key)
+                assert np.array_equal(got[i], exp), (world, t, i)
+            plan = ShardedPlan(node, logn, mext, B, plain_modulus=t)
+            r1 = [tdev(ct1) for _ in range(world)]; r2 = [tdev(ct2) for _ in range(world)]
+            ro = [torch.full((B, 2, L - 1, n), -1, dtype=torch.int64, device="cuda:0") for _ in range(world)]
+            torch.cuda.synchronize()
+            plan.mult_dev(r1, r2, dk, ro)
+            for r in range(world):
+                assert np.array_equal(host(ro[r]), got), (world, t, r)
+            plan.close()
+        node.free_replicas(dk)
+    finally:
+        node.close()
