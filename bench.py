@@ -93,7 +93,7 @@ def parse(argv=None):
 def self_launch(args) -> int:
     """--gpus N > 1 without a torch.distributed environment: become the launcher of N ranks on this node."""
     n = args.gpus
-    if not args.launcher_selftest:
+    if not args.launcher_selftest and not os.environ.get("HP_BENCH_SHARE_GPU"):
         import torch
 
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
@@ -348,7 +348,7 @@ def timed_launches(torch, hd, eng, fn, family, steps, dev):
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     launches, kern_ms = eng.prof_end()
-    dt = hd.max_over_ranks(t1 - t0, device=dev)
+    dt = hd.max_over_ranks(t1 - t0, device="cpu" if os.environ.get("HP_BENCH_SHARE_GPU") else dev)
     hd.barrier()
     return dt, launches, kern_ms
 
@@ -484,14 +484,23 @@ def main() -> int:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a number for the wrong job size",
               file=sys.stderr)
         return 2
+    # TEST MODE (tests/test_bench_contract.py): the ranks of a multi-rank run share GPU 0 and rendezvous over gloo, so that the whole
+    # N > 1 code path of this file runs on a one-GPU box.  The line says so; it is not a scaling number.
+    share_gpu = bool(os.environ.get("HP_BENCH_SHARE_GPU")) and world > 1
+    if share_gpu:
+        local = 0
     if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
         print(f"bench.py: rank {rank} needs HIP device {local}, {torch.cuda.device_count() if torch.cuda.is_available() else 0} "
               f"visible (no CPU fallback)", file=sys.stderr)
         return 2
     torch.cuda.set_device(local)
-    hd.init("nccl", device=torch.device(f"cuda:{local}"))   # "nccl" is RCCL on ROCm; rendezvous + timing fences only
+    if share_gpu:
+        hd.init("gloo")
+    else:
+        hd.init("nccl", device=torch.device(f"cuda:{local}"))   # "nccl" is RCCL on ROCm; rendezvous + timing fences only
     rccl_ranks = dist.get_world_size() if dist.is_initialized() else 1
     dev = f"cuda:{local}"
+    cdev = "cpu" if share_gpu else dev     # where the tensors of the few collectives live
     eng = Engine(local)
     period = args.input_period
     verify = None          # callable -> (ok, compared, classes) run after the timed region
@@ -682,7 +691,7 @@ def main() -> int:
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     launches, kern_ms = eng.prof_end()
-    elapsed = hd.max_over_ranks(t1 - t0, device=dev)
+    elapsed = hd.max_over_ranks(t1 - t0, device=cdev)
     hd.barrier()
 
     value = units_per_step * world * args.steps / elapsed
@@ -691,6 +700,9 @@ def main() -> int:
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "u64", "data": "synthetic", "config": cfg,
     }
+    if share_gpu:
+        res["data"] = "synthetic (TEST MODE: the ranks share ONE GPU over gloo; exercises the multi-rank path, not a scaling number)"
+        res["backend"] = "gloo"
     # ---- output check on the timed buffers (every rank checks its own; the verdict is the AND over ranks) ----------
     failed = False
     if extras:
@@ -700,7 +712,7 @@ def main() -> int:
             ok, compared, classes, kind = verify()
         except Exception as e:   # a missing checker must not look like a pass
             ok, compared, classes, kind = False, 0, 0, f"error: {e!r}"
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=cdev)
         if dist.is_initialized():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         res["verified"] = bool(flag.item())

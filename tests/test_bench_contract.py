@@ -83,3 +83,23 @@ def test_bench_refuses_two_gpus_on_a_one_gpu_box():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 2 and "refusing" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_two_ranks_end_to_end_on_one_gpu():
+    """The N > 1 path of bench.py as the driver runs it (`bench.py --gpus 2` starts its own ranks; shard seeds per rank, fences,
+    max over ranks, verification on every rank + AND over ranks, transform / coefficient-wise / by-N legs in lockstep, one line
+    from rank 0), with the test switch that lets the two ranks share this box's GPU over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HP_BENCH_SHARE_GPU"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=1800, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.stdout[-2000:], out.stderr[-3000:])
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["rccl_ranks"] == 2 and r["backend"] == "gloo" and "TEST MODE" in r["data"]
+    assert r["verified"] is True and r["verify"]["outputs_compared_per_gpu"] == 256
+    assert r["ntt"]["verified"] is True and r["coeffwise"]["mul"]["verified"] is True
+    assert all(e["verified"] for e in r["ckks_by_N"].values())
+    assert "cpu_baseline" not in r            # CPU legs only at N = 1
+    assert r["value"] > 0 and r["config"]["batch_per_gpu"] == 256
