@@ -18,8 +18,9 @@
 //     wave-local: each wave owns 2048 consecutive coefficients there, so they need no
 //     s_barrier and waves drift apart, overlapping one wave's LDS traffic with another's
 //     integer multiplies.  Only the A <-> B exchange is workgroup-wide (3 barriers);
-//   * LDS word address of coefficient i is i ^ ((i >> 5) & 31): every ds_read_b32 /
-//     ds_write_b32 of every exchange hits 32 distinct banks per 32-lane group;
+//   * LDS word address of coefficient i is i ^ ((i >> 5) & 31) (forward kernels at N = 32768: i + (i >> 5), a padded buffer
+//     whose register offsets are all immediates): every ds_read_b32 / ds_write_b32 of every exchange hits 32 distinct banks
+//     per 32-lane group;
 //   * twiddles are (w, floor(w*2^64/q)) pairs read as one 16-byte load from per-modulus tables
 //     laid out [slot][class] (hp_tables.cpp) so a wavefront reads consecutive pairs; the
 //     tables are shared by the whole batch and live in L2 -- work items are numbered
@@ -211,20 +212,34 @@ HP_DEV void inv_pass(u64 (&x)[32], const Tab tbl, u32 ncls, u32 cls, u64 nq, u64
 //   layout C ("contiguous"): r,                   i = (tid << 5) | r
 //   layout S ("stream"):    r = (s << 1) | e,     i = (wave << 11) | (s << 7) | (lane << 1) | e
 //                           (a lane moves 16 contiguous bytes, a wave 1 KiB per HBM instruction)
-template <int LOGN> struct Addr {
+// N = 32768 uses a PADDED buffer instead (word address i + (i >> 5), 132 KiB): every register's offset is then an immediate of the
+// ds instruction and the 279 v_xor per thread disappear; it is conflict-free for all four layouts at that size only (at N <= 16384
+// the strided layout A collides, and the padding would cost the second workgroup per CU its LDS).
+// (forward kernels only: the inverse kernel with the padded buffer spills 34 registers and runs 4 % slower)
+template <int LOGN, bool PADDED = false> struct Addr {
     using G = Geo<LOGN>;
+    static constexpr int LOGN_ = LOGN;
+    static constexpr bool PAD = PADDED;
+    static constexpr int WORDS = PAD ? G::N + G::N / 32 : G::N;
     u32 a_base;   // ((tid << PB) ^ h) with h = bits 9..5 of (tid << PB)
     u32 b_base;   // (blk << 10) | j
     u32 c_base;   // (tid << 5) | (tid & 31)
     u32 s_base;   // (wave << 11) | ((lane >> 4) << 5) | (((lane & 15) << 1) ^ (lane >> 4))
     HP_DEV void init(u32 tid) {
+        const u32 lane = tid & 63u, wave = tid >> 6;
+        if (PAD) {   // PB == 0; byte offsets of i + (i >> 5) with the register-dependent part left to lay_addr()
+            a_base = (tid + (tid >> 5)) << 2;
+            b_base = ((tid >> 5) * 1056u + (tid & 31u)) << 2;
+            c_base = (tid * 33u) << 2;
+            s_base = (wave * 2112u + 2u * lane + (lane >> 4)) << 2;
+            return;
+        }
         // all four are BYTE offsets into the exchange buffer (word index * 4): an access then costs one v_xor, the
         // additive part of lay_addr() folds into the ds instruction's immediate offset
         const u32 t = tid << G::PB;
         a_base = (t ^ ((t >> 5) & 31u)) << 2;
         b_base = (((tid >> 5) << 10) | (tid & 31u)) << 2;
         c_base = ((tid << 5) | (tid & 31u)) << 2;
-        const u32 lane = tid & 63u, wave = tid >> 6;
         s_base = ((wave << 11) | ((lane >> 4) << 5) | (((lane & 15u) << 1) ^ (lane >> 4))) << 2;
     }
 };
@@ -239,15 +254,21 @@ HP_DEV u32 opaque(u32 v) {
     return v;
 }
 
-template <int LOGN, int LAY> HP_DEV u32 lay_base(const Addr<LOGN> &ad) {
+template <int LAY, class AD> HP_DEV u32 lay_base(const AD &ad) {
     if (LAY == LAY_A) return ad.a_base;
     if (LAY == LAY_B) return ad.b_base;
     if (LAY == LAY_C) return ad.c_base;
     return ad.s_base;
 }
 
-template <int LOGN, int LAY> HP_DEV u32 lay_addr(u32 base, int r) {
+template <int LOGN, int LAY, bool PAD> HP_DEV u32 lay_addr(u32 base, int r) {
     using G = Geo<LOGN>;
+    if (PAD) {
+        if (LAY == LAY_A) return base + (u32)r * (1056u * 4u);                       // i = (r << 10) | tid
+        if (LAY == LAY_B) return base + (u32)r * (33u * 4u);                         // i = (blk << 10) | (r << 5) | j
+        if (LAY == LAY_C) return base + (u32)r * 4u;                                 // i = (tid << 5) | r
+        return base + ((u32)(r >> 1) * 132u + (u32)(r & 1)) * 4u;                    // i = (wave << 11) | (s << 7) | (lane << 1) | e
+    }
     if (LAY == LAY_A) return (base ^ ((u32)(r & ((1 << G::PB) - 1)) << 2)) + ((u32)((r >> G::PB) << 10) << 2);
     if (LAY == LAY_B) return (base ^ ((u32)r << 2)) + ((u32)(r << 5) << 2);
     if (LAY == LAY_C) return base ^ ((u32)r << 2);
@@ -273,35 +294,37 @@ HP_DEV u32 &lds_w(u32 *lds, u32 byte_off) { return *reinterpret_cast<u32 *>(rein
 // Transpose the workgroup's coefficients from register layout FROM to layout TO through LDS, one
 // 32-bit half at a time.  WG: the exchange crosses waves (needs s_barrier); otherwise it is
 // confined to the wave's own 2048-word region and relies on in-order LDS execution per wave.
-template <int LOGN, int FROM, int TO, bool WG>
-HP_DEV void exchange(u64 (&x)[32], u32 *lds, const Addr<LOGN> &ad) {
+template <int LOGN, int FROM, int TO, bool WG, class AD>
+HP_DEV void exchange(u64 (&x)[32], u32 *lds, const AD &ad) {
+    static_assert(AD::LOGN_ == LOGN, "address set of another ring degree");
+    constexpr bool PAD = AD::PAD;
     u32 keep[32];
     {
-        const u32 fb = opaque(lay_base<LOGN, FROM>(ad));
+        const u32 fb = opaque(lay_base<FROM>(ad));
 #pragma unroll
         for (int r = 0; r < 32; ++r) {
-            lds_w(lds, lay_addr<LOGN, FROM>(fb, r)) = lo32(x[r]);
+            lds_w(lds, lay_addr<LOGN, FROM, PAD>(fb, r)) = lo32(x[r]);
             keep[r] = hi32(x[r]);
         }
     }
     exch_fence<WG>();
     u32 nlo[32];
     {
-        const u32 tb = opaque(lay_base<LOGN, TO>(ad));
+        const u32 tb = opaque(lay_base<TO>(ad));
 #pragma unroll
-        for (int r = 0; r < 32; ++r) nlo[r] = lds_w(lds, lay_addr<LOGN, TO>(tb, r));
+        for (int r = 0; r < 32; ++r) nlo[r] = lds_w(lds, lay_addr<LOGN, TO, PAD>(tb, r));
     }
     exch_fence<WG>();
     {
-        const u32 fb = opaque(lay_base<LOGN, FROM>(ad));
+        const u32 fb = opaque(lay_base<FROM>(ad));
 #pragma unroll
-        for (int r = 0; r < 32; ++r) lds_w(lds, lay_addr<LOGN, FROM>(fb, r)) = keep[r];
+        for (int r = 0; r < 32; ++r) lds_w(lds, lay_addr<LOGN, FROM, PAD>(fb, r)) = keep[r];
     }
     exch_fence<WG>();
     {
-        const u32 tb = opaque(lay_base<LOGN, TO>(ad));
+        const u32 tb = opaque(lay_base<TO>(ad));
 #pragma unroll
-        for (int r = 0; r < 32; ++r) x[r] = mk64(nlo[r], lds_w(lds, lay_addr<LOGN, TO>(tb, r)));
+        for (int r = 0; r < 32; ++r) x[r] = mk64(nlo[r], lds_w(lds, lay_addr<LOGN, TO, PAD>(tb, r)));
     }
 }
 
@@ -401,7 +424,8 @@ HP_DEV void load_flight(const u64 *src, u32 tid, u64 (&x)[32]) {
 template <int LOGN, bool DROP, int FLAV = 0>
 HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
     using G = Geo<LOGN>;
-    __shared__ u32 lds[G::N];
+    using AD = Addr<LOGN, LOGN == 15>;
+    __shared__ u32 lds[AD::WORDS];
     __shared__ u64v2 lds_tw[31 * (1 << G::A)];
     const u32 w = hp_xcd_remap(blockIdx.x, job.W);
     HpItem it;
@@ -411,7 +435,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
     const cptr_limb lp = (cptr_limb)(job.limbs + __builtin_amdgcn_readfirstlane(it.limb));
     const u64 q = lp->q, two_q = lp->two_q, nq = lp->neg_q;
     const u32 tid = threadIdx.x;
-    Addr<LOGN> ad;
+    AD ad;
     ad.init(tid);
     // stage the middle pass's twiddles (one pair per thread): the load is issued first, the LDS write after
     // the coefficient loads are in flight; it becomes visible through the barriers of the A->B exchange
@@ -635,10 +659,10 @@ template <int LOGN, bool STRICT, bool PSCAL>
 __global__ void __launch_bounds__(InvGeo<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv(HpNttJob job) {
     using G = Geo<LOGN>;
     constexpr int LPW = InvGeo<LOGN>::LPW, TT = InvGeo<LOGN>::TT;
-    __shared__ u32 lds_all[G::N * LPW];
+    __shared__ u32 lds_all[Addr<LOGN>::WORDS * LPW];
     __shared__ u64v2 lds_tw[31 * 32];
     const u32 sub = threadIdx.x / G::T, tid = threadIdx.x % G::T;   // limb of the workgroup, thread within the limb
-    u32 *lds = lds_all + sub * G::N;
+    u32 *lds = lds_all + sub * Addr<LOGN>::WORDS;
     HpItem it;
     bool active = true;
     if (LPW == 1) {
