@@ -173,6 +173,54 @@ HP_DEV void hp_butterfly2_nq(u64 &lo_a, u64 &hi_a, u64 &lo_b, u64 &hi_b, u64 wa,
     lo_b = bs;
 }
 
+// The same with the twiddle words in SGPRs (first pass of a transform: wave-uniform twiddles from scalar loads): every multiply
+// of the block names at most one SGPR, so the words need not be copied into VGPRs (124 v_mov per thread in the first pass).
+HP_DEV void hp_butterfly2_nq_sw(u64 &lo_a, u64 &hi_a, u64 &lo_b, u64 &hi_b, u64 wa, u64 wha, u64 wb, u64 whb, u64 two_q,
+                             u32 n0, u32 n1) {
+    const u32 ap0 = (u32)wha, ap1 = (u32)(wha >> 32), aw0 = (u32)wa, aw1 = (u32)(wa >> 32);
+    const u32 bp0 = (u32)whb, bp1 = (u32)(whb >> 32), bw0 = (u32)wb, bw1 = (u32)(wb >> 32);
+    const u32 ax0 = (u32)hi_a, ax1 = (u32)(hi_a >> 32), bx0 = (u32)hi_b, bx1 = (u32)(hi_b >> 32);
+    const u64 aA = (u64)ax1 * ap0 + (u64)__umulhi(ax0, ap0);
+    const u64 bA = (u64)bx1 * bp0 + (u64)__umulhi(bx0, bp0);
+    u64 aB, aG, aE, bB, bG, bE, sd;
+    u32 ac, bc;
+    // The low-product chains G start from the other butterfly input instead of 0 (wrapping u64, like the reference's
+    // x[l] + t): lo + t costs nothing, and hi = lo + 2q - t becomes (2 lo + 2q) - (lo + t).
+    asm("v_mad_u64_u32 %0, vcc, %9, %10, %11\n\t"     // aB = ax0*ap1 + aA, carry -> vcc
+        "v_mad_u64_u32 %1, %8, %9, %12, %21\n\t"      // aG = ax0*aw0 + lo_a
+        "v_mad_u64_u32 %2, %8, %9, %13, 0\n\t"        // aE = ax0*aw1
+        "v_addc_co_u32_e64 %3, vcc, 0, 0, vcc\n\t"    // ac
+        "v_mad_u64_u32 %4, vcc, %15, %18, %16\n\t"    // bB = bx0*bp1 + bA, carry -> vcc
+        "v_mad_u64_u32 %2, %8, %14, %12, %2\n\t"      // aE += ax1*aw0
+        "v_mad_u64_u32 %5, %8, %15, %19, %22\n\t"     // bG = bx0*bw0 + lo_b
+        "v_addc_co_u32_e64 %7, vcc, 0, 0, vcc\n\t"    // bc
+        "v_mad_u64_u32 %6, %8, %15, %20, 0\n\t"       // bE = bx0*bw1
+        "v_mad_u64_u32 %6, %8, %17, %19, %6"            // bE += bx1*bw0
+        : "=&v"(aB), "=&v"(aG), "=&v"(aE), "=&v"(ac), "=&v"(bB), "=&v"(bG), "=&v"(bE), "=&v"(bc), "=&s"(sd)
+        : "v"(ax0), "s"(ap1), "v"(aA), "s"(aw0), "s"(aw1), "v"(ax1), "v"(bx0), "v"(bA), "v"(bx1), "s"(bp1), "s"(bw0),
+          "s"(bw1), "v"(lo_a), "v"(lo_b)
+        : "vcc");
+    const u64 aU = ((u64)ac << 32) | (aB >> 32), bU = ((u64)bc << 32) | (bB >> 32);
+    const u64 aQ = (u64)ax1 * ap1 + aU, bQ = (u64)bx1 * bp1 + bU;
+    const u32 aq0 = (u32)aQ, aq1 = (u32)(aQ >> 32), bq0 = (u32)bQ, bq1 = (u32)(bQ >> 32);
+    asm("v_mad_u64_u32 %0, %4, %5, %10, %0\n\t"
+        "v_mad_u64_u32 %2, %4, %7, %10, %2\n\t"
+        "v_mad_u64_u32 %1, %4, %5, %9, %1\n\t"
+        "v_mad_u64_u32 %3, %4, %7, %9, %3\n\t"
+        "v_mad_u64_u32 %0, %4, %6, %9, %0\n\t"
+        "v_mad_u64_u32 %2, %4, %8, %9, %2"
+        : "+v"(aE), "+v"(aG), "+v"(bE), "+v"(bG), "=&s"(sd)
+        : "v"(aq0), "v"(aq1), "v"(bq0), "v"(bq1), "s"(n0), "s"(n1));
+    u32 ath, bth;
+    asm("v_add_u32 %0, %1, %2" : "=v"(ath) : "v"((u32)(aG >> 32)), "v"((u32)aE));
+    asm("v_add_u32 %0, %1, %2" : "=v"(bth) : "v"((u32)(bG >> 32)), "v"((u32)bE));
+    const u64 as = ((u64)ath << 32) | (u32)aG, bs = ((u64)bth << 32) | (u32)bG;   // lo + t
+    hi_a = ((lo_a << 1) + two_q) - as;
+    lo_a = as;
+    hi_b = ((lo_b << 1) + two_q) - bs;
+    lo_b = bs;
+}
+
 // ntt.cpp:171-175
 HP_DEV u64 hp_shift_fold(u64 x, u64 q, u32 k, u32 fix) { return x - ((x >> k) - (u64)fix) * q; }
 

@@ -74,6 +74,7 @@ HP_DEV u64x2 gload(gptr_u64x2 p, size_t i) {   // one global_load_dwordx4
 //        pass: 31 * 2^A pairs forward, 31 * 32 pairs inverse).  Each entry is needed by exactly one half-wave,
 //        so from global memory every read would be an L1 miss; from LDS it is a broadcast ds_read_b128.
 struct GTab {
+    static constexpr bool scalar = false;
     static constexpr int depth = TW_DEPTH;   // slots of L2 latency to cover
     gptr_u64x2 p;
     HP_DEV explicit GTab(const u64x2 *generic) : p((gptr_u64x2)generic) {}
@@ -85,12 +86,14 @@ typedef const u64v2 __attribute__((address_space(4))) * cptr_u64x2;
 typedef const HpLimb __attribute__((address_space(4))) * cptr_limb;
 constexpr int STAB_DEPTH = 4;   // 2 / 8 / 16 measured the same or worse
 struct STab {
+    static constexpr bool scalar = true;
     static constexpr int depth = STAB_DEPTH;   // held in SGPRs; SMEM returns out of order, so every use waits for all of them
     cptr_u64x2 p;
     HP_DEV explicit STab(const u64x2 *generic) : p((cptr_u64x2)generic) {}
     HP_DEV u64x2 operator()(u32 i) const { const u64v2 v = p[i]; return u64x2{v.x, v.y}; }
 };
 struct LTab {
+    static constexpr bool scalar = false;
     static constexpr int depth = 2;          // LDS latency is short
     lptr_u64x2 p;
     HP_DEV explicit LTab(const u64v2 *shared) : p((lptr_u64x2)shared) {}
@@ -164,7 +167,8 @@ HP_DEV void pass_slots(u64 (&x)[32], u64x2 (&ring)[D], const Tab &tbl, u32 ncls,
                     pre(x, ra);          // rb == ra + 1: one 16-byte load
                     pre(x, ra | bit);
                 }
-                hp_butterfly2_nq(x[ra], x[ra | bit], x[rb], x[rb | bit], tw.x, tw.y, tw.x, tw.y, two_q, n0, n1);
+                if constexpr (Tab::scalar) hp_butterfly2_nq_sw(x[ra], x[ra | bit], x[rb], x[rb | bit], tw.x, tw.y, tw.x, tw.y, two_q, n0, n1);
+                else hp_butterfly2_nq(x[ra], x[ra | bit], x[rb], x[rb | bit], tw.x, tw.y, tw.x, tw.y, two_q, n0, n1);
                 if (o & 2) __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (cnt == 2) { if constexpr (S & 1) __builtin_amdgcn_sched_barrier(0); }
@@ -174,7 +178,8 @@ HP_DEV void pass_slots(u64 (&x)[32], u64x2 (&ring)[D], const Tab &tbl, u32 ncls,
             const u64x2 tw2 = ring[(S + 1 - S0) % D];
             if constexpr (S + 1 + D < S1) ring[(S + 1 - S0) % D] = tbl((u32)(S + 1 + D) * ncls + cls);
             constexpr int ra = slot_reg<FWD>(S, 0), rb = slot_reg<FWD>(S + 1, 0);
-            hp_butterfly2_nq(x[ra], x[ra | bit], x[rb], x[rb | bit], tw.x, tw.y, tw2.x, tw2.y, two_q, n0, n1);
+            if constexpr (Tab::scalar) hp_butterfly2_nq_sw(x[ra], x[ra | bit], x[rb], x[rb | bit], tw.x, tw.y, tw2.x, tw2.y, two_q, n0, n1);
+            else hp_butterfly2_nq(x[ra], x[ra | bit], x[rb], x[rb | bit], tw.x, tw.y, tw2.x, tw2.y, two_q, n0, n1);
             if constexpr (((S - 15) & 2) != 0) __builtin_amdgcn_sched_barrier(0);
             pass_slots<FWD, S + 2, S0, S1, D>(x, ring, tbl, ncls, cls, two_q, n0, n1);
         }
