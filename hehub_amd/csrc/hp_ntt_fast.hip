@@ -79,6 +79,24 @@ struct GTab {
     gptr_u64x2 p;
     HP_DEV explicit GTab(const u64x2 *generic) : p((gptr_u64x2)generic) {}
     HP_DEV u64x2 operator()(u32 i) const { const u64v2 v = p[i]; return u64x2{v.x, v.y}; }
+    HP_DEV u64x2 at(u32 row, u32 ncls, u32 cls) const { return (*this)(row * ncls + cls); }
+};
+// BTab: the same table read with BUFFER loads: address = descriptor base (SGPRs) + per-launch scalar offset (SGPR, the slot) + one
+//       32-bit lane offset (VGPR, computed once) -- no 64-bit address arithmetic on the vector ALU per slot (the global form
+//       costs a v_add_co / v_addc pair per load: 66 instructions per thread in the last pass).
+typedef u32 __attribute__((ext_vector_type(4))) v4u32;
+struct BTab {
+    static constexpr bool scalar = false;
+    static constexpr int depth = TW_DEPTH;
+    __amdgpu_buffer_rsrc_t rsrc;
+    // raw buffer over the whole address range above the table (no bounds clamp wanted), gfx9-family data format word
+    HP_DEV explicit BTab(const u64x2 *uniform_base)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc((void *)uniform_base, 0, 0x7fffffff, 0x00020000)) {}
+    // entry (row * ncls + cls) of 16-byte pairs: row * ncls is wave-uniform, cls per lane
+    HP_DEV u64x2 at(u32 row, u32 ncls, u32 cls) const {
+        const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, cls << 4, (row * ncls) << 4, 0);
+        return u64x2{((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z};
+    }
 };
 // STab: wave-uniform entries of a global table (the first pass of a transform): constant address space, so the
 //       loads are scalar (s_load_dwordx4 through the scalar cache) and take no vector-memory slots.
@@ -91,6 +109,7 @@ struct STab {
     cptr_u64x2 p;
     HP_DEV explicit STab(const u64x2 *generic) : p((cptr_u64x2)generic) {}
     HP_DEV u64x2 operator()(u32 i) const { const u64v2 v = p[i]; return u64x2{v.x, v.y}; }
+    HP_DEV u64x2 at(u32 row, u32 ncls, u32 cls) const { return (*this)(row * ncls + cls); }
 };
 struct LTab {
     static constexpr bool scalar = false;
@@ -98,6 +117,7 @@ struct LTab {
     lptr_u64x2 p;
     HP_DEV explicit LTab(const u64v2 *shared) : p((lptr_u64x2)shared) {}
     HP_DEV u64x2 operator()(u32 i) const { const u64v2 v = p[i]; return u64x2{v.x, v.y}; }
+    HP_DEV u64x2 at(u32 row, u32 ncls, u32 cls) const { return (*this)(row * ncls + cls); }
 };
 
 constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
@@ -157,7 +177,7 @@ HP_DEV void pass_slots(u64 (&x)[32], u64x2 (&ring)[D], const Tab &tbl, u32 ncls,
         constexpr int cnt = 1 << (4 - ilog2c(S + 1));   // butterflies that use this slot's twiddle
         constexpr int bit = slot_bit<FWD>(S);
         const u64x2 tw = ring[(S - S0) % D];
-        if constexpr (S + D < S1) ring[(S - S0) % D] = tbl((u32)(S + D) * ncls + cls);
+        if constexpr (S + D < S1) ring[(S - S0) % D] = tbl.at((u32)(S + D), ncls, cls);
         if constexpr (cnt >= 2) {
 #pragma unroll
             for (int o = 0; o < cnt; o += 2) {
@@ -176,7 +196,7 @@ HP_DEV void pass_slots(u64 (&x)[32], u64x2 (&ring)[D], const Tab &tbl, u32 ncls,
         } else {
             static_assert(S + 1 < S1, "single-butterfly slots come in pairs");
             const u64x2 tw2 = ring[(S + 1 - S0) % D];
-            if constexpr (S + 1 + D < S1) ring[(S + 1 - S0) % D] = tbl((u32)(S + 1 + D) * ncls + cls);
+            if constexpr (S + 1 + D < S1) ring[(S + 1 - S0) % D] = tbl.at((u32)(S + 1 + D), ncls, cls);
             constexpr int ra = slot_reg<FWD>(S, 0), rb = slot_reg<FWD>(S + 1, 0);
             if constexpr (Tab::scalar) hp_butterfly2_nq_sw(x[ra], x[ra | bit], x[rb], x[rb | bit], tw.x, tw.y, tw2.x, tw2.y, two_q, n0, n1);
             else hp_butterfly2_nq(x[ra], x[ra | bit], x[rb], x[rb | bit], tw.x, tw.y, tw2.x, tw2.y, two_q, n0, n1);
@@ -191,7 +211,7 @@ HP_DEV void run_pass(u64 (&x)[32], const Tab tbl, u32 ncls, u32 cls, u64 nq, u64
     u64x2 ring[D];
 #pragma unroll
     for (int s = S0; s < S0 + D; ++s)
-        if (s < S1) ring[(s - S0) % D] = tbl((u32)s * ncls + cls);
+        if (s < S1) ring[(s - S0) % D] = tbl.at((u32)s, ncls, cls);
     pass_slots<FWD, S0, S0, S1, D, Tab, Pre>(x, ring, tbl, ncls, cls, two_q, (u32)nq, (u32)(nq >> 32), pre);
 }
 
@@ -550,7 +570,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
     exchange<LOGN, LAY_B, LAY_C, false>(x, lds, ad);
     TRACE_MARK();   // 5
     // pass C: global stages A+6..logN, per-thread twiddles
-    fwd_pass<4, 0>(x, GTab(lp->fwd_k + 31 * (1 << G::A)), (u32)G::T, tid, nq, two_q);
+    fwd_pass<4, 0>(x, BTab(lp->fwd_k + 31 * (1 << G::A)), (u32)G::T, tid, nq, two_q);
     TRACE_MARK();   // 6
     // final fold (ntt.cpp:171-175)
     {
@@ -725,7 +745,7 @@ __global__ void __launch_bounds__(InvGeo<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv(H
     inv_pass<0, 4>(x, LTab(lds_tw), 32u, tid & 31u, nq, two_q);
     exchange<LOGN, LAY_B, LAY_A, true>(x, lds, ad);
     // pass C': levels 10..logN-1, per-thread twiddles
-    inv_pass<G::PB, 4>(x, GTab(lp->inv_k + 31 + 31 * 32), (u32)G::T, tid, nq, two_q);
+    inv_pass<G::PB, 4>(x, BTab(lp->inv_k + 31 + 31 * 32), (u32)G::T, tid, nq, two_q);
     if constexpr (InvGeo<LOGN>::STREAM_EPILOGUE) {
         // N <= 8192: in layout A a thread owns 2^PB >= 4 consecutive coefficients, so a 16-byte store instruction would write
         // a quarter or half of every cache line it touches: measured 1.9 x the algorithmic write traffic at N = 4096
@@ -737,14 +757,14 @@ __global__ void __launch_bounds__(InvGeo<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv(H
         exchange<LOGN, LAY_A, LAY_S, true>(x, lds, ad);
         if (!active) return;   // (after the last barrier of the kernel)
         const size_t off = (((size_t)(tid >> 6)) << 11) + ((tid & 63u) << 1);
-        const gptr_u64x2 sc = (gptr_u64x2)(lp->inv_ref + G::N + off);
+        const BTab sc(lp->inv_ref + G::N);   // pairs of coefficient off + (s << 7) + e: row = s, 128 pairs per row, lane part off + e
         u64 *d = it.dst + off;
         const u64 psc = job.post_scalar, psh = job.post_scalar_h;
 #pragma unroll
         for (int s0 = 0; s0 < 16; s0 += 2) {
             u64x2 f[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) f[e] = gload(sc, ((size_t)(s0 + (e >> 1)) << 7) + (e & 1));
+            for (int e = 0; e < 4; ++e) f[e] = sc.at((u32)(s0 + (e >> 1)), 128u, (u32)off + (u32)(e & 1));
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = 2 * s0 + e;
@@ -762,7 +782,7 @@ __global__ void __launch_bounds__(InvGeo<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv(H
     // fold, multiply by psi^-i * N^-1 (ntt.cpp:214-222), optional scalar + strict reduction, store (layout A)
     {
         const u32 k = lp->k, fix = lp->fix;
-        const gptr_u64x2 sc = (gptr_u64x2)(lp->inv_ref + G::N + ((size_t)tid << G::PB));
+        const BTab sc(lp->inv_ref + G::N);   // pair of coefficient (kk << 10) + (tid << PB) + pp: row = kk, 1024 pairs per row
         u64 *d = it.dst + ((size_t)tid << G::PB);
         const u64 psc = job.post_scalar, psh = job.post_scalar_h;
 #pragma unroll
@@ -771,7 +791,7 @@ __global__ void __launch_bounds__(InvGeo<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv(H
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = r0 + e, kk = r >> G::PB, pp = r & ((1 << G::PB) - 1);
-                f[e] = gload(sc, ((size_t)kk << 10) + pp);
+                f[e] = sc.at((u32)kk, 1024u, (tid << G::PB) + (u32)pp);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
