@@ -57,8 +57,8 @@ WORKLOADS = ["ckks", "ntt", "ntt15", "intt", "intt15", "bgv", "rotate", "ckks-li
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="ckks", choices=WORKLOADS)
     ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (0 = BASELINE config value)")
     ap.add_argument("--logn", type=int, default=0,
