@@ -285,42 +285,27 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner(const HpLimb *__restr
 // Same sums, PT ciphertexts per thread: the 2L key words of a (k, i) pair are loaded once and multiplied into PT
 // ciphertexts' accumulators, so the key traffic through L2 / Infinity Cache (2L of the 3L+2 words per (p,k,i) above)
 // drops by PT.  n is even for every supported ring (N >= 2) and chunks are even-sized: always two words per lane.
-// The digit loop is branch-free (a ragged last group re-reads its last ciphertext and skips the store) and
-// double-buffered by hand: the PT + 2 loads of digit j+1 are in flight while digit j is multiplied.
+//
+// Addressing is what bounded the first version of this kernel: a wave issued 218 SCALAR instructions per digit (64-bit row
+// addresses for PT + 2 loads, each a multiply chain) next to 130 vector ones, and a SIMD issues at most one scalar instruction
+// per turn -- VALUBusy 63 % with HBM at 57 %.  Now every stream is a buffer descriptor set up once per workgroup (PT digit
+// rows, PT caller limbs for the diagonal, the key column), the lane offset is computed once per sweep, and the digit index
+// moves ONE scalar offset per stream: ~10 scalar instructions per digit.
+// The diagonal j == k (the caller's NTT-form limb, rgsw.cpp:99-101) comes first, then the L-1 (special prime: L) digit rows
+// in a branch-free, hand double-buffered loop; u128 sums wrap, so the order of the terms does not matter.
+typedef u32 __attribute__((ext_vector_type(4))) v4u;
+typedef u32 __attribute__((ext_vector_type(2))) v2u;
+constexpr int KS_NT = 2;   // buffer-load cache policy bit "nt": digits are read exactly once, keep them from evicting the key column
+
 template <int PT> struct KsRow {
     U2 g0, g1;
     U2 d[PT];
 };
 
-// packed: the digit rows of this output modulus are in the HP_PACK48 format (hp_device.h); the diagonal j == k is the
-// caller's NTT-form limb and always plain u64
-template <int PT>
-HP_DEV void ks_load(KsRow<PT> &r, u32 j, u32 k, u32 L, u32 Le, u32 key_Le, u32 kcol, u32 n, u32 i, const u32 (&pc)[PT],
-                    const u64 *digits, const u64 *pt, u32 pt_pstride, const u64 *key, bool packed) {
-    typedef u64 __attribute__((ext_vector_type(2))) vv;
-    typedef u32 __attribute__((ext_vector_type(2))) v2u;
-    r.g0 = *reinterpret_cast<const U2 *>(key + (((size_t)j * 2 + 0) * key_Le + kcol) * n + i);
-    r.g1 = *reinterpret_cast<const U2 *>(key + (((size_t)j * 2 + 1) * key_Le + kcol) * n + i);
-    if (packed && j != k) {
-#pragma unroll
-        for (int c = 0; c < PT; c++) {
-            const u32 *row = reinterpret_cast<const u32 *>(digits + (((size_t)pc[c] * L + j) * Le + k) * n);
-            const v2u lo = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(row + i));
-            const u32 hi = __builtin_nontemporal_load(row + n + (i >> 1));
-            r.d[c].x = lo.x | ((u64)(hi & 0xffffu) << 32);
-            r.d[c].y = lo.y | ((u64)(hi >> 16) << 32);
-        }
-        return;
-    }
-#pragma unroll
-    for (int c = 0; c < PT; c++) {
-        const u64 *d = (j == k) ? pt + ((size_t)pc[c] * pt_pstride + j) * n : digits + (((size_t)pc[c] * L + j) * Le + k) * n;
-        // digits are read exactly once: non-temporal, so they do not evict the key column from L2
-        const vv t = __builtin_nontemporal_load(reinterpret_cast<const vv *>(d + i));
-        r.d[c].x = t.x;
-        r.d[c].y = t.y;
-    }
+HP_DEV __amdgpu_buffer_rsrc_t ks_rsrc(const void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000);
 }
+HP_DEV U2 ks_u2(const v4u &v) { return U2{((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z}; }
 
 template <int PT> HP_DEV void ks_mac(const KsRow<PT> &r, HpAcc (&acc)[PT][2][2]) {
     const u64 kw[2][2] = {{r.g0.x, r.g0.y}, {r.g1.x, r.g1.y}};
@@ -328,6 +313,53 @@ template <int PT> HP_DEV void ks_mac(const KsRow<PT> &r, HpAcc (&acc)[PT][2][2])
     for (int c = 0; c < PT; c++)
 #pragma unroll
         for (int h = 0; h < 2; h++) hp_mac2(acc[c][h][0], r.d[c].x, kw[h][0], acc[c][h][1], r.d[c].y, kw[h][1]);
+}
+
+// PACKED: the digit rows of this output modulus are in the HP_PACK48 format (hp_device.h)
+template <int PT, bool PACKED>
+HP_DEV void ks_sweep(const __amdgpu_buffer_rsrc_t (&rd)[PT], const __amdgpu_buffer_rsrc_t (&rp)[PT], __amdgpu_buffer_rsrc_t rk,
+                     u32 i, u32 n, u32 L, u32 k, u32 d_stride, u32 k_stride, u32 k_half, HpAcc (&acc)[PT][2][2]) {
+    const u32 v16 = i << 3, v8 = i << 2, v4 = i << 1;   // lane byte offsets: plain words / low planes / high planes
+    const bool diag = k < L;
+    const u32 T = diag ? L - 1 : L;                     // digit rows besides the diagonal
+    auto load_key = [&](KsRow<PT> &r, u32 j) {
+        const u32 so = __builtin_amdgcn_readfirstlane(j * k_stride);   // (wave-uniform: keeps the row offsets in SGPRs)
+        r.g0 = ks_u2(__builtin_amdgcn_raw_buffer_load_b128(rk, v16, so, 0));
+        r.g1 = ks_u2(__builtin_amdgcn_raw_buffer_load_b128(rk, v16, so + k_half, 0));
+    };
+    auto load_digit = [&](KsRow<PT> &r, u32 t) {
+        const u32 j = t + ((diag && t >= k) ? 1u : 0u);
+        load_key(r, j);
+        const u32 so = __builtin_amdgcn_readfirstlane(j * d_stride);
+#pragma unroll
+        for (int c = 0; c < PT; c++) {
+            if (PACKED) {
+                const v2u lo = __builtin_amdgcn_raw_buffer_load_b64(rd[c], v8, so, KS_NT);
+                const u32 hi = __builtin_amdgcn_raw_buffer_load_b32(rd[c], v4, so + (n << 2), KS_NT);
+                r.d[c].x = lo.x | ((u64)(hi & 0xffffu) << 32);
+                r.d[c].y = lo.y | ((u64)(hi >> 16) << 32);
+            } else {
+                r.d[c] = ks_u2(__builtin_amdgcn_raw_buffer_load_b128(rd[c], v16, so, KS_NT));
+            }
+        }
+    };
+    KsRow<PT> ra, rb;
+    if (diag) {
+        load_key(rb, k);
+#pragma unroll
+        for (int c = 0; c < PT; c++) rb.d[c] = ks_u2(__builtin_amdgcn_raw_buffer_load_b128(rp[c], v16, 0, KS_NT));
+    }
+    if (T) load_digit(ra, 0);
+    if (diag) ks_mac<PT>(rb, acc);
+    if (!T) return;
+    u32 t = 0;
+    for (; t + 2 <= T; t += 2) {
+        load_digit(rb, t + 1);
+        ks_mac<PT>(ra, acc);
+        load_digit(ra, min(t + 2, T - 1));   // last: harmless re-read
+        ks_mac<PT>(rb, acc);
+    }
+    if (t < T) ks_mac<PT>(ra, acc);
 }
 
 template <int PT>
@@ -342,9 +374,18 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner_blk(const HpLimb *__r
     const u64 q = limbs[k].q, mqinv = limbs[k].mqinv;
     const u32 kcol = (k == L) ? key_Le - 1 : k;   // key made for more moduli (extension): special prime = its last column
     const bool packed = ((pack_mask >> k) & 1u) != 0;
-    u32 pc[PT];
+    // descriptors: digit row (p, j = 0, k) -- the digit index adds j * Le * 8n bytes; the caller's limb (p, k); the key column
+    // (j = 0, half 0, kcol) -- j adds 2 * key_Le * 8n bytes, the second half key_Le * 8n.  (32-bit offsets: L (L + 1) * 8n and
+    // 2 L key_Le * 8n stay below 2^30 bytes at N = 32768 with the 32 limbs the engine allows.)
+    __amdgpu_buffer_rsrc_t rd[PT], rp[PT];
 #pragma unroll
-    for (int c = 0; c < PT; c++) pc[c] = min(p0 + c, P - 1);
+    for (int c = 0; c < PT; c++) {
+        const u32 p = min(p0 + c, P - 1);   // a ragged last group re-reads its last ciphertext and skips the store
+        rd[c] = ks_rsrc(digits + ((size_t)p * L * Le + k) * n);
+        rp[c] = ks_rsrc(pt + ((size_t)p * pt_pstride + min(k, L - 1)) * n);
+    }
+    const __amdgpu_buffer_rsrc_t rk = ks_rsrc(key + (size_t)kcol * n);
+    const u32 d_stride = (Le * n) << 3, k_half = (key_Le * n) << 3, k_stride = k_half << 1;
     const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
     for (u32 i = chunk * ELEM_CHUNK + threadIdx.x * 2; i < end; i += ELEM_THREADS * 2) {
         HpAcc acc[PT][2][2];   // [ciphertext][half][word]
@@ -352,16 +393,8 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner_blk(const HpLimb *__r
         for (int c = 0; c < PT; c++)
 #pragma unroll
             for (int h = 0; h < 2; h++) { hp_acc_zero(acc[c][h][0]); hp_acc_zero(acc[c][h][1]); }
-        KsRow<PT> ra, rb;
-        ks_load<PT>(ra, 0, k, L, Le, key_Le, kcol, n, i, pc, digits, pt, pt_pstride, key, packed);
-        u32 j = 0;
-        for (; j + 2 <= L; j += 2) {
-            ks_load<PT>(rb, j + 1, k, L, Le, key_Le, kcol, n, i, pc, digits, pt, pt_pstride, key, packed);
-            ks_mac<PT>(ra, acc);
-            ks_load<PT>(ra, min(j + 2, L - 1), k, L, Le, key_Le, kcol, n, i, pc, digits, pt, pt_pstride, key, packed);   // last: harmless re-read
-            ks_mac<PT>(rb, acc);
-        }
-        if (j < L) ks_mac<PT>(ra, acc);
+        if (packed) ks_sweep<PT, true>(rd, rp, rk, i, n, L, k, d_stride, k_stride, k_half, acc);
+        else ks_sweep<PT, false>(rd, rp, rk, i, n, L, k, d_stride, k_stride, k_half, acc);
 #pragma unroll
         for (int c = 0; c < PT; c++) {
             const u32 p = p0 + c;
