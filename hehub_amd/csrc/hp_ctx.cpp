@@ -269,6 +269,7 @@ int hp_ctx_create(int device, hp_ctx **out) {
     c->stream = c->own_stream;
     c->no_fused_drop = getenv("HP_NO_FUSED_DROP") != nullptr;
     c->no_pack48 = getenv("HP_NO_PACK48") != nullptr;
+    if (const char *e = getenv("HP_PACK48_MIN_LOGN")) c->pack48_min_logn = atoi(e);
     c->hks_two_step = getenv("HP_HKS_TWO_STEP") != nullptr;
     c->hks_combine_kernel = getenv("HP_HKS_COMBINE_KERNEL") != nullptr;
     if (const char *e = getenv("HP_DROP_GROUP")) c->drop_group = atoi(e) > 0 ? atoi(e) : 0;

@@ -308,7 +308,8 @@ HP_DEV u64 hp_sub_lazy(u64 a, u64 b, u64 two_q) {
 // written by the digit-spread transform, read by the key-switch inner product; 6 instead of 8 bytes per word cross HBM in both
 // directions).  A row keeps its 8N-byte slot: [u32 lo[N]] [u16 hi[N]] [2N bytes unused]; word i = lo[i] | (u64)hi[i] << 32.
 // (One 12-byte record per pair of words, moved with dwordx3 accesses, measured no faster than plain rows: the accesses straddle
-// cache lines.  Two planes: -4 % on the inner product, -1.5 % on the spread launch at N = 32768; no gain at N = 8192.)
+// cache lines.  Two planes: -13..-16 % on the inner product at every tiled ring degree once that kernel addressed its rows through
+// buffer descriptors, -1.5 % on the spread launch at N = 32768.)
 // XCD-aware work-item remap: consecutive blockIdx values land on different XCDs
 // (block b -> XCD b % 8, observed placement; used for L2 locality only).  Work
 // items are numbered so that neighbours share a modulus (twiddle table); this

@@ -9,11 +9,11 @@ import params as P
 from hehub_amd.engine import Engine
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--workload", default="ckks"); ap.add_argument("--batch", type=int, default=0); ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--workload", default="ckks"); ap.add_argument("--logn", type=int, default=0); ap.add_argument("--batch", type=int, default=0); ap.add_argument("--reps", type=int, default=5)
 a = ap.parse_args()
 eng = Engine(0)
 if a.workload == "ckks":
-    logn, mext, B = P.C3_LOGN, P.C3_MODULI_EXT, a.batch or 256
+    logn, mext, B = a.logn or P.C3_LOGN, P.C3_MODULI_EXT, a.batch or 256
     run = lambda: eng.ckks_mult(mext, ct1, ct2, key, out=out)
 else:
     logn, mext, B = P.C5_LOGN, P.C5_MODULI_EXT, a.batch or 512
