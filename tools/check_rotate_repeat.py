@@ -1,3 +1,5 @@
+"""Repeat a C3 batch-256 rotation after a multiplication and compare every run with the first one word for word (GPU box): a
+non-deterministic kernel shows up as rows that differ between runs.  python tools/check_rotate_repeat.py"""
 import os, sys, torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,7 +14,7 @@ g = lambda *s: torch.randint(0, 1 << 40, s, dtype=torch.int64, device="cuda")
 ct1, ct2, key = g(B, 2, L, n), g(B, 2, L, n), g(L, 2, L + 1, n)
 out = eng.ckks_mult(mext, ct1, ct2, key)
 ref = eng.ckks_rotate(mext, ct1, key, 5).clone()
-for it in range(6):
+for it in range(12):
     r = eng.ckks_rotate(mext, ct1, key, 5)
     bad = (r != ref)
     rows = bad.any(-1).nonzero()
