@@ -1,0 +1,84 @@
+"""Register / scratch / LDS budgets of the shipped kernels, read from the metadata of the built library (CPU tier: hipcc
+cross-compiles, nothing runs).  The transforms are VALU-bound with one workgroup per CU at N = 32768: a spill in their hot
+loops or an inner product that drops below two waves per SIMD is a performance regression that no parity test notices."""
+import os
+import re
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.skipif(
+    not (os.path.exists("/opt/rocm/lib/llvm/bin/clang-offload-bundler") and shutil.which("objcopy") and shutil.which("c++filt")),
+    reason="needs the ROCm LLVM tools")
+
+
+@pytest.fixture(scope="module")
+def meta():
+    from hehub_amd.build import build_lib
+    from kernel_meta import kernel_meta
+    return kernel_meta(build_lib())
+
+
+def pick(meta, pattern):
+    found = {k: v for k, v in meta.items() if re.search(pattern, k)}
+    assert found, pattern
+    return found
+
+
+def test_every_tiled_size_is_built(meta):
+    for logn in range(11, 16):
+        pick(meta, rf"k_ntt_fwd<{logn}>")
+        pick(meta, rf"k_ntt_inv<{logn}, ")
+        for flav in range(5):
+            pick(meta, rf"k_ntt_fwd_drop<{logn}, {flav}>")
+
+
+def test_forward_transforms_do_not_spill(meta):
+    for name, r in pick(meta, r"k_ntt_fwd<\d+>").items():
+        assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, (name, r)
+        assert r["vgpr_count"] <= 128, (name, r)           # four waves per SIMD
+
+
+def test_n32768_kernels(meta):
+    """one workgroup (16 waves x <= 128 VGPRs, 144-148 KiB of LDS) per CU: no spills in the C3 kernels"""
+    for name, r in pick(meta, r"k_ntt_(fwd|inv)<15").items():
+        assert r["vgpr_spill_count"] == 0, (name, r)
+        assert 140 * 1024 <= r["group_segment_fixed_size"] <= 160 * 1024, (name, r)
+    for name, r in pick(meta, r"k_ntt_fwd_drop<15, [1-4]>").items():
+        assert r["vgpr_spill_count"] <= 2, (name, r)
+
+
+def test_fused_drop_flavours(meta):
+    """compile-time flavours (the CKKS / BGV pipelines): at most two spilled registers; the run-time flavour 0 (rotations,
+    hybrid key switch inputs) is known to spill ~40-48 and is not on the headline path"""
+    for name, r in pick(meta, r"k_ntt_fwd_drop<\d+, [1-4]>").items():
+        assert r["vgpr_spill_count"] <= 2, (name, r)
+    for name, r in pick(meta, r"k_ntt_fwd_drop<\d+, 0>").items():
+        assert r["vgpr_spill_count"] <= 48, (name, r)
+
+
+def test_inverse_small_sizes_budget(meta):
+    """multi-limb workgroups at N <= 8192, one limb at 16384: a few spilled registers are the measured optimum (an occupancy of
+    four waves per SIMD matters more); the budget is today's count"""
+    for name, r in pick(meta, r"k_ntt_inv<1[1-4], ").items():
+        assert r["vgpr_spill_count"] <= 24, (name, r)
+
+
+def test_inner_product_occupancy(meta):
+    (name, r), = pick(meta, r"k_ks_inner_blk<4>").items()
+    assert r["vgpr_spill_count"] == 0 and r["vgpr_count"] <= 256, (name, r)     # two waves per SIMD
+    (name, r), = pick(meta, r"k_ks_inner_blk<2>").items()
+    assert r["vgpr_spill_count"] == 0 and r["vgpr_count"] <= 128, (name, r)     # four
+
+
+def test_no_kernel_spills_scalars_or_exceeds_lds(meta):
+    for name, r in meta.items():
+        if "k_hks_" not in name:   # (the hybrid extension's conversions with >= 5 special primes keep their constants in spilled SGPRs)
+            assert r.get("sgpr_spill_count", 0) == 0, (name, r)
+        assert r.get("group_segment_fixed_size", 0) <= 160 * 1024, (name, r)
+    for name, r in pick(meta, r"^(void )?k_(tensor|poly_binary|poly_unary|drop_rem|drop_fin|gather|vec)").items():
+        assert r["vgpr_spill_count"] == 0, (name, r)
