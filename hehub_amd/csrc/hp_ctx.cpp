@@ -273,7 +273,7 @@ int hp_ctx_create(int device, hp_ctx **out) {
     c->hks_two_step = getenv("HP_HKS_TWO_STEP") != nullptr;
     c->hks_combine_kernel = getenv("HP_HKS_COMBINE_KERNEL") != nullptr;
     if (const char *e = getenv("HP_DROP_GROUP")) c->drop_group = atoi(e) > 0 ? atoi(e) : 0;
-    if (const char *e = getenv("HP_SPREAD_GROUP")) c->spread_group = atoi(e) > 0 ? atoi(e) : 0;   // measured: 2..6 alike, -2 % on the launch
+    if (const char *e = getenv("HP_SPREAD_GROUP")) c->spread_group = atoi(e) > 0 ? atoi(e) : 0;   // measured (tools/ab_groups.sh): 4..8 beat 2 by 2-3 % on the launch since the rows are packed; 11 (all moduli) loses it again
     if (const char *e = getenv("HP_MULT_STREAMS")) c->mult_streams = atoi(e) >= 2 ? 2 : 1;
     if (const char *e = getenv("HP_MULT_CHUNK")) c->mult_chunk = (size_t)atol(e);
     *out = c;
