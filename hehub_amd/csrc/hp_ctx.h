@@ -67,7 +67,7 @@ struct hp_ctx {
     hipStream_t aux[2] = {nullptr, nullptr};
     hipEvent_t ev_start = nullptr, ev_done[2] = {nullptr, nullptr};
     // knobs, read from the environment once when the context is created (all default to the measured-best setting)
-    int drop_group = 2;           // HP_DROP_GROUP=G: the same numbering for the fused drop launch (every limb reads one coefficient row)
+    int drop_group = 4;           // HP_DROP_GROUP=G: the same numbering for the fused drop launch (every limb reads one coefficient row)
     int spread_group = 4;         // HP_SPREAD_GROUP=G: digit-spread launch numbered by groups of G moduli (0: modulus-major)
     bool hks_two_step = false;    // HP_HKS_TWO_STEP: hybrid mult = switch, then a separate rescale (instead of the merged transform)
     bool hks_combine_kernel = false;   // HP_HKS_COMBINE_KERNEL: the merged ModDown + rescale combination as its own kernel
