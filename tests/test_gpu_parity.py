@@ -339,7 +339,7 @@ def test_maximum_number_of_moduli(eng, orc, logn):
         eng.ckks_rotate(mext + _ntt_primes(L + 2, logn)[-1:], eng.empty((1, 2, L + 1, n)), eng.empty((L + 1, 2, L + 2, n)), 1)
 
 
-@pytest.mark.parametrize("logn,L,B", [(4, 3, 3), (11, 4, 5), (12, 10, 2), (11, 31, 2)])
+@pytest.mark.parametrize("logn,L,B", [(4, 3, 3), (11, 4, 5), (12, 10, 2), (11, 31, 2), (11, 1, 5), (12, 2, 7), (3, 1, 2)])
 def test_ext_prod_with_arbitrary_words(eng, orc, logn, L, B):
     """rgsw.cpp:121-153 accumulates in wrapping u128 and never looks at the size of a word: inputs and key words that use
     all 64 bits (no valid ciphertext has them) must still give the reference's words -- this is what drives every carry
