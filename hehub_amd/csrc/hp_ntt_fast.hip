@@ -372,6 +372,30 @@ HP_DEV void st_stream(u64 *p, const V2 &v) {
     __builtin_nontemporal_store(vv{v.x, v.y}, reinterpret_cast<vv *>(p));
 }
 
+// A coefficient row as a buffer: 16 bytes per lane at (lane byte offset, wave-uniform byte offset), non-temporal like ld_stream / st_stream
+struct StreamBuf {
+    __amdgpu_buffer_rsrc_t rsrc;
+    // the row address is the same for the whole workgroup; say so (readfirstlane), or the compiler keeps the descriptor in VGPRs
+    // and wraps every access in a loop over its distinct values
+    HP_DEV static u64 *uniform(const u64 *row) {
+        const u64 a = reinterpret_cast<u64>(row);
+        const u32 lo = (u32)__builtin_amdgcn_readfirstlane((u32)a), hi = (u32)__builtin_amdgcn_readfirstlane((u32)(a >> 32));   // (the builtin returns int)
+        return reinterpret_cast<u64 *>(((u64)hi << 32) | lo);
+    }
+    HP_DEV explicit StreamBuf(const u64 *row) : rsrc(__builtin_amdgcn_make_buffer_rsrc(uniform(row), 0, 0x7fffffff, 0x00020000)) {}
+    HP_DEV V2 load(u32 voff, u32 soff) const {
+        const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 2);
+        return V2{((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z};
+    }
+    // Stores take the row offset in the LANE offset and no scalar offset.  With an SGPR soffset the assembler assumes that a
+    // 16-byte buffer store has read its data by the time the next instruction issues and pads nothing; on gfx950 it has not: a
+    // VALU instruction right behind the store that overwrites a data register changed what the last lanes of each 16-lane pass
+    // stored (found as rare wrong words in lanes 12-15, 28-31, ... of one row).  Without soffset the hazard is known and padded.
+    HP_DEV void store(u32 voff, const V2 &v) const {
+        __builtin_amdgcn_raw_buffer_store_b128(v4u32{(u32)v.x, (u32)(v.x >> 32), (u32)v.y, (u32)(v.y >> 32)}, rsrc, voff, 0, 2);
+    }
+};
+
 // value held by the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2], no LDS involved
 HP_DEV u64 from_pair_lane(u64 v) {
     const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0xB1, 0xF, 0xF, true);
@@ -606,11 +630,17 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
         // rescaling.cpp:72-74 / mod_switch.cpp:72-76 (+ the += of relinearize, ckks/arith.cpp:70-71):
         // out = ((x - NTT(rem)) * inv) [* (q_last mod t)] [+ addend], all in the lazy representation
         const u32 k = it.limb, p2 = it.poly;
-        const size_t off = (((size_t)(tid >> 6)) << 11) + ((tid & 63u) << 1);
-        const u64 *xs = da->x + ((size_t)p2 * da->L + k) * G::N + off;
-        const u64 *as = (FLAV == 2 || FLAV == 4 || (FLAV == 0 && da->addend && ((da->add_mask >> (p2 & 1)) & 1u)))
-                            ? da->addend + ((size_t)(p2 >> 1) * da->add_ct_stride + (size_t)(p2 & 1) * da->add_poly_stride + k) * G::N + off : nullptr;
-        u64 *d = da->out + ((size_t)p2 * da->out_stride + k) * G::N + off;
+        // the three streams (x row, addend row, output row) through buffer descriptors: one lane offset for all of them, the row
+        // step (s << 7 words) in an SGPR for the loads, in the instruction's immediate / one 32-bit add for the stores -- no 64-bit
+        // address arithmetic on the vector ALU in the epilogue
+        const u32 voff = ((((tid >> 6)) << 11) + ((tid & 63u) << 1)) << 3;
+        // (wave-uniform; said explicitly so that the run-time flavour branches on an SGPR instead of masking lanes)
+        const bool has_add = FLAV == 2 || FLAV == 4 ||
+                             (FLAV == 0 && __builtin_amdgcn_readfirstlane((da->addend && ((da->add_mask >> (p2 & 1)) & 1u)) ? 1 : 0) != 0);
+        const StreamBuf xs(da->x + ((size_t)p2 * da->L + k) * G::N);
+        const StreamBuf as(has_add ? da->addend + ((size_t)(p2 >> 1) * da->add_ct_stride + (size_t)(p2 & 1) * da->add_poly_stride + k) * G::N
+                                   : da->x);
+        const StreamBuf d(da->out + ((size_t)p2 * da->out_stride + k) * G::N);
         const u64 inv = da->dc.inv[k], invh = da->dc.inv_h[k], ql = da->dc.qlt[k], qlh = da->dc.qlt_h[k];
         const bool bgv = FLAV ? (FLAV >= 3) : da->dc.bgv != 0, fin_on = FLAV ? false : da->fin_on != 0;
         const u64 fin = da->fin[k], finh = da->fin_h[k];
@@ -622,18 +652,18 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
         V2 xr[EPI_DEPTH], ar[EPI_DEPTH];
 #pragma unroll
         for (int s = 0; s < EPI_DEPTH; ++s) {
-            xr[s] = ld_stream(xs + ((size_t)s << 7));
-            if (as) ar[s] = ld_stream(as + ((size_t)s << 7));
+            xr[s] = xs.load(voff, (u32)s << 10);
+            if (has_add) ar[s] = as.load(voff, (u32)s << 10);
         }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const V2 xv = xr[s % EPI_DEPTH];
             V2 av{0, 0};
-            if (as) av = ar[s % EPI_DEPTH];
+            if (has_add) av = ar[s % EPI_DEPTH];
             __builtin_amdgcn_sched_barrier(0);
             if (s + EPI_DEPTH < 16) {
-                xr[s % EPI_DEPTH] = ld_stream(xs + ((size_t)(s + EPI_DEPTH) << 7));
-                if (as) ar[s % EPI_DEPTH] = ld_stream(as + ((size_t)(s + EPI_DEPTH) << 7));
+                xr[s % EPI_DEPTH] = xs.load(voff, (u32)(s + EPI_DEPTH) << 10);
+                if (has_add) ar[s % EPI_DEPTH] = as.load(voff, (u32)(s + EPI_DEPTH) << 10);
             }
             __builtin_amdgcn_sched_barrier(0);
             u64 v0 = hp_harvey_lazy_nq(hp_sub_lazy(xv.x, x[2 * s], two_q), inv, invh, n0, n1);
@@ -642,7 +672,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
                 v0 = hp_harvey_lazy_nq(v0, ql, qlh, n0, n1);
                 v1 = hp_harvey_lazy_nq(v1, ql, qlh, n0, n1);
             }
-            if (as) {
+            if (has_add) {
                 v0 = hp_add_lazy(v0, av.x, two_q);
                 v1 = hp_add_lazy(v1, av.y, two_q);
             }
@@ -650,8 +680,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
                 v0 = hp_harvey_lazy_nq(v0, fin, finh, n0, n1);
                 v1 = hp_harvey_lazy_nq(v1, fin, finh, n0, n1);
             }
-            V2 v{v0, v1};
-            st_stream(d + ((size_t)s << 7), v);
+            d.store(voff + ((u32)s << 10), V2{v0, v1});
         }
     }
     TRACE_MARK();   // 9: stores issued

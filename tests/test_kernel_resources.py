@@ -82,3 +82,17 @@ def test_no_kernel_spills_scalars_or_exceeds_lds(meta):
         assert r.get("group_segment_fixed_size", 0) <= 160 * 1024, (name, r)
     for name, r in pick(meta, r"^(void )?k_(tensor|poly_binary|poly_unary|drop_rem|drop_fin|gather|vec)").items():
         assert r["vgpr_spill_count"] == 0, (name, r)
+
+
+def test_no_wide_buffer_store_with_scalar_offset():
+    """gfx950: a buffer store of more than 8 bytes per lane may still be reading its data registers when the next instruction
+    issues.  The assembler pads that only when the store has NO scalar offset register; with one, a VALU instruction right
+    behind the store that overwrites a data register changes what the last lanes of each 16-lane pass write (found in round 2:
+    rare wrong words in rotations, NOTES.md).  So no shipped kernel may contain such a store."""
+    from hehub_amd.build import build_lib
+    from kernel_meta import disassembly
+    text = disassembly(build_lib())
+    stores = [l for l in text.splitlines() if re.search(r"buffer_store_(dwordx[34]|format_xyzw?)\b", l)]
+    assert stores                                      # the fused drop's epilogue uses them
+    bad = [l for l in stores if re.search(r"buffer_store_\w+\s+v\[\d+:\d+\],\s*(v\d+|off),\s*s\[\d+:\d+\],\s*s\d+", l)]
+    assert not bad, bad[:3]

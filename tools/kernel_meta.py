@@ -12,6 +12,31 @@ MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def code_objects(lib, tmp):
+    """the gfx950 code objects bundled in the library (one per translation unit), as files under tmp"""
+    fat = os.path.join(tmp, "fat.bin")
+    subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
+    data = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(re.escape(MAGIC), data)]
+    out = []
+    for n, s in enumerate(starts):
+        blob = os.path.join(tmp, f"b{n}.bin")
+        open(blob, "wb").write(data[s:starts[n + 1] if n + 1 < len(starts) else len(data)])
+        co = os.path.join(tmp, f"co{n}.o")
+        subprocess.run([f"{LLVM}/clang-offload-bundler", "--type=o", "--unbundle", f"--input={blob}",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True, capture_output=True)
+        out.append(co)
+    return out
+
+
+def disassembly(lib=None):
+    """llvm-objdump -d of every code object, concatenated"""
+    lib = lib or os.path.join(ROOT, "hehub_amd", "lib", "libhehub_amd.so")
+    with tempfile.TemporaryDirectory() as tmp:
+        return "\n".join(subprocess.run([f"{LLVM}/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
+                         for co in code_objects(lib, tmp))
+
+
 def kernel_meta(lib=None):
     lib = lib or os.path.join(ROOT, "hehub_amd", "lib", "libhehub_amd.so")
     out = {}
