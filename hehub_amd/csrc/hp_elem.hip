@@ -14,6 +14,17 @@ struct alignas(16) U2 {
     u64 x, y;
 };
 
+// streaming accesses (read once / written once per launch, far more data than L2 holds): non-temporal
+HP_DEV U2 ld_nt(const u64 *p) {
+    typedef u64 __attribute__((ext_vector_type(2))) vv;
+    const vv v = __builtin_nontemporal_load(reinterpret_cast<const vv *>(p));
+    return U2{v.x, v.y};
+}
+HP_DEV void st_nt(u64 *p, const U2 &v) {
+    typedef u64 __attribute__((ext_vector_type(2))) vv;
+    __builtin_nontemporal_store(vv{v.x, v.y}, reinterpret_cast<vv *>(p));
+}
+
 static inline void elem_grid(u32 n, u32 rows, u32 &chunks, dim3 &grid) {
     chunks = (n + ELEM_CHUNK - 1) / ELEM_CHUNK;
     grid = dim3(chunks * rows, 1, 1);
@@ -30,13 +41,13 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_poly_binary(const HpLimb *__re
     const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
     for (u32 i = chunk * ELEM_CHUNK + threadIdx.x * 2; i < end; i += ELEM_THREADS * 2) {
         if (i + 1 < end) {
-            U2 va = *reinterpret_cast<const U2 *>(a + base + i);
-            U2 vb = *reinterpret_cast<const U2 *>(b + base + i);
+            U2 va = ld_nt(a + base + i);
+            U2 vb = ld_nt(b + base + i);
             U2 r;
             if (OP == HP_ADD) { r.x = hp_add_lazy(va.x, vb.x, m.two_q); r.y = hp_add_lazy(va.y, vb.y, m.two_q); }
             if (OP == HP_SUB) { r.x = hp_sub_lazy(va.x, vb.x, m.two_q); r.y = hp_sub_lazy(va.y, vb.y, m.two_q); }
             if (OP == HP_MUL) { r.x = hp_mul_hybrid_lazy(va.x, vb.x, m); r.y = hp_mul_hybrid_lazy(va.y, vb.y, m); }
-            *reinterpret_cast<U2 *>(out + base + i) = r;
+            st_nt(out + base + i, r);
         } else {
             u64 va = a[base + i], vb = b[base + i], r = 0;
             if (OP == HP_ADD) r = hp_add_lazy(va, vb, m.two_q);
@@ -70,10 +81,10 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_poly_unary(const HpLimb *__res
     const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
     for (u32 i = chunk * ELEM_CHUNK + threadIdx.x * 2; i < end; i += ELEM_THREADS * 2) {
         if (i + 1 < end) {
-            U2 v = *reinterpret_cast<const U2 *>(a + base + i);
+            U2 v = ld_nt(a + base + i);
             if (STRICT) { v.x = hp_strict(v.x, q); v.y = hp_strict(v.y, q); }
             else { v.x = hp_harvey_lazy(v.x, s, sh, q); v.y = hp_harvey_lazy(v.y, s, sh, q); }
-            *reinterpret_cast<U2 *>(out + base + i) = v;
+            st_nt(out + base + i, v);
         } else {
             u64 v = a[base + i];
             out[base + i] = STRICT ? hp_strict(v, q) : hp_harvey_lazy(v, s, sh, q);
@@ -103,7 +114,8 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_gather(const u32 *__restrict__
     const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
     const size_t base = (size_t)row * n;
     const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
-    for (u32 i = chunk * ELEM_CHUNK + threadIdx.x; i < end; i += ELEM_THREADS) out[base + i] = in[base + perm[i]];
+    // (the gathered row is re-read line by line and wants the caches; the output is written once)
+    for (u32 i = chunk * ELEM_CHUNK + threadIdx.x; i < end; i += ELEM_THREADS) __builtin_nontemporal_store(in[base + perm[i]], out + base + i);
 }
 
 hipError_t hp_launch_gather(const u32 *perm, u32 n, u32 rows, const u64 *in, u64 *out, hipStream_t stream) {
@@ -193,8 +205,8 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_tensor(const HpLimb *__restric
     const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
     for (u32 i = chunk * ELEM_CHUNK + threadIdx.x * 2; i < end; i += ELEM_THREADS * 2) {
         if (i + 1 < end) {
-            U2 va0 = *reinterpret_cast<const U2 *>(a0 + i), va1 = *reinterpret_cast<const U2 *>(a1 + i);
-            U2 vb0 = *reinterpret_cast<const U2 *>(b0 + i), vb1 = *reinterpret_cast<const U2 *>(b1 + i);
+            U2 va0 = ld_nt(a0 + i), va1 = ld_nt(a1 + i);
+            U2 vb0 = ld_nt(b0 + i), vb1 = ld_nt(b1 + i);
             U2 r0, r1, r2;
             r0.x = hp_mul_hybrid_lazy(va0.x, vb0.x, m);
             r0.y = hp_mul_hybrid_lazy(va0.y, vb0.y, m);
@@ -202,9 +214,9 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_tensor(const HpLimb *__restric
             r1.y = hp_add_lazy(hp_mul_hybrid_lazy(va0.y, vb1.y, m), hp_mul_hybrid_lazy(va1.y, vb0.y, m), m.two_q);
             r2.x = hp_mul_hybrid_lazy(va1.x, vb1.x, m);
             r2.y = hp_mul_hybrid_lazy(va1.y, vb1.y, m);
-            *reinterpret_cast<U2 *>(d0 + i) = r0;
-            *reinterpret_cast<U2 *>(d1 + i) = r1;
-            *reinterpret_cast<U2 *>(d2 + i) = r2;
+            st_nt(d0 + i, r0);
+            st_nt(d1 + i, r1);
+            st_nt(d2 + i, r2);
         } else {
             u64 x0 = a0[i], x1 = a1[i], y0 = b0[i], y1 = b1[i];
             d0[i] = hp_mul_hybrid_lazy(x0, y0, m);
@@ -405,7 +417,9 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner_blk(const HpLimb *__r
                     hp_acc_value(acc[c][h][0], l0, h0);
                     hp_acc_value(acc[c][h][1], l1, h1);
                     U2 v{hp_montgomery128_lazy(l0, h0, q, mqinv), hp_montgomery128_lazy(l1, h1, q, mqinv)};
-                    *reinterpret_cast<U2 *>(out + (((size_t)p * 2 + h) * Le + k) * n + i) = v;
+                    // (written once, read by the next kernel from HBM anyway: non-temporal, the key column keeps its place in L2)
+                    typedef u64 __attribute__((ext_vector_type(2))) vv;
+                    __builtin_nontemporal_store(vv{v.x, v.y}, reinterpret_cast<vv *>(out + (((size_t)p * 2 + h) * Le + k) * n + i));
                 }
             }
         }
