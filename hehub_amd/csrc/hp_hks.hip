@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(HKS_THREADS) k_hks_inner(const HpLimb *__restr
                     hp_acc_value(acc[c][h][0], l0, h0);
                     hp_acc_value(acc[c][h][1], l1, h1);
                     U2 v{hp_montgomery128_lazy(l0, h0, q, mqinv), hp_montgomery128_lazy(l1, h1, q, mqinv)};
-                    *reinterpret_cast<U2 *>(out + (((size_t)p * 2 + h) * E + m) * n + i) = v;
+                    __builtin_nontemporal_store(vv{v.x, v.y}, reinterpret_cast<vv *>(out + (((size_t)p * 2 + h) * E + m) * n + i));   // written once, read from HBM by the next kernel
                 }
             }
         }
