@@ -172,6 +172,9 @@ int drop_apply(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, 
         memset(&da, 0, sizeof(da));
         da.dc = dc; da.x = x; da.L = (u32)L; da.addend = addend; da.add_poly_stride = (u32)add_poly_stride;
         da.add_ct_stride = (u32)add_ct_stride; da.add_mask = add_mask; da.out = out; da.out_stride = (u32)(L - 1);
+        da.small_rem = 1;   // rescaling.cpp:54-58: strict_barrett_{q_k}(c), c < q_last -- one conditional subtraction when q_last <= 2 q_k
+        for (size_t k = k0; k < k1; k++)
+            if (plan->consts[L - 1].q > 2 * plan->consts[k].q) da.small_rem = 0;
         ProfScope ps(ctx, "ntt_drop");   // its own family: a different kernel (k_ntt_fwd_drop) with 2-3x the bytes of a plain transform
         return chk(ctx, hp_launch_ntt_fast_drop(fj, da, ctx->stream), "fused drop NTT");
     }

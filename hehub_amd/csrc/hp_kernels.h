@@ -107,6 +107,8 @@ struct HpDropConsts {
 // loading, and finishes with out = ((x - NTT(rem)) * inv) [* (q_last mod t)] [+ addend] while storing.
 struct HpDropArgs {
     HpDropConsts dc;
+    int small_rem;         // 1: q_last <= 2 q_k for every limb of the launch: the remainder of c < q_last is c - [c >= q_k] q_k (the canonical
+                           //    residue either way; saves the Barrett quotient).  Honoured by the compile-time flavours only.
     int raw_input;         // 1: the transform's input rows already are the per-limb remainders (hybrid key switch): no
                            //    Barrett / centring prologue
     u32 out_stride;        // limbs between consecutive polynomials of out (L - 1 for a plain drop)

@@ -154,7 +154,7 @@ struct SwapPre {
     static constexpr bool on = true;
     HP_DEV void operator()(u64 (&x)[32], int r) const { lazy_swap(x, r); }
 };
-template <bool SWAP, bool BGV> struct DropPre {
+template <bool SWAP, bool BGV, bool SMALL> struct DropPre {
     static constexpr bool on = true;
     u64 q, bc, bump, half, tk, tkh;
     u32 n0, n1;
@@ -163,7 +163,7 @@ template <bool SWAP, bool BGV> struct DropPre {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const u64 c = x[r + e];
-            u64 v = hp_strict(hp_barrett_lazy_nq(c, bc, n0, n1), q);
+            u64 v = SMALL ? hp_strict(c, q) : hp_strict(hp_barrett_lazy_nq(c, bc, n0, n1), q);   // SMALL: c < q_last <= 2q
             if (c >= half) v += bump;
             if (BGV) v = hp_harvey_lazy_nq(v, tk, tkh, n0, n1);
             x[r + e] = v;
@@ -470,7 +470,7 @@ HP_DEV void load_flight(const u64 *src, u32 tid, u64 (&x)[32]) {
 // FLAV (fused drop only): 0 = every option decided at run time; 1..4 = the shapes of the CKKS / BGV pipelines with the options
 // fixed at compile time (Barrett prologue, no final multiplication; 1: CKKS, no addend; 2: CKKS, addend on both polynomials;
 // 3 / 4: the same with the BGV factors), which takes ~100 uniform branches out of the prologue and the store loop
-template <int LOGN, bool DROP, int FLAV = 0>
+template <int LOGN, bool DROP, int FLAV = 0, bool SMALL = false>
 HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
     using G = Geo<LOGN>;
     using AD = Addr<LOGN, LOGN == 15>;
@@ -512,7 +512,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
                 const u64 c = x[r];
-                u64 v = hp_strict(hp_barrett_lazy_nq(c, bc, (u32)nq, (u32)(nq >> 32)), q);
+                u64 v = SMALL ? hp_strict(c, q) : hp_strict(hp_barrett_lazy_nq(c, bc, (u32)nq, (u32)(nq >> 32)), q);
                 if (c >= half) v += bump;
                 if (bgv) v = hp_harvey_lazy_nq(v, tk, tkh, (u32)nq, (u32)(nq >> 32));
                 x[r] = v;
@@ -577,7 +577,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
     // pass A: global stages 1..A, wave-uniform twiddles seq[1 .. 2^A - 1]
     if constexpr (LZ_DROP) {
         const u32 k = it.limb;
-        const DropPre<G::PB == 0, (FLAV >= 3)> pre{q, lp->barrett_c, q - da->dc.r[k], da->dc.half_q_last, da->dc.t[k], da->dc.t_h[k],
+        const DropPre<G::PB == 0, (FLAV >= 3), SMALL> pre{q, lp->barrett_c, q - da->dc.r[k], da->dc.half_q_last, da->dc.t[k], da->dc.t_h[k],
                                                     (u32)nq, (u32)(nq >> 32)};
         fwd_pass<4, G::PB, STab>(x, STab(lp->fwd_ref + 1), 1u, 0u, nq, two_q, pre);
     } else if constexpr (LZ) {
@@ -693,9 +693,9 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd(HpNtt
 }
 
 // forward NTT with the drop-last-prime prologue/epilogue fused in (HpDropArgs in kernel-argument memory)
-template <int LOGN, int FLAV>
+template <int LOGN, int FLAV, bool SMALL>
 __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd_drop(HpNttJob job, HpDropArgs da) {
-    ntt_fwd_body<LOGN, true, FLAV>(job, &da);
+    ntt_fwd_body<LOGN, true, FLAV, SMALL>(job, &da);
 }
 
 // ---- inverse kernel ----------------------------------------------------------------------------
@@ -890,11 +890,14 @@ static hipError_t launch_drop(const HpNttJob &job, const HpDropArgs &da, hipStre
         else if (da.add_mask == 3u) flav = 2;
         if (flav && da.dc.bgv) flav += 2;
     }
-    if (flav == 1) k_ntt_fwd_drop<LOGN, 1><<<job.W, Geo<LOGN>::T, 0, stream>>>(job, da);
-    else if (flav == 2) k_ntt_fwd_drop<LOGN, 2><<<job.W, Geo<LOGN>::T, 0, stream>>>(job, da);
-    else if (flav == 3) k_ntt_fwd_drop<LOGN, 3><<<job.W, Geo<LOGN>::T, 0, stream>>>(job, da);
-    else if (flav == 4) k_ntt_fwd_drop<LOGN, 4><<<job.W, Geo<LOGN>::T, 0, stream>>>(job, da);
-    else k_ntt_fwd_drop<LOGN, 0><<<job.W, Geo<LOGN>::T, 0, stream>>>(job, da);
+    const bool small = flav != 0 && da.small_rem != 0;   // (SMALL: the prologue's Barrett quotient is not needed, see HpDropArgs)
+#define HP_DROP_LAUNCH(F, S) k_ntt_fwd_drop<LOGN, F, S><<<job.W, Geo<LOGN>::T, 0, stream>>>(job, da)
+    if (flav == 1) { if (small) HP_DROP_LAUNCH(1, true); else HP_DROP_LAUNCH(1, false); }
+    else if (flav == 2) { if (small) HP_DROP_LAUNCH(2, true); else HP_DROP_LAUNCH(2, false); }
+    else if (flav == 3) { if (small) HP_DROP_LAUNCH(3, true); else HP_DROP_LAUNCH(3, false); }
+    else if (flav == 4) { if (small) HP_DROP_LAUNCH(4, true); else HP_DROP_LAUNCH(4, false); }
+    else HP_DROP_LAUNCH(0, false);
+#undef HP_DROP_LAUNCH
     return hipGetLastError();
 }
 
