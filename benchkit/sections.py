@@ -1,0 +1,173 @@
+"""The extra sections of the default line (timed AFTER the headline region, same fences): the other half of BASELINE's
+metric (limb transforms per second), the coefficient-wise kernels, hom-mult/s at the smaller ring degrees, BASELINE's
+config 2 (C2) and config 5 (C5, BGV) at their exact shapes, and the measured HBM stream ceiling.  `lib` is the CPU
+checker handed in by bench.py (None: no output checks)."""
+from __future__ import annotations
+
+from .inputs import Batch, compare_classes, rand_words
+from .timing import HBM_PEAK_GBS, Run, rate_entry, roofline_entry, timed_launches
+from .workloads import Scheme, Transform
+
+
+def _check_transforms(run: Run, lib, moduli, xb):
+    """one forward and one inverse application on a fresh copy of the periodic batch, every polynomial compared"""
+    import numpy as np
+
+    idx, host = xb.classes()
+    y = xb.fresh()
+    run.eng.ntt_(moduli, y)
+    fwd = np.stack([lib.poly_ntt(moduli, host[c]) for c in range(len(idx))])
+    ok1, cnt = compare_classes(run.torch, y, fwd, xb.period, idx)
+    run.eng.intt_(moduli, y)
+    inv = np.stack([lib.poly_intt(moduli, fwd[c]) for c in range(len(idx))])
+    ok2, _ = compare_classes(run.torch, y, inv, xb.period, idx)
+    return bool(ok1 and ok2), cnt
+
+
+def transform_rates(run: Run, lib):
+    """forward / inverse limb transforms at N = 4096 .. 32768 (north star: "NTT/INTT ... at N in {4096..32768}"), the C3
+    ciphertext moduli (2^16 | q - 1 for all of them), 2.5 GiB in place per launch = the limbs of the C3 ciphertext batch (5120 at
+    N = 32768, 20 per CU); one application of each transform checked against the checker on the periodic batch afterwards"""
+    P, eng, steps = run.P, run.eng, run.args.steps
+    moduli = P.C3_Q
+    L = len(moduli)
+    out = {}
+    # (key, log2 N, polynomials): by-N entries at the bytes of the C3 ciphertext batch (256 x 2 polynomials of 10 limbs at
+    # N = 32768 = 2.5 GiB), plus "steady": as many limb transforms per launch as the digit-spread launch of the C3 step (25 600 =
+    # 100 per CU; a launch's first and last rounds cost about one and a half items, which 20 rounds do not amortise)
+    shapes = [(str(1 << logn), logn, (512 << 15) >> logn) for logn in (12, 13, 14, 15)] + [("steady_32768", 15, 2560)]
+    for key, logn, B in shapes:
+        n = 1 << logn
+        xb = Batch(run.torch, B, (L, n), moduli, run.dev, 40 + logn + 100 * run.rank, 3)
+        x = xb.full
+        ent = {"N": n, "limbs_per_launch": B * L, "bytes_in_place": B * L * n * 8}
+        for name, fam, fn in (("forward", "ntt", lambda: eng.ntt_(moduli, x)), ("inverse", "intt", lambda: eng.intt_(moduli, x))):
+            dt, launches, kern_ms = timed_launches(run, fn, fam, steps)
+            ent[name] = rate_entry(B * L, 16.0 * n, steps, run.world, dt, launches, kern_ms)
+            ent[name]["unit"] = "limb-NTT/s"
+        if lib is not None:
+            ent["verified"], ent["verified_polynomials"] = _check_transforms(run, lib, moduli, xb)
+        out[key] = ent
+        del x, xb
+    return out
+
+
+def c2_section(run: Run, lib):
+    """BASELINE config 2 exactly (bench/ntt_bm.cpp:9-26 is the reference's set-up): N = 16384, the first four
+    50-bit list primes, 1024 polynomials x 4 limbs = 512 MiB in place, forward and inverse passes timed separately, every one
+    of the 4096 limbs compared with the checker (periodic batch, fresh application)"""
+    P, eng, steps = run.P, run.eng, max(run.args.steps, 20)
+    wl = Transform(run, "ntt", 0, 0, 3, seed=2)
+    moduli, x, n = wl.moduli, wl.x, wl.n
+    ent = {"workload": wl.cfg["workload"], "N": n, "limbs": wl.L, "batch_per_gpu": wl.B, "limbs_per_launch": wl.B * wl.L,
+           "bytes_in_place": wl.B * wl.L * n * 8, "moduli": [int(q) for q in moduli], "steps": steps}
+    for name, fam, fn in (("forward", "ntt", lambda: eng.ntt_(moduli, x)), ("inverse", "intt", lambda: eng.intt_(moduli, x))):
+        dt, launches, kern_ms = timed_launches(run, fn, fam, steps, warm=3)
+        e = rate_entry(wl.B * wl.L, 16.0 * n, steps, run.world, dt, launches, kern_ms)
+        e["unit"] = "limb-NTT/s"
+        e["ms_per_pass"] = 1e3 * dt / steps
+        if launches:
+            e["roofline"] = roofline_entry(fam, 16.0 * n * wl.B * wl.L, steps, launches, kern_ms, dt, wl.logn, False)
+        ent[name] = e
+    if lib is not None:
+        ent["verified"], polys = _check_transforms(run, lib, moduli, wl.xb)
+        ent["verified_limbs"] = polys * wl.L
+    return ent
+
+
+def coeffwise_rates(run: Run, lib):
+    """RnsPolynomial operator* (hybrid Montgomery + Harvey product, rns.cpp:120-140) and operator+= (rns.cpp:58-87) at the
+    C3 limb shape: 24*N algorithmic bytes per limb; 3 x 512 MiB touched per launch"""
+    import numpy as np
+
+    P, eng, steps = run.P, run.eng, run.args.steps
+    moduli = P.C3_Q
+    L, n = len(moduli), 1 << P.C3_LOGN
+    B = (512 << 20) // (8 * n * L)
+    a = Batch(run.torch, B, (L, n), moduli, run.dev, 61 + 100 * run.rank, 3)
+    b = Batch(run.torch, B, (L, n), moduli, run.dev, 62 + 100 * run.rank, 3)
+    o = eng.empty((B, L, n))
+    out = {"N": n, "limbs_per_launch": B * L}
+    for name, fn, ref in (("mul", lambda: eng.poly_mul(moduli, a.full, b.full, out=o), "poly_mul"),
+                          ("add", lambda: eng.poly_add(moduli, a.full, b.full, out=o), "poly_add")):
+        dt, launches, kern_ms = timed_launches(run, fn, "elem", steps)
+        out[name] = rate_entry(B * L, 24.0 * n, steps, run.world, dt, launches, kern_ms)
+        out[name]["unit"] = "limb-op/s"
+        if lib is not None:
+            idx, ha = a.classes()
+            _, hb = b.classes()
+            exp = np.stack([getattr(lib, ref)(moduli, ha[c], hb[c]) for c in range(len(idx))])
+            ok, cnt = compare_classes(run.torch, o, exp, a.period, idx)
+            out[name]["verified"] = bool(ok)
+            out[name]["verified_polynomials"] = cnt
+    return out
+
+
+def ckks_rates(run: Run, lib):
+    """ckks::mult + relinearize + rescale_inplace at the smaller ring degrees the north star names (N = 4096, 8192, 16384; the C3
+    moduli chain, L = 10, batch 256 per GPU), timed like the headline and every output checked against the checker"""
+    out = {}
+    for logn in (12, 13, 14):
+        wl = Scheme(run, "ckks", 0, logn, 3, seed=300 + logn)
+        dt, _, _ = timed_launches(run, wl.step, "none", run.args.steps)
+        per_gpu = wl.B * run.args.steps / dt
+        ent = {"N": wl.n, "L": wl.L, "batch_per_gpu": wl.B, "per_s": per_gpu * run.world, "unit": "hom-mult/s",
+               "A_step_frac_of_hbm_peak": wl.pipeline_roofline(per_gpu, HBM_PEAK_GBS)["frac_of_hbm_peak"]}
+        if lib is not None:
+            ok, cnt, _ = wl.verify(lib)
+            ent["verified"] = bool(ok)
+            ent["verified_outputs"] = cnt
+        out[str(wl.n)] = ent
+        del wl
+    return out
+
+
+def bgv_section(run: Run, lib):
+    """BASELINE config 5 at its per-GPU shape (bgv/arith.cpp:59-79 + mod_switch.cpp:13-78; N = 8192, L = 6, t = 65537,
+    4096 / 8 = 512 ciphertext pairs per GPU), timed like the headline; the dominant kernel's roofline entry (digit-spread
+    k_ntt_fwd launch) from the library's events; every one of the 512 outputs compared with the checker"""
+    steps = max(run.args.steps, 20)
+    wl = Scheme(run, "bgv", 0, 0, 3, seed=5)
+    dt, launches, kern_ms = timed_launches(run, wl.step, wl.family, steps, warm=3)
+    per_gpu = wl.B * steps / dt
+    ent = {"workload": wl.cfg["workload"], "N": wl.n, "L": wl.L, "plain_modulus": wl.t, "batch_per_gpu": wl.B,
+           "per_s": per_gpu * run.world, "unit": "hom-mult/s", "steps": steps, "ms_per_step": 1e3 * dt / steps,
+           "A_step_bytes_per_op": wl.a_limbs * 8 * wl.n, "pipeline_roofline": wl.pipeline_roofline(per_gpu, HBM_PEAK_GBS)}
+    if launches:
+        ent["roofline"] = roofline_entry(wl.family, wl.alg_bytes_per_step, steps, launches, kern_ms, dt, wl.logn, True)
+    if lib is not None:
+        ok, cnt, classes = wl.verify(lib)
+        ent["verified"] = bool(ok)
+        ent["verified_outputs"] = cnt
+        ent["checker_evaluations"] = classes
+    return ent
+
+
+def hbm_copy_ceiling(run: Run):
+    """The measured stream ceiling beside the 8 TB/s spec peak: 1 GiB -> 1 GiB device-to-device, read + write
+    bytes over the kernel time, (a) the engine's own copy kernel (hp_dev_copy: 16 bytes per lane, non-temporal -- the access
+    pattern of every coefficient-wise kernel) from the library's HIP events, (b) the HIP runtime's device-to-device copy
+    (torch copy_ = hipMemcpyDtoDAsync) between torch events on the same stream.  The ceiling is the better of the two."""
+    torch, eng = run.torch, run.eng
+    words = 1 << 27
+    src = torch.empty(words, dtype=torch.int64, device=run.dev).random_()
+    dst = torch.empty_like(src)
+    steps = 20
+    dt, launches, kern_ms = timed_launches(run, lambda: eng.copy(src, out=dst), "copy", steps, warm=3)
+    ok = bool(torch.equal(src, dst))
+    ours = 2.0 * 8 * words * launches / (kern_ms * 1e-3) / 1e9 if launches else None
+    dst.zero_()
+    for _ in range(3):
+        dst.copy_(src)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(steps):
+        dst.copy_(src)
+    b.record()
+    torch.cuda.synchronize()
+    rt = 2.0 * 8 * words * steps / (a.elapsed_time(b) * 1e-3) / 1e9
+    best = max(v for v in (ours, rt) if v)
+    return {"hbm_copy_ceiling_GBps": best, "frac_of_spec_peak": best / HBM_PEAK_GBS, "bytes_per_copy": 8 * words,
+            "engine_copy_kernel_GBps": ours, "engine_copy_verified": ok, "hip_memcpy_d2d_GBps": rt,
+            "counts": "read + write bytes", "steps": steps}

@@ -56,6 +56,7 @@ SIGNATURES = {
     "hp_dev_poly_mul": (INT, [P, szt, szt, P, szt, P, P, P]),
     "hp_dev_poly_scalar_mul": (INT, [P, szt, szt, P, szt, P, P, P]),
     "hp_dev_poly_reduce_strict": (INT, [P, szt, szt, P, szt, P]),
+    "hp_dev_copy": (INT, [P, szt, P, P]),
     "hp_dev_poly_involution": (INT, [P, szt, szt, szt, P, P]),
     "hp_dev_poly_cycle": (INT, [P, szt, szt, szt, szt, P, P]),
     "hp_dev_mult_low_level": (INT, [P, szt, szt, P, szt, P, P, P]),

@@ -183,6 +183,18 @@ int hp_dev_poly_reduce_strict(hp_ctx *ctx, size_t n, size_t L, const uint64_t *m
     return chk(ctx, hp_launch_poly_strict(plan->d_limbs, (u32)L, (u32)n, (u32)(batch * L), x, ctx->stream), "poly_strict");
 }
 
+int hp_dev_copy(hp_ctx *ctx, size_t words, const uint64_t *d_src, uint64_t *d_dst) {
+    HP_ENTER(ctx);
+    HP_REQUIRE(ctx, d_src, d_dst);
+    HP_ALIGNED(ctx, d_src, d_dst);
+    if (words == 0 || d_src == d_dst) return HP_OK;
+    if (words >> 35) return fail(ctx, HP_EUNSUPPORTED, "hp_dev_copy: at most 2^35 words (256 GiB) per call");
+    const uintptr_t a = (uintptr_t)d_src, b = (uintptr_t)d_dst;
+    if ((a < b && b < a + words * 8) || (b < a && a < b + words * 8)) return fail(ctx, HP_EINVAL, "hp_dev_copy: ranges overlap");
+    ProfScope ps(ctx, "copy");
+    return chk(ctx, hp_launch_copy(words, d_src, d_dst, ctx->stream), "copy");
+}
+
 int hp_dev_poly_involution(hp_ctx *ctx, size_t logn, size_t L, size_t batch, const uint64_t *in, uint64_t *out) {
     HP_ENTER(ctx);
     HP_REQUIRE(ctx, in, out);

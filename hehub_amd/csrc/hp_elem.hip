@@ -108,6 +108,37 @@ hipError_t hp_launch_poly_strict(const HpLimb *limbs, u32 L, u32 n, u32 rows, u6
     return hipGetLastError();
 }
 
+// ---- deep copy of device words: allocator.h:113-118 (SmartArray's copy constructor) for limbs that live in HBM ----------
+// Also the engine's measured stream ceiling (bench.py "hbm_copy_ceiling_GBps"): one read and one write stream, nothing else.
+#define COPY_UNROLL 4
+__global__ void __launch_bounds__(ELEM_THREADS) k_copy(size_t pairs, const u64 *__restrict__ in, u64 *__restrict__ out) {
+    // a workgroup moves COPY_UNROLL x 4 KiB; the loads of a round are issued together
+    const size_t base = (size_t)blockIdx.x * (ELEM_THREADS * COPY_UNROLL) + threadIdx.x;
+    U2 v[COPY_UNROLL];
+#pragma unroll
+    for (int u = 0; u < COPY_UNROLL; ++u) {
+        const size_t i = base + (size_t)u * ELEM_THREADS;
+        if (i < pairs) v[u] = ld_nt(in + 2 * i);
+    }
+#pragma unroll
+    for (int u = 0; u < COPY_UNROLL; ++u) {
+        const size_t i = base + (size_t)u * ELEM_THREADS;
+        if (i < pairs) st_nt(out + 2 * i, v[u]);
+    }
+}
+
+hipError_t hp_launch_copy(size_t words, const u64 *in, u64 *out, hipStream_t stream) {
+    const size_t pairs = words >> 1;
+    if (pairs) {
+        const size_t per = (size_t)ELEM_THREADS * COPY_UNROLL;
+        k_copy<<<dim3((unsigned)((pairs + per - 1) / per)), ELEM_THREADS, 0, stream>>>(pairs, in, out);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (words & 1) return hipMemcpyAsync(out + words - 1, in + words - 1, 8, hipMemcpyDeviceToDevice, stream);
+    return hipSuccess;
+}
+
 // ---- gathers: permutation.cpp:28-75 -------------------------------------------------
 __global__ void __launch_bounds__(ELEM_THREADS) k_gather(const u32 *__restrict__ perm, u32 n, u32 chunks,
                                                         const u64 *__restrict__ in, u64 *__restrict__ out) {

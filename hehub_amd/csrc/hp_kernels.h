@@ -61,6 +61,8 @@ struct HpScalars {
 hipError_t hp_launch_poly_scalar_mul(const HpLimb *limbs, const HpScalars &sc, u32 L, u32 n, u32 rows,
                                      const u64 *a, u64 *out, hipStream_t stream);
 hipError_t hp_launch_poly_strict(const HpLimb *limbs, u32 L, u32 n, u32 rows, u64 *x, hipStream_t stream);
+// out = in, `words` u64 (16-byte aligned rows; an odd last word goes through hipMemcpyAsync)
+hipError_t hp_launch_copy(size_t words, const u64 *in, u64 *out, hipStream_t stream);
 hipError_t hp_launch_gather(const u32 *perm, u32 n, u32 rows, const u64 *in, u64 *out, hipStream_t stream);
 hipError_t hp_launch_reverse(u32 n, u32 rows, const u64 *in, u64 *out, hipStream_t stream);
 

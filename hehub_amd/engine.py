@@ -200,6 +200,12 @@ class Engine:
         self._chk(self.lib.hp_dev_poly_reduce_strict(self.h, n, L, _u64arr(moduli), B, self._ptr(x)))
         return x
 
+    def copy(self, src, out=None):
+        """deep copy of device words (hp_dev_copy)"""
+        out = self.empty(src.shape) if out is None else out
+        self._chk(self.lib.hp_dev_copy(self.h, src.numel(), self._ptr(src), self._ptr(out)))
+        return out
+
     def poly_involution(self, a):
         B, L, n = a.shape
         out = self.empty(a.shape)

@@ -135,6 +135,9 @@ int hp_dev_poly_scalar_mul(hp_ctx *ctx, size_t n, size_t L, const uint64_t *modu
 /* mod_arith.h:65-72 */
 int hp_dev_poly_reduce_strict(hp_ctx *ctx, size_t n, size_t L, const uint64_t *moduli, size_t batch,
                               uint64_t *d_x);
+/* allocator.h:113-118 (SmartArray(const SmartArray&): a deep copy) for words that live on the device: d_dst[i] = d_src[i],
+ * ranges must not overlap.  One streaming kernel on the ctx stream; bench.py also times it as the measured HBM stream ceiling. */
+int hp_dev_copy(hp_ctx *ctx, size_t words, const uint64_t *d_src, uint64_t *d_dst);
 /* permutation.cpp:59-75 / :28-57 (NTT-form gathers) */
 int hp_dev_poly_involution(hp_ctx *ctx, size_t logn, size_t L, size_t batch, const uint64_t *d_in,
                            uint64_t *d_out);

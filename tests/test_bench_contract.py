@@ -61,6 +61,19 @@ def test_default_line_carries_both_halves_of_the_metric():
         assert cw[op]["verified"] is True and 0.2 < cw[op]["frac_of_hbm_peak"] < 1
     node = r["cpu_baseline_node"]
     assert node["cores"] == 2 and node["value"] > r["cpu_baseline"]["value"] * 0.8 and "cores_visible" in node
+    assert "cpu_quota_cores" in node and "host_limited" in node and 0 < node["parallel_efficiency"] < 1.5
+    # BASELINE configs 2 and 5 at their exact shapes, and the measured stream ceiling
+    c2 = r["c2"]
+    assert c2["N"] == 16384 and c2["limbs"] == 4 and c2["batch_per_gpu"] == 1024 and c2["verified"] is True and c2["verified_limbs"] == 4096
+    assert c2["moduli"] == [1125899904679937, 1125899903827969, 1125899903500289, 1125899903107073]
+    for d in ("forward", "inverse"):
+        assert c2[d]["per_s"] > 0 and 0.05 < c2[d]["roofline"]["frac"] < 1 and c2[d]["cpu_baseline"]["value"] > 0
+    bgv = r["bgv"]
+    assert bgv["N"] == 8192 and bgv["L"] == 6 and bgv["plain_modulus"] == 65537 and bgv["batch_per_gpu"] == 512
+    assert bgv["verified"] is True and bgv["verified_outputs"] == 512 and bgv["A_step_bytes_per_op"] == 396 * 65536
+    assert 0.3 < bgv["pipeline_roofline"]["frac_of_hbm_peak"] < 1 and 0.05 < bgv["roofline"]["frac"] < 1
+    assert bgv["cpu_baseline"]["value"] > 0 and bgv["per_s"] > 2 * r["value"]
+    assert 2000 < r["hbm_copy_ceiling_GBps"] < 8000 and r["hbm_copy"]["engine_copy_verified"] is True
 
 
 @pytest.mark.gpu
@@ -103,3 +116,24 @@ def test_two_ranks_end_to_end_on_one_gpu():
     assert all(e["verified"] for e in r["ckks_by_N"].values())
     assert "cpu_baseline" not in r            # CPU legs only at N = 1
     assert r["value"] > 0 and r["config"]["batch_per_gpu"] == 256
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,batch", [("ckks", 256), ("bgv", 512)])
+def test_eight_ranks_end_to_end_on_one_gpu(workload, batch):
+    """BASELINE configs 4 and 5 as the driver launches them (`bench.py --gpus 8`): eight ranks with the per-GPU batch of the
+    config (2048 / 8 = 256 CKKS pairs, 4096 / 8 = 512 BGV pairs), own seeds per rank, every rank's outputs verified, one
+    line from rank 0 -- in the test mode where the ranks share this box's GPU over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HP_BENCH_SHARE_GPU"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", workload, "--steps", "2",
+                          "--warmup", "1", "--no-rates"], capture_output=True, text=True, timeout=1800, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.stdout[-2000:], out.stderr[-3000:])
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["rccl_ranks"] == 8 and r["backend"] == "gloo" and "TEST MODE" in r["data"]
+    assert r["scaling"] == "weak" and r["config"]["batch_per_gpu"] == batch
+    assert r["verified"] is True and r["verify"]["outputs_compared_per_gpu"] == batch
+    assert r["metric"] == ("ckks_hom_mult_per_s" if workload == "ckks" else "bgv_hom_mult_per_s")
+    assert abs(r["value"] - 8 * batch * 1e3 / r["ms_per_step"]) < 1e-6 * r["value"]     # whole-job aggregate over the 8 ranks
+    assert "cpu_baseline" not in r and "roofline" in r and "pipeline_roofline" in r

@@ -485,3 +485,22 @@ def test_digit_workspace_packing_is_invisible(eng, orc):
                 assert np.array_equal(e.to_host(e.ckks_mult(mext, e.to_device(ct1), e.to_device(ct2), dk)), exp_mul)
         finally:
             plain.close()
+
+
+def test_dev_copy(eng):
+    """hp_dev_copy: the deep copy of device words (allocator.h:113-118 for HBM-resident limbs); odd counts, overlap, NULL"""
+    import torch
+
+    from hehub_amd.engine import InvalidArgument
+
+    for words in (1, 2, 3, 1023, 1024, 2048 * 4 + 2, (1 << 20) + 7):
+        src = torch.randint(-2**62, 2**62, (words + 2,), dtype=torch.int64, device="cuda:0")
+        dst = torch.full((words + 4,), 7, dtype=torch.int64, device="cuda:0")
+        eng._chk(eng.lib.hp_dev_copy(eng.h, words, eng._ptr(src), eng._ptr(dst[2:])))     # (dst + 2 words: 16-byte aligned)
+        assert torch.equal(dst[2:2 + words], src[:words]) and (dst[:2] == 7).all() and (dst[2 + words:] == 7).all()
+    buf = torch.zeros(4096, dtype=torch.int64, device="cuda:0")
+    with pytest.raises(InvalidArgument, match="overlap"):
+        eng._chk(eng.lib.hp_dev_copy(eng.h, 2048, eng._ptr(buf), eng._ptr(buf[1024:])))
+    with pytest.raises(InvalidArgument, match="aligned"):
+        eng._chk(eng.lib.hp_dev_copy(eng.h, 8, eng._ptr(buf), eng._ptr(buf[1:])))
+    eng._chk(eng.lib.hp_dev_copy(eng.h, 0, eng._ptr(buf), eng._ptr(buf)))
