@@ -415,12 +415,14 @@ HP_DEV u64 from_pair_lane(u64 v) {
 #endif
 #define HP_TRACE_SLOTS 12
 __device__ u64 g_trace[2 * 2048 * 16 * HP_TRACE_SLOTS];
-#define TRACE_DECL u64 tr__[HP_TRACE_SLOTS]; int tri__ = 0; tr__[10] = ((u64)__builtin_amdgcn_s_getreg(63492) << 32) | (u32)__builtin_amdgcn_s_getreg((31 << 11) | 20); tr__[11] = blockIdx.x;
+#define TRACE_DECL u64 tr__[HP_TRACE_SLOTS]; int tri__ = 0; tr__[10] = ((u64)__builtin_amdgcn_s_getreg(63492) << 32) | (u32)__builtin_amdgcn_s_getreg((31 << 11) | 20); tr__[11] = t_entry__;
+#define TRACE_ENTRY __builtin_amdgcn_sched_barrier(0); const u64 t_entry__ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
 #define TRACE_MARK() do { __builtin_amdgcn_sched_barrier(0); tr__[tri__++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define TRACE_FLUSH() do { if ((threadIdx.x == 0 || threadIdx.x == blockDim.x - 64) && HP_TRACE_SEL) { \
         for (int i__ = 0; i__ < HP_TRACE_SLOTS; i__++) g_trace[(HP_TRACE_IDX * 2 + (threadIdx.x != 0)) * HP_TRACE_SLOTS + i__] = (i__ < tri__ || i__ >= 10) ? tr__[i__] : 0; } } while (0)
 #else
 #define TRACE_DECL
+#define TRACE_ENTRY
 #define TRACE_MARK() do { } while (0)
 #define TRACE_FLUSH() do { } while (0)
 #endif
@@ -476,6 +478,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
     using AD = Addr<LOGN, LOGN == 15>;
     __shared__ u32 lds[AD::WORDS];
     __shared__ u64v2 lds_tw[31 * (1 << G::A)];
+    TRACE_ENTRY
     const u32 w = hp_xcd_remap(blockIdx.x, job.W);
     HpItem it;
     if (!hp_decode_item(job, w, it)) return;
@@ -715,13 +718,19 @@ __global__ void __launch_bounds__(InvGeo<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv(H
     constexpr int LPW = InvGeo<LOGN>::LPW, TT = InvGeo<LOGN>::TT;
     __shared__ u32 lds_all[Addr<LOGN>::WORDS * LPW];
     __shared__ u64v2 lds_tw[31 * 32];
+    TRACE_ENTRY
     const u32 sub = threadIdx.x / G::T, tid = threadIdx.x % G::T;   // limb of the workgroup, thread within the limb
     u32 *lds = lds_all + sub * Addr<LOGN>::WORDS;
     HpItem it;
     bool active = true;
     if (LPW == 1) {
+        // (every inverse launch is HP_NTT_BATCH without groups: launch() rejects anything else)
         const u32 w = hp_xcd_remap(blockIdx.x, job.W);
-        if (!hp_decode_item(job, w, it)) return;
+        const u32 k = w / job.P, p = w % job.P;
+        it.src = job.src + ((size_t)p * job.src_pstride + (size_t)k * job.src_kstride) * G::N;
+        it.dst = job.dst + ((size_t)p * job.dst_pstride + k) * G::N;
+        it.limb = k;
+        it.poly = p;
     } else {
         // HP_NTT_BATCH only (every inverse launch is one): ceil(P / LPW) workgroups per modulus, modulus-major like the item
         // numbering; a group past the last polynomial re-reads the last one and stores nothing
@@ -750,6 +759,8 @@ __global__ void __launch_bounds__(InvGeo<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv(H
         stg[i] = (e < 31u * 32u) ? ((gptr_u64x2)(lp->inv_k + 31))[e] : u64v2{0, 0};
     }
 
+    TRACE_DECL
+    TRACE_MARK();   // 0: entry (constants and staging loads issued)
     u64 x[32];
     {
         const u64 *s = it.src + (((size_t)(tid >> 6)) << 11) + ((tid & 63u) << 1);
@@ -765,16 +776,30 @@ __global__ void __launch_bounds__(InvGeo<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv(H
         const u32 e = threadIdx.x + (u32)i * TT;
         if (e < 31u * 32u) lds_tw[e] = stg[i];
     }
-    __syncthreads();   // the staged twiddles are read by other waves in pass B' (the exchanges before it are wave-local)
+#ifdef HP_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    TRACE_MARK();   // 1: coefficients have arrived
     exchange<LOGN, LAY_S, LAY_C, false>(x, lds, ad);
+    TRACE_MARK();   // 2
     // pass A': levels 0..4 (pairs 1,2,4,8,16 apart), wave-uniform twiddles
     inv_pass<0, 4>(x, STab(lp->inv_k), 1u, 0u, nq, two_q);
+    TRACE_MARK();   // 3
     exchange<LOGN, LAY_C, LAY_B, false>(x, lds, ad);
+    TRACE_MARK();   // 4
+    // The staged twiddles are read by other waves in pass B'; everything before it is wave-local, so this is the first point
+    // where the waves have to meet.  (The barrier used to sit right after the loads: a workgroup's vector loads queue in wave
+    // order behind each other at the CU's ~17 B/clk, the last wave gets its staging load out ~10 k cycles after the first, and
+    // until then the first waves sat at the barrier with their coefficients long there: -5..8 % per launch at N = 32768.)
+    __syncthreads();
     // pass B': levels 5..9, twiddles depend on j = tid & 31
     inv_pass<0, 4>(x, LTab(lds_tw), 32u, tid & 31u, nq, two_q);
+    TRACE_MARK();   // 5
     exchange<LOGN, LAY_B, LAY_A, true>(x, lds, ad);
+    TRACE_MARK();   // 6
     // pass C': levels 10..logN-1, per-thread twiddles
     inv_pass<G::PB, 4>(x, BTab(lp->inv_k + 31 + 31 * 32), (u32)G::T, tid, nq, two_q);
+    TRACE_MARK();   // 7
     if constexpr (InvGeo<LOGN>::STREAM_EPILOGUE) {
         // N <= 8192: in layout A a thread owns 2^PB >= 4 consecutive coefficients, so a 16-byte store instruction would write
         // a quarter or half of every cache line it touches: measured 1.9 x the algorithmic write traffic at N = 4096
@@ -832,6 +857,7 @@ __global__ void __launch_bounds__(InvGeo<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv(H
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        TRACE_MARK();   // 8: scaled
         if (!active) return;   // (after the last barrier of the kernel)
         if (G::PB == 0) {   // mirror of the forward load: lane pairs assemble 16-byte stores
             const bool odd = (tid & 1u) != 0;
@@ -857,6 +883,8 @@ __global__ void __launch_bounds__(InvGeo<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv(H
             }
         }
     }
+    TRACE_MARK();   // 9: stores issued
+    TRACE_FLUSH();
 }
 
 template <int LOGN> hipError_t launch(const HpNttJob &job, hipStream_t stream) {
@@ -865,7 +893,7 @@ template <int LOGN> hipError_t launch(const HpNttJob &job, hipStream_t stream) {
         return hipGetLastError();
     }
     constexpr int LPW = InvGeo<LOGN>::LPW, TT = InvGeo<LOGN>::TT;
-    if (LPW > 1 && job.mode != HP_NTT_BATCH) return hipErrorNotSupported;
+    if (job.mode != HP_NTT_BATCH || job.pair_moduli) return hipErrorNotSupported;
     const u32 grid = LPW == 1 ? job.W : job.L * ((job.P + LPW - 1) / LPW);
     if (job.use_post_scalar && job.strict) k_ntt_inv<LOGN, true, true><<<grid, TT, 0, stream>>>(job);
     else if (job.use_post_scalar) return hipErrorNotSupported;
