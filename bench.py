@@ -79,6 +79,9 @@ def parse(argv=None):
     ap.add_argument("--no-rates", action="store_true", help="ckks workload: skip the extra sections (ntt, coeffwise, c2, bgv, ...)")
     ap.add_argument("--hks-alpha", type=int, default=2, help="ckks-hks: ciphertext moduli per key-switch digit")
     ap.add_argument("--hks-k", type=int, default=2, help="ckks-hks: number of (50-bit) special primes")
+    ap.add_argument("--limb-transport", default=None, choices=["p2p", "allgather"],
+                    help="ckks-limb: exchange of the key-switch digits as batched peer-to-peer sends (default) or as ONE "
+                         "all_gather collective (ncclAllGather on RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU budget of the cpu_baseline sample")
     ap.add_argument("--cpu-procs", type=int, default=-1,

@@ -205,11 +205,12 @@ class Scheme(Workload):
             # the exchange of the key-switch digits between the ranks; total work is fixed as N grows -> strong scaling
             from hehub_amd.sharded import Comm, ShardedMult
 
-            self.comm, self.sm = Comm(), ShardedMult(eng, self.mext, run.world)
+            self.comm, self.sm = Comm(transport=getattr(run.args, "limb_transport", None)), ShardedMult(eng, self.mext, run.world)
             self.bufs = self.sm.buffers(B, n)
             title = "C3 shape, limb-sharded latency mode: ckks::mult + relinearize + rescale_inplace"
             self.scaling = "strong"
             self.units_per_step = B / run.world   # `value` multiplies by world: the batch is shared, not replicated work
+            self.transport = self.comm.transport
         elif name == "rotate":
             self.metric, self.unit = "ckks_rotation_per_s", "rotation/s"
             title = "C3 shape: ckks::rotate (gather + key switch + drop of the special prime)"
@@ -230,6 +231,8 @@ class Scheme(Workload):
                     "input_period": self.b1.period, "A_step_bytes_per_op": self.a_limbs * 8 * n}
         if self.t:
             self.cfg["plain_modulus"] = self.t
+        if name == "ckks-limb":
+            self.cfg["digit_exchange"] = self.transport
 
     def step(self):
         eng, ct1, ct2 = self.run.eng, self.b1.full, self.b2.full

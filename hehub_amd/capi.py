@@ -82,6 +82,7 @@ SIGNATURES = {
     "hp_node_size": (szt, [P]),
     "hp_node_ctx": (P, [P, szt]),
     "hp_node_last_error": (C.c_char_p, [P]),
+    "hp_node_peer_matrix": (INT, [P, P]),
     "hp_node_slice": (INT, [P, szt, szt, C.POINTER(szt), C.POINTER(szt)]),
     "hp_node_sync": (INT, [P]),
     "hp_node_replicate": (INT, [P, P, szt, P]),

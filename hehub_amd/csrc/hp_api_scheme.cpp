@@ -146,8 +146,10 @@ int drop_coeffs(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2,
 // out[k] = ((x[k] - NTT_k(centre(barrett_k(clast)))) * inv_k) [* (q_last mod t)] [+ addend[k]] for the limbs k in [k0, k1)
 // of the L-1 that remain.  rem: workspace of P2*(k1-k0)*n words (unused by the fused tiled path).
 int drop_apply(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, size_t k0, size_t k1, const HpDropConsts &dc0,
-               const u64 *x, const u64 *clast, const u64 *addend, size_t add_poly_stride, size_t add_ct_stride, u32 add_mask,
-               u64 *out, u64 *rem) {
+               const u64 *x, const u64 *clast, bool clast_strict, const u64 *addend, size_t add_poly_stride, size_t add_ct_stride,
+               u32 add_mask, u64 *out, u64 *rem) {
+    // clast_strict: the caller vouches that every word of clast is below q_last (drop_last: it has just been written by a
+    // strict inverse transform).  Rows handed in over the C ABI get the full Barrett reduction, which is right for any u64.
     const size_t n = (size_t)1 << logn, kc = k1 - k0;
     if (kc == 0) return HP_OK;
     // shift everything that is indexed by the limb number to the first limb of the range
@@ -172,7 +174,7 @@ int drop_apply(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, 
         memset(&da, 0, sizeof(da));
         da.dc = dc; da.x = x; da.L = (u32)L; da.addend = addend; da.add_poly_stride = (u32)add_poly_stride;
         da.add_ct_stride = (u32)add_ct_stride; da.add_mask = add_mask; da.out = out; da.out_stride = (u32)(L - 1);
-        da.small_rem = 1;   // rescaling.cpp:54-58: strict_barrett_{q_k}(c), c < q_last -- one conditional subtraction when q_last <= 2 q_k
+        da.small_rem = clast_strict ? 1 : 0;   // rescaling.cpp:54-58: strict_barrett_{q_k}(c), c < q_last -- one conditional subtraction when q_last <= 2 q_k
         for (size_t k = k0; k < k1; k++)
             if (plan->consts[L - 1].q > 2 * plan->consts[k].q) da.small_rem = 0;
         ProfScope ps(ctx, "ntt_drop");   // its own family: a different kernel (k_ntt_fwd_drop) with 2-3x the bytes of a plain transform
@@ -205,7 +207,7 @@ int drop_last(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, b
     u64 *rem = cv.take(P2 * (L - 1) * n);
     int rc;
     if ((rc = drop_coeffs(ctx, plan, logn, L, P2, bgv, t, x, clast))) return rc;
-    return drop_apply(ctx, plan, logn, L, P2, 0, L - 1, dc, x, clast, addend, add_poly_stride, add_ct_stride, add_mask, out, rem);
+    return drop_apply(ctx, plan, logn, L, P2, 0, L - 1, dc, x, clast, true, addend, add_poly_stride, add_ct_stride, add_mask, out, rem);
 }
 } // namespace hpi
 
@@ -568,7 +570,7 @@ int hp_dev_drop_apply_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *
     u64 *rem = cv.take(P2 * (k1 - k0) * n);
     HpDropConsts dc;
     make_drop_consts(plan, L, plain_modulus != 0, plain_modulus, dc);
-    return drop_apply(ctx, plan, logn, L, P2, k0, k1, dc, x, clast, addend, add_poly_stride, add_ct_stride, add_mask, out, rem);
+    return drop_apply(ctx, plan, logn, L, P2, k0, k1, dc, x, clast, false, addend, add_poly_stride, add_ct_stride, add_mask, out, rem);
 }
 
 } // extern "C"

@@ -20,6 +20,18 @@ int fail(hp_ctx *ctx, int code, const std::string &msg) {
     return code;
 }
 
+// for code that runs WITHOUT the context lock (the node layer's worker threads between entry points): the message goes to
+// the calling thread's slot only, so hp_last_error() on that thread returns it and ctx->err is not written unlocked
+int fail_local(hp_ctx *ctx, int code, const std::string &msg) {
+    tl_err_ctx = ctx;
+    tl_err_msg = msg;
+    return code;
+}
+int chk_local(hp_ctx *ctx, hipError_t e, const char *what) {
+    if (e != hipSuccess) return fail_local(ctx, HP_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+    return HP_OK;
+}
+
 int chk(hp_ctx *ctx, hipError_t e, const char *what) {
     if (e != hipSuccess) return fail(ctx, HP_EHIP, std::string(what) + ": " + hipGetErrorString(e));
     return HP_OK;
@@ -258,30 +270,39 @@ int hp_ctx_create(int device, hp_ctx **out) {
     if (!out) return HP_EINVAL;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return HP_EHIP;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (hipSetDevice(device) != hipSuccess) return HP_EHIP;
     hp_ctx *c = new (std::nothrow) hp_ctx();
     if (!c) return HP_ENOMEM;
     c->device = device;
-    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    const hipError_t es = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);   // the caller's current device is not ours to change
+    if (es != hipSuccess) {
         delete c;
         return HP_EHIP;
     }
     c->stream = c->own_stream;
     c->no_fused_drop = getenv("HP_NO_FUSED_DROP") != nullptr;
     c->no_pack48 = getenv("HP_NO_PACK48") != nullptr;
-    if (const char *e = getenv("HP_PACK48_MIN_LOGN")) c->pack48_min_logn = atoi(e);
+    // (every numeric knob is clamped to the range its code path is written for; tests/test_gpu_knobs.py runs the extremes)
+    auto clampi = [](long v, long lo, long hi) { return v < lo ? lo : v > hi ? hi : v; };
+    if (const char *e = getenv("HP_PACK48_MIN_LOGN")) c->pack48_min_logn = (int)clampi(atol(e), 11, 16);
     c->hks_two_step = getenv("HP_HKS_TWO_STEP") != nullptr;
     c->hks_combine_kernel = getenv("HP_HKS_COMBINE_KERNEL") != nullptr;
-    if (const char *e = getenv("HP_DROP_GROUP")) c->drop_group = atoi(e) > 0 ? atoi(e) : 0;
-    if (const char *e = getenv("HP_SPREAD_GROUP")) c->spread_group = atoi(e) > 0 ? atoi(e) : 0;   // measured (tools/ab_groups.sh): 4..8 beat 2 by 2-3 % on the launch since the rows are packed; 11 (all moduli) loses it again
+    if (const char *e = getenv("HP_DROP_GROUP")) c->drop_group = (int)clampi(atol(e), 0, HP_MAX_LIMBS);
+    if (const char *e = getenv("HP_SPREAD_GROUP")) c->spread_group = (int)clampi(atol(e), 0, HP_MAX_LIMBS);   // measured (tools/ab_groups.sh): 4..8 beat 2 by 2-3 % on the launch since the rows are packed; 11 (all moduli) loses it again
     if (const char *e = getenv("HP_MULT_STREAMS")) c->mult_streams = atoi(e) >= 2 ? 2 : 1;
-    if (const char *e = getenv("HP_MULT_CHUNK")) c->mult_chunk = (size_t)atol(e);
+    if (const char *e = getenv("HP_MULT_CHUNK")) c->mult_chunk = (size_t)clampi(atol(e), 0, 1l << 30);
     *out = c;
     return HP_OK;
 }
 
 void hp_ctx_destroy(hp_ctx *ctx) {
     if (!ctx) return;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev};
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (auto &kv : ctx->tables) {

@@ -119,10 +119,19 @@ inline bool any_misaligned(std::initializer_list<const void *> ptrs) {
 #define HP_ALIGNED(ctx, ...) \
     if (hpi::any_misaligned({__VA_ARGS__})) return hpi::fail(ctx, HP_EINVAL, "device pointers must be 16-byte aligned")
 
+// every entry point runs with the context's device current and puts the caller's device back when it returns: an application
+// that drives several GPUs from one thread (or uses torch next to the engine) keeps allocating where it thinks it does
 struct Guard {
     hp_ctx *ctx;
     std::unique_lock<std::mutex> lk;
-    explicit Guard(hp_ctx *c) : ctx(c), lk(c->mu) { (void)hipSetDevice(c->device); }
+    int prev = -1;
+    explicit Guard(hp_ctx *c) : ctx(c), lk(c->mu) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != c->device) (void)hipSetDevice(c->device);
+    }
+    ~Guard() {
+        if (prev >= 0 && prev != ctx->device) (void)hipSetDevice(prev);
+    }
 };
 // first statement of every entry point: a NULL context is an argument error, not a crash; then the context lock
 #define HP_ENTER(ctx)                 \
@@ -130,6 +139,8 @@ struct Guard {
     hpi::Guard guard__(ctx)
 
 int chk(hp_ctx *ctx, hipError_t e, const char *what);
+int fail_local(hp_ctx *ctx, int code, const std::string &msg);   // without the context lock: calling thread's slot only
+int chk_local(hp_ctx *ctx, hipError_t e, const char *what);
 int upload(hp_ctx *ctx, const void *host, size_t bytes, void **dptr);
 
 // ---- caches -----------------------------------------------------------------------------------------------

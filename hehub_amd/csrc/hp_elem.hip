@@ -461,6 +461,9 @@ hipError_t hp_launch_ks_inner(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u
                               const u64 *pt, u32 pt_pstride, const u64 *key, u64 *out, u32 pack_mask, hipStream_t stream) {
     if (kc == 0) return hipSuccess;
     if (pack_mask && !(n >= 2 && P >= 2)) return hipErrorInvalidValue;   // the one-ciphertext kernel reads plain rows only
+    // the blocked kernels address digit rows and key columns through buffer descriptors with 32-bit byte offsets
+    // (j * (L+1) * 8n and j * 2 key_Le * 8n + key_Le * 8n, j < L): an offset past 2^31 would read zeros, not fault
+    if ((u64)L * (L + 1) * 8u * n >= (1ull << 31) || 2ull * L * key_Le * 8u * n >= (1ull << 31)) return hipErrorInvalidValue;
     u32 chunks; dim3 grid;
     // ciphertexts per thread: four share every key word in registers (1 or 2 measured 1.5 % slower at the C3 shape)
     const int PT = (n >= 2 && P >= 4) ? 4 : (n >= 2 && P >= 2) ? 2 : 1;

@@ -19,6 +19,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -64,12 +65,19 @@ struct Worker {
     std::function<int()> task;
     bool has_task = false, done = false, quit = false;
     int rc = HP_OK;
+    std::string msg;   // the failing call's message, taken on the worker thread itself (its thread-local slot is the right one)
 };
+
+// status of a rank whose own calls all succeeded but which stopped because a peer failed (limb-sharded mode): reported only
+// when no rank has a failure of its own
+constexpr int HP_PEER_FAILED = 1000;
 
 } // namespace
 
 struct hp_node {
     std::vector<int> devices;
+    std::vector<char> peer;   // [a * size + b] != 0: rank a writes rank b's device memory directly (same device, or peer access enabled)
+    bool no_peer = false;     // HP_NODE_NO_PEER: pretend no pair has direct access (tests: the staged exchange on a one-GPU box)
     std::vector<hp_ctx *> ctx;
     std::vector<std::unique_ptr<Worker>> workers;
     std::unique_ptr<HostBarrier> barrier;
@@ -112,21 +120,32 @@ int run_all(hp_node *node, const std::function<int(size_t)> &fn) {
         Worker *w = node->workers[r].get();
         {
             std::lock_guard<std::mutex> lk(w->mu);
-            w->task = [&fn, r] { return fn(r); };
+            w->msg.clear();
+            w->task = [&fn, r, node, w] {
+                const int rc = fn(r);
+                if (rc != HP_OK && rc != HP_PEER_FAILED) w->msg = hp_last_error(node->ctx[r]);
+                return rc;
+            };
             w->has_task = true;
             w->done = false;
         }
         w->cv.notify_all();
     }
     int first = HP_OK;
+    bool peer_failed = false;
     for (size_t r = 0; r < n; r++) {
         Worker *w = node->workers[r].get();
         std::unique_lock<std::mutex> lk(w->mu);
         w->cv.wait(lk, [&] { return w->done; });
-        if (w->rc != HP_OK && first == HP_OK) {
+        if (w->rc == HP_PEER_FAILED) peer_failed = true;
+        else if (w->rc != HP_OK && first == HP_OK) {
             first = w->rc;
-            node->err = "rank " + std::to_string(r) + ": " + hp_last_error(node->ctx[r]);
+            node->err = "rank " + std::to_string(r) + ": " + w->msg;
         }
+    }
+    if (first == HP_OK && peer_failed) {   // (cannot happen: somebody's own failure is what stops the others)
+        first = HP_ELOGIC;
+        node->err = "a rank stopped because a peer failed, but no rank reported a failure of its own";
     }
     return first;
 }
@@ -168,6 +187,9 @@ int hp_node_create(const int *devices, size_t count, hp_node **out) {
     if (!devices || !out || count == 0 || count > 64) return HP_EINVAL;
     hp_node *node = new (std::nothrow) hp_node();
     if (!node) return HP_ENOMEM;
+    int prev_dev = -1;
+    if (hipGetDevice(&prev_dev) != hipSuccess) prev_dev = -1;
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev_dev};   // the caller's device stays current
     node->devices.assign(devices, devices + count);
     for (size_t r = 0; r < count; r++) {
         hp_ctx *c = nullptr;
@@ -179,17 +201,21 @@ int hp_node_create(const int *devices, size_t count, hp_node **out) {
         }
         node->ctx.push_back(c);
     }
-    // peer access between every pair of distinct devices (direct writes over xGMI in the limb-sharded mode)
+    // peer access between every pair of distinct devices (direct writes over xGMI in the limb-sharded mode); what was granted is
+    // kept per pair (hp_node_peer_matrix) and the limb-sharded plan stages through page-locked host memory where it was not
+    node->no_peer = getenv("HP_NODE_NO_PEER") != nullptr;
+    node->peer.assign(count * count, 0);
     for (size_t a = 0; a < count; a++)
         for (size_t b = 0; b < count; b++) {
-            if (devices[a] == devices[b]) continue;
+            if (node->no_peer) { node->peer[a * count + b] = (a == b); continue; }
+            if (devices[a] == devices[b]) { node->peer[a * count + b] = 1; continue; }
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can) {
                 (void)hipSetDevice(devices[a]);
-                hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { /* copies fall back to staged transfers inside the runtime */ }
-                (void)hipGetLastError();
+                const hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
+                node->peer[a * count + b] = (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled);
             }
+            (void)hipGetLastError();
         }
     node->staging.resize(count);
     node->barrier.reset(new HostBarrier(count));
@@ -222,6 +248,12 @@ void hp_node_destroy(hp_node *node) {
 size_t hp_node_size(const hp_node *node) { return node ? node->ctx.size() : 0; }
 hp_ctx *hp_node_ctx(hp_node *node, size_t rank) { return (node && rank < node->ctx.size()) ? node->ctx[rank] : nullptr; }
 const char *hp_node_last_error(hp_node *node) { return node ? node->err.c_str() : "null node"; }
+
+int hp_node_peer_matrix(const hp_node *node, int *matrix) {
+    if (!node || !matrix) return HP_EINVAL;
+    for (size_t i = 0; i < node->peer.size(); i++) matrix[i] = node->peer[i];
+    return HP_OK;
+}
 
 int hp_node_slice(const hp_node *node, size_t total, size_t rank, size_t *lo, size_t *hi) {
     if (!node || !lo || !hi || rank >= node->ctx.size()) return HP_EINVAL;
@@ -354,6 +386,8 @@ struct hp_node_sharded {
         uint64_t *ct1 = nullptr, *ct2 = nullptr, *quad = nullptr, *coef = nullptr, *ks = nullptr, *c_p = nullptr, *relin = nullptr,
                  *c_q = nullptr, *out = nullptr;
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // coef sent, c_p sent, c_q sent, result sent
+        // page-locked host staging per exchange, allocated only for a rank that has a peer it cannot write directly
+        uint64_t *hstage[4] = {nullptr, nullptr, nullptr, nullptr};
     };
     std::vector<Rank> rk;
 };
@@ -366,14 +400,70 @@ size_t owner_of(const hp_node_sharded *p, size_t k) {
     return 0;
 }
 
-// rows x (limbs lo..hi of a row of `row_limbs` limbs) from this rank's buffer into the same place of a peer's buffer
-int copy_limbs(hp_ctx *ctx, hipStream_t s, uint64_t *dst, const uint64_t *src, size_t rows, size_t row_limbs, size_t lo, size_t hi,
-               size_t n) {
-    if (hi <= lo || rows == 0) return HP_OK;
-    const size_t pitch = row_limbs * n * 8, width = (hi - lo) * n * 8;
-    hipError_t e = hipMemcpy2DAsync((char *)dst + lo * n * 8, pitch, (const char *)src + lo * n * 8, pitch, width, rows,
-                                    hipMemcpyDeviceToDevice, s);
-    return chk(ctx, e, "peer copy of owned limbs");
+// What one rank sends in one exchange: `rows` rows of `row_limbs` limbs, of which the limbs [lo, hi) travel (a contiguous
+// buffer is one row of one "limb" of `n` words).  Source and destinations have the same layout.
+struct Block {
+    size_t rows = 0, row_limbs = 1, lo = 0, hi = 0, n = 0;
+    size_t pitch() const { return row_limbs * n * 8; }
+    size_t width() const { return (hi - lo) * n * 8; }
+    size_t bytes() const { return rows * width(); }
+    bool empty() const { return rows == 0 || hi <= lo; }
+};
+
+// the four exchanges of one multiplication as seen from rank r (what r sends)
+Block block_of(const hp_node_sharded *p, size_t e, size_t r) {
+    const size_t L = p->L, B = p->batch, n = (size_t)1 << p->logn;
+    const size_t k0 = p->own[r].first, k1 = p->own[r].second;
+    Block b;
+    b.n = n;
+    switch (e) {
+    case 0: b.rows = B; b.row_limbs = L; b.lo = std::min(k0, L); b.hi = std::min(k1, L); break;                  // coefficient limbs
+    case 1: if (r == owner_of(p, L)) { b.rows = 1; b.hi = 1; b.n = 2 * B * n; } break;                             // c_p
+    case 2: if (r == owner_of(p, L - 1)) { b.rows = 1; b.hi = 1; b.n = 2 * B * n; } break;                         // c_q
+    default: b.rows = 2 * B; b.row_limbs = L - 1; b.lo = std::min(k0, L - 1); b.hi = std::min(k1, L - 1); break;   // result limbs
+    }
+    return b;
+}
+
+bool direct(const hp_node *node, size_t from, size_t to) { return node->peer[from * node->ctx.size() + to] != 0; }
+
+// Sender side of an exchange, on rank r's stream: a direct peer write into every destination it may write (one xGMI link per
+// shard), ONE copy of the block into its page-locked staging buffer for all the others (they fetch it after the rendezvous).
+int send_block(hp_node_sharded *p, size_t r, size_t e, hipStream_t s, const uint64_t *src, const std::function<uint64_t *(size_t)> &dst_of,
+               const std::function<bool(size_t)> &is_dest) {
+    hp_node *node = p->node;
+    hp_ctx *c = node->ctx[r];
+    const Block b = block_of(p, e, r);
+    if (b.empty()) return HP_OK;
+    bool need_stage = false;
+    for (size_t d = 0; d < node->ctx.size(); d++) {
+        if (d == r || !is_dest(d)) continue;
+        if (!direct(node, r, d)) { need_stage = true; continue; }
+        const hipError_t er = hipMemcpy2DAsync((char *)dst_of(d) + b.lo * b.n * 8, b.pitch(), (const char *)src + b.lo * b.n * 8, b.pitch(),
+                                               b.width(), b.rows, hipMemcpyDeviceToDevice, s);
+        if (er != hipSuccess) return chk_local(c, er, "peer copy of owned limbs");
+    }
+    if (need_stage) {
+        if (!p->rk[r].hstage[e]) return fail_local(c, HP_ELOGIC, "limb-sharded plan has no staging buffer for a peer without direct access");
+        const hipError_t er = hipMemcpy2DAsync(p->rk[r].hstage[e], b.width(), (const char *)src + b.lo * b.n * 8, b.pitch(), b.width(), b.rows,
+                                               hipMemcpyDeviceToHost, s);
+        if (er != hipSuccess) return chk_local(c, er, "staging copy of owned limbs (no peer access)");
+    }
+    return HP_OK;
+}
+
+// Receiver side, on rank r's stream, after the rendezvous: wait for the sender's event; where the sender could not write
+// here directly, fetch its block from its staging buffer.
+int recv_block(hp_node_sharded *p, size_t r, size_t e, hipStream_t s, size_t from, uint64_t *dst) {
+    hp_node *node = p->node;
+    hp_ctx *c = node->ctx[r];
+    const Block b = block_of(p, e, from);
+    if (b.empty()) return HP_OK;
+    hipError_t er = hipStreamWaitEvent(s, p->rk[from].ev[e], 0);
+    if (er != hipSuccess) return chk_local(c, er, "wait for a peer's exchange");
+    if (direct(node, from, r)) return HP_OK;
+    er = hipMemcpy2DAsync((char *)dst + b.lo * b.n * 8, b.pitch(), p->rk[from].hstage[e], b.width(), b.width(), b.rows, hipMemcpyHostToDevice, s);
+    return er == hipSuccess ? (int)HP_OK : chk_local(c, er, "fetch of a peer's staged limbs (no peer access)");
 }
 
 void free_plan(hp_node_sharded *p) {
@@ -383,14 +473,22 @@ void free_plan(hp_node_sharded *p) {
         auto &R = p->rk[r];
         for (uint64_t *b : {R.ct1, R.ct2, R.quad, R.coef, R.ks, R.c_p, R.relin, R.c_q, R.out})
             if (b) (void)hp_dev_free(c, b);
+        for (uint64_t *h : R.hstage)
+            if (h) (void)hp_host_free(c, h);
+        int prev = -1;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         (void)hipSetDevice(p->node->devices[r]);
         for (hipEvent_t e : R.ev)
             if (e) (void)hipEventDestroy(e);
+        if (prev >= 0) (void)hipSetDevice(prev);
     }
     delete p;
 }
 
 // One multiplication, every rank in lockstep on its worker thread.  d_in != nullptr: inputs are already on the devices.
+// (Runs on the worker threads BETWEEN entry points, i.e. without the contexts' locks: failures of the HIP calls made here go
+// to the calling thread's message slot only (chk_local); a context handed out by hp_node_ctx must not be switched to another
+// stream while a node call is running.)
 int sharded_run(hp_node_sharded *p, const uint64_t *h_ct1, const uint64_t *h_ct2, const uint64_t *const *d_ct1,
                 const uint64_t *const *d_ct2, uint64_t *const *d_key, uint64_t *h_out, uint64_t *const *d_out) {
     hp_node *node = p->node;
@@ -405,6 +503,7 @@ int sharded_run(hp_node_sharded *p, const uint64_t *h_ct1, const uint64_t *h_ct2
             if (status[r].load()) return false;
         return true;
     };
+    const auto everyone = [](size_t) { return true; };
     return run_all(node, [&](size_t r) {
         hp_ctx *c = node->ctx[r];
         auto &R = p->rk[r];
@@ -430,54 +529,49 @@ int sharded_run(hp_node_sharded *p, const uint64_t *h_ct1, const uint64_t *h_ct2
         // stage 1: tensor product and strict coefficients of the owned digits              ckks/arith.cpp:55-62, rgsw.cpp:103-105
         if (!rc) step(hp_dev_mult_low_level_range(c, logn, L, mext, B, a0, a1, ct1, ct2, R.quad));
         if (!rc) step(hp_dev_ks_coef_range(c, logn, L, mext, B, a0, a1, d2, 3 * L, R.coef));
-        // exchange 1: owned coefficient limbs straight into every peer's coef buffer
-        for (size_t d = 0; d < W && !rc; d++)
-            if (d != r) step(copy_limbs(c, s, p->rk[d].coef, R.coef, B, L, a0, a1, n));
-        if (!rc) step(chk(c, hipEventRecord(R.ev[0], s), "event"));
+        // exchange 1: owned coefficient limbs into every peer's coef buffer
+        if (!rc) step(send_block(p, r, 0, s, R.coef, [&](size_t d) { return p->rk[d].coef; }, everyone));
+        if (!rc) step(chk_local(c, hipEventRecord(R.ev[0], s), "event"));
         node->barrier->wait();
         if (all_ok())
             for (size_t d = 0; d < W && !rc; d++)
-                if (d != r) step(chk(c, hipStreamWaitEvent(s, p->rk[d].ev[0], 0), "wait"));
+                if (d != r) step(recv_block(p, r, 0, s, d, R.coef));
         // stage 2: digits + inner product for the owned output moduli; the owner of p prepares the coefficients of its limb
         if (!rc && all_ok()) step(hp_dev_ks_inner_range(c, logn, L, mext, B, k0, k1, R.coef, d2, 3 * L, d_key[r], R.ks));
         if (!rc && all_ok() && r == own_p) {
             step(hp_dev_drop_coeffs(c, logn, L + 1, mext, inner_t, 2 * B, R.ks, R.c_p));
-            for (size_t d = 0; d < W && !rc; d++)
-                if (d != r) step(chk(c, hipMemcpyAsync(p->rk[d].c_p, R.c_p, 2 * B * n * 8, hipMemcpyDeviceToDevice, s), "peer copy c_p"));
+            if (!rc) step(send_block(p, r, 1, s, R.c_p, [&](size_t d) { return p->rk[d].c_p; }, everyone));
         }
-        if (!rc) step(chk(c, hipEventRecord(R.ev[1], s), "event"));
+        if (!rc) step(chk_local(c, hipEventRecord(R.ev[1], s), "event"));
         node->barrier->wait();
-        if (all_ok() && !rc && r != own_p) step(chk(c, hipStreamWaitEvent(s, p->rk[own_p].ev[1], 0), "wait"));
+        if (all_ok() && !rc && r != own_p) step(recv_block(p, r, 1, s, own_p, R.c_p));
         // stage 3: drop p on the owned limbs (+= d0, d1); the owner of q_{L-1} prepares that limb's coefficients
         if (!rc && all_ok())
             step(hp_dev_drop_apply_range(c, logn, L + 1, mext, inner_t, 2 * B, a0, a1, R.ks, R.c_p, R.quad, L, 3 * L, 3, R.relin));
         if (!rc && all_ok() && r == own_q) {
             step(hp_dev_drop_coeffs(c, logn, L, mext, p->t, 2 * B, R.relin, R.c_q));
-            for (size_t d = 0; d < W && !rc; d++)
-                if (d != r) step(chk(c, hipMemcpyAsync(p->rk[d].c_q, R.c_q, 2 * B * n * 8, hipMemcpyDeviceToDevice, s), "peer copy c_q"));
+            if (!rc) step(send_block(p, r, 2, s, R.c_q, [&](size_t d) { return p->rk[d].c_q; }, everyone));
         }
-        if (!rc) step(chk(c, hipEventRecord(R.ev[2], s), "event"));
+        if (!rc) step(chk_local(c, hipEventRecord(R.ev[2], s), "event"));
         node->barrier->wait();
-        if (all_ok() && !rc && r != own_q) step(chk(c, hipStreamWaitEvent(s, p->rk[own_q].ev[2], 0), "wait"));
+        if (all_ok() && !rc && r != own_q) step(recv_block(p, r, 2, s, own_q, R.c_q));
         // stage 4: drop q_{L-1} on the owned limbs; result limbs go to rank 0 (and to the caller's per-rank buffers)
         uint64_t *out = d_out ? d_out[r] : R.out;
         if (!rc && all_ok()) step(hp_dev_drop_apply_range(c, logn, L, mext, p->t, 2 * B, b0, b1, R.relin, R.c_q, nullptr, 0, 0, 0, out));
-        if (d_out) {   // every rank ends up with the whole result
-            for (size_t d = 0; d < W && !rc && all_ok(); d++)
-                if (d != r) step(copy_limbs(c, s, d_out[d], out, 2 * B, L - 1, b0, b1, n));
-        } else if (r != 0 && !rc && all_ok()) {
-            step(copy_limbs(c, s, p->rk[0].out, out, 2 * B, L - 1, b0, b1, n));
+        if (!rc && all_ok()) {
+            if (d_out) step(send_block(p, r, 3, s, out, [&](size_t d) { return d_out[d]; }, everyone));   // every rank ends up with the whole result
+            else if (r != 0) step(send_block(p, r, 3, s, out, [&](size_t d) { return p->rk[d].out; }, [](size_t d) { return d == 0; }));
         }
-        if (!rc) step(chk(c, hipEventRecord(R.ev[3], s), "event"));
+        if (!rc) step(chk_local(c, hipEventRecord(R.ev[3], s), "event"));
         node->barrier->wait();
         if (all_ok() && !rc && (d_out || r == 0))
             for (size_t d = 0; d < W && !rc; d++)
-                if (d != r) step(chk(c, hipStreamWaitEvent(s, p->rk[d].ev[3], 0), "wait"));
+                if (d != r) step(recv_block(p, r, 3, s, d, out));
         if (!rc && all_ok() && !d_out && r == 0) step(hp_memcpy_d2h(c, h_out, R.out, B * 2 * (L - 1) * n * 8));
         // the call returns with every stream drained: the next call may overwrite peers' buffers at once
         step(hp_sync(c));
         node->barrier->wait();
-        if (!rc && !all_ok()) rc = HP_ELOGIC;   // another rank failed: this rank's result is not valid either
+        if (!rc && !all_ok()) rc = HP_PEER_FAILED;   // another rank failed: this rank's result is not valid either
         return rc;
     });
 }
@@ -518,6 +612,16 @@ int hp_node_sharded_create(hp_node *node, size_t logn, size_t L, const uint64_t 
         (void)hipSetDevice(node->devices[r]);
         for (auto &e : R.ev)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return (int)HP_EHIP;
+        // page-locked staging for the blocks this rank sends, only if some peer cannot be written directly
+        bool all_direct = true;
+        for (size_t d = 0; d < W; d++) all_direct = all_direct && direct(node, r, d);
+        if (!all_direct)
+            for (size_t e = 0; e < 4; e++) {
+                const Block b = block_of(p, e, r);
+                if (b.empty()) continue;
+                int rc2 = hp_host_alloc(c, b.bytes(), (void **)&R.hstage[e]);
+                if (rc2) return rc2;
+            }
         return (int)HP_OK;
     });
     if (rc) {

@@ -122,6 +122,10 @@ struct LTab {
 
 constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
 
+// BTab / StreamBuf address with 32-bit byte offsets into descriptors without a bounds clamp: the largest offsets are
+// (31 rows x 1024 classes + 1023) pairs of 16 bytes for a table and one limb (8 N bytes) for a coefficient row
+static_assert((31ull * 1024 + 1024) * 16 < (1ull << 31) && (8ull << 15) < (1ull << 31), "buffer offsets must stay below 2^31");
+
 // register index of the o-th butterfly of slot s (compile-time): forward idx = bits above b, o = bits below b;
 // inverse the other way round
 template <bool FWD> constexpr int slot_reg(int s, int o) {

@@ -10,8 +10,8 @@ static hipEvent_t get_event(hp_ctx *ctx) {
         ctx->event_pool.pop_back();
         return e;
     }
-    hipEvent_t e;
-    (void)hipEventCreate(&e);
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;   // the scope then stays off (ProfScope checks)
     return e;
 }
 
@@ -20,6 +20,12 @@ ProfScope::ProfScope(hp_ctx *c, const char *family) : ctx(c) {
     if (on) {
         ev.a = get_event(c);
         ev.b = get_event(c);
+        if (!ev.a || !ev.b) {   // no events to be had: this launch goes untimed
+            if (ev.a) c->event_pool.push_back(ev.a);
+            if (ev.b) c->event_pool.push_back(ev.b);
+            on = false;
+            return;
+        }
         (void)hipEventRecord(ev.a, c->stream);
     }
 }
@@ -51,17 +57,23 @@ int hp_prof_end(hp_ctx *ctx, size_t *launches, double *total_ms) {
     HP_ENTER(ctx);
     ctx->prof_on = false;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // every event goes back to the pool exactly once and the list is emptied BEFORE any error return (an event left in both
+    // would be handed to two scopes and destroyed twice)
     double total = 0;
+    hipError_t bad = hipSuccess;
+    const size_t count = ctx->prof_events.size();
     for (auto &ev : ctx->prof_events) {
         float ms = 0;
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev.a, ev.b));
+        const hipError_t e = hipEventElapsedTime(&ms, ev.a, ev.b);
+        if (e != hipSuccess && bad == hipSuccess) bad = e;
         total += ms;
         ctx->event_pool.push_back(ev.a);
         ctx->event_pool.push_back(ev.b);
     }
-    if (launches) *launches = ctx->prof_events.size();
-    if (total_ms) *total_ms = total;
     ctx->prof_events.clear();
+    if (bad != hipSuccess) return fail(ctx, HP_EHIP, std::string("hipEventElapsedTime: ") + hipGetErrorString(bad));
+    if (launches) *launches = count;
+    if (total_ms) *total_ms = total;
     return HP_OK;
 }
 

@@ -45,6 +45,12 @@ class Node:
         msg = self.lib.hp_node_last_error(self.h).decode()
         raise (InvalidArgument if rc == capi.HP_EINVAL else HpError)(rc, msg)
 
+    def peer_matrix(self) -> np.ndarray:
+        """[a][b] = 1 when rank a writes rank b's device memory directly (hp_node_peer_matrix)"""
+        m = (C.c_int * (self.world * self.world))()
+        self._chk(self.lib.hp_node_peer_matrix(self.h, m))
+        return np.array(m[:], dtype=np.int32).reshape(self.world, self.world)
+
     def pinned(self, shape) -> np.ndarray:
         """uint64 array in page-locked host memory (hp_host_alloc on rank 0's context); free with unpin()"""
         words = int(np.prod(shape))

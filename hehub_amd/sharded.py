@@ -67,11 +67,24 @@ class Comm:
     once per buffer shape and kept.  "gloo" (tests) stages through host memory.  (In ONE process the same exchange is
     done with direct peer writes by the C node layer, hehub_amd/csrc/hp_node.cpp.)"""
 
-    def __init__(self, group=None):
+    TRANSPORTS = ("p2p", "allgather")
+
+    def __init__(self, group=None, transport=None):
+        """transport: "p2p" (default) = the batched isend / irecv exchange described above; "allgather" = ONE collective
+        (torch.distributed.all_gather = ncclAllGather on RCCL), the form BASELINE's north star names -- every rank contributes a
+        slice padded to the largest one (a collective needs equal counts: 11 moduli over 8 ranks send 2 limbs from every rank,
+        16 instead of 11 limbs on the wire) and RCCL runs its ring / tree over the links.  HP_SHARDED_TRANSPORT selects it from
+        the environment, `bench.py --workload ckks-limb --limb-transport allgather` from the command line: the day an 8-GPU node
+        is at hand, p2p against the collective is one A/B run (DESIGN.md section 6 says why p2p is the default)."""
+        import os
+
         import torch.distributed as dist
 
         self.dist = dist
         self.group = group
+        self.transport = transport or os.environ.get("HP_SHARDED_TRANSPORT", "p2p")
+        if self.transport not in self.TRANSPORTS:
+            raise ValueError(f"unknown transport {self.transport!r}: one of {self.TRANSPORTS}")
         self._stage = {}
         if not dist.is_initialized():       # single process: both exchanges are the identity
             self.world, self.rank, self.staged = 1, 0, False
@@ -95,10 +108,36 @@ class Comm:
             self._stage[key] = st
         return st
 
+    def _gather_collective(self, buf, ranges):
+        """the same exchange as one all_gather of equal-sized (padded) slices"""
+        import torch
+
+        rows, _, n = buf.shape
+        wmax = max(hi - lo for lo, hi in ranges)
+        key = ("ag", buf.data_ptr(), tuple(buf.shape), tuple(ranges), self.staged)
+        st = self._stage.get(key)
+        if st is None:
+            dev = "cpu" if self.staged else buf.device
+            st = (torch.zeros((rows, wmax, n), dtype=buf.dtype, device=dev),
+                  [torch.empty((rows, wmax, n), dtype=buf.dtype, device=dev) for _ in range(self.world)])
+            if len(self._stage) > 16:
+                self._stage.clear()
+            self._stage[key] = st
+        send, recv = st
+        lo, hi = ranges[self.rank]
+        if hi > lo:
+            send[:, :hi - lo].copy_(buf[:, lo:hi])
+        self.dist.all_gather(recv, send, group=self.group)
+        for r, (a, b) in enumerate(ranges):
+            if r != self.rank and b > a:
+                buf[:, a:b].copy_(recv[r][:, :b - a])
+
     def all_gather_limbs(self, buf, ranges):
         """buf: [rows][limbs][n]; rank r holds valid data in buf[:, ranges[r][0]:ranges[r][1]] and ends up with all."""
         if self.world == 1 or max(hi - lo for lo, hi in ranges) == 0:
             return
+        if self.transport == "allgather":
+            return self._gather_collective(buf, ranges)
         dist = self.dist
         st = self._buffers(buf, ranges)
         lo, hi = ranges[self.rank]

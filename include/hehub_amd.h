@@ -261,7 +261,12 @@ int hp_node_create(const int *devices, size_t count, hp_node **out);
 void hp_node_destroy(hp_node *node);
 size_t hp_node_size(const hp_node *node);
 hp_ctx *hp_node_ctx(hp_node *node, size_t rank);      /* the rank's engine context, for the hp_dev_* entry points */
-const char *hp_node_last_error(hp_node *node);
+const char *hp_node_last_error(hp_node *node);   /* "rank r: <message of that rank's failing call>"; the first rank with a failure of its own */
+/* matrix[a * size + b] = 1 when rank a can write rank b's device memory directly (same device, or hipDeviceEnablePeerAccess
+ * succeeded at hp_node_create), else 0.  The limb-sharded plan below writes peers directly where it can and stages through
+ * page-locked host memory where it cannot (sender: one device-to-host copy of its block; receiver: host-to-device after the
+ * rendezvous).  HP_NODE_NO_PEER in the environment at hp_node_create forces 0 for every pair a != b (tests / debugging). */
+int hp_node_peer_matrix(const hp_node *node, int *matrix);
 int hp_node_slice(const hp_node *node, size_t total, size_t rank, size_t *lo, size_t *hi);
 int hp_node_sync(hp_node *node);
 /* copy a read-only host object (a key-switching key) to every rank: d_copies[rank] receives the device pointers */
@@ -288,7 +293,8 @@ int hp_node_dev_bgv_mult_relin_modswitch(hp_node *node, size_t logn, size_t L, c
 /* Limb-sharded ("latency") mode: ONE batch processed by all ranks, cut by output modulus (the limb-range stages above);
  * rank r owns a contiguous range of q_0..q_{L-1}, p (hp_node_sharded_range; sizes differ by at most one, the special prime
  * in a smallest range).  Exchanges are direct peer writes: the owner copies its limbs into every peer's buffer (one xGMI link
- * per shard, no ring, no padding), ordered by HIP events; all buffers belong to the plan.  With L+1 moduli over W ranks the
+ * per shard, no ring, no padding), ordered by HIP events; all buffers belong to the plan.  Pairs without peer access
+ * (hp_node_peer_matrix) go through the owner's page-locked staging buffer instead.  With L+1 moduli over W ranks the
  * speed-up is bounded by (L+1) / ceil((L+1)/W): 11 moduli over 8 GPUs -> 5.5 x.  plain_modulus 0: CKKS pipeline. */
 typedef struct hp_node_sharded hp_node_sharded;
 int hp_node_sharded_create(hp_node *node, size_t logn, size_t L, const uint64_t *moduli_ext, uint64_t plain_modulus, size_t batch,

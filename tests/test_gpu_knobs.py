@@ -1,0 +1,55 @@
+"""The engine's tuning knobs (environment variables read once at hp_ctx_create, hp_ctx.cpp) change schedules and workspace
+formats, never results: every knob at its extremes and at out-of-range values (which are clamped) must give the oracle's words
+("none is validated for range in tests")."""
+import numpy as np
+import pytest
+
+import params as P
+from oracle.pyoracle import SplitMix
+
+pytestmark = pytest.mark.gpu
+
+KNOBS = [
+    {},
+    {"HP_SPREAD_GROUP": "0"}, {"HP_SPREAD_GROUP": "1"}, {"HP_SPREAD_GROUP": "3"}, {"HP_SPREAD_GROUP": "1000"}, {"HP_SPREAD_GROUP": "-5"},
+    {"HP_DROP_GROUP": "0"}, {"HP_DROP_GROUP": "1"}, {"HP_DROP_GROUP": "7"}, {"HP_DROP_GROUP": "99999"},
+    {"HP_NO_PACK48": "1"}, {"HP_PACK48_MIN_LOGN": "0"}, {"HP_PACK48_MIN_LOGN": "15"}, {"HP_PACK48_MIN_LOGN": "99"},
+    {"HP_NO_FUSED_DROP": "1"},
+    {"HP_MULT_STREAMS": "2"}, {"HP_MULT_STREAMS": "2", "HP_MULT_CHUNK": "3"}, {"HP_MULT_CHUNK": "1"}, {"HP_MULT_CHUNK": "-1"},
+    {"HP_MULT_STREAMS": "7", "HP_MULT_CHUNK": "100000000000"},
+]
+
+
+@pytest.fixture(scope="module")
+def cases(orc):
+    out = []
+    for logn, mext, B, seed in ((12, [P.P50[1]] + P.P40[:4] + [P.P50[0]], 5, 801), (15, P.C3_MODULI_EXT, 2, 802)):
+        n, L = 1 << logn, len(mext) - 1
+        rng = SplitMix(seed)
+        ct1, ct2 = rng.poly((B, 2, L, n), mext[:L]), rng.poly((B, 2, L, n), mext[:L])
+        key = rng.poly((L, 2, L + 1, n), mext)
+        exp = {"ckks": np.stack([orc.ckks_mult(mext, ct1[i], ct2[i], key) for i in range(B)]),
+               "bgv": np.stack([orc.bgv_mult(mext, P.C5_T, ct1[i], ct2[i], key) for i in range(B)]),
+               "rot": np.stack([orc.ckks_rotate(mext, ct1[i], key, 3) for i in range(B)])}
+        out.append((mext, ct1, ct2, key, exp))
+    return out
+
+
+@pytest.mark.parametrize("env", KNOBS, ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()) or "defaults")
+def test_knob_settings_give_the_same_words(cases, monkeypatch, env):
+    from hehub_amd.engine import Engine
+
+    for k in ("HP_SPREAD_GROUP", "HP_DROP_GROUP", "HP_NO_PACK48", "HP_PACK48_MIN_LOGN", "HP_NO_FUSED_DROP", "HP_MULT_STREAMS",
+              "HP_MULT_CHUNK"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    eng = Engine(0)      # the knobs are read here
+    try:
+        for mext, ct1, ct2, key, exp in cases:
+            d1, d2, dk = eng.to_device(ct1), eng.to_device(ct2), eng.to_device(key)
+            assert np.array_equal(eng.to_host(eng.ckks_mult(mext, d1, d2, dk)), exp["ckks"]), env
+            assert np.array_equal(eng.to_host(eng.bgv_mult(mext, P.C5_T, d1, d2, dk)), exp["bgv"]), env
+            assert np.array_equal(eng.to_host(eng.ckks_rotate(mext, d1, dk, 3)), exp["rot"]), env
+    finally:
+        eng.close()

@@ -162,3 +162,95 @@ def test_device_resident_entry_points(orc, world):
         node.free_replicas(dk)
     finally:
         node.close()
+
+
+def test_peer_matrix_and_the_staged_exchange(orc, monkeypatch):
+    """hp_node_peer_matrix reports which rank pairs write each other directly; with HP_NODE_NO_PEER (the injected "no peer
+    access" switch) no pair does and the limb-sharded plan must take its staged branch (owner -> page-locked host -> peer) --
+    same words as the direct branch and as the oracle, host- and device-resident entry points."""
+    import torch
+
+    from hehub_amd.node import Node, ShardedPlan
+
+    world, logn, mext, B = 3, 12, [P.P50[1]] + P.P40[:3] + [P.P50[0]], 3
+    n, L = 1 << logn, len(mext) - 1
+    ct1, ct2, key = case(logn, mext, B, 5150)
+    results = {}
+    for mode in ("direct", "staged"):
+        if mode == "staged":
+            monkeypatch.setenv("HP_NODE_NO_PEER", "1")
+        else:
+            monkeypatch.delenv("HP_NODE_NO_PEER", raising=False)
+        node = Node([0] * world)
+        try:
+            m = node.peer_matrix()
+            assert m.shape == (world, world) and (np.diag(m) == 1).all()
+            assert (m == 1).all() if mode == "direct" else (m == np.eye(world, dtype=np.int32)).all()   # ranks share device 0
+            dk = node.replicate(key)
+            for t in (0, P.C5_T):
+                plan = ShardedPlan(node, logn, mext, B, plain_modulus=t)
+                out = plan.mult(ct1, ct2, dk)
+                for i in range(B):
+                    exp = orc.bgv_mult(mext, t, ct1[i], ct2[i], key) if t else orc.ckks_mult(mext, ct1[i], ct2[i], key)
+                    assert np.array_equal(out[i], exp), (mode, t, i)
+                tdev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to("cuda:0")
+                r1 = [tdev(ct1) for _ in range(world)]; r2 = [tdev(ct2) for _ in range(world)]
+                ro = [torch.full((B, 2, L - 1, n), -1, dtype=torch.int64, device="cuda:0") for _ in range(world)]
+                torch.cuda.synchronize()
+                plan.mult_dev(r1, r2, dk, ro)
+                for r in range(world):
+                    assert np.array_equal(ro[r].cpu().numpy().view(np.uint64), out), (mode, t, r)
+                results[(mode, t)] = out
+                plan.close()
+            node.free_replicas(dk)
+        finally:
+            node.close()
+    for t in (0, P.C5_T):
+        assert np.array_equal(results[("direct", t)], results[("staged", t)])
+
+
+def test_node_leaves_the_callers_device_alone():
+    """hp_node_create / hp_ctx_* calls run with their own device current and put the caller's back"""
+    import torch
+
+    from hehub_amd.node import Node
+
+    before = torch.cuda.current_device()
+    node = Node([0, 0])
+    try:
+        assert torch.cuda.current_device() == before
+        a = node.pinned((4,))
+        node.unpin(a)
+        assert torch.cuda.current_device() == before
+    finally:
+        node.close()
+    assert torch.cuda.current_device() == before
+
+
+def test_failing_rank_is_the_one_reported():
+    """run_all keeps the message of the rank whose own call failed (taken on that rank's worker thread), not of a rank that
+    merely stopped because a peer did: a limb-sharded call with one rank's key pointer NULL"""
+    import ctypes as C
+
+    from hehub_amd import capi
+    from hehub_amd.node import Node, ShardedPlan
+
+    node = Node([0, 0, 0])
+    try:
+        logn, mext, B = 11, [P.P40[0], P.P40[1], P.P50[0]], 1
+        ct1, ct2, key = case(logn, mext, B, 77)
+        plan = ShardedPlan(node, logn, mext, B)
+        dk = node.replicate(key)
+        keys = (C.c_void_p * 3)(*[dk[r] for r in range(3)])
+        keys[2] = None                                   # rank 2 gets no key
+        out = np.zeros((B, 2, len(mext) - 2, 1 << logn), dtype=np.uint64)
+        rc = node.lib.hp_node_sharded_mult(plan.h, ct1.ctypes.data_as(capi.P), ct2.ctypes.data_as(capi.P), keys, out.ctypes.data_as(capi.P))
+        msg = node.lib.hp_node_last_error(node.h).decode()
+        assert rc == capi.HP_EINVAL and msg.startswith("rank 2:") and "NULL" in msg, (rc, msg)
+        # the node is usable afterwards
+        good = plan.mult(ct1, ct2, dk)
+        assert good.shape == out.shape
+        plan.close()
+        node.free_replicas(dk)
+    finally:
+        node.close()

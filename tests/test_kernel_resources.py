@@ -96,3 +96,35 @@ def test_no_wide_buffer_store_with_scalar_offset():
     assert stores                                      # the fused drop's epilogue uses them
     bad = [l for l in stores if re.search(r"buffer_store_\w+\s+v\[\d+:\d+\],\s*(v\d+|off),\s*s\[\d+:\d+\],\s*s\d+", l)]
     assert not bad, bad[:3]
+
+
+def test_vcc_carry_wait_states():
+    """The hand-scheduled product chains (hp_device.h: hp_harvey_lazy_nq, hp_barrett_lazy_nq, hp_butterfly2_nq*) read the carry
+    that a v_mad_u64_u32 left in vcc with `v_addc_co_u32 v, vcc, 0, 0, vcc`.  The spacing the compiler itself keeps between the
+    two on gfx950 is two independent instructions (or `s_nop 1`); the asm strings place them by hand, so the shipped code is
+    checked: every such reader has its vcc writer at least three instructions above it, with no label (branch target) in
+    between."""
+    from hehub_amd.build import build_lib
+    from kernel_meta import disassembly
+    lines = [l.split("//")[0].rstrip() for l in disassembly(build_lib()).splitlines()]
+    lines = [l for l in lines if l.strip()]
+    readers = [i for i, l in enumerate(lines) if re.search(r"v_addc_co_u32_e64 v\d+, vcc, 0, 0, vcc", l)]
+    assert len(readers) > 10000          # 2 per dual butterfly, 240 butterflies per tiled kernel
+    writes_vcc = re.compile(r"^\s*(v_\w+\s+(v\[\d+:\d+\]|v\d+),\s*vcc\b|v_cmp\w*\s+vcc\b|s_\w+\s+vcc\b)")
+    bad = []
+    for i in readers:
+        dist = None
+        for back in range(1, 12):
+            l = lines[i - back]
+            if l.rstrip().endswith(":") or not l.startswith(("\t", " ")):      # a label: cannot vouch for the path into it
+                break
+            m = re.match(r"\s*s_nop (\d+)", l)
+            if m and int(m.group(1)) >= 1 and back == 1:
+                dist = 99                                                       # explicit wait states right in front of the reader
+                break
+            if writes_vcc.match(l):
+                dist = back
+                break
+        if dist is None or dist < 3:
+            bad.append((i, dist, lines[max(0, i - 4):i + 1]))
+    assert not bad, bad[:2]

@@ -40,7 +40,8 @@ import torch
 from hehub_amd import dist as hd
 from hehub_amd.sharded import Comm, limb_ranges, clip
 world, rank = hd.init("gloo")
-comm = Comm()
+comm = Comm(transport=sys.argv[2] if len(sys.argv) > 2 else None)
+assert comm.transport == (sys.argv[2] if len(sys.argv) > 2 else "p2p")
 ranges = clip(limb_ranges(4, world), 3)          # 3 limbs over 2 ranks: (0,2) and (2,3)
 full = torch.arange(5 * 3 * 8, dtype=torch.int64).reshape(5, 3, 8) * 7 + 1
 buf = torch.zeros_like(full)
@@ -71,8 +72,11 @@ def _spawn(script_text, tmp_path, extra_args=(), timeout=600):
     assert "rank 0 ok" in outs[0] and "rank 1 ok" in outs[1], outs
 
 
-def test_exchanges_two_rank_gloo(tmp_path):
-    _spawn(COMM_WORKER, tmp_path)
+@pytest.mark.parametrize("transport", ["p2p", "allgather"])
+def test_exchanges_two_rank_gloo(tmp_path, transport):
+    """both transports of the digit exchange: batched isend / irecv of exact slices, and ONE all_gather of padded slices (the
+    collective BASELINE's north star names)"""
+    _spawn(COMM_WORKER, tmp_path, extra_args=(transport,))
 
 
 def _case(orc, logn, mext, B, seed):
@@ -127,7 +131,7 @@ from hehub_amd.sharded import Comm, ShardedMult
 from oracle.pyoracle import Oracle, SplitMix
 world, rank = hd.init("gloo")
 torch.cuda.set_device(0)
-orc, eng, comm = Oracle("orc"), Engine(0), Comm()
+orc, eng, comm = Oracle("orc"), Engine(0), Comm(transport=sys.argv[2] if len(sys.argv) > 2 else None)
 logn, mext, B = 12, P.P40[:4] + [P.P50[0]], 2
 n, L = 1 << logn, len(mext) - 1
 rng = SplitMix(77)                         # same seed on both ranks: the ciphertexts are replicated
@@ -149,5 +153,6 @@ print("rank", rank, "ok")
 
 
 @pytest.mark.gpu
-def test_two_processes_one_gpu_gloo(tmp_path):
-    _spawn(GPU_WORKER, tmp_path, timeout=900)
+@pytest.mark.parametrize("transport", ["p2p", "allgather"])
+def test_two_processes_one_gpu_gloo(tmp_path, transport):
+    _spawn(GPU_WORKER, tmp_path, extra_args=(transport,), timeout=900)
