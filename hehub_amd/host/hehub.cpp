@@ -1,6 +1,8 @@
 // hehub.cpp -- implementation of the hehub-compatible host layer over the C ABI.  No arithmetic on
-// ring elements happens in this file: it validates arguments the way the reference does, stages host
-// limbs into contiguous device batches, calls the engine and copies the results back.
+// ring elements happens in this file: it validates arguments the way the reference does, finds (or puts)
+// the operands' words on the device, calls the engine and binds the results to the objects it returns.
+// Operands stay in HBM between calls: in the own-mirror build every vector carries its device copy
+// (hehub.hpp), in the binding build a cache of device copies is keyed by the host objects (opt-in).
 //
 // Two ways to build it:
 //   default                      against hehub.hpp, our own mirror of the reference's types (hehub_amd/host);
@@ -23,7 +25,12 @@
 #include "fhe/primitives/rgsw.h"
 #include "fhe/primitives/rlwe.h"
 struct hp_ctx;
-namespace hehub { namespace amd { hp_ctx *engine(); } }
+namespace hehub { namespace amd {
+hp_ctx *engine();
+struct TransferStats {
+    unsigned long long h2d_bytes = 0, d2h_bytes = 0, h2d_copies = 0, d2h_copies = 0, engine_calls = 0;
+};
+} }
 #else
 #include "hehub.hpp"
 #endif
@@ -33,6 +40,8 @@ namespace hehub { namespace amd { hp_ctx *engine(); } }
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <initializer_list>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -55,49 +64,433 @@ hp_ctx *engine() {
 
 } // namespace amd
 
+// =====================================================================================================
+// where the words are: pooled device blocks, the two copies of a vector, PCIe accounting
+// =====================================================================================================
+namespace amd {
+
+// A device allocation out of a per-size free list (hehub pools its host blocks the same way and never gives them back to
+// the OS, allocator.h:19-49).  Everything this layer enqueues goes to ONE stream, so a block that returns to the pool can be
+// handed out again at once: the next user's kernels are ordered behind the last user's.
+struct DevBlock {
+    u64 *p = nullptr;
+    size_t words = 0;
+};
+
 namespace {
 
-// number of engine calls made through this layer; printed at exit when HEHUB_AMD_VERBOSE is set, so a run of
-// somebody else's test-suite over this layer can show that the work really went to the device
-struct CallCounter {
-    unsigned long long n = 0;
-    ~CallCounter() {
-        if (std::getenv("HEHUB_AMD_VERBOSE")) std::fprintf(stderr, "hehub_amd: %llu engine calls (%s)\n", n, hp_version());
-    }
-} g_calls;
+TransferStats g_stats;
 
 void check(int rc) {
-    g_calls.n++;
+    g_stats.engine_calls++;
     if (rc == HP_OK) return;
-    std::string msg = hp_last_error(amd::engine());   // the calling thread's own last failure (hp_ctx.cpp)
+    std::string msg = hp_last_error(engine());   // the calling thread's own last failure (hp_ctx.cpp)
     if (rc == HP_EINVAL) throw std::invalid_argument(msg);
     if (rc == HP_ELOGIC) throw std::logic_error(msg);
     throw std::runtime_error("hehub_amd: " + msg);
 }
 
-// RAII device buffer of `words` u64
-struct DevBuf {
-    u64 *p = nullptr;
-    explicit DevBuf(size_t words) {
-        void *d = nullptr;
-        check(hp_dev_alloc(amd::engine(), words * sizeof(u64), &d));
-        p = (u64 *)d;
+// printed at exit when HEHUB_AMD_VERBOSE is set, so a run of somebody else's test-suite over this layer can show that the
+// work really went to the device and how much crossed PCIe
+struct Report {
+    ~Report() {
+        if (std::getenv("HEHUB_AMD_VERBOSE"))
+            std::fprintf(stderr, "hehub_amd: %llu engine calls (%s); PCIe: %llu copies / %.1f MiB to the device, %llu copies / %.1f MiB back\n",
+                         g_stats.engine_calls, hp_version(), g_stats.h2d_copies, g_stats.h2d_bytes / 1048576.0, g_stats.d2h_copies,
+                         g_stats.d2h_bytes / 1048576.0);
     }
-    ~DevBuf() {
-        if (p) hp_dev_free(amd::engine(), p);
-    }
-    DevBuf(const DevBuf &) = delete;
-    DevBuf &operator=(const DevBuf &) = delete;
-};
+} g_report;
 
-void put_poly(u64 *dst, const RnsIntVec &v, size_t limbs) {
-    const size_t n = v.dimension();
-    for (size_t k = 0; k < limbs; k++) check(hp_memcpy_h2d(amd::engine(), dst + k * n, v[(int)k].data(), n * sizeof(u64)));
+// Heap-allocated and never destroyed on purpose: a static object's destructor would run hipFree during static destruction at
+// process exit, when the HIP runtime may already be gone (crash or hang at exit).  Pooled blocks go back with the process.
+struct Pool {
+    std::mutex mu;
+    std::map<size_t, std::vector<u64 *>> free;
+    size_t free_bytes = 0;
+    size_t cap_bytes = (size_t)8 << 30;   // beyond this a returned block goes back to the device (HEHUB_AMD_POOL_MIB)
+};
+Pool &pool() {
+    static Pool &p = *[] {
+        Pool *q = new Pool;
+        if (const char *e = std::getenv("HEHUB_AMD_POOL_MIB")) q->cap_bytes = (size_t)std::atol(e) << 20;
+        return q;
+    }();
+    return p;
 }
 
-void get_poly(RnsIntVec &v, const u64 *src, size_t limbs) {
+} // namespace
+
+using BlockRef = std::shared_ptr<DevBlock>;
+
+BlockRef alloc_block(size_t words) {
+    if (words == 0) words = 2;
+    Pool &P = pool();
+    u64 *p = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        auto it = P.free.find(words);
+        if (it != P.free.end() && !it->second.empty()) {
+            p = it->second.back();
+            it->second.pop_back();
+            P.free_bytes -= words * 8;
+        }
+    }
+    if (!p) {
+        void *d = nullptr;
+        check(hp_dev_alloc(engine(), words * sizeof(u64), &d));
+        p = (u64 *)d;
+    }
+    return BlockRef(new DevBlock{p, words}, [](DevBlock *b) {
+        Pool &Q = pool();
+        bool keep;
+        {
+            std::lock_guard<std::mutex> lk(Q.mu);
+            keep = Q.free_bytes + b->words * 8 <= Q.cap_bytes;
+            if (keep) {
+                Q.free[b->words].push_back(b->p);
+                Q.free_bytes += b->words * 8;
+            }
+        }
+        if (!keep) (void)hp_dev_free(engine(), b->p);
+        delete b;
+    });
+}
+
+void h2d(u64 *dst, const u64 *src, size_t words) {
+    check(hp_memcpy_h2d(engine(), dst, src, words * sizeof(u64)));
+    g_stats.h2d_bytes += words * 8;
+    g_stats.h2d_copies++;
+}
+void d2h(u64 *dst, const u64 *src, size_t words) {
+    check(hp_memcpy_d2h(engine(), dst, src, words * sizeof(u64)));
+    g_stats.d2h_bytes += words * 8;
+    g_stats.d2h_copies++;
+}
+
+TransferStats transfer_stats() { return g_stats; }
+
+// words on the device for one engine call: `p` points at [polys][limbs][N]; `hold` keeps a temporary / cached block alive
+// until the call has been enqueued (the pool hands blocks out in stream order, so that is long enough)
+struct Src {
+    const u64 *p = nullptr;
+    BlockRef hold;
+};
+// a fresh block for the words an engine call produces
+struct Dst {
+    BlockRef blk;
+    u64 *p = nullptr;
+    explicit Dst(size_t words) : blk(alloc_block(words)), p(blk->p) {}
+};
+
+#ifndef HEHUB_AMD_BIND_REFERENCE
+// ---- own mirror: the vector carries its device copy -----------------------------------------------------------
+namespace {
+unsigned long long next_stamp() {
+    static unsigned long long s = 0;
+    return ++s;
+}
+} // namespace
+
+struct Access {
+    static size_t words(const RnsIntVec &v, size_t limbs) { return limbs * v.dimension(); }
+    // the device copy of the first `limbs` limbs, uploading the host words if they are newer
+    static Src in(const RnsIntVec &v, size_t limbs) {
+        const size_t n = v.dimension();
+        if (!v.dev_ok_) {
+            if (!v.blk_ || v.off_ + v.count_ * n > v.blk_->words) {   // (a view keeps its place: sibling views are disjoint)
+                v.blk_ = alloc_block(v.count_ * n);
+                v.off_ = 0;
+            }
+            for (size_t k = 0; k < v.count_; k++) h2d(v.blk_->p + v.off_ + k * n, v.limbs_[k].data(), n);
+            v.dev_ok_ = true;
+        }
+        (void)limbs;
+        return Src{v.blk_->p + v.off_, v.blk_};
+    }
+    // the vector's own device words, to be overwritten in place by an engine call that has read them (operator+= ...)
+    static u64 *inout(RnsIntVec &v) {
+        Src s = in(v, v.count_);
+        v.host_ok_ = false;
+        v.stamp_ = next_stamp();
+        return const_cast<u64 *>(s.p);
+    }
+    // a result vector of the given shape whose words are the view [off, off + limbs * N) of a block an engine call fills
+    static void shape(RnsIntVec &v, size_t n, size_t limbs, const std::vector<u64> &moduli) {
+        size_t lg = 0;
+        while (((size_t)1 << lg) < n) lg++;
+        v.logn_ = lg;
+        v.count_ = limbs;
+        v.q_.assign(moduli.begin(), moduli.begin() + limbs);
+        v.limbs_.clear();
+    }
+    static void bind(RnsIntVec &v, const Dst &d, size_t off, size_t limbs) {
+        (void)limbs;
+        v.blk_ = d.blk;
+        v.off_ = off;
+        v.dev_ok_ = true;
+        v.host_ok_ = false;
+        v.limbs_.clear();
+        v.stamp_ = next_stamp();
+    }
+    // identity of the words for the key cache: exact (every way to change the words changes the stamp)
+    static unsigned long long stamp(const RnsIntVec &v) {
+        if (!v.stamp_) v.stamp_ = next_stamp();
+        return v.stamp_;
+    }
+    static bool adjacent(const RnsIntVec &a, const RnsIntVec &b, size_t limbs) {
+        return a.dev_ok_ && b.dev_ok_ && a.blk_ == b.blk_ && b.off_ == a.off_ + limbs * a.dimension();
+    }
+    // move the (current) device copy to another place that already holds the same words
+    static void rehome(const RnsIntVec &v, const BlockRef &blk, size_t off) {
+        if (!v.dev_ok_) return;
+        v.blk_ = blk;
+        v.off_ = off;
+    }
+    static void sync_host(const RnsIntVec &v) {
+        if (v.host_ok_) return;
+        const size_t n = v.dimension();
+        v.limbs_.assign(v.count_, RnsIntVec::ComponentData());
+        for (size_t k = 0; k < v.count_; k++) {
+            v.limbs_[k].resize(n);
+            d2h(v.limbs_[k].data(), v.blk_->p + v.off_ + k * n, n);
+        }
+        v.host_ok_ = true;
+    }
+    static void host_written(RnsIntVec &v) {
+        sync_host(v);
+        v.dev_ok_ = false;
+        v.stamp_ = next_stamp();
+    }
+    static void copy_from(RnsIntVec &dst, const RnsIntVec &o) {
+        dst.logn_ = o.logn_; dst.count_ = o.count_; dst.q_ = o.q_;
+        dst.blk_.reset(); dst.off_ = 0; dst.limbs_.clear();
+        dst.stamp_ = next_stamp();
+        if (o.dev_ok_ && o.count_) {   // device-to-device: the host copy (if any) is not duplicated, it can be fetched again
+            const size_t w = o.count_ * o.dimension();
+            dst.blk_ = alloc_block(w);
+            check(hp_dev_copy(engine(), w, o.blk_->p + o.off_, dst.blk_->p));
+            dst.dev_ok_ = true;
+            dst.host_ok_ = false;
+        } else {
+            dst.limbs_ = o.limbs_;
+            dst.host_ok_ = true;
+            dst.dev_ok_ = false;
+        }
+    }
+    static void steal(RnsIntVec &dst, RnsIntVec &o) {
+        dst.logn_ = o.logn_; dst.count_ = o.count_; dst.q_ = std::move(o.q_); dst.limbs_ = std::move(o.limbs_);
+        dst.blk_ = std::move(o.blk_); dst.off_ = o.off_; dst.host_ok_ = o.host_ok_; dst.dev_ok_ = o.dev_ok_; dst.stamp_ = o.stamp_;
+        o.logn_ = 0; o.count_ = 0; o.q_.clear(); o.limbs_.clear(); o.blk_.reset(); o.off_ = 0; o.host_ok_ = true; o.dev_ok_ = false;
+        o.stamp_ = 0;
+    }
+};
+
+#else
+// ---- binding hehub's own types: host objects are hehub's, the device side is a cache --------------------------------
+// hehub's limbs are host memory that anybody may read at any time, so every result is copied back when it is produced.  What
+// can be saved is the way TO the device: with HEHUB_AMD_CT_CACHE=<entries> the layer remembers which device block holds the
+// words of which host polynomial (recognised by the address of its first limb, its shape and four sampled words of every
+// limb) -- an operand that was uploaded or produced by an earlier call is then not uploaded again.  Like the key cache below
+// it is opt-in: a polynomial that is modified in place on the host without touching any sampled word would go unnoticed.
+namespace {
+
+struct CtCache {
+    struct Entry {
+        std::vector<u64> sig;   // address, limbs, n, then 4 words per limb
+        BlockRef blk;
+        size_t off = 0;
+    };
+    std::mutex mu;
+    std::vector<Entry> lru;   // most recently used last
+    size_t cap = 0;
+};
+CtCache &ct_cache() {
+    static CtCache &c = *[] {
+        CtCache *q = new CtCache;
+        if (const char *e = std::getenv("HEHUB_AMD_CT_CACHE")) q->cap = (size_t)std::atol(e);
+        return q;
+    }();
+    return c;
+}
+std::vector<u64> signature(const RnsIntVec &v, size_t limbs) {
     const size_t n = v.dimension();
-    for (size_t k = 0; k < limbs; k++) check(hp_memcpy_d2h(amd::engine(), v[(int)k].data(), src + k * n, n * sizeof(u64)));
+    std::vector<u64> sig{(u64)(uintptr_t)v[0].data(), (u64)limbs, (u64)n};
+    for (size_t k = 0; k < limbs; k++) {
+        const u64 *w = v[(int)k].data();
+        sig.insert(sig.end(), {w[0], w[n / 3], w[(2 * n) / 3], w[n - 1]});
+    }
+    return sig;
+}
+void cache_put(const RnsIntVec &v, size_t limbs, const BlockRef &blk, size_t off) {
+    CtCache &C = ct_cache();
+    if (!C.cap || limbs == 0) return;
+    auto sig = signature(v, limbs);
+    std::lock_guard<std::mutex> lk(C.mu);
+    for (size_t i = 0; i < C.lru.size(); i++)
+        if (C.lru[i].sig[0] == sig[0]) {   // one entry per host address
+            C.lru.erase(C.lru.begin() + i);
+            break;
+        }
+    if (C.lru.size() >= C.cap) C.lru.erase(C.lru.begin());
+    C.lru.push_back(CtCache::Entry{std::move(sig), blk, off});
+}
+bool cache_get(const RnsIntVec &v, size_t limbs, BlockRef &blk, size_t &off) {
+    CtCache &C = ct_cache();
+    if (!C.cap || limbs == 0) return false;
+    const u64 addr = (u64)(uintptr_t)v[0].data();
+    std::lock_guard<std::mutex> lk(C.mu);
+    for (size_t i = 0; i < C.lru.size(); i++) {
+        auto &e = C.lru[i];
+        if (e.sig[0] != addr) continue;
+        // an entry made for MORE limbs serves a prefix (ciphertext after remove_components): compare the common part
+        if (e.sig[2] != v.dimension() || e.sig[1] < limbs) return false;
+        auto sig = signature(v, limbs);
+        for (size_t j = 3; j < sig.size(); j++)
+            if (sig[j] != e.sig[j]) return false;
+        auto hit = e;
+        C.lru.erase(C.lru.begin() + i);
+        C.lru.push_back(hit);
+        blk = hit.blk;
+        off = hit.off;
+        return true;
+    }
+    return false;
+}
+
+} // namespace
+
+struct Access {
+    static size_t words(const RnsIntVec &v, size_t limbs) { return limbs * v.dimension(); }
+    static Src in(const RnsIntVec &v, size_t limbs) {
+        BlockRef blk;
+        size_t off = 0;
+        if (cache_get(v, limbs, blk, off)) return Src{blk->p + off, blk};
+        const size_t n = v.dimension();
+        blk = alloc_block(limbs * n);
+        for (size_t k = 0; k < limbs; k++) h2d(blk->p + k * n, v[(int)k].data(), n);
+        cache_put(v, limbs, blk, 0);
+        return Src{blk->p, blk};
+    }
+    static void shape(RnsIntVec &v, size_t n, size_t limbs, const std::vector<u64> &moduli) {
+        v = RnsIntVec(RnsIntVec::Params{n, limbs, std::vector<u64>(moduli.begin(), moduli.begin() + limbs)});
+    }
+    // hehub's object is host memory: the result comes back now; the device copy is remembered for the next consumer
+    static void bind(RnsIntVec &v, const Dst &d, size_t off, size_t limbs) {
+        const size_t n = v.dimension();
+        for (size_t k = 0; k < limbs; k++) d2h(v[(int)k].data(), d.p + off + k * n, n);
+        cache_put(v, limbs, d.blk, off);
+    }
+    static bool adjacent(const RnsIntVec &a, const RnsIntVec &b, size_t limbs) {
+        BlockRef ba, bb;
+        size_t oa = 0, ob = 0;
+        return cache_get(a, limbs, ba, oa) && cache_get(b, limbs, bb, ob) && ba == bb && ob == oa + limbs * a.dimension();
+    }
+};
+#endif
+
+// [polys.size()][limbs][N] contiguous on the device: the polynomials' own words when they already lie like that (the two
+// halves of a ciphertext an engine call produced), otherwise gathered into a temporary block by device copies
+Src gather(std::initializer_list<const RnsIntVec *> polys, size_t limbs) {
+    const RnsIntVec *first = *polys.begin();
+    bool adj = true;
+    const RnsIntVec *prev = nullptr;
+    for (const RnsIntVec *p : polys) {
+        if (prev && !Access::adjacent(*prev, *p, limbs)) adj = false;
+        prev = p;
+    }
+    if (polys.size() == 1 || adj) return Access::in(*first, limbs);
+    const size_t w = Access::words(*first, limbs);
+    BlockRef tmp = alloc_block(w * polys.size());
+    size_t i = 0;
+    bool whole = true;
+    for (const RnsIntVec *p : polys) {
+        Src s = Access::in(*p, limbs);
+        if (w) check(hp_dev_copy(engine(), w, s.p, tmp->p + i * w));
+        whole = whole && p->component_count() == limbs;
+        i++;
+    }
+#ifndef HEHUB_AMD_BIND_REFERENCE
+    // the gathered block becomes the polynomials' home (same words, another place: invisible to the caller), so the next
+    // call finds the halves of this ciphertext side by side and copies nothing
+    if (whole) {
+        i = 0;
+        for (const RnsIntVec *p : polys) Access::rehome(*p, tmp, (i++) * w);
+    }
+#endif
+    return Src{tmp->p, tmp};
+}
+
+} // namespace amd
+
+using amd::Access;
+using amd::check;
+using amd::Dst;
+using amd::Src;
+
+#ifndef HEHUB_AMD_BIND_REFERENCE
+// =====================================================================================================
+// rns.h: the vector itself (own mirror)
+// =====================================================================================================
+RnsIntVec::RnsIntVec(size_t dimension, size_t components, const std::vector<u64> &moduli) {
+    size_t lg = 0;
+    while (((size_t)1 << lg) < dimension) lg++;
+    if (dimension == 0 || dimension != (size_t)1 << lg) throw std::invalid_argument("dimension should be a 2-power.");   // rns.cpp:17-22
+    if (moduli.size() < components) throw std::invalid_argument("No matching number of moduli provided to create RnsIntVec.");
+    logn_ = lg;
+    count_ = components;
+    q_.assign(moduli.begin(), moduli.begin() + components);
+    limbs_.assign(components, ComponentData(dimension));
+}
+RnsIntVec::RnsIntVec(const RnsIntVec::Params &p) : RnsIntVec(p.dimension, p.component_count, p.moduli) {}
+RnsIntVec::RnsIntVec(const RnsIntVec &o) { Access::copy_from(*this, o); }
+RnsIntVec::RnsIntVec(RnsIntVec &&o) noexcept { Access::steal(*this, o); }
+RnsIntVec &RnsIntVec::operator=(const RnsIntVec &o) {
+    if (this != &o) Access::copy_from(*this, o);
+    return *this;
+}
+RnsIntVec &RnsIntVec::operator=(RnsIntVec &&o) noexcept {
+    if (this != &o) Access::steal(*this, o);
+    return *this;
+}
+std::vector<RnsIntVec::ComponentData> &RnsIntVec::host_rw() {
+    Access::host_written(*this);
+    return limbs_;
+}
+const std::vector<RnsIntVec::ComponentData> &RnsIntVec::host_ro() const {
+    Access::sync_host(*this);
+    return limbs_;
+}
+bool RnsIntVec::operator==(const RnsIntVec &o) const {
+    return logn_ == o.logn_ && count_ == o.count_ && q_ == o.q_ && host_ro() == o.host_ro();
+}
+
+void RnsIntVec::add_components(const std::vector<u64> &new_moduli, size_t adding) {
+    if (new_moduli.size() < adding) throw std::invalid_argument("No matching number of moduli provided to add components.");
+    host_rw();   // the new limbs are host words (zero): the host copy becomes the current one
+    blk_.reset();
+    off_ = 0;
+    q_.insert(q_.end(), new_moduli.begin(), new_moduli.end());   // rns.cpp:41: every supplied modulus is appended, `adding` limbs are
+    limbs_.insert(limbs_.end(), adding, ComponentData(dimension()));
+    count_ += adding;
+}
+
+void RnsIntVec::remove_components(size_t removing) {
+    if (component_count() < removing) throw std::invalid_argument("Trying to remove components more than existing.");
+    q_.resize(q_.size() - removing);
+    count_ -= removing;                       // both copies keep their first limbs: a device view simply gets shorter
+    if (host_ok_) limbs_.resize(count_);
+    stamp_ = 0;
+}
+#endif
+
+namespace {
+
+// a result polynomial of the given shape (no host words are allocated for it in the own-mirror build)
+RnsPolynomial result_poly(size_t n, size_t limbs, const std::vector<u64> &moduli, PolyRepForm form) {
+    RnsPolynomial p;
+    Access::shape(p, n, limbs, moduli);
+    p.rep_form = form;
+    return p;
 }
 
 // rns.cpp:59-72 shared precondition of += and -=
@@ -114,27 +507,41 @@ size_t check_addsub(const RnsIntVec &self, const RnsIntVec &b) {
 
 enum class Bin { add, sub, mul };
 
-void run_binary(Bin op, const RnsIntVec &a, const RnsIntVec &b, RnsIntVec &out, size_t L) {
-    const size_t n = a.dimension();
-    if (L == 0 || n == 0) return;
-    DevBuf da(L * n), db(L * n);
-    put_poly(da.p, a, L);
-    put_poly(db.p, b, L);
+void dev_binary(Bin op, size_t n, size_t L, const u64 *m, size_t batch, const u64 *a, const u64 *b, u64 *out) {
     auto *ctx = amd::engine();
-    const u64 *m = a.modulus_vec().data();
-    if (op == Bin::add) check(hp_dev_poly_add(ctx, n, L, m, 1, da.p, db.p, da.p));
-    if (op == Bin::sub) check(hp_dev_poly_sub(ctx, n, L, m, 1, da.p, db.p, da.p));
-    if (op == Bin::mul) check(hp_dev_poly_mul(ctx, n, L, m, 1, da.p, db.p, da.p));
-    get_poly(out, da.p, L);
+    if (op == Bin::add) check(hp_dev_poly_add(ctx, n, L, m, batch, a, b, out));
+    if (op == Bin::sub) check(hp_dev_poly_sub(ctx, n, L, m, batch, a, b, out));
+    if (op == Bin::mul) check(hp_dev_poly_mul(ctx, n, L, m, batch, a, b, out));
+}
+
+// self (op)= b on the first L limbs, in place
+void run_inplace(Bin op, RnsIntVec &self, const RnsIntVec &b, size_t L) {
+    const size_t n = self.dimension();
+    if (L == 0 || n == 0) return;
+    Src sb = Access::in(b, L);
+#ifndef HEHUB_AMD_BIND_REFERENCE
+    u64 *p = Access::inout(self);   // the vector's own device words: hp_dev_poly_* allow d_out == d_a
+    dev_binary(op, n, L, self.modulus_vec().data(), 1, p, sb.p, p);
+#else
+    Src sa = Access::in(self, L);
+    Dst d(L * n);
+    dev_binary(op, n, L, self.modulus_vec().data(), 1, sa.p, sb.p, d.p);
+    Access::bind(self, d, 0, L);
+#endif
 }
 
 void scalar_mul(RnsIntVec &self, const std::vector<u64> &scalars) {
     const size_t n = self.dimension(), L = self.component_count();
     if (L == 0) return;
-    DevBuf d(L * n);
-    put_poly(d.p, self, L);
-    check(hp_dev_poly_scalar_mul(amd::engine(), n, L, self.modulus_vec().data(), 1, scalars.data(), d.p, d.p));
-    get_poly(self, d.p, L);
+#ifndef HEHUB_AMD_BIND_REFERENCE
+    u64 *p = Access::inout(self);
+    check(hp_dev_poly_scalar_mul(amd::engine(), n, L, self.modulus_vec().data(), 1, scalars.data(), p, p));
+#else
+    Src s = Access::in(self, L);
+    Dst d(L * n);
+    check(hp_dev_poly_scalar_mul(amd::engine(), n, L, self.modulus_vec().data(), 1, scalars.data(), s.p, d.p));
+    Access::bind(self, d, 0, L);
+#endif
 }
 
 void check_ct_wellformed(const RlweCt &ct) {   // rescaling.cpp:15-29, mod_switch.cpp:14-28
@@ -178,39 +585,43 @@ size_t check_ext_prod(const RlwePt &pt, const RgswCt &rgsw, std::vector<u64> &ex
     return rgsw.size();
 }
 
-void put_key(u64 *dst, const RgswCt &rgsw, size_t L, size_t n) {
-    for (size_t j = 0; j < L; j++)
-        for (size_t h = 0; h < 2; h++) put_poly(dst + ((j * 2 + h) * (L + 1)) * n, rgsw[j][h], L + 1);
-}
-
-// Device copy of a key-switching key for one call.  A key is 2L(L+1) limbs (55 MiB at N=32768, L=10) and is the same
-// object call after call, so staging it every time dominates the host-pointer path.  With HEHUB_AMD_KEY_CACHE=<entries>
-// the layer keeps up to that many keys resident, recognised by the address of their first limb, their shape and four
-// sampled words of every limb (a key that is modified in place between calls without touching any sampled word would go
-// unnoticed: that is why the cache is opt-in).  Default: no cache, the key is staged per call.
+// Device copy of a key-switching key: u64[L][2][L+1][N], one block, assembled from the key's 2L polynomials.  A key is
+// 2L(L+1) limbs (55 MiB at N=32768, L=10) and the same object call after call, so assembling it every time dominates.
+//   own mirror:        the last HEHUB_AMD_KEY_CACHE (default 4) keys stay resident, recognised EXACTLY: every polynomial
+//                      carries a stamp that changes whenever its words can have changed (RnsIntVec, hehub.hpp)
+//   binding hehub's:   with HEHUB_AMD_KEY_CACHE=<entries> keys stay resident, recognised by the address of their first
+//                      limb, their shape and four sampled words of every limb (a key that is modified in place between
+//                      calls without touching any sampled word would go unnoticed: that is why the cache is opt-in there);
+//                      default: the key is staged per call
 class DevKey {
 public:
     DevKey(const RgswCt &rgsw, size_t L, size_t n) {
+#ifndef HEHUB_AMD_BIND_REFERENCE
+        static const size_t cap = std::getenv("HEHUB_AMD_KEY_CACHE") ? (size_t)std::atoi(std::getenv("HEHUB_AMD_KEY_CACHE")) : 4;
+#else
         static const size_t cap = std::getenv("HEHUB_AMD_KEY_CACHE") ? (size_t)std::atoi(std::getenv("HEHUB_AMD_KEY_CACHE")) : 0;
+#endif
         const size_t words = L * 2 * (L + 1) * n;
         if (cap == 0) {
-            own_.reset(new DevBuf(words));
-            put_key(own_->p, rgsw, L, n);
-            p_ = own_->p;
+            own_ = amd::alloc_block(words);
+            assemble(own_->p, rgsw, L, n);
             return;
         }
-        std::vector<u64> sig{(u64)(uintptr_t)rgsw[0][0][0].data(), (u64)L, (u64)n};
+        std::vector<u64> sig{(u64)L, (u64)n};
         for (size_t j = 0; j < L; j++)
-            for (size_t h = 0; h < 2; h++)
+            for (size_t h = 0; h < 2; h++) {
+#ifndef HEHUB_AMD_BIND_REFERENCE
+                sig.push_back(Access::stamp(rgsw[j][h]));
+#else
+                sig.push_back((u64)(uintptr_t)rgsw[j][h][0].data());
                 for (size_t k = 0; k <= L; k++) {
                     const u64 *w = rgsw[j][h][(int)k].data();
                     sig.insert(sig.end(), {w[0], w[n / 3], w[(2 * n) / 3], w[n - 1]});
                 }
-        // Heap-allocated and never destroyed on purpose: a static object's destructor would run hipFree during static
-        // destruction at process exit, when the HIP runtime may already be gone (crash or hang at exit).  The cached
-        // device blocks go back with the process.
-        typedef std::vector<std::pair<std::vector<u64>, std::shared_ptr<DevBuf>>> Cache;   // most recently used last
-        static std::mutex &mu = *new std::mutex;
+#endif
+            }
+        typedef std::vector<std::pair<std::vector<u64>, amd::BlockRef>> Cache;   // most recently used last
+        static std::mutex &mu = *new std::mutex;   // (never destroyed, like the pool)
         static Cache &cache = *new Cache;
         std::lock_guard<std::mutex> lock(mu);
         for (size_t i = 0; i < cache.size(); i++)
@@ -219,28 +630,35 @@ public:
                 cache.erase(cache.begin() + i);
                 cache.push_back(hit);
                 own_ = hit.second;
-                p_ = own_->p;
                 return;
             }
-        own_.reset(new DevBuf(words));
-        put_key(own_->p, rgsw, L, n);
-        p_ = own_->p;
+        own_ = amd::alloc_block(words);
+        assemble(own_->p, rgsw, L, n);
         if (cache.size() >= cap) cache.erase(cache.begin());
         cache.emplace_back(std::move(sig), own_);
     }
-    const u64 *p() const { return p_; }
+    const u64 *p() const { return own_->p; }
 
 private:
-    std::shared_ptr<DevBuf> own_;
-    u64 *p_ = nullptr;
+    static void assemble(u64 *dst, const RgswCt &rgsw, size_t L, size_t n) {
+        for (size_t j = 0; j < L; j++)
+            for (size_t h = 0; h < 2; h++) {
+                u64 *row = dst + ((j * 2 + h) * (L + 1)) * n;
+#ifndef HEHUB_AMD_BIND_REFERENCE
+                Src s = Access::in(rgsw[j][h], L + 1);   // (a key polynomial that lives on the device is copied there)
+                check(hp_dev_copy(amd::engine(), (L + 1) * n, s.p, row));
+#else
+                for (size_t k = 0; k <= L; k++) amd::h2d(row + k * n, rgsw[j][h][(int)k].data(), n);
+#endif
+            }
+    }
+    amd::BlockRef own_;
 };
 
-RlweCt make_ct(size_t n, size_t L, const std::vector<u64> &moduli, const u64 *src) {
-    RlweCt ct{RnsPolynomial(n, L, moduli), RnsPolynomial(n, L, moduli)};
-    for (int h = 0; h < 2; h++) {
-        get_poly(ct[h], src + (size_t)h * L * n, L);
-        ct[h].rep_form = PolyRepForm::value;
-    }
+// the two polynomials of a result ciphertext as views of the block an engine call filled: [2][L][N]
+RlweCt make_ct(size_t n, size_t L, const std::vector<u64> &moduli, const Dst &d) {
+    RlweCt ct{result_poly(n, L, moduli, PolyRepForm::value), result_poly(n, L, moduli, PolyRepForm::value)};
+    for (int h = 0; h < 2; h++) Access::bind(ct[h], d, (size_t)h * L * n, L);
     return ct;
 }
 
@@ -249,15 +667,15 @@ RlweCt relinearize_common(const std::array<RnsPolynomial, 3> &quad, const RlweKs
     std::vector<u64> mext;
     const size_t L0 = check_ext_prod(quad[2], key, mext);
     const size_t n = quad[2].dimension(), L = quad[2].component_count();
-    DevBuf dq(3 * L * n), dout(2 * L * n);
-    DevKey dk(key, L0, n);
-    for (int h = 0; h < 3; h++) put_poly(dq.p + (size_t)h * L * n, quad[h], L);
-    const size_t logn = quad[2].log_dimension();
     if (bgv && L0 != L) throw std::invalid_argument("Inconsistent RGSW ciphertext.");   // no higher-level keys for the BGV quirk path
+    DevKey dk(key, L0, n);
+    Src dq = amd::gather({&quad[0], &quad[1], &quad[2]}, L);
+    Dst dout(2 * L * n);
+    const size_t logn = quad[2].log_dimension();
     if (bgv) check(hp_dev_bgv_relinearize(amd::engine(), logn, L, mext.data(), 1 /* bgv.h:32 */, 1, dq.p, dk.p(), dout.p));
     else check(hp_dev_ckks_relinearize_at(amd::engine(), logn, L, L0, mext.data(), 1, dq.p, dk.p(), dout.p));
     std::vector<u64> q(mext.begin(), mext.begin() + L);
-    return make_ct(n, L, q, dout.p);
+    return make_ct(n, L, q, dout);
 }
 
 template <class Quad, class Ct> Quad mult_low_level_common(const Ct &ct1, const Ct &ct2) {
@@ -271,17 +689,15 @@ template <class Quad, class Ct> Quad mult_low_level_common(const Ct &ct1, const 
     std::vector<u64> m1(ct1[0].modulus_vec()), m2(ct2[0].modulus_vec());
     m1.resize(L); m2.resize(L);
     if (m1 != m2) throw std::invalid_argument("Operands' moduli mismatch.");
-    DevBuf d1(2 * L * n), d2(2 * L * n), dq(3 * L * n);
-    for (int h = 0; h < 2; h++) {
-        put_poly(d1.p + (size_t)h * L * n, ct1[h], L);
-        put_poly(d2.p + (size_t)h * L * n, ct2[h], L);
-    }
+    // (a ciphertext with more limbs than L does not lie as [2][L][N]: gather() then copies the first L limbs of each half)
+    Src d1 = amd::gather({&ct1[0], &ct1[1]}, L);
+    Src d2 = amd::gather({&ct2[0], &ct2[1]}, L);
+    Dst dq(3 * L * n);
     check(hp_dev_mult_low_level(amd::engine(), ct1[0].log_dimension(), L, m1.data(), 1, d1.p, d2.p, dq.p));
     Quad quad;
     for (int h = 0; h < 3; h++) {
-        quad[h] = RnsPolynomial(n, L, m1);
-        get_poly(quad[h], dq.p + (size_t)h * L * n, L);
-        quad[h].rep_form = PolyRepForm::value;
+        quad[h] = result_poly(n, L, m1, PolyRepForm::value);
+        Access::bind(quad[h], dq, (size_t)h * L * n, L);
     }
     return quad;
 }
@@ -289,55 +705,29 @@ template <class Quad, class Ct> Quad mult_low_level_common(const Ct &ct1, const 
 void drop_last_prime(RlweCt &ct, bool bgv, u64 t) {
     check_ct_wellformed(ct);
     const size_t n = ct[0].dimension(), L = ct[0].component_count(), logn = ct[0].log_dimension();
-    DevBuf din(2 * L * n), dout(2 * (L - 1) * n);
-    for (int h = 0; h < 2; h++) put_poly(din.p + (size_t)h * L * n, ct[h], L);
-    const u64 *m = ct[0].modulus_vec().data();
-    if (bgv) check(hp_dev_bgv_mod_switch(amd::engine(), logn, L, m, t, 1, din.p, dout.p));
-    else check(hp_dev_ckks_rescale(amd::engine(), logn, L, m, 1, din.p, dout.p));
+    Src din = amd::gather({&ct[0], &ct[1]}, L);
+    Dst dout(2 * (L - 1) * n);
+    const std::vector<u64> m(ct[0].modulus_vec());
+    if (bgv) check(hp_dev_bgv_mod_switch(amd::engine(), logn, L, m.data(), t, 1, din.p, dout.p));
+    else check(hp_dev_ckks_rescale(amd::engine(), logn, L, m.data(), 1, din.p, dout.p));
     for (int h = 0; h < 2; h++) {
         ct[h].remove_components();
-        get_poly(ct[h], dout.p + (size_t)h * (L - 1) * n, L - 1);
+        Access::bind(ct[h], dout, (size_t)h * (L - 1) * n, L - 1);
     }
 }
 
 } // namespace
 
 // =====================================================================================================
-// rns.h / rns.cpp
+// rns.h / rns.cpp: operators
 // =====================================================================================================
-#ifndef HEHUB_AMD_BIND_REFERENCE
-RnsIntVec::RnsIntVec(size_t dimension, size_t components, const std::vector<u64> &moduli) {
-    size_t lg = 0;
-    while (((size_t)1 << lg) < dimension) lg++;
-    if (dimension == 0 || dimension != (size_t)1 << lg) throw std::invalid_argument("dimension should be a 2-power.");   // rns.cpp:17-22
-    if (moduli.size() < components) throw std::invalid_argument("No matching number of moduli provided to create RnsIntVec.");
-    logn_ = lg;
-    q_.assign(moduli.begin(), moduli.begin() + components);
-    limbs_.assign(components, ComponentData(dimension));
-}
-
-RnsIntVec::RnsIntVec(const RnsIntVec::Params &p) : RnsIntVec(p.dimension, p.component_count, p.moduli) {}
-
-void RnsIntVec::add_components(const std::vector<u64> &new_moduli, size_t adding) {
-    if (new_moduli.size() < adding) throw std::invalid_argument("No matching number of moduli provided to add components.");
-    q_.insert(q_.end(), new_moduli.begin(), new_moduli.end());   // rns.cpp:41: every supplied modulus is appended, `adding` limbs are
-    limbs_.insert(limbs_.end(), adding, ComponentData(dimension()));
-}
-
-void RnsIntVec::remove_components(size_t removing) {
-    if (component_count() < removing) throw std::invalid_argument("Trying to remove components more than existing.");
-    q_.resize(q_.size() - removing);
-    limbs_.resize(limbs_.size() - removing);
-}
-#endif
-
 const RnsIntVec &operator+=(RnsIntVec &self, const RnsIntVec &b) {
-    run_binary(Bin::add, self, b, self, check_addsub(self, b));
+    run_inplace(Bin::add, self, b, check_addsub(self, b));
     return self;
 }
 
 const RnsIntVec &operator-=(RnsIntVec &self, const RnsIntVec &b) {
-    run_binary(Bin::sub, self, b, self, check_addsub(self, b));
+    run_inplace(Bin::sub, self, b, check_addsub(self, b));
     return self;
 }
 
@@ -348,8 +738,14 @@ RnsIntVec operator*(const RnsIntVec &a, const RnsIntVec &b) {
     moduli.resize(components);
     b_moduli.resize(components);
     if (moduli != b_moduli) throw std::invalid_argument("Operands' moduli mismatch.");
-    RnsIntVec result(RnsIntVec::Params{a.dimension(), components, moduli});
-    run_binary(Bin::mul, a, b, result, components);
+    RnsIntVec result;
+    Access::shape(result, a.dimension(), components, moduli);
+    const size_t n = a.dimension();
+    if (components == 0 || n == 0) return result;
+    Src sa = Access::in(a, components), sb = Access::in(b, components);
+    Dst d(components * n);
+    dev_binary(Bin::mul, n, components, moduli.data(), 1, sa.p, sb.p, d.p);
+    Access::bind(result, d, 0, components);
     return result;
 }
 
@@ -430,10 +826,7 @@ void batched_montgomery_128_lazy(const u64 q, const size_t len, const u128 in[],
 void reduce_strict(RnsPolynomial &p) {
     const size_t n = p.dimension(), L = p.component_count();
     if (L == 0) return;
-    DevBuf d(L * n);
-    put_poly(d.p, p, L);
-    check(hp_dev_poly_reduce_strict(amd::engine(), n, L, p.modulus_vec().data(), 1, d.p));
-    get_poly(p, d.p, L);
+    check(hp_dev_poly_reduce_strict(amd::engine(), n, L, p.modulus_vec().data(), 1, Access::inout(p)));
 }
 
 // host-side scalar, as in the reference (mod_arith.cpp:136-149): Bezout coefficient lifted to [0, prime)
@@ -461,12 +854,11 @@ void intt_negacyclic_inplace_lazy(const size_t logn, const u64 q, u64 v[]) {
 #ifndef HEHUB_AMD_BIND_REFERENCE   // ntt.h:41-92 (inline per-limb loops) stay the reference's
 static void poly_transform(RnsPolynomial &p, bool inverse, bool strict) {
     const size_t n = p.dimension(), L = p.component_count();
+    (void)n;
     if (L) {
-        DevBuf d(L * n);
-        put_poly(d.p, p, L);
-        if (inverse) check(hp_dev_intt(amd::engine(), p.log_dimension(), L, p.modulus_vec().data(), 1, d.p, strict ? 1 : 0));
-        else check(hp_dev_ntt(amd::engine(), p.log_dimension(), L, p.modulus_vec().data(), 1, d.p));
-        get_poly(p, d.p, L);
+        u64 *d = Access::inout(p);
+        if (inverse) check(hp_dev_intt(amd::engine(), p.log_dimension(), L, p.modulus_vec().data(), 1, d, strict ? 1 : 0));
+        else check(hp_dev_ntt(amd::engine(), p.log_dimension(), L, p.modulus_vec().data(), 1, d));
     }
     p.rep_form = inverse ? PolyRepForm::coeff : PolyRepForm::value;
 }
@@ -485,14 +877,13 @@ void cache_ntt_factors_strict(const u64 logn, const std::vector<u64> &moduli) {
 static RnsPolynomial gather(const RnsPolynomial &p, bool is_cycle, size_t step) {
     if (p.rep_form != PolyRepForm::value) throw std::invalid_argument("poly_ntt is expected to be in NTT value form");
     const size_t n = p.dimension(), L = p.component_count();
-    RnsPolynomial out(n, L, p.modulus_vec());
-    out.rep_form = PolyRepForm::value;
+    RnsPolynomial out = result_poly(n, L, p.modulus_vec(), PolyRepForm::value);
     if (L == 0) return out;
-    DevBuf din(L * n), dout(L * n);
-    put_poly(din.p, p, L);
+    Src din = Access::in(p, L);
+    Dst dout(L * n);
     if (is_cycle) check(hp_dev_poly_cycle(amd::engine(), p.log_dimension(), L, 1, step, din.p, dout.p));
     else check(hp_dev_poly_involution(amd::engine(), p.log_dimension(), L, 1, din.p, dout.p));
-    get_poly(out, dout.p, L);
+    Access::bind(out, dout, 0, L);
     return out;
 }
 RnsPolynomial cycle(const RnsPolynomial &p, const size_t step) { return gather(p, true, step); }
@@ -502,8 +893,27 @@ RnsPolynomial involution(const RnsPolynomial &p) { return gather(p, false, 0); }
 // rlwe.h / rgsw.h
 // =====================================================================================================
 #ifndef HEHUB_AMD_BIND_REFERENCE   // rlwe.cpp:83-101: thin compositions of the operators above
-RlweCt add(const RlweCt &a, const RlweCt &b) { return RlweCt{a[0] + b[0], a[1] + b[1]}; }
-RlweCt sub(const RlweCt &a, const RlweCt &b) { return RlweCt{a[0] - b[0], a[1] - b[1]}; }
+// both halves in ONE launch when the two ciphertexts have the same shape (the result's halves then lie side by side, ready
+// for the next scheme-level call); the checks are operator+= 's (rns.h:207-218, rns.cpp:59-72), half by half, in its order
+static RlweCt addsub(const RlweCt &a, const RlweCt &b, bool sub) {
+    size_t L[2];
+    for (int h = 0; h < 2; h++) {
+        if (a[h].rep_form != b[h].rep_form) throw std::invalid_argument("Operands are in different representation form.");
+        L[h] = check_addsub(a[h], b[h]);
+    }
+    const size_t n = a[0].dimension();
+    const bool same = L[0] == L[1] && L[0] > 0 && a[1].dimension() == n && a[0].modulus_vec() == a[1].modulus_vec() &&
+                      b[0].component_count() == L[0] && b[1].component_count() == L[0];
+    if (!same) return sub ? RlweCt{a[0] - b[0], a[1] - b[1]} : RlweCt{a[0] + b[0], a[1] + b[1]};
+    Src sa = amd::gather({&a[0], &a[1]}, L[0]), sb = amd::gather({&b[0], &b[1]}, L[0]);
+    Dst d(2 * L[0] * n);
+    dev_binary(sub ? Bin::sub : Bin::add, n, L[0], a[0].modulus_vec().data(), 2, sa.p, sb.p, d.p);
+    RlweCt r{result_poly(n, L[0], a[0].modulus_vec(), a[0].rep_form), result_poly(n, L[0], a[1].modulus_vec(), a[1].rep_form)};
+    for (int h = 0; h < 2; h++) Access::bind(r[h], d, (size_t)h * L[0] * n, L[0]);
+    return r;
+}
+RlweCt add(const RlweCt &a, const RlweCt &b) { return addsub(a, b, false); }
+RlweCt sub(const RlweCt &a, const RlweCt &b) { return addsub(a, b, true); }
 RlweCt add_plain_core(const RlweCt &ct, const RlwePt &pt) { return RlweCt{ct[0] + pt, ct[1]}; }
 RlweCt sub_plain_core(const RlweCt &ct, const RlwePt &pt) { return RlweCt{ct[0] - pt, ct[1]}; }
 RlweCt mult_plain_core(const RlweCt &ct, const RlwePt &pt) { return RlweCt{ct[0] * pt, ct[1] * pt}; }
@@ -513,11 +923,11 @@ RlweCt ext_prod_montgomery(const RlwePt &pt, const RgswCt &rgsw) {
     std::vector<u64> mext;
     const size_t L0 = check_ext_prod(pt, rgsw, mext);
     const size_t n = pt.dimension(), L = pt.component_count();
-    DevBuf dp(L * n), dout(2 * (L + 1) * n);
     DevKey dk(rgsw, L0, n);
-    put_poly(dp.p, pt, L);
+    Src dp = Access::in(pt, L);
+    Dst dout(2 * (L + 1) * n);
     check(hp_dev_ext_prod_montgomery_at(amd::engine(), pt.log_dimension(), L, L0, mext.data(), 1, dp.p, dk.p(), dout.p));
-    return make_ct(n, L + 1, mext, dout.p);
+    return make_ct(n, L + 1, mext, dout);
 }
 
 // rlwe.h decrypt_core (rlwe.cpp:74-81): `c0 + c1 * sk`, INTT, reduce_strict as ONE device call instead of 3L host
@@ -537,15 +947,12 @@ RlwePt decrypt_core(const RlweCt &ct, const RlweSk &sk) {
     if (Lp < L) throw std::invalid_argument("Operand b contains less components than self.");
     m1.resize(L);
     if (c0.modulus_vec() != m1) throw std::invalid_argument("Operands' moduli mismatch.");
-    RnsPolynomial pt(n, L, m1);
-    pt.rep_form = PolyRepForm::coeff;
+    RnsPolynomial pt = result_poly(n, L, m1, PolyRepForm::coeff);
     if (L == 0) return pt;
-    DevBuf dct(2 * L * n), dsk(L * n), dpt(L * n);
-    put_poly(dct.p, c0, L);
-    put_poly(dct.p + L * n, c1, L);
-    put_poly(dsk.p, sk, L);
+    Src dct = amd::gather({&c0, &c1}, L), dsk = Access::in(sk, L);
+    Dst dpt(L * n);
     check(hp_dev_rlwe_decrypt_core(amd::engine(), c0.log_dimension(), L, m1.data(), 1, dct.p, dsk.p, dpt.p));
-    get_poly(pt, dpt.p, L);
+    Access::bind(pt, dpt, 0, L);
     return pt;
 }
 
@@ -556,20 +963,20 @@ RnsPolynomial rns_base_transform(RnsPolynomial in, const std::vector<u64> &new_m
         throw std::logic_error("Trying to perform RNS base transformation on NTT values.");
     const size_t n = in.dimension(), L = in.component_count();
     if (L == 1) {
-        RnsPolynomial out(n, new_moduli.size(), new_moduli);
+        RnsPolynomial out = result_poly(n, new_moduli.size(), new_moduli, PolyRepForm::coeff);
         if (new_moduli.empty()) return out;
-        DevBuf din(n), dout(new_moduli.size() * n);
-        put_poly(din.p, in, 1);
+        Src din = Access::in(in, 1);
+        Dst dout(new_moduli.size() * n);
         check(hp_dev_rns_base_from_single(amd::engine(), n, in.modulus_at(0), new_moduli.size(), new_moduli.data(), 1, din.p, dout.p));
-        get_poly(out, dout.p, new_moduli.size());
+        Access::bind(out, dout, 0, new_moduli.size());
         return out;
     }
     if (new_moduli.size() == 1) {   // both branches of rns_transform.cpp:39-104 on the device
-        RnsPolynomial out(n, 1, new_moduli);
-        DevBuf din(L * n), dout(n);
-        put_poly(din.p, in, L);
+        RnsPolynomial out = result_poly(n, 1, new_moduli, PolyRepForm::coeff);
+        Src din = Access::in(in, L);
+        Dst dout(n);
         check(hp_dev_rns_base_to_single(amd::engine(), n, L, in.modulus_vec().data(), new_moduli[0], 1, din.p, dout.p));
-        get_poly(out, dout.p, 1);
+        Access::bind(out, dout, 0, 1);
         return out;
     }
     throw "under development";   // rns_transform.cpp:123
@@ -662,13 +1069,13 @@ static CkksCt key_switched(const CkksCt &ct, const RlweKsk &key, bool conj, size
     const size_t L0 = check_ext_prod(ct[1], key, mext);
     const size_t n = ct[1].dimension(), L = ct[1].component_count(), logn = ct[1].log_dimension();
     if (ct[0].dimension() != n || ct[0].component_count() != L) throw std::invalid_argument("Ill-formed ciphertext.");
-    DevBuf dct(2 * L * n), dout(2 * L * n);
     DevKey dk(key, L0, n);
-    for (int h = 0; h < 2; h++) put_poly(dct.p + (size_t)h * L * n, ct[h], L);
+    Src dct = amd::gather({&ct[0], &ct[1]}, L);
+    Dst dout(2 * L * n);
     if (conj) check(hp_dev_ckks_conjugate_at(amd::engine(), logn, L, L0, mext.data(), 1, dct.p, dk.p(), dout.p));
     else check(hp_dev_ckks_rotate_at(amd::engine(), logn, L, L0, mext.data(), 1, step, dct.p, dk.p(), dout.p));
     std::vector<u64> q(mext.begin(), mext.begin() + L);
-    CkksCt r = make_ct(n, L, q, dout.p);
+    CkksCt r = make_ct(n, L, q, dout);
     r.scaling_factor = ct.scaling_factor;
     return r;
 }

@@ -15,14 +15,16 @@
 // rns_base_transform.  A hehub build keeps its own files for those and links this layer for the rest
 // (INTEGRATION.md).
 //
-// This is the per-call drop-in path: every call moves its operands over PCIe.  Throughput code uses
-// the device-resident batch entry points of the C ABI directly.
+// Operands stay in HBM between calls (see RnsIntVec below); batches of ciphertexts use the device-resident batch entry
+// points of the C ABI directly.
 #pragma once
 
 #include <array>
 #include <cstddef>
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
+#include <utility>
 #include <vector>
 
 struct hp_ctx;
@@ -39,9 +41,27 @@ namespace amd {
 hp_ctx *engine();
 } // namespace amd
 
-// Stand-alone mirror of hehub's RNS vector (rns.h:15-115): the public names a caller of hehub uses, over plain
-// std::vector limbs (hehub pools SmartArray blocks).  Only built when hehub's own headers are not (the real binding
-// compiles against those: -DHEHUB_AMD_BIND_REFERENCE).
+// Stand-alone mirror of hehub's RNS vector (rns.h:15-115): the public names a caller of hehub uses.  Only built when hehub's own
+// headers are not (the real binding compiles against those: -DHEHUB_AMD_BIND_REFERENCE).
+//
+// DEVICE RESIDENCY.  hehub's limbs are pooled host blocks (allocator.h:105-220); here a vector's limbs live where they were
+// last written: results of engine calls stay in HBM (one contiguous [L][N] view of a pooled device block) and are copied to the
+// host only when somebody looks at the words -- operator[], components(), begin() / end() / last(), operator== -- while words
+// written on the host are uploaded by the first engine call that consumes them.  Two flags per vector say which copy is
+// current; a non-const host accessor hands out writable words, so it marks the device copy stale.  A program that keeps to
+// hehub's API between encrypt and decrypt (ckks::mult / add / rotate / rescale_inplace ... chains) therefore crosses PCIe
+// once per input ciphertext and once per result it actually reads.  Value semantics are hehub's: a copy is a deep copy
+// (device to device when the device copy is current), a move leaves the source empty (allocator.h:113-155).
+namespace amd {
+struct DevBlock;   // a pooled device allocation (hehub.cpp)
+struct Access;     // the binding's view of a vector's two copies (hehub.cpp)
+/// bytes and calls that crossed PCIe through this layer since the process started, and engine calls made
+struct TransferStats {
+    unsigned long long h2d_bytes = 0, d2h_bytes = 0, h2d_copies = 0, d2h_copies = 0, engine_calls = 0;
+};
+TransferStats transfer_stats();
+} // namespace amd
+
 class RnsIntVec {
 public:
     using ComponentData = std::vector<u64>;   // one limb: N words modulo modulus_at(k)
@@ -54,35 +74,50 @@ public:
     RnsIntVec() = default;
     RnsIntVec(size_t dimension, size_t components, const std::vector<u64> &moduli);
     RnsIntVec(const Params &params);
+    RnsIntVec(const RnsIntVec &o);
+    RnsIntVec(RnsIntVec &&o) noexcept;
+    RnsIntVec &operator=(const RnsIntVec &o);
+    RnsIntVec &operator=(RnsIntVec &&o) noexcept;
+    ~RnsIntVec() = default;
 
     // shape
     size_t log_dimension() const { return logn_; }
-    size_t dimension() const { return limbs_.empty() && !logn_ ? 0 : (size_t)1 << logn_; }
-    size_t component_count() const { return limbs_.size(); }
-    Params params() const { return Params{dimension(), limbs_.size(), q_}; }
+    size_t dimension() const { return count_ == 0 && !logn_ ? 0 : (size_t)1 << logn_; }
+    size_t component_count() const { return count_; }
+    Params params() const { return Params{dimension(), count_, q_}; }
     u64 modulus_at(int k) const { return q_[k]; }
     const std::vector<u64> &modulus_vec() const { return q_; }
-    bool operator==(const RnsIntVec &o) const { return logn_ == o.logn_ && q_ == o.q_ && limbs_ == o.limbs_; }
+    bool operator==(const RnsIntVec &o) const;
 
-    // limbs
-    ComponentData &operator[](int k) { return limbs_[k]; }
-    const ComponentData &operator[](int k) const { return limbs_[k]; }
-    std::vector<ComponentData> &components() { return limbs_; }
-    const std::vector<ComponentData> &components() const { return limbs_; }
-    auto begin() { return limbs_.begin(); }
-    auto end() { return limbs_.end(); }
-    auto last() { return limbs_.end() - 1; }
-    auto begin() const { return limbs_.cbegin(); }
-    auto end() const { return limbs_.cend(); }
-    auto last() const { return limbs_.cend() - 1; }
+    // limbs (host words: these synchronise with the device copy, see above)
+    ComponentData &operator[](int k) { return host_rw()[k]; }
+    const ComponentData &operator[](int k) const { return host_ro()[k]; }
+    std::vector<ComponentData> &components() { return host_rw(); }
+    const std::vector<ComponentData> &components() const { return host_ro(); }
+    auto begin() { return host_rw().begin(); }
+    auto end() { return host_rw().end(); }
+    auto last() { return host_rw().end() - 1; }
+    auto begin() const { return host_ro().cbegin(); }
+    auto end() const { return host_ro().cend(); }
+    auto last() const { return host_ro().cend() - 1; }
 
     void add_components(const std::vector<u64> &new_moduli, size_t adding = 1);
     void remove_components(size_t removing = 1);
 
+    /// true when the current words are in HBM only (no host copy has been made since the last engine call wrote them)
+    bool device_resident() const { return dev_ok_ && !host_ok_; }
+
 private:
-    size_t logn_ = 0;
+    friend struct amd::Access;
+    std::vector<ComponentData> &host_rw();               // current host words, writable: the device copy becomes stale
+    const std::vector<ComponentData> &host_ro() const;   // current host words, read-only: both copies stay current
+    size_t logn_ = 0, count_ = 0;
     std::vector<u64> q_;
-    std::vector<ComponentData> limbs_;
+    mutable std::vector<ComponentData> limbs_;       // host copy, count_ limbs when host_ok_
+    mutable std::shared_ptr<amd::DevBlock> blk_;     // device copy: limb k at block + off_ + k * N words
+    mutable size_t off_ = 0;
+    mutable bool host_ok_ = true, dev_ok_ = false;
+    mutable unsigned long long stamp_ = 0;           // changes whenever the words may have changed (key cache, hehub.cpp)
 };
 
 class RnsPolynomial : public RnsIntVec {
@@ -90,7 +125,7 @@ public:
     using RnsIntVec::RnsIntVec;
     enum class RepForm { coeff, value };
     RnsPolynomial() {}
-    RnsPolynomial(RnsIntVec &&v) : RnsIntVec(v) {}
+    RnsPolynomial(RnsIntVec &&v) : RnsIntVec(std::move(v)) {}
     RepForm rep_form = RepForm::coeff;
 };
 using RnsPolyParams = RnsPolynomial::Params;

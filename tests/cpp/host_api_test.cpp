@@ -430,6 +430,115 @@ static void test_ragged_operands() {   // rns.cpp:59-72 (+= on the first self.co
     }
 }
 
+
+// Device residency of the mirror's vectors (hehub.hpp; allocator.h:105-220 is what hehub does on the host): value semantics
+// and host access must behave exactly as if the words had never left the host, while PCIe is crossed only when somebody looks.
+static void test_device_residency() {
+    const size_t N = 4096;
+    const std::vector<u64> q{1099510054913ull, 1099507695617ull, 1099506515969ull};
+    auto fill = [&](RnsPolynomial &p, u64 seed) {
+        for (size_t k = 0; k < p.component_count(); k++)
+            for (size_t i = 0; i < N; i++) p[(int)k][i] = (seed * 1000003ull + k * 7919ull + i * 104729ull) % q[k];
+    };
+    RnsPolynomial a(N, 3, q), b(N, 3, q);
+    fill(a, 1); fill(b, 2);
+    const RnsPolynomial a_host(a);          // host-only copies to compare against
+    REQUIRE(!a.device_resident() && !a_host.device_resident());
+    auto s0 = amd::transfer_stats();
+    ntt_negacyclic_inplace_lazy(a);         // uploads a once, result stays in HBM
+    ntt_negacyclic_inplace_lazy(b);
+    auto s1 = amd::transfer_stats();
+    REQUIRE(a.device_resident() && b.device_resident());
+    REQUIRE(s1.h2d_bytes - s0.h2d_bytes == 2 * 3 * N * 8 && s1.d2h_bytes == s0.d2h_bytes);
+    RnsPolynomial c = a * b;                // operands and result on the device: nothing crosses
+    c += a;
+    RnsPolynomial d(c);                     // deep copy, device to device
+    d *= (u64)3;                            // must not touch c
+    auto s2 = amd::transfer_stats();
+    REQUIRE(s2.h2d_bytes == s1.h2d_bytes && s2.d2h_bytes == s1.d2h_bytes && c.device_resident() && d.device_resident());
+    // the same computation on words that go through the host after every step
+    RnsPolynomial ah(a_host), bh(N, 3, q);
+    fill(bh, 2);
+    ntt_negacyclic_inplace_lazy(ah); (void)ah[0][0];
+    ntt_negacyclic_inplace_lazy(bh); (void)bh[0][0];
+    RnsPolynomial ch = ah * bh; (void)ch[0][0];
+    ch += ah; (void)ch[0][0];
+    RnsPolynomial dh(ch);
+    dh *= (u64)3;
+    REQUIRE((const RnsIntVec &)c == (const RnsIntVec &)ch);      // (fetches c: one download)
+    REQUIRE((const RnsIntVec &)d == (const RnsIntVec &)dh);
+    REQUIRE(!((const RnsIntVec &)c == (const RnsIntVec &)d));
+    auto s3 = amd::transfer_stats();
+    // a const look keeps both copies current: the next engine call uploads nothing
+    const RnsPolynomial &cc = c;
+    const u64 w = cc[1][17];
+    c += a;
+    auto s4 = amd::transfer_stats();
+    REQUIRE(s4.h2d_bytes == s3.h2d_bytes);
+    // a writable look makes the host copy the current one: the next engine call uploads it, and sees the change
+    RnsPolynomial e(c);
+    e[1][17] = (w + 1) % q[1];
+    auto s5 = amd::transfer_stats();
+    e += a;
+    auto s6 = amd::transfer_stats();
+    REQUIRE(s6.h2d_bytes - s5.h2d_bytes == 3 * N * 8);
+    RnsPolynomial f(c);
+    f += a;
+    REQUIRE(!((const RnsIntVec &)e == (const RnsIntVec &)f));   // e differs from f in exactly the word that was written
+    {
+        const RnsPolynomial &ce = e, &cf = f;
+        size_t diff = 0;
+        for (int k = 0; k < 3; k++)
+            for (size_t i = 0; i < N; i++) diff += ce[k][i] != cf[k][i];
+        REQUIRE(diff == 1);
+    }
+    // move leaves the source empty (allocator.h:137-155); the target keeps the device words
+    RnsPolynomial g(std::move(f));
+    REQUIRE(f.component_count() == 0 && f.dimension() == 0 && g.component_count() == 3 && g.device_resident() == false);
+    RnsPolynomial h = a * b;
+    RnsPolynomial h2(std::move(h));
+    REQUIRE(h.component_count() == 0 && h2.device_resident());
+    // remove_components / add_components on words that are in HBM only
+    RnsPolynomial r = a * b;
+    const RnsPolynomial r_full(r);
+    r.remove_components();
+    REQUIRE(r.component_count() == 2 && r.modulus_vec().size() == 2 && r.device_resident());
+    {
+        const RnsPolynomial &cr = r, &cf = r_full;
+        bool same = true;
+        for (int k = 0; k < 2; k++) same = same && cr[k] == cf[k];
+        REQUIRE(same);
+    }
+    RnsPolynomial r2 = a * b;
+    r2.add_components({65537});
+    REQUIRE(r2.component_count() == 4 && r2.modulus_at(3) == 65537 && !r2.device_resident());
+    {
+        const RnsPolynomial &cr = r2, &cf = r_full;
+        bool same = true, zero = true;
+        for (int k = 0; k < 3; k++) same = same && cr[k] == cf[k];
+        for (size_t i = 0; i < N; i++) zero = zero && cr[3][i] == 0;
+        REQUIRE(same && zero);
+    }
+    // assignment over a device-resident object, self-assignment
+    RnsPolynomial t1 = a * b, t2(N, 3, q);
+    t2 = t1;
+    t1 *= (u64)5;
+    REQUIRE((const RnsIntVec &)t2 == (const RnsIntVec &)r_full);
+    t2 = *&t2;
+    REQUIRE((const RnsIntVec &)t2 == (const RnsIntVec &)r_full);
+    // the halves of a ciphertext that an engine call produced feed the next scheme-level call without a copy: a chain of
+    // additions and a product crosses PCIe for the inputs only
+    RlweCt x{a, b}, y{b, a};
+    auto s7 = amd::transfer_stats();
+    RlweCt z = add(x, y);
+    for (int i = 0; i < 5; i++) z = add(z, x);
+    z = sub(z, y);
+    auto s8 = amd::transfer_stats();
+    REQUIRE(s8.h2d_bytes == s7.h2d_bytes && s8.d2h_bytes == s7.d2h_bytes && z[0].device_resident() && z[1].device_resident());
+    RnsPolynomial chk0 = a;   // the same operations one polynomial at a time chk0 += b; for (int i = 0; i < 5; i++) chk0 += a; chk0 -= b;
+    REQUIRE((const RnsIntVec &)z[0] == (const RnsIntVec &)chk0);
+}
+
 int main() {
     test_batched_barrett();
     test_batched_mul_mod();
@@ -440,6 +549,7 @@ int main() {
     test_scheme_level_vs_oracle();
     test_plain_ops_and_decrypt_core();
     test_ragged_operands();
+    test_device_residency();
     std::printf("%s: %d checks, %d failures\n", g_fail ? "FAILED" : "All tests passed", g_checks, g_fail);
     return g_fail ? 1 : 0;
 }

@@ -17,7 +17,8 @@ def build_binary():
     build_host()
     build_oracle(ref=False)
     src = os.path.join(ROOT, "tests", "cpp", "host_api_test.cpp")
-    if not os.path.exists(BIN) or os.path.getmtime(BIN) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(LIBDIR, "libhehub_amd_host.so"))):
+    deps = [src, os.path.join(LIBDIR, "libhehub_amd_host.so"), os.path.join(ROOT, "hehub_amd", "host", "hehub.hpp")]
+    if not os.path.exists(BIN) or os.path.getmtime(BIN) < max(os.path.getmtime(d) for d in deps):
         subprocess.run(["g++", "-O1", "-std=c++17", src, "-o", BIN, f"-I{ROOT}/hehub_amd/host", f"-L{LIBDIR}",
                         "-lhehub_amd_host", "-lhehub_amd", f"-L{ROOT}/oracle", "-lhehub_oracle",
                         f"-Wl,-rpath,{LIBDIR}", f"-Wl,-rpath,{ROOT}/oracle", "-Wl,-rpath,/opt/rocm/lib"], check=True)
