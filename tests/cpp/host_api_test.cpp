@@ -535,7 +535,10 @@ static void test_device_residency() {
     z = sub(z, y);
     auto s8 = amd::transfer_stats();
     REQUIRE(s8.h2d_bytes == s7.h2d_bytes && s8.d2h_bytes == s7.d2h_bytes && z[0].device_resident() && z[1].device_resident());
-    RnsPolynomial chk0 = a;   // the same operations one polynomial at a time chk0 += b; for (int i = 0; i < 5; i++) chk0 += a; chk0 -= b;
+    RnsPolynomial chk0 = a;   // the same operations one polynomial at a time
+    chk0 += b;
+    for (int i = 0; i < 5; i++) chk0 += a;
+    chk0 -= b;
     REQUIRE((const RnsIntVec &)z[0] == (const RnsIntVec &)chk0);
 }
 

@@ -11,7 +11,7 @@ tag, d = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, 
 SPECS = [("ntt15", r"k_ntt_fwdILi15", "k_ntt_fwd_logn15", 256 * 11), ("intt15", r"k_ntt_invILi15", "k_ntt_inv_logn15", 256 * 11),
          ("ntt", r"k_ntt_fwdILi14", "k_ntt_fwd_logn14", 1024 * 4), ("intt", r"k_ntt_invILi14", "k_ntt_inv_logn14", 1024 * 4),
          ("ntt12", r"k_ntt_fwdILi12", "k_ntt_fwd_logn12", 3724 * 11), ("intt12", r"k_ntt_invILi12", "k_ntt_inv_logn12", 3724 * 11),
-         ("ckks", r"k_ntt_fwdILi15", "k_ntt_fwd_logn15_spread", 64 * 100)]
+         ("ckks", r"k_ntt_fwdILi15", "k_ntt_fwd_logn15_spread", 64 * 100), ("bgv", r"k_ntt_fwdILi13", "k_ntt_fwd_logn13_spread", 128 * 36)]
 out_path = os.path.join(ROOT, "profiles", "traffic.json")
 tr = json.load(open(out_path)) if os.path.exists(out_path) else {}
 for name, kre, entry, limbs in SPECS:
@@ -30,7 +30,7 @@ for name, kre, entry, limbs in SPECS:
     logn = int(re.search(r"logn(\d+)", entry).group(1))
     e = {"limbs_per_dispatch": limbs, "fetch_size_kb": fetch, "write_size_kb": write,
          "bytes_per_limb": round((2 * fetch + write) * 1024 / limbs), "algorithmic_bytes_per_limb": 16 << logn,
-         "source": f"round 2 (profiles/{tag}_pmc_{name}_summary.txt)"}
+         "source": f"round {int(tag[1:3])} (profiles/{tag}_pmc_{name}_summary.txt)"}
     valu, gui, waves, insts = g("SQ_ACTIVE_INST_VALU"), g("GRBM_GUI_ACTIVE"), g("SQ_WAVES"), g("SQ_INSTS_VALU")
     if valu and gui:
         e["valu_busy"] = round(4 * valu / 32 / gui, 3)
