@@ -240,6 +240,13 @@ struct Access {
     static bool adjacent(const RnsIntVec &a, const RnsIntVec &b, size_t limbs) {
         return a.dev_ok_ && b.dev_ok_ && a.blk_ == b.blk_ && b.off_ == a.off_ + limbs * a.dimension();
     }
+    // give the device copy up when the host copy is current too (the block returns to the pool once its last user is gone)
+    static void drop_device_copy(const RnsIntVec &v) {
+        if (!v.host_ok_ || !v.dev_ok_) return;
+        v.dev_ok_ = false;
+        v.blk_.reset();
+        v.off_ = 0;
+    }
     // move the (current) device copy to another place that already holds the same words
     static void rehome(const RnsIntVec &v, const BlockRef &blk, size_t off) {
         if (!v.dev_ok_) return;
@@ -647,6 +654,7 @@ private:
 #ifndef HEHUB_AMD_BIND_REFERENCE
                 Src s = Access::in(rgsw[j][h], L + 1);   // (a key polynomial that lives on the device is copied there)
                 check(hp_dev_copy(amd::engine(), (L + 1) * n, s.p, row));
+                Access::drop_device_copy(rgsw[j][h]);     // the assembled block is the key's device form: no second 55 MiB
 #else
                 for (size_t k = 0; k <= L; k++) amd::h2d(row + k * n, rgsw[j][h][(int)k].data(), n);
 #endif

@@ -51,7 +51,8 @@ hp_ctx *engine();
 // current; a non-const host accessor hands out writable words, so it marks the device copy stale.  A program that keeps to
 // hehub's API between encrypt and decrypt (ckks::mult / add / rotate / rescale_inplace ... chains) therefore crosses PCIe
 // once per input ciphertext and once per result it actually reads.  Value semantics are hehub's: a copy is a deep copy
-// (device to device when the device copy is current), a move leaves the source empty (allocator.h:113-155).
+// (device to device when the device copy is current), a move leaves the source empty (allocator.h:113-155).  Like hehub
+// itself (process-global unsynchronised caches and pools) the layer is for ONE thread at a time.
 namespace amd {
 struct DevBlock;   // a pooled device allocation (hehub.cpp)
 struct Access;     // the binding's view of a vector's two copies (hehub.cpp)
