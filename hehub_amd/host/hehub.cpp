@@ -40,6 +40,7 @@ struct TransferStats {
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <initializer_list>
 #include <map>
 #include <memory>
@@ -169,6 +170,40 @@ void d2h(u64 *dst, const u64 *src, size_t words) {
 
 TransferStats transfer_stats() { return g_stats; }
 
+#ifndef HEHUB_AMD_BIND_REFERENCE
+// A polynomial's limbs are separate host vectors but one contiguous device view: they cross PCIe as ONE copy through a
+// page-locked staging buffer (DMA at the link rate; L pageable copies of 8 N bytes each cost 2-3 x as much at N = 32768).
+// The buffer grows to the largest polynomial seen and stays (never freed, like the pool).
+namespace {
+u64 *pinned(size_t words) {
+    static u64 *buf = nullptr;
+    static size_t cap = 0;
+    if (words > cap) {
+        if (buf) (void)hp_host_free(engine(), buf);
+        void *p = nullptr;
+        check(hp_host_alloc(engine(), words * sizeof(u64), &p));
+        buf = (u64 *)p;
+        cap = words;
+    }
+    return buf;
+}
+} // namespace
+void h2d_limbs(u64 *dst, const std::vector<std::vector<u64>> &limbs, size_t count, size_t n) {
+    if (count == 0 || n == 0) return;
+    if (count == 1) return h2d(dst, limbs[0].data(), n);
+    u64 *st = pinned(count * n);
+    for (size_t k = 0; k < count; k++) std::memcpy(st + k * n, limbs[k].data(), n * sizeof(u64));
+    h2d(dst, st, count * n);
+}
+void d2h_limbs(std::vector<std::vector<u64>> &limbs, const u64 *src, size_t count, size_t n) {
+    if (count == 0 || n == 0) return;
+    if (count == 1) return d2h(limbs[0].data(), src, n);
+    u64 *st = pinned(count * n);
+    d2h(st, src, count * n);
+    for (size_t k = 0; k < count; k++) std::memcpy(limbs[k].data(), st + k * n, n * sizeof(u64));
+}
+#endif
+
 // words on the device for one engine call: `p` points at [polys][limbs][N]; `hold` keeps a temporary / cached block alive
 // until the call has been enqueued (the pool hands blocks out in stream order, so that is long enough)
 struct Src {
@@ -201,7 +236,7 @@ struct Access {
                 v.blk_ = alloc_block(v.count_ * n);
                 v.off_ = 0;
             }
-            for (size_t k = 0; k < v.count_; k++) h2d(v.blk_->p + v.off_ + k * n, v.limbs_[k].data(), n);
+            h2d_limbs(v.blk_->p + v.off_, v.limbs_, v.count_, n);
             v.dev_ok_ = true;
         }
         (void)limbs;
@@ -228,8 +263,7 @@ struct Access {
         v.blk_ = d.blk;
         v.off_ = off;
         v.dev_ok_ = true;
-        v.host_ok_ = false;
-        v.limbs_.clear();
+        v.host_ok_ = false;   // (the host vectors, if any, stay allocated: a reference a caller still holds reads stale words, not freed memory)
         v.stamp_ = next_stamp();
     }
     // identity of the words for the key cache: exact (every way to change the words changes the stamp)
@@ -256,11 +290,9 @@ struct Access {
     static void sync_host(const RnsIntVec &v) {
         if (v.host_ok_) return;
         const size_t n = v.dimension();
-        v.limbs_.assign(v.count_, RnsIntVec::ComponentData());
-        for (size_t k = 0; k < v.count_; k++) {
-            v.limbs_[k].resize(n);
-            d2h(v.limbs_[k].data(), v.blk_->p + v.off_ + k * n, n);
-        }
+        v.limbs_.resize(v.count_);   // (vectors that exist are refreshed in place: a reference a caller holds sees the new words)
+        for (size_t k = 0; k < v.count_; k++) v.limbs_[k].resize(n);
+        d2h_limbs(v.limbs_, v.blk_->p + v.off_, v.count_, n);
         v.host_ok_ = true;
     }
     static void host_written(RnsIntVec &v) {

@@ -90,7 +90,8 @@ public:
     const std::vector<u64> &modulus_vec() const { return q_; }
     bool operator==(const RnsIntVec &o) const;
 
-    // limbs (host words: these synchronise with the device copy, see above)
+    // limbs (host words: these synchronise with the device copy, see above).  A reference obtained here shows the vector's
+    // words as of that moment: after the next engine call on the vector, ask again.
     ComponentData &operator[](int k) { return host_rw()[k]; }
     const ComponentData &operator[](int k) const { return host_ro()[k]; }
     std::vector<ComponentData> &components() { return host_rw(); }
