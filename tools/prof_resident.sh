@@ -1,0 +1,12 @@
+#!/bin/bash
+# Device residency behind hehub's object API (GPU box): the same program (examples/resident_chain.cpp) as hehub on the CPU, as
+# hehub's headers over the binding (with / without the opt-in caches) and as the own mirror.   tools/prof_resident.sh > out.txt
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd $R
+for a in "15 10 24" "13 6 24"; do
+  echo "== own mirror (examples/resident_chain $a)"; examples/resident_chain $a
+  [ -x oracle/_ref/ref_chain_cpu ] && { echo "== hehub on the CPU (oracle/_ref/ref_chain_cpu $a)"; oracle/_ref/ref_chain_cpu $a; }
+  [ -x oracle/_ref/ref_chain_amd ] && { echo "== hehub's headers over the binding, HEHUB_AMD_CT_CACHE=64 HEHUB_AMD_KEY_CACHE=4"
+                                        HEHUB_AMD_CT_CACHE=64 HEHUB_AMD_KEY_CACHE=4 HEHUB_AMD_VERBOSE=1 oracle/_ref/ref_chain_amd $a 2>&1
+                                        echo "== hehub's headers over the binding, no caches"; HEHUB_AMD_VERBOSE=1 oracle/_ref/ref_chain_amd $a 2>&1; }
+done

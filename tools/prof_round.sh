@@ -30,9 +30,4 @@ tools/prof_pmc.sh ${TAG}_mul --workload mul --steps 3 --warmup 1
 tools/prof_pmc.sh ${TAG}_ckks --workload ckks --steps 2 --warmup 1 --batch 64
 tools/prof_pmc.sh ${TAG}_bgv --workload bgv --steps 2 --warmup 1 --batch 128
 # device residency behind hehub's object API: the same program as hehub on the CPU, over the binding, and over the own mirror
-( for a in "15 10 24" "13 6 24"; do
-    echo "== own mirror (examples/resident_chain $a)"; examples/resident_chain $a
-    [ -x oracle/_ref/ref_chain_cpu ] && { echo "== hehub on the CPU (oracle/_ref/ref_chain_cpu $a)"; oracle/_ref/ref_chain_cpu $a; }
-    [ -x oracle/_ref/ref_chain_amd ] && { echo "== hehub's headers over the binding, caches on"; HEHUB_AMD_CT_CACHE=64 HEHUB_AMD_KEY_CACHE=4 HEHUB_AMD_VERBOSE=1 oracle/_ref/ref_chain_amd $a 2>&1;
-                                          echo "== hehub's headers over the binding, no caches"; HEHUB_AMD_VERBOSE=1 oracle/_ref/ref_chain_amd $a 2>&1; }
-  done ) > gpurun_out/${TAG}_resident_chain.txt 2>&1
+tools/prof_resident.sh > gpurun_out/${TAG}_resident_chain.txt 2>&1
