@@ -30,6 +30,7 @@
 // (tools/ubench_*.hip), 88 % VALUBusy in the PMC passes at 35-44 % of HBM peak; see DESIGN.md 4.1.
 #include "hp_kernels.h"
 #include "hp_ntt_job.h"
+#include <type_traits>
 
 namespace {
 
@@ -473,9 +474,10 @@ HP_DEV void load_flight(const u64 *src, u32 tid, u64 (&x)[32]) {
     }
 }
 
-// FLAV (fused drop only): 0 = every option decided at run time; 1..4 = the shapes of the CKKS / BGV pipelines with the options
+// FLAV (fused drop only): 0 = every option decided at run time; 1..5 = the shapes of the CKKS / BGV pipelines with the options
 // fixed at compile time (Barrett prologue, no final multiplication; 1: CKKS, no addend; 2: CKKS, addend on both polynomials;
-// 3 / 4: the same with the BGV factors), which takes ~100 uniform branches out of the prologue and the store loop
+// 3 / 4: the same with the BGV factors; 5: CKKS, addend on polynomial 0 only = rotations), which takes ~100 uniform branches
+// out of the prologue and the store loop
 template <int LOGN, bool DROP, int FLAV = 0, bool SMALL = false>
 HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
     using G = Geo<LOGN>;
@@ -514,7 +516,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
         const u32 k = it.limb;
         const u64 bc = lp->barrett_c, bump = q - da->dc.r[k], half = da->dc.half_q_last;
         const u64 tk = da->dc.t[k], tkh = da->dc.t_h[k];
-        const bool bgv = FLAV ? (FLAV >= 3) : da->dc.bgv != 0;
+        const bool bgv = FLAV ? (FLAV == 3 || FLAV == 4) : da->dc.bgv != 0;
         if (!LZ_DROP && (FLAV || !da->raw_input)) {
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
@@ -584,7 +586,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
     // pass A: global stages 1..A, wave-uniform twiddles seq[1 .. 2^A - 1]
     if constexpr (LZ_DROP) {
         const u32 k = it.limb;
-        const DropPre<G::PB == 0, (FLAV >= 3), SMALL> pre{q, lp->barrett_c, q - da->dc.r[k], da->dc.half_q_last, da->dc.t[k], da->dc.t_h[k],
+        const DropPre<G::PB == 0, (FLAV == 3 || FLAV == 4), SMALL> pre{q, lp->barrett_c, q - da->dc.r[k], da->dc.half_q_last, da->dc.t[k], da->dc.t_h[k],
                                                     (u32)nq, (u32)(nq >> 32)};
         fwd_pass<4, G::PB, STab>(x, STab(lp->fwd_ref + 1), 1u, 0u, nq, two_q, pre);
     } else if constexpr (LZ) {
@@ -642,16 +644,21 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
         // address arithmetic on the vector ALU in the epilogue
         const u32 voff = ((((tid >> 6)) << 11) + ((tid & 63u) << 1)) << 3;
         // (wave-uniform; said explicitly so that the run-time flavour branches on an SGPR instead of masking lanes)
-        const bool has_add = FLAV == 2 || FLAV == 4 ||
+        // flavour 5 (rotations / conjugations, ckks/arith.cpp:75-93): the moved c0 is added to polynomial 0 only
+        const bool has_add = FLAV == 2 || FLAV == 4 || (FLAV == 5 && __builtin_amdgcn_readfirstlane((p2 & 1u) == 0 ? 1 : 0) != 0) ||
                              (FLAV == 0 && __builtin_amdgcn_readfirstlane((da->addend && ((da->add_mask >> (p2 & 1)) & 1u)) ? 1 : 0) != 0);
         const StreamBuf xs(da->x + ((size_t)p2 * da->L + k) * G::N);
         const StreamBuf as(has_add ? da->addend + ((size_t)(p2 >> 1) * da->add_ct_stride + (size_t)(p2 & 1) * da->add_poly_stride + k) * G::N
                                    : da->x);
         const StreamBuf d(da->out + ((size_t)p2 * da->out_stride + k) * G::N);
         const u64 inv = da->dc.inv[k], invh = da->dc.inv_h[k], ql = da->dc.qlt[k], qlh = da->dc.qlt_h[k];
-        const bool bgv = FLAV ? (FLAV >= 3) : da->dc.bgv != 0, fin_on = FLAV ? false : da->fin_on != 0;
+        const bool bgv = FLAV ? (FLAV == 3 || FLAV == 4) : da->dc.bgv != 0, fin_on = FLAV ? false : da->fin_on != 0;
         const u64 fin = da->fin[k], finh = da->fin_h[k];
         const u32 n0 = (u32)nq, n1 = (u32)(nq >> 32);
+        // one copy of the row loop per value of has_add where it is only known at run time (flavours 0 and 5): the loop body
+        // then has no branch on it
+        auto rows = [&](auto add_tag) {
+        constexpr bool ADD = decltype(add_tag)::value;
         // The 16 rows are software-pipelined by hand: the operand loads run EPI_DEPTH rows ahead of their use (ring in
         // registers, the twiddle ring is dead by now), otherwise every row waits for its own two loads with
         // vmcnt(0) -- which also drains the stores of the previous row -- and the epilogue costs 32 exposed round trips.
@@ -660,17 +667,17 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
 #pragma unroll
         for (int s = 0; s < EPI_DEPTH; ++s) {
             xr[s] = xs.load(voff, (u32)s << 10);
-            if (has_add) ar[s] = as.load(voff, (u32)s << 10);
+            if (ADD) ar[s] = as.load(voff, (u32)s << 10);
         }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const V2 xv = xr[s % EPI_DEPTH];
             V2 av{0, 0};
-            if (has_add) av = ar[s % EPI_DEPTH];
+            if (ADD) av = ar[s % EPI_DEPTH];
             __builtin_amdgcn_sched_barrier(0);
             if (s + EPI_DEPTH < 16) {
                 xr[s % EPI_DEPTH] = xs.load(voff, (u32)(s + EPI_DEPTH) << 10);
-                if (has_add) ar[s % EPI_DEPTH] = as.load(voff, (u32)(s + EPI_DEPTH) << 10);
+                if (ADD) ar[s % EPI_DEPTH] = as.load(voff, (u32)(s + EPI_DEPTH) << 10);
             }
             __builtin_amdgcn_sched_barrier(0);
             u64 v0 = hp_harvey_lazy_nq(hp_sub_lazy(xv.x, x[2 * s], two_q), inv, invh, n0, n1);
@@ -679,7 +686,7 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
                 v0 = hp_harvey_lazy_nq(v0, ql, qlh, n0, n1);
                 v1 = hp_harvey_lazy_nq(v1, ql, qlh, n0, n1);
             }
-            if (has_add) {
+            if (ADD) {
                 v0 = hp_add_lazy(v0, av.x, two_q);
                 v1 = hp_add_lazy(v1, av.y, two_q);
             }
@@ -689,6 +696,11 @@ HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
             }
             d.store(voff + ((u32)s << 10), V2{v0, v1});
         }
+        };
+        if constexpr (FLAV == 2 || FLAV == 4) rows(std::true_type{});
+        else if constexpr (FLAV == 1 || FLAV == 3) rows(std::false_type{});
+        else if (has_add) rows(std::true_type{});
+        else rows(std::false_type{});
     }
     TRACE_MARK();   // 9: stores issued
     TRACE_FLUSH();
@@ -920,7 +932,8 @@ static hipError_t launch_drop(const HpNttJob &job, const HpDropArgs &da, hipStre
     if (!da.fin_on && !da.raw_input && !da.comb) {
         if (!da.addend || da.add_mask == 0) flav = 1;
         else if (da.add_mask == 3u) flav = 2;
-        if (flav && da.dc.bgv) flav += 2;
+        else if (da.add_mask == 1u && !da.dc.bgv) flav = 5;   // rotation / conjugation: += moved[0]
+        if (flav && flav != 5 && da.dc.bgv) flav += 2;
     }
     const bool small = flav != 0 && da.small_rem != 0;   // (SMALL: the prologue's Barrett quotient is not needed, see HpDropArgs)
 #define HP_DROP_LAUNCH(F, S) k_ntt_fwd_drop<LOGN, F, S><<<job.W, Geo<LOGN>::T, 0, stream>>>(job, da)
@@ -928,6 +941,7 @@ static hipError_t launch_drop(const HpNttJob &job, const HpDropArgs &da, hipStre
     else if (flav == 2) { if (small) HP_DROP_LAUNCH(2, true); else HP_DROP_LAUNCH(2, false); }
     else if (flav == 3) { if (small) HP_DROP_LAUNCH(3, true); else HP_DROP_LAUNCH(3, false); }
     else if (flav == 4) { if (small) HP_DROP_LAUNCH(4, true); else HP_DROP_LAUNCH(4, false); }
+    else if (flav == 5) { if (small) HP_DROP_LAUNCH(5, true); else HP_DROP_LAUNCH(5, false); }
     else HP_DROP_LAUNCH(0, false);
 #undef HP_DROP_LAUNCH
     return hipGetLastError();

@@ -33,7 +33,7 @@ def test_every_tiled_size_is_built(meta):
     for logn in range(11, 16):
         pick(meta, rf"k_ntt_fwd<{logn}>")
         pick(meta, rf"k_ntt_inv<{logn}, ")
-        for flav in range(5):
+        for flav in range(6):
             pick(meta, rf"k_ntt_fwd_drop<{logn}, {flav}[,>]")
 
 
@@ -48,14 +48,14 @@ def test_n32768_kernels(meta):
     for name, r in pick(meta, r"k_ntt_(fwd|inv)<15").items():
         assert r["vgpr_spill_count"] == 0, (name, r)
         assert 140 * 1024 <= r["group_segment_fixed_size"] <= 160 * 1024, (name, r)
-    for name, r in pick(meta, r"k_ntt_fwd_drop<15, [1-4][,>]").items():
+    for name, r in pick(meta, r"k_ntt_fwd_drop<15, [1-5][,>]").items():
         assert r["vgpr_spill_count"] <= 2, (name, r)
 
 
 def test_fused_drop_flavours(meta):
-    """compile-time flavours (the CKKS / BGV pipelines): at most two spilled registers; the run-time flavour 0 (rotations,
+    """compile-time flavours (the CKKS / BGV pipelines, rotations): at most two spilled registers; the run-time flavour 0 (rotations,
     hybrid key switch inputs) is known to spill ~40-48 and is not on the headline path"""
-    for name, r in pick(meta, r"k_ntt_fwd_drop<\d+, [1-4][,>]").items():
+    for name, r in pick(meta, r"k_ntt_fwd_drop<\d+, [1-5][,>]").items():
         assert r["vgpr_spill_count"] <= 2, (name, r)
     for name, r in pick(meta, r"k_ntt_fwd_drop<\d+, 0[,>]").items():
         assert r["vgpr_spill_count"] <= 48, (name, r)
