@@ -257,8 +257,8 @@ template <int LOGN, bool PADDED = false> struct Addr {
     u32 s_base;   // (wave << 11) | ((lane >> 4) << 5) | (((lane & 15) << 1) ^ (lane >> 4))
     HP_DEV void init(u32 tid) {
         const u32 lane = tid & 63u, wave = tid >> 6;
-        if (PAD) {   // PB == 0; byte offsets of i + (i >> 5) with the register-dependent part left to lay_addr()
-            a_base = (tid + (tid >> 5)) << 2;
+        if (PAD) {   // byte offsets of i + (i >> 5) with the register-dependent part left to lay_addr()
+            a_base = ((tid << G::PB) + ((tid << G::PB) >> 5)) << 2;   // (the passenger bits pp < 2^PB <= 32 do not reach bit 5)
             b_base = ((tid >> 5) * 1056u + (tid & 31u)) << 2;
             c_base = (tid * 33u) << 2;
             s_base = (wave * 2112u + 2u * lane + (lane >> 4)) << 2;
@@ -294,7 +294,7 @@ template <int LAY, class AD> HP_DEV u32 lay_base(const AD &ad) {
 template <int LOGN, int LAY, bool PAD> HP_DEV u32 lay_addr(u32 base, int r) {
     using G = Geo<LOGN>;
     if (PAD) {
-        if (LAY == LAY_A) return base + (u32)r * (1056u * 4u);                       // i = (r << 10) | tid
+        if (LAY == LAY_A) return base + ((u32)(r >> G::PB) * 1056u + (u32)(r & ((1 << G::PB) - 1))) * 4u;   // i = (kk << 10) | (tid << PB) | pp
         if (LAY == LAY_B) return base + (u32)r * (33u * 4u);                         // i = (blk << 10) | (r << 5) | j
         if (LAY == LAY_C) return base + (u32)r * 4u;                                 // i = (tid << 5) | r
         return base + ((u32)(r >> 1) * 132u + (u32)(r & 1)) * 4u;                    // i = (wave << 11) | (s << 7) | (lane << 1) | e
@@ -481,7 +481,7 @@ HP_DEV void load_flight(const u64 *src, u32 tid, u64 (&x)[32]) {
 template <int LOGN, bool DROP, int FLAV = 0, bool SMALL = false>
 HP_DEV void ntt_fwd_body(const HpNttJob &job, const HpDropArgs *da) {
     using G = Geo<LOGN>;
-    using AD = Addr<LOGN, LOGN == 15>;
+    using AD = Addr<LOGN, LOGN == 15>;   // (re-checked in round 3 with the general PB form below: N = 16384 / 8192 still spill 28 / 39-46 registers with it)
     __shared__ u32 lds[AD::WORDS];
     __shared__ u64v2 lds_tw[31 * (1 << G::A)];
     TRACE_ENTRY
