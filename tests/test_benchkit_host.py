@@ -38,3 +38,25 @@ def test_usable_cores_takes_the_minimum(tmp_path):
     assert p == 1
     p, facts = host.usable_cores(2, str(tmp_path / "none"))
     assert p == min(2, aff) and facts["cpu_quota_cores"] is None
+
+
+def test_roofline_arithmetic():
+    """benchkit/timing.py: the `roofline` object of the line is bytes / launch time against the 8 TB/s spec peak, with the
+    per-limb PMC traffic of the kernel shape scaled to the launch"""
+    from benchkit.timing import HBM_PEAK_GBS, rate_entry, roofline_entry
+
+    n, limbs, steps = 1 << 15, 25600, 20
+    alg = 16.0 * n * limbs                      # algorithmic bytes per step (one launch per step)
+    r = roofline_entry("ntt", alg, steps, launches=steps, kern_ms=steps * 3.75, elapsed=steps * 8.6e-3, logn=15, spread=True)
+    assert r["bound"] == "hbm" and r["peak"] == HBM_PEAK_GBS == 8000.0 and r["unit"] == "GB/s" and r["launches"] == steps
+    assert abs(r["achieved"] - alg / 3.75e-3 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
+    assert abs(r["share_of_step_time"] - 3.75 / 8.6) < 1e-9 and r["algorithmic_bytes_per_launch"] == alg
+    # the committed PMC measurement of the digit-spread launch: less HBM traffic than algorithmic bytes (sources from L2, packed rows)
+    assert r["traffic"] is not None and 0.3 * alg < r["traffic"] < alg and 0.5 < r["valu_busy"] < 1.0
+    plain = roofline_entry("ntt", alg, steps, steps, steps * 3.9, steps * 3.9e-3, 15, spread=False)
+    assert plain["traffic"] > r["traffic"] and abs(plain["traffic"] / alg - 1.0) < 0.05        # in-place launch: ~1.0 x algorithmic
+    assert roofline_entry("elem", 24.0 * n * 2040, 5, 5, 5 * 0.28, 5 * 0.28e-3, 15, False)["traffic"] is None
+    e = rate_entry(units_per_launch=5120, bytes_per_unit=16.0 * n, steps=10, world=2, dt=10e-3, launches=10, kern_ms=9.0)
+    assert abs(e["per_s"] - 5120 * 2 * 10 / 10e-3) < 1e-6 and abs(e["avg_launch_ms"] - 0.9) < 1e-12
+    assert abs(e["frac_of_hbm_peak"] - 5120 * 16.0 * n / 0.9e-3 / 1e9 / 8000.0) < 1e-12
+    assert "achieved_GBps" not in rate_entry(1, 1.0, 1, 1, 1.0, 0, 0.0)
