@@ -86,7 +86,7 @@ def test_binding_ct_cache_saves_the_uploads():
     up0, down0, d0 = mib({})
     up1, down1, d1 = mib({"HEHUB_AMD_CT_CACHE": "64", "HEHUB_AMD_KEY_CACHE": "4"})
     once = (2 * 2 * L + 2 * (2 * L * (L + 1))) * n * 8 / 1048576.0
-    # hehub's own ckks::add is `auto r(a); r += b` (rns.h:220-233): the copy r is a NEW host object the cache has never seen,
+    # hehub's own ckks::add is `auto r(a); r += b` (rlwe.cpp:83-85 -> rns.h:218-222): the copy r is a NEW host object the cache has never seen,
     # so each accumulation uploads one ciphertext; everything else (operands, keys, products, rotations) goes up once
     copies = (shape[2] - 1) * 2 * L * n * 8 / 1048576.0
     assert d0 == d1 and abs(down0 - down1) < 0.2
