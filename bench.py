@@ -82,6 +82,11 @@ def parse(argv=None):
     ap.add_argument("--limb-transport", default=None, choices=["p2p", "allgather"],
                     help="ckks-limb: exchange of the key-switch digits as batched peer-to-peer sends (default) or as ONE "
                          "all_gather collective (ncclAllGather on RCCL)")
+    ap.add_argument("--no-force-dist", action="store_true",
+                    help="ONE rank: do not create the torch.distributed process group.  By default a one-rank run creates it too "
+                         "(backend nccl = RCCL, world size 1), so that the barrier, the MAX / MIN all-reduces on device tensors and "
+                         "the communicator set-up of an N-GPU job run on a one-GPU box; a failure there is recorded in the line "
+                         "(`rccl.error`) and the run goes on without a group")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU budget of the cpu_baseline sample")
     ap.add_argument("--cpu-procs", type=int, default=-1,
@@ -305,11 +310,24 @@ def main() -> int:
               f"visible (no CPU fallback)", file=sys.stderr)
         return 2
     torch.cuda.set_device(local)
+    rccl_info = {"initialised": False}
     if share_gpu:
         hd.init("gloo")
     else:
-        hd.init("nccl", device=torch.device(f"cuda:{local}"))   # "nccl" is RCCL on ROCm; rendezvous + timing fences only
-    rccl_ranks = dist.get_world_size() if dist.is_initialized() else 1
+        t_init = time.perf_counter()
+        try:   # "nccl" is RCCL on ROCm; rendezvous + timing fences only
+            hd.init("nccl", device=torch.device(f"cuda:{local}"), force=(world == 1 and not args.no_force_dist))
+            if dist.is_initialized():
+                hd.barrier()               # the first collective creates the communicator
+                rccl_info = {"initialised": True, "backend": dist.get_backend(), "init_s": round(time.perf_counter() - t_init, 3),
+                             "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+        except Exception as e:
+            if world > 1:
+                raise
+            rccl_info = {"initialised": False, "error": repr(e)[:300]}
+    # dist_ranks: size of the process group whatever its backend (1 = none); rccl_ranks: ranks of an initialised RCCL communicator
+    dist_ranks = dist.get_world_size() if dist.is_initialized() else 1
+    rccl_ranks = dist_ranks if (dist.is_initialized() and dist.get_backend() == "nccl") else 0
     dev = f"cuda:{local}"
     run = Run(torch=torch, hd=hd, eng=Engine(local), P=P, args=args, world=world, rank=rank, dev=dev,
               cdev="cpu" if share_gpu else dev)
@@ -332,7 +350,8 @@ def main() -> int:
 
     value = wl.units_per_step * world * args.steps / elapsed
     res = {
-        "metric": wl.metric, "value": value, "unit": wl.unit, "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps,
+        "metric": wl.metric, "value": value, "unit": wl.unit, "n_gpus": world, "dist_ranks": dist_ranks, "rccl_ranks": rccl_ranks, "rccl": rccl_info,
+        "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": wl.scaling,
         "vs_baseline": None, "dtype": "u64", "data": "synthetic", "config": wl.cfg,
     }

@@ -53,7 +53,7 @@ def launcher_selftest(args) -> int:
     ranks = dist.get_world_size() if dist.is_initialized() else 1
     if rank == 0:
         print(json.dumps({"metric": "launcher_selftest", "value": world * args.steps / elapsed, "unit": "dummy-step/s",
-                          "n_gpus": world, "rccl_ranks": ranks, "backend": "gloo", "steps": args.steps, "warmup": args.warmup,
+                          "n_gpus": world, "dist_ranks": ranks, "rccl_ranks": 0, "backend": "gloo", "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "none", "data": "none (launcher self-test: no engine work, no claim)",
                           "config": {"workload": "launcher self-test"}}))

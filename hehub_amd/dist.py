@@ -25,12 +25,24 @@ def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def init(backend: str, device=None):
+def init(backend: str, device=None, force: bool = False):
+    """Rendezvous.  A one-rank job needs no process group; `force` (bench.py --force-dist, HP_FORCE_DIST=1) creates it anyway,
+    so that a one-GPU box runs exactly what an N-GPU job runs: the RCCL communicator, device-side barrier / all_reduce."""
     import torch.distributed as dist
 
     world, rank, _ = env_world()
-    if world > 1 and not dist.is_initialized():
+    force = force or bool(os.environ.get("HP_FORCE_DIST"))
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket() as s:
+                    s.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(s.getsockname()[1])
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL peer buffers)
         kwargs = {"device_id": device} if (device is not None and backend == "nccl") else {}
         dist.init_process_group(backend, **kwargs)

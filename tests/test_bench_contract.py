@@ -30,7 +30,8 @@ def test_bench_line_has_the_contract_fields(workload):
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cpu) and cpu["kind"] in ("reference", "port") and cpu["cores"] == 1
     # every output of the timed buffers was compared with the CPU checker (periodic batch: 3 checker evaluations)
     assert r["verified"] is True and r["verify"]["outputs_compared_per_gpu"] == 8 and r["verify"]["checker_evaluations"] == 3
-    assert r["rccl_ranks"] == 1
+    # a one-rank run creates the RCCL communicator too (what an N-GPU job does first), and says so
+    assert r["dist_ranks"] == 1 and r["rccl_ranks"] == 1 and r["rccl"]["initialised"] is True and r["rccl"]["backend"] == "nccl"
 
 
 @pytest.mark.gpu
@@ -110,7 +111,7 @@ def test_two_ranks_end_to_end_on_one_gpu():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, (out.stdout[-2000:], out.stderr[-3000:])
     r = json.loads(lines[0])
-    assert r["n_gpus"] == 2 and r["rccl_ranks"] == 2 and r["backend"] == "gloo" and "TEST MODE" in r["data"]
+    assert r["n_gpus"] == 2 and r["dist_ranks"] == 2 and r["rccl_ranks"] == 0 and r["backend"] == "gloo" and "TEST MODE" in r["data"]
     assert r["verified"] is True and r["verify"]["outputs_compared_per_gpu"] == 256
     assert r["ntt"]["verified"] is True and r["coeffwise"]["mul"]["verified"] is True
     assert all(e["verified"] for e in r["ckks_by_N"].values())
@@ -131,7 +132,7 @@ def test_eight_ranks_end_to_end_on_one_gpu(workload, batch):
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, (out.stdout[-2000:], out.stderr[-3000:])
     r = json.loads(lines[0])
-    assert r["n_gpus"] == 8 and r["rccl_ranks"] == 8 and r["backend"] == "gloo" and "TEST MODE" in r["data"]
+    assert r["n_gpus"] == 8 and r["dist_ranks"] == 8 and r["rccl_ranks"] == 0 and r["backend"] == "gloo" and "TEST MODE" in r["data"]
     assert r["scaling"] == "weak" and r["config"]["batch_per_gpu"] == batch
     assert r["verified"] is True and r["verify"]["outputs_compared_per_gpu"] == batch
     assert r["metric"] == ("ckks_hom_mult_per_s" if workload == "ckks" else "bgv_hom_mult_per_s")

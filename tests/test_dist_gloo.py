@@ -67,7 +67,7 @@ def test_bench_gpus2_launches_its_own_ranks():
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert p.returncode == 0 and len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
     r = json.loads(lines[0])
-    assert r["n_gpus"] == 2 and r["rccl_ranks"] == 2 and r["steps"] == 3 and r["metric"] == "launcher_selftest"
+    assert r["n_gpus"] == 2 and r["dist_ranks"] == 2 and r["rccl_ranks"] == 0 and r["steps"] == 3 and r["metric"] == "launcher_selftest"
     assert r["ms_per_step"] >= 2.0      # the dummy step sleeps 2 ms: the timed region really ran `steps` steps
 
 
