@@ -25,6 +25,27 @@ def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on fd 1 when its first communicator is created; a bench line is ONE JSON line on stdout.
+    While the group is created (and its first collective runs) fd 1 points at fd 2."""
+
+    def __enter__(self):
+        import sys
+
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import sys
+
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def init(backend: str, device=None, force: bool = False):
     """Rendezvous.  A one-rank job needs no process group; `force` (bench.py --force-dist, HP_FORCE_DIST=1) creates it anyway,
     so that a one-GPU box runs exactly what an N-GPU job runs: the RCCL communicator, device-side barrier / all_reduce."""
@@ -45,7 +66,10 @@ def init(backend: str, device=None, force: bool = False):
                     os.environ["MASTER_PORT"] = str(s.getsockname()[1])
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL peer buffers)
         kwargs = {"device_id": device} if (device is not None and backend == "nccl") else {}
-        dist.init_process_group(backend, **kwargs)
+        with _StdoutToStderr():
+            dist.init_process_group(backend, **kwargs)
+            if backend == "nccl":
+                dist.barrier()     # the first collective creates the communicator (and prints RCCL's banner)
     return world, rank
 
 
