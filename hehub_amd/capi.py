@@ -40,6 +40,8 @@ SIGNATURES = {
     "hp_memcpy_h2d": (INT, [P, P, P, szt]),
     "hp_memcpy_d2h": (INT, [P, P, P, szt]),
     "hp_ctx_set_force_generic": (INT, [P, INT]),
+    "hp_ctx_set_parity_level": (INT, [P, INT]),
+    "hp_ctx_get_parity_level": (INT, [P]),
     "hp_ntt_negacyclic_inplace_lazy": (INT, [P, szt, u64, P]),
     "hp_intt_negacyclic_inplace_lazy": (INT, [P, szt, u64, P]),
     "hp_cache_ntt_factors_strict": (INT, [P, szt, P, szt]),

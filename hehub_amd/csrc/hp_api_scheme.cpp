@@ -21,6 +21,7 @@ int ks_coef(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P, size
     const size_t n = (size_t)1 << logn;
     HpNttJob j = batch_job(plan, logn, j1 - j0, P, pt + j0 * n, coef + j0 * n, pt_pstride, L, 1, 1);
     j.limbs = plan->d_limbs + j0;
+    if (ctx->cur_a) j.limbs_a = plan->d_limbs_a + j0;   // strict either way: the same words at both levels
     return run_ntt(ctx, j);
 }
 
@@ -74,6 +75,10 @@ int ks_digits_inner(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t
     if (sj.pair_moduli > L) sj.pair_moduli = (u32)L;
     // digit rows of the output moduli whose words are provably below 2^48 cross HBM as 6 bytes per word (HP_PACK48)
     sj.pack_mask = strict_coef ? spread_pack_mask(ctx, plan, logn, L, P, k0, k1) : 0u;
+    // level A: digit rows as canonical residues (the inner product below is the same integer kernel: its u128 sums then differ
+    // from rgsw.cpp:126-149's by multiples of q_k, its Montgomery outputs are congruent to the reference's and below 2 q_k).
+    // Caller-supplied coefficient rows (limb-range stages) are not known to be below 2^50: level B.
+    if (ctx->cur_a && strict_coef) sj.limbs_a = plan->d_limbs_a;
     if ((rc = run_ntt(ctx, sj))) return rc;
     // (iii) u128 inner product + Montgomery                         rgsw.cpp:121-153
     {
@@ -134,10 +139,15 @@ int drop_coeffs(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2,
     lj.limbs = plan->d_limbs + (L - 1); lj.src = x + (L - 1) * n; lj.dst = clast; lj.logn = (u32)logn; lj.L = 1;
     lj.P = (u32)P2; lj.src_pstride = (u32)L; lj.dst_pstride = 1; lj.src_kstride = 1; lj.W = (u32)P2; lj.mode = HP_NTT_BATCH;
     lj.inverse = 1; lj.strict = 1;
+    if (ctx->cur_a) lj.limbs_a = plan->d_limbs_a + (L - 1);
     if (bgv) {
         const u64 s = hp::inverse_mod_prime(t, q_last) % q_last;
         lj.post_scalar = s;
         lj.post_scalar_h = hp::harvey_quotient(s, q_last);
+        if (lj.limbs_a) {
+            lj.post_scalar = hp::f64_bits((double)s);
+            lj.post_scalar_h = hp::f64_bits((double)s / (double)q_last);
+        }
         lj.use_post_scalar = 1;
     }
     return run_ntt(ctx, lj);
@@ -178,6 +188,21 @@ int drop_apply(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, 
         for (size_t k = k0; k < k1; k++)
             if (plan->consts[L - 1].q > 2 * plan->consts[k].q) da.small_rem = 0;
         ProfScope ps(ctx, "ntt_drop");   // its own family: a different kernel (k_ntt_fwd_drop) with 2-3x the bytes of a plain transform
+        const bool a_shape = add_mask == 0 || !addend || add_mask == 3u || (add_mask == 1u && !dc.bgv);
+        if (ctx->cur_a && clast_strict && a_shape) {
+            // level A: the same launch on the FP64 kernel; every constant as the pair of doubles (v, RN(v / q_k))
+            fj.limbs_a = plan->d_limbs_a + k0;
+            const double ql = (double)dc.q_last;
+            da.dc.q_last = hp::f64_bits(ql);
+            da.dc.half_q_last = hp::f64_bits((double)dc.half_q_last);
+            for (size_t k = 0; k < kc; k++) {
+                const double qk = (double)plan->consts[k0 + k].q;
+                da.dc.inv[k] = hp::f64_bits((double)dc.inv[k]); da.dc.inv_h[k] = hp::f64_bits((double)dc.inv[k] / qk);
+                da.dc.t[k] = hp::f64_bits((double)dc.t[k]); da.dc.t_h[k] = hp::f64_bits((double)dc.t[k] / qk);
+                da.dc.qlt[k] = hp::f64_bits((double)dc.qlt[k]); da.dc.qlt_h[k] = hp::f64_bits((double)dc.qlt[k] / qk);
+            }
+            return chk(ctx, hp_launch_ntt_a_drop(fj, da, ctx->stream), "fused drop NTT (level A)");
+        }
         return chk(ctx, hp_launch_ntt_fast_drop(fj, da, ctx->stream), "fused drop NTT");
     }
     {
@@ -253,6 +278,8 @@ static int dev_ext_prod(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const
     if (rc || (rc = key_level_ok(ctx, L, key_L0))) return rc;
     const Plan *plan;
     if ((rc = get_plan(ctx, logn, moduli_ext, L + 1, true, &plan))) return rc;
+    LevelScope lvl(ctx, plan);   // this call at parity level A if the context asks for it and the chain allows
+    if (lvl.rc) return lvl.rc;
     const size_t n = (size_t)1 << logn;
     if ((rc = ws_reserve(ctx, ext_prod_ws_words(n, L, batch) * 8))) return rc;
     Carver cv(ctx->ws);
@@ -278,6 +305,8 @@ static int dev_drop_locked(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *m
     const Plan *plan;
     int rc = get_plan(ctx, logn, moduli, L, true, &plan);
     if (rc) return rc;
+    LevelScope lvl(ctx, plan);   // this call at parity level A if the context asks for it and the chain allows
+    if (lvl.rc) return lvl.rc;
     const size_t n = (size_t)1 << logn;
     if ((rc = ws_reserve(ctx, drop_ws_words(n, L, 2 * batch) * 8))) return rc;
     Carver cv(ctx->ws);
@@ -334,6 +363,8 @@ static int dev_relin(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const ui
     if (bgv && inner_t == 0) return fail(ctx, HP_EINVAL, "plain modulus must be positive");
     const Plan *plan;
     if ((rc = get_plan(ctx, logn, moduli_ext, L + 1, true, &plan))) return rc;
+    LevelScope lvl(ctx, plan);   // this call at parity level A if the context asks for it and the chain allows
+    if (lvl.rc) return lvl.rc;
     const size_t n = (size_t)1 << logn;
     if ((rc = ws_reserve(ctx, relin_ws_words(n, L, batch) * 8))) return rc;
     Carver cv(ctx->ws);
@@ -364,6 +395,8 @@ static int dev_ckks_automorphism(hp_ctx *ctx, size_t logn, size_t L, size_t key_
     if (!conj && step >= ((size_t)1 << 17)) return fail(ctx, HP_EINVAL, "rotation step out of range");
     const Plan *plan;
     if ((rc = get_plan(ctx, logn, moduli_ext, L + 1, true, &plan))) return rc;
+    LevelScope lvl(ctx, plan);   // this call at parity level A if the context asks for it and the chain allows
+    if (lvl.rc) return lvl.rc;
     const size_t n = (size_t)1 << logn;
     const size_t words = padded(batch * 2 * L * n) / 8 + padded(batch * 2 * (L + 1) * n) / 8 + ext_prod_ws_words(n, L, batch) +
                          drop_ws_words(n, L + 1, 2 * batch);
@@ -399,6 +432,8 @@ static int dev_mult(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uin
     if (bgv && t == 0) return fail(ctx, HP_EINVAL, "plain modulus must be positive");
     const Plan *plan;
     if ((rc = get_plan(ctx, logn, moduli_ext, L + 1, true, &plan))) return rc;
+    LevelScope lvl(ctx, plan);   // this call at parity level A if the context asks for it and the chain allows
+    if (lvl.rc) return lvl.rc;
     const size_t n = (size_t)1 << logn;
     // Sub-batches alternate between two internal streams so that the HBM-bound kernels of one sub-batch (tensor,
     // key-switch inner product) can overlap the multiply-bound transforms of the other.  HP_MULT_CHUNK /

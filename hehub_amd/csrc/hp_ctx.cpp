@@ -104,12 +104,64 @@ static int get_plan_impl(hp_ctx *ctx, size_t logn, const uint64_t *moduli, size_
     }
     int rc = upload(ctx, limbs.data(), limbs.size() * sizeof(HpLimb), (void **)&plan.d_limbs);
     if (rc) return rc;
+    plan.logn = with_ntt ? logn : 0;
     auto ins = ctx->plans.emplace(key, std::move(plan));
     *out = &ins.first->second;
     return HP_OK;
 }
 int get_plan(hp_ctx *ctx, size_t logn, const uint64_t *moduli, size_t count, bool with_ntt, const Plan **out) {
     return contained(ctx, [&] { return get_plan_impl(ctx, logn, moduli, count, with_ntt, out); });
+}
+
+// Parity level A: per-limb records + tables of doubles for a plan whose moduli are all below 2^50 and whose ring degree has
+// tiled kernels.  Built from the same host tables as level B (pairs_to_f64), cached per (q, logn).
+static int ensure_plan_a_impl(hp_ctx *ctx, const Plan *plan, bool *ok) {
+    *ok = false;
+    if (plan->a_state == 1) { *ok = true; return HP_OK; }
+    if (plan->a_state < 0) return HP_OK;
+    const size_t logn = plan->logn;
+    bool can = logn >= 11 && logn <= 15 && !ctx->force_generic;
+    for (const hp::ModConsts &c : plan->consts)
+        if (c.q >= ((u64)1 << 50) || c.q < 3) can = false;
+    if (!can) { plan->a_state = -1; return HP_OK; }
+    std::vector<HpLimbA> limbs(plan->consts.size());
+    for (size_t k = 0; k < limbs.size(); k++) {
+        const u64 q = plan->consts[k].q;
+        auto key = std::make_pair(q, logn);
+        auto it = ctx->tables_a.find(key);
+        if (it == ctx->tables_a.end()) {
+            std::vector<hp::Pair> fwd, inv, fk, ik, t;
+            hp::build_fwd_ref(q, logn, fwd);
+            hp::build_inv_ref(q, logn, inv);
+            hp::build_fwd_fast(fwd, logn, fk);
+            hp::build_inv_fast(inv, logn, ik);
+            DevTables d;
+            int rc;
+            hp::pairs_to_f64(fwd, q, t);
+            if ((rc = upload(ctx, t.data(), t.size() * sizeof(hp::Pair), (void **)&d.fwd_ref))) return rc;
+            hp::pairs_to_f64(inv, q, t);
+            if ((rc = upload(ctx, t.data(), t.size() * sizeof(hp::Pair), (void **)&d.inv_ref))) return rc;
+            hp::pairs_to_f64(fk, q, t);
+            if ((rc = upload(ctx, t.data(), t.size() * sizeof(hp::Pair), (void **)&d.fwd_k))) return rc;
+            hp::pairs_to_f64(ik, q, t);
+            if ((rc = upload(ctx, t.data(), t.size() * sizeof(hp::Pair), (void **)&d.inv_k))) return rc;
+            it = ctx->tables_a.emplace(key, d).first;
+        }
+        HpLimbA &l = limbs[k];
+        memset(&l, 0, sizeof(l));
+        l.q = (double)q; l.qinv = 1.0 / (double)q; l.qi = q; l.wide = q >= ((u64)1 << 44) ? 1u : 0u;
+        l.fwd_ref = it->second.fwd_ref; l.inv_ref = it->second.inv_ref; l.fwd_k = it->second.fwd_k; l.inv_k = it->second.inv_k;
+    }
+    HpLimbA *d = nullptr;
+    int rc = upload(ctx, limbs.data(), limbs.size() * sizeof(HpLimbA), (void **)&d);
+    if (rc) return rc;
+    plan->d_limbs_a = d;
+    plan->a_state = 1;
+    *ok = true;
+    return HP_OK;
+}
+int ensure_plan_a(hp_ctx *ctx, const Plan *plan, bool *ok) {
+    return contained(ctx, [&] { return ensure_plan_a_impl(ctx, plan, ok); });
 }
 
 // A bounded cache of small device objects that is full gets emptied: kernels that may still read the entries are
@@ -229,7 +281,8 @@ int run_ntt(hp_ctx *ctx, const HpNttJob &job) {
     hipError_t e;
     {
         ProfScope ps(ctx, job.inverse ? "intt" : "ntt");
-        if (tiled_ok(ctx, job.logn)) e = hp_launch_ntt_fast(job, ctx->stream);
+        if (job.limbs_a) e = hp_launch_ntt_a(job, ctx->stream);
+        else if (tiled_ok(ctx, job.logn)) e = hp_launch_ntt_fast(job, ctx->stream);
         else e = hp_launch_ntt_generic(job, ctx->stream);
     }
     if (e != hipSuccess) return fail(ctx, HP_EHIP, std::string("transform launch: ") + hipGetErrorString(e));
@@ -294,9 +347,18 @@ int hp_ctx_create(int device, hp_ctx **out) {
     if (const char *e = getenv("HP_SPREAD_GROUP")) c->spread_group = (int)clampi(atol(e), 0, HP_MAX_LIMBS);   // measured (tools/ab_groups.sh): 4..8 beat 2 by 2-3 % on the launch since the rows are packed; 11 (all moduli) loses it again
     if (const char *e = getenv("HP_MULT_STREAMS")) c->mult_streams = atoi(e) >= 2 ? 2 : 1;
     if (const char *e = getenv("HP_MULT_CHUNK")) c->mult_chunk = (size_t)clampi(atol(e), 0, 1l << 30);
+    if (const char *e = getenv("HP_PARITY_LEVEL")) c->parity_level = (e[0] == 'A' || e[0] == 'a' || e[0] == '1') ? 1 : 0;
     *out = c;
     return HP_OK;
 }
+
+int hp_ctx_set_parity_level(hp_ctx *ctx, int level) {
+    HP_ENTER(ctx);
+    if (level != HP_PARITY_B && level != HP_PARITY_A) return fail(ctx, HP_EINVAL, "parity level: HP_PARITY_B (0) or HP_PARITY_A (1)");
+    ctx->parity_level = level;
+    return HP_OK;
+}
+int hp_ctx_get_parity_level(hp_ctx *ctx) { return ctx ? ctx->parity_level : HP_EINVAL; }
 
 void hp_ctx_destroy(hp_ctx *ctx) {
     if (!ctx) return;
@@ -309,7 +371,11 @@ void hp_ctx_destroy(hp_ctx *ctx) {
         (void)hipFree(kv.second.fwd_ref); (void)hipFree(kv.second.inv_ref);
         (void)hipFree(kv.second.fwd_k); (void)hipFree(kv.second.inv_k);
     }
-    for (auto &kv : ctx->plans) (void)hipFree(kv.second.d_limbs);
+    for (auto &kv : ctx->tables_a) {
+        (void)hipFree(kv.second.fwd_ref); (void)hipFree(kv.second.inv_ref);
+        (void)hipFree(kv.second.fwd_k); (void)hipFree(kv.second.inv_k);
+    }
+    for (auto &kv : ctx->plans) { (void)hipFree(kv.second.d_limbs); if (kv.second.d_limbs_a) (void)hipFree(kv.second.d_limbs_a); }
     for (auto &kv : ctx->perms) (void)hipFree(kv.second);
     for (auto &kv : ctx->crt) (void)hipFree(kv.second);
     for (auto &kv : ctx->hks) (void)hipFree(kv.second);

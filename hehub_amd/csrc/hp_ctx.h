@@ -31,6 +31,11 @@ struct DevTables {
 struct Plan {
     HpLimb *d_limbs = nullptr;
     std::vector<hp::ModConsts> consts;
+    // parity level A: the FP64 per-limb records, built on first use (ensure_plan_a); a_state 0 = not tried, 1 = ready,
+    // -1 = not available for this chain (a modulus >= 2^50, or a ring degree without tiled kernels)
+    mutable HpLimbA *d_limbs_a = nullptr;
+    mutable int a_state = 0;
+    size_t logn = 0;
 };
 
 struct ProfEvent {
@@ -50,7 +55,12 @@ struct hp_ctx {
     std::mutex mu;
     std::string err;
     bool force_generic = false;
+    // parity level of the scheme-level pipelines (hp_ctx_set_parity_level; HP_PARITY_LEVEL=A): 0 = B, raw words identical to
+    // hehub's (default); 1 = A, canonical residues through the FP64 transforms of hp_ntt_a.hip where the chain allows
+    int parity_level = 0;
+    bool cur_a = false;           // set for the duration of one entry point (under the context lock): this call runs at level A
     std::map<std::pair<u64, size_t>, hpi::DevTables> tables;          // (q, logn)
+    std::map<std::pair<u64, size_t>, hpi::DevTables> tables_a;        // (q, logn): the same tables as (w, w / q) doubles (parity level A)
     std::map<std::pair<size_t, std::vector<u64>>, hpi::Plan> plans;   // (logn, moduli); logn == 0: no transforms needed
     std::map<std::pair<size_t, size_t>, u32 *> perms;                 // (logn, step mod N/2) -> gather map
     std::map<std::pair<std::vector<u64>, u64>, HpCrtConsts *> crt;    // (old moduli, new modulus) -> CRT-branch constants
@@ -147,6 +157,22 @@ int upload(hp_ctx *ctx, const void *host, size_t bytes, void **dptr);
 int get_tables(hp_ctx *ctx, u64 q, size_t logn, DevTables &out);
 // device array of per-limb constants for a modulus chain; with_ntt == false skips the twiddles
 int get_plan(hp_ctx *ctx, size_t logn, const uint64_t *moduli, size_t count, bool with_ntt, const Plan **out);
+// level-A records of a plan (built once); *ok = false when the chain / ring degree has no level-A kernels (the call then runs at B)
+int ensure_plan_a(hp_ctx *ctx, const Plan *plan, bool *ok);
+// first thing a scheme-level entry point does after get_plan: decides whether THIS call runs at level A
+struct LevelScope {
+    hp_ctx *ctx;
+    int rc = 0;
+    LevelScope(hp_ctx *c, const Plan *plan) : ctx(c) {
+        c->cur_a = false;
+        if (c->parity_level == 1 && plan) {
+            bool ok = false;
+            rc = ensure_plan_a(c, plan, &ok);
+            c->cur_a = (rc == 0) && ok;
+        }
+    }
+    ~LevelScope() { ctx->cur_a = false; }
+};
 // gather map of cycle(poly, step) (permutation.cpp:39-53): out[to] = in[perm[to]]
 int get_cycle_perm(hp_ctx *ctx, size_t logn, size_t step, const u32 **out);
 int get_crt_consts(hp_ctx *ctx, const uint64_t *moduli, size_t L, u64 t, const HpCrtConsts **out);

@@ -35,6 +35,17 @@ struct HpLimb {
     const u64x2 *inv_k;     // inverse pairs in fast-kernel order
 };
 
+// Parity level A (hp_ntt_a.hip): the same per-limb record for the FP64 residue transforms.  Tables have the layouts of
+// HpLimb's, every pair (w, w') replaced by the IEEE doubles (w, RN(w / q)) (bit patterns in the u64x2).  q < 2^50.
+struct HpLimbA {
+    double q;
+    double qinv;    // RN(1 / q)
+    u64 qi;         // q as an integer
+    u32 wide;       // q >= 2^44: coefficients are brought back to |x| <= q/2 between the passes (see hp_ntt_a.hip)
+    u32 pad_;
+    const u64x2 *fwd_ref, *inv_ref, *fwd_k, *inv_k;
+};
+
 #define HP_DEV __device__ __forceinline__
 
 HP_DEV u64 hp_mulhi(u64 a, u64 b) { return __umul64hi(a, b); }

@@ -44,11 +44,17 @@ struct HpNttJob {
     // multiplication BEFORE the strict reduction (mod_switch.cpp:49-50); s_h == 0 and s == 0 -> off
     u64 post_scalar, post_scalar_h;
     int use_post_scalar;
+    // parity level A (opt-in, hp_ctx_set_parity_level): non-NULL = the launch goes to the FP64 residue kernels of hp_ntt_a.hip,
+    // which return CANONICAL residues (equal to reduce_strict of the level-B words); post_scalar / post_scalar_h then hold the
+    // bit patterns of the doubles (s, RN(s / q))
+    const HpLimbA *limbs_a;
 };
 
 hipError_t hp_launch_ntt_generic(const HpNttJob &job, hipStream_t stream);
 // fast path: logn in [11,15]; returns hipErrorNotSupported otherwise
 hipError_t hp_launch_ntt_fast(const HpNttJob &job, hipStream_t stream);
+// the same tiling with FP64 residue butterflies (job.limbs_a; HP_NTT_BATCH and HP_NTT_SPREAD; the inverse is always strict)
+hipError_t hp_launch_ntt_a(const HpNttJob &job, hipStream_t stream);
 
 // ---- coefficient-wise kernels on [rows][n], limb of a row = row % L ---------------
 enum HpBinOp : int { HP_ADD = 0, HP_SUB = 1, HP_MUL = 2 };
@@ -127,6 +133,9 @@ struct HpDropArgs {
 };
 // job: HP_NTT_BATCH over L-1 limbs and P2 polynomials with src = clast [P2][n] (src_pstride 1, src_kstride 0)
 hipError_t hp_launch_ntt_fast_drop(const HpNttJob &job, const HpDropArgs &da, hipStream_t stream);
+// level A: dc.q_last / half_q_last and the pairs (inv, inv_h), (t, t_h), (qlt, qlt_h) hold bit patterns of doubles (v, RN(v / q_k));
+// r, small_rem, raw_input, fin, comb are not used; output rows are canonical residues
+hipError_t hp_launch_ntt_a_drop(const HpNttJob &job, const HpDropArgs &da, hipStream_t stream);
 
 // clast [P2][n] (strict coefficients of the last limb) -> rem [P2][L-1][n]
 hipError_t hp_launch_drop_rem(const HpLimb *limbs, const HpDropConsts &dc, u32 Lm1, u32 n, u32 P2,

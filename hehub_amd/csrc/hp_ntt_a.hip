@@ -1,0 +1,470 @@
+// hp_ntt_a.hip -- parity level A (SURVEY.md section 8 "Parity levels"; opt-in through hp_ctx_set_parity_level): the tiled
+// negacyclic NTT / INTT of hp_ntt_fast.hip with the butterfly's modular product computed in error-free FP64 arithmetic instead of
+// the exact Harvey quotient.  Every output word is the CANONICAL residue in [0, q): congruent to the reference's lazy word
+// (ntt.cpp:155-175, :178-223, rescaling.cpp:46-75, mod_switch.cpp:45-77) and equal to reduce_strict of it -- not the same
+// representative, which is why this is level A and off by default.
+//
+// Why: the level-B butterfly is 16 integer VALU instructions (10 of them 32-bit multiplies) = 62 cycles per wave-butterfly and the
+// transforms are bound by exactly that.  For q < 2^50 the residue of x w needs 8 FP64 instructions
+// (tools/ubench_bfly_f64.hip: 31.5 cycles, exact on 2 x 10^9 random and edge cases):
+//     h = RN(x w)            l = fma(x, w, -h)             x w = h + l exactly (error-free product)
+//     k = rint(x u)          u = RN(w / q), precomputed    |k - x w / q| <= 1/2 + |x| 2^-52
+//     t = fma(-k, q, h) + l                                 = x w - k q exactly, |t| <= q (1/2 + |x| 2^-52)
+//     hi' = lo - t           lo' = lo + t
+// All values are integers held exactly in doubles (signed, |x| < 2^53).  Growth: a stage adds at most |t| to a coefficient.
+//   narrow limbs (q < 2^44): inputs below 2^50 (strict residues of any modulus of the chain, or centred last-limb coefficients)
+//     stay below 2^51 through 15 stages -- no reduction until the end;
+//   wide limbs (2^44 <= q < 2^50): x <- x - rint(x / q) q (3 instructions, |x| <= q/2 afterwards) after every pass: a pass of five
+//     stages takes |x| <= q/2 to < 5.7 q < 2^53 (recurrence B' = B (1 + q 2^-52) + q/2), and 2^50 to < 7.2 * 2^50 in the first pass.
+// The 64-bit patterns of the doubles travel through the same registers, LDS exchanges and table layouts as the integer kernels
+// (hp_ntt_tile.h); tables hold (w, u) as doubles (hp_tables.cpp: pairs_to_f64).  HBM rows stay u64 words: converted on load
+// (words must be below 2^52: every lazy word hehub or this engine produces is below 2 q <= 2^51) and on store.
+#include "hp_ntt_tile.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+typedef const HpLimbA __attribute__((address_space(4))) * cptr_limba;
+
+HP_DEV double D(u64 v) { return __builtin_bit_cast(double, v); }
+HP_DEV u64 U(double d) { return __builtin_bit_cast(u64, d); }
+constexpr double TWO52 = 4503599627370496.0;
+HP_DEV double from_word(u64 w) { return D(w | 0x4330000000000000ull) - TWO52; }        // w < 2^52
+HP_DEV u64 to_word(double v) { return U(v + TWO52) & 0x000FFFFFFFFFFFFFull; }           // integral 0 <= v < 2^52
+
+// x w - rint(x w / q) q, exactly (|x| < 2^52, 0 <= w < q < 2^50, u = RN(w / q))
+HP_DEV double a_modmul(double x, double w, double u, double q) {
+    const double h = x * w;
+    const double l = __builtin_fma(x, w, -h);
+    const double k = __builtin_rint(x * u);
+    const double r = __builtin_fma(-k, q, h);
+    return r + l;
+}
+HP_DEV double a_reduce(double x, double qinv, double q) { return __builtin_fma(-__builtin_rint(x * qinv), q, x); }   // |result| <= q/2 (+ 1 ulp of the quotient)
+HP_DEV double a_nonneg(double v, double q) { return v < 0.0 ? v + q : v; }                                          // (-q, q) -> [0, q)
+HP_DEV u64 a_canon(double x, double qinv, double q) { return to_word(a_nonneg(a_reduce(x, qinv, q), q)); }
+
+HP_DEV void a_bfly(u64 &lo, u64 &hi, double w, double u, double q) {
+    const double xl = D(lo), t = a_modmul(D(hi), w, u, q);
+    hi = U(xl - t);
+    lo = U(xl + t);
+}
+HP_DEV void a_reduce_all(u64 (&x)[32], double qinv, double q) {
+#pragma unroll
+    for (int r = 0; r < 32; ++r) x[r] = U(a_reduce(D(x[r]), qinv, q));
+}
+
+// ---- load-side work of the forward kernels, done per 16-byte load right before the first butterfly that touches it ----------
+template <bool SWAP> struct ConvPre {
+    static constexpr bool on = true;
+    HP_DEV void operator()(u64 (&x)[32], int r) const {
+        if (SWAP) lazy_swap(x, r);
+        x[r] = U(from_word(x[r]));
+        x[r + 1] = U(from_word(x[r + 1]));
+    }
+};
+// fused drop-last-prime: c (strict modulo q_last) -> the centred representative c - [c >= q_last / 2] q_last, which is congruent
+// modulo q_k to the remainder rescaling.cpp:54-69 builds (Barrett_k(c) + [c >= q_last/2] (q_k - q_last mod q_k)); BGV: times t
+template <bool SWAP, bool BGV> struct DropPreA {
+    static constexpr bool on = true;
+    double q, q_last, half, tw, tu;
+    HP_DEV void operator()(u64 (&x)[32], int r) const {
+        if (SWAP) lazy_swap(x, r);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            double c = from_word(x[r + e]);
+            c = (c >= half) ? c - q_last : c;
+            if (BGV) c = a_modmul(c, tw, tu, q);
+            x[r + e] = U(c);
+        }
+    }
+};
+
+// ---- passes: the slot schedule of hp_ntt_fast.hip (pass_slots) with the FP64 butterfly ---------------------------------------
+template <bool FWD, int S, int S0, int S1, int DEP, class Tab, class Pre = NoPre>
+HP_DEV void pass_slots_a(u64 (&x)[32], u64x2 (&ring)[DEP], const Tab &tbl, u32 ncls, u32 cls, double q, const Pre &pre = Pre()) {
+    if constexpr (S < S1) {
+        constexpr int cnt = 1 << (4 - ilog2c(S + 1));
+        constexpr int bit = slot_bit<FWD>(S);
+        const u64x2 tw = ring[(S - S0) % DEP];
+        if constexpr (S + DEP < S1) ring[(S - S0) % DEP] = tbl.at((u32)(S + DEP), ncls, cls);
+        if constexpr (cnt >= 2) {
+#pragma unroll
+            for (int o = 0; o < cnt; o += 2) {
+                const int ra = slot_reg<FWD>(S, o), rb = slot_reg<FWD>(S, o + 1);
+                if constexpr (Pre::on && S == 0) {
+                    static_assert(!Pre::on || (FWD && S0 == 0), "load-side work: first slot of a forward pass");
+                    pre(x, ra);
+                    pre(x, ra | bit);
+                }
+                a_bfly(x[ra], x[ra | bit], D(tw.x), D(tw.y), q);
+                a_bfly(x[rb], x[rb | bit], D(tw.x), D(tw.y), q);
+                if (o & 2) __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (cnt == 2) { if constexpr (S & 1) __builtin_amdgcn_sched_barrier(0); }
+            pass_slots_a<FWD, S + 1, S0, S1, DEP, Tab, Pre>(x, ring, tbl, ncls, cls, q, pre);
+        } else {
+            static_assert(S + 1 < S1, "single-butterfly slots come in pairs");
+            const u64x2 tw2 = ring[(S + 1 - S0) % DEP];
+            if constexpr (S + 1 + DEP < S1) ring[(S + 1 - S0) % DEP] = tbl.at((u32)(S + 1 + DEP), ncls, cls);
+            constexpr int ra = slot_reg<FWD>(S, 0), rb = slot_reg<FWD>(S + 1, 0);
+            a_bfly(x[ra], x[ra | bit], D(tw.x), D(tw.y), q);
+            a_bfly(x[rb], x[rb | bit], D(tw2.x), D(tw2.y), q);
+            if constexpr (((S - 15) & 2) != 0) __builtin_amdgcn_sched_barrier(0);
+            pass_slots_a<FWD, S + 2, S0, S1, DEP>(x, ring, tbl, ncls, cls, q);
+        }
+    }
+}
+template <bool FWD, int S0, int S1, int DEP, class Tab, class Pre = NoPre>
+HP_DEV void run_pass_a(u64 (&x)[32], const Tab tbl, u32 ncls, u32 cls, double q, const Pre &pre = Pre()) {
+    u64x2 ring[DEP];
+#pragma unroll
+    for (int s = S0; s < S0 + DEP; ++s)
+        if (s < S1) ring[(s - S0) % DEP] = tbl.at((u32)s, ncls, cls);
+    pass_slots_a<FWD, S0, S0, S1, DEP, Tab, Pre>(x, ring, tbl, ncls, cls, q, pre);
+}
+template <int BLO, class Tab, class Pre = NoPre>
+HP_DEV void fwd_pass_a(u64 (&x)[32], const Tab tbl, u32 ncls, u32 cls, double q, const Pre &pre = Pre()) {
+    run_pass_a<true, 0, (1 << (5 - BLO)) - 1, Tab::depth, Tab, Pre>(x, tbl, ncls, cls, q, pre);
+}
+template <int BLO, class Tab> HP_DEV void inv_pass_a(u64 (&x)[32], const Tab tbl, u32 ncls, u32 cls, double q) {
+    run_pass_a<false, (1 << BLO) - 1, 31, Tab::depth>(x, tbl, ncls, cls, q);
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------------------------
+// FLAV (fused drop): 1 CKKS, no addend; 2 CKKS, addend on both polynomials (relinearize's +=, ckks/arith.cpp:70-71); 3 / 4 the
+// same with the BGV factors (mod_switch.cpp:70,76); 5 CKKS, addend on polynomial 0 only (rotations, ckks/arith.cpp:75-93)
+template <int LOGN, bool DROP, int FLAV>
+HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
+    using G = Geo<LOGN>;
+    using AD = Addr<LOGN, LOGN == 15>;
+    __shared__ u32 lds[AD::WORDS];
+    __shared__ u64v2 lds_tw[31 * (1 << G::A)];
+    const u32 w = hp_xcd_remap(blockIdx.x, job.W);
+    HpItem it;
+    if (!hp_decode_item(job, w, it)) return;
+    const cptr_limba lp = (cptr_limba)(job.limbs_a + __builtin_amdgcn_readfirstlane(it.limb));
+    const double q = lp->q, qinv = lp->qinv;
+    const bool wide = lp->wide != 0;
+    const u32 tid = threadIdx.x;
+    AD ad;
+    ad.init(tid);
+    u64v2 stg = {0, 0};
+    if (tid < 31u * (1u << G::A)) stg = ((gptr_u64x2)lp->fwd_k)[tid];
+    u64 x[32];
+    constexpr bool SW = G::PB == 0;   // N = 32768: registers left as loaded, sorted into columns by the lane-pair swap of the first stage
+    load_flight<LOGN, SW>(it.src, tid, x);
+    if (tid < 31u * (1u << G::A)) lds_tw[tid] = stg;
+    constexpr bool BGV = FLAV == 3 || FLAV == 4;
+    // pass A: global stages 1..A, wave-uniform twiddles seq[1 .. 2^A - 1]
+    if constexpr (DROP) {
+        const u32 k = it.limb;
+        const DropPreA<SW, BGV> pre{q, D(da->dc.q_last), D(da->dc.half_q_last), D(da->dc.t[k]), D(da->dc.t_h[k])};
+        fwd_pass_a<G::PB, STab>(x, STab(lp->fwd_ref + 1), 1u, 0u, q, pre);
+    } else {
+        fwd_pass_a<G::PB, STab>(x, STab(lp->fwd_ref + 1), 1u, 0u, q, ConvPre<SW>());
+    }
+    if (wide) a_reduce_all(x, qinv, q);
+    exchange<LOGN, LAY_A, LAY_B, true>(x, lds, ad);
+    // pass B: global stages A+1..A+5, twiddles depend on the 1024-block
+    fwd_pass_a<0>(x, LTab(lds_tw), 1u << G::A, tid >> 5, q);
+    if (wide) a_reduce_all(x, qinv, q);
+    exchange<LOGN, LAY_B, LAY_C, false>(x, lds, ad);
+    // pass C: global stages A+6..logN, per-thread twiddles
+    fwd_pass_a<0>(x, BTab(lp->fwd_k + 31 * (1 << G::A)), (u32)G::T, tid, q);
+    if (!DROP) {
+        // canonical residues, as words
+#pragma unroll
+        for (int r = 0; r < 32; ++r) x[r] = a_canon(D(x[r]), qinv, q);
+    } else if (wide) {
+        a_reduce_all(x, qinv, q);
+    }
+    exchange<LOGN, LAY_C, LAY_S, false>(x, lds, ad);
+    if (!DROP) {
+        const size_t off = (((size_t)(tid >> 6)) << 11) + ((tid & 63u) << 1);
+        if (job.mode == HP_NTT_SPREAD && ((job.pack_mask >> it.limb) & 1u)) {
+            // HP_PACK48 (hp_device.h): canonical residues of a modulus below 2^47 always fit
+            typedef u32 __attribute__((ext_vector_type(2))) v2u;
+            u32 *lo = reinterpret_cast<u32 *>(it.dst) + off;
+            u32 *hi = reinterpret_cast<u32 *>(it.dst) + G::N + (off >> 1);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                __builtin_nontemporal_store(v2u{lo32(x[2 * s]), lo32(x[2 * s + 1])}, reinterpret_cast<v2u *>(lo + ((size_t)s << 7)));
+                __builtin_nontemporal_store((hi32(x[2 * s]) & 0xffffu) | (hi32(x[2 * s + 1]) << 16), hi + ((size_t)s << 6));
+            }
+        } else {
+            u64 *d = it.dst + off;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                V2 v{x[2 * s], x[2 * s + 1]};
+                st_stream(d + ((size_t)s << 7), v);
+            }
+        }
+    } else {
+        // rescaling.cpp:72-74 / mod_switch.cpp:72-76 (+ the += of relinearize): ((x - NTT(rem)) * inv) [* (q_last mod t)] [+ addend]
+        // as a residue: x and the addend are lazy words of the caller's rows (below 2^51), the result is canonical
+        const u32 k = it.limb, p2 = it.poly;
+        const u32 voff = ((((tid >> 6)) << 11) + ((tid & 63u) << 1)) << 3;
+        const bool has_add = FLAV == 2 || FLAV == 4 || (FLAV == 5 && __builtin_amdgcn_readfirstlane((p2 & 1u) == 0 ? 1 : 0) != 0);
+        const StreamBuf xs(da->x + ((size_t)p2 * da->L + k) * G::N);
+        const StreamBuf as(has_add ? da->addend + ((size_t)(p2 >> 1) * da->add_ct_stride + (size_t)(p2 & 1) * da->add_poly_stride + k) * G::N
+                                   : da->x);
+        const StreamBuf d(da->out + ((size_t)p2 * da->out_stride + k) * G::N);
+        const double inv = D(da->dc.inv[k]), invu = D(da->dc.inv_h[k]), ql = D(da->dc.qlt[k]), qlu = D(da->dc.qlt_h[k]);
+        auto rows = [&](auto add_tag) {
+            constexpr bool ADD = decltype(add_tag)::value;
+            constexpr int EPI_DEPTH = HP_EPI_DEPTH;
+            V2 xr[EPI_DEPTH], ar[EPI_DEPTH];
+#pragma unroll
+            for (int s = 0; s < EPI_DEPTH; ++s) {
+                xr[s] = xs.load(voff, (u32)s << 10);
+                if (ADD) ar[s] = as.load(voff, (u32)s << 10);
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const V2 xv = xr[s % EPI_DEPTH];
+                V2 av{0, 0};
+                if (ADD) av = ar[s % EPI_DEPTH];
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + EPI_DEPTH < 16) {
+                    xr[s % EPI_DEPTH] = xs.load(voff, (u32)(s + EPI_DEPTH) << 10);
+                    if (ADD) ar[s % EPI_DEPTH] = as.load(voff, (u32)(s + EPI_DEPTH) << 10);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                double v0 = a_modmul(from_word(xv.x) - D(x[2 * s]), inv, invu, q);
+                double v1 = a_modmul(from_word(xv.y) - D(x[2 * s + 1]), inv, invu, q);
+                if (BGV) {
+                    v0 = a_modmul(v0, ql, qlu, q);
+                    v1 = a_modmul(v1, ql, qlu, q);
+                }
+                if (ADD) {
+                    v0 += from_word(av.x);
+                    v1 += from_word(av.y);
+                }
+                d.store(voff + ((u32)s << 10), V2{a_canon(v0, qinv, q), a_canon(v1, qinv, q)});
+            }
+        };
+        if constexpr (FLAV == 2 || FLAV == 4) rows(std::true_type{});
+        else if constexpr (FLAV == 1 || FLAV == 3) rows(std::false_type{});
+        else if (has_add) rows(std::true_type{});
+        else rows(std::false_type{});
+    }
+}
+
+template <int LOGN>
+__global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd_a(HpNttJob job) {
+    ntt_fwd_a_body<LOGN, false, 0>(job, nullptr);
+}
+template <int LOGN, int FLAV>
+__global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd_drop_a(HpNttJob job, HpDropArgs da) {
+    ntt_fwd_a_body<LOGN, true, FLAV>(job, &da);
+}
+
+// ---- inverse (always returns canonical residues: intt_negacyclic_inplace of ntt.h:88-92) -----------------------------------
+template <int LOGN> struct InvGeoA {
+    static constexpr int LPW = LOGN >= 14 ? 1 : (512 >> (LOGN - 5));   // limbs of one modulus per workgroup (hp_ntt_fast.hip: InvGeo)
+    static constexpr int TT = Geo<LOGN>::T * LPW;
+    static constexpr bool STREAM_EPILOGUE = LOGN <= 13;
+};
+
+template <int LOGN, bool PSCAL>
+__global__ void __launch_bounds__(InvGeoA<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv_a(HpNttJob job) {
+    using G = Geo<LOGN>;
+    constexpr int LPW = InvGeoA<LOGN>::LPW, TT = InvGeoA<LOGN>::TT;
+    __shared__ u32 lds_all[Addr<LOGN>::WORDS * LPW];
+    __shared__ u64v2 lds_tw[31 * 32];
+    const u32 sub = threadIdx.x / G::T, tid = threadIdx.x % G::T;
+    u32 *lds = lds_all + sub * Addr<LOGN>::WORDS;
+    HpItem it;
+    bool active = true;
+    if (LPW == 1) {
+        const u32 w = hp_xcd_remap(blockIdx.x, job.W);
+        const u32 k = w / job.P, p = w % job.P;
+        it.src = job.src + ((size_t)p * job.src_pstride + (size_t)k * job.src_kstride) * G::N;
+        it.dst = job.dst + ((size_t)p * job.dst_pstride + k) * G::N;
+        it.limb = k;
+        it.poly = p;
+    } else {
+        const u32 bpm = (job.P + LPW - 1) / LPW;
+        const u32 wb = hp_xcd_remap(blockIdx.x, job.L * bpm);
+        const u32 k = wb / bpm, p0 = (wb % bpm) * LPW + sub;
+        active = p0 < job.P;
+        const u32 p = active ? p0 : job.P - 1;
+        it.src = job.src + ((size_t)p * job.src_pstride + (size_t)k * job.src_kstride) * G::N;
+        it.dst = job.dst + ((size_t)p * job.dst_pstride + k) * G::N;
+        it.limb = k;
+        it.poly = p;
+    }
+    const cptr_limba lp = (cptr_limba)(job.limbs_a + __builtin_amdgcn_readfirstlane(it.limb));
+    const double q = lp->q, qinv = lp->qinv;
+    const bool wide = lp->wide != 0;
+    Addr<LOGN> ad;
+    ad.init(tid);
+    constexpr int NSTG = (31 * 32 + TT - 1) / TT;
+    u64v2 stg[NSTG];
+#pragma unroll
+    for (int i = 0; i < NSTG; ++i) {
+        const u32 e = threadIdx.x + (u32)i * TT;
+        stg[i] = (e < 31u * 32u) ? ((gptr_u64x2)(lp->inv_k + 31))[e] : u64v2{0, 0};
+    }
+    u64 x[32];
+    {
+        const u64 *s = it.src + (((size_t)(tid >> 6)) << 11) + ((tid & 63u) << 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const V2 v = ld_stream(s + ((size_t)r << 7));
+            x[2 * r] = v.x;
+            x[2 * r + 1] = v.y;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NSTG; ++i) {
+        const u32 e = threadIdx.x + (u32)i * TT;
+        if (e < 31u * 32u) lds_tw[e] = stg[i];
+    }
+#pragma unroll
+    for (int r = 0; r < 32; ++r) x[r] = U(from_word(x[r]));
+    if (wide) a_reduce_all(x, qinv, q);   // lazy words up to 2 q
+    exchange<LOGN, LAY_S, LAY_C, false>(x, lds, ad);
+    inv_pass_a<0>(x, STab(lp->inv_k), 1u, 0u, q);
+    if (wide) a_reduce_all(x, qinv, q);
+    exchange<LOGN, LAY_C, LAY_B, false>(x, lds, ad);
+    __syncthreads();   // the staged twiddles are read by other waves from here on
+    inv_pass_a<0>(x, LTab(lds_tw), 32u, tid & 31u, q);
+    if (wide) a_reduce_all(x, qinv, q);
+    exchange<LOGN, LAY_B, LAY_A, true>(x, lds, ad);
+    inv_pass_a<G::PB>(x, BTab(lp->inv_k + 31 + 31 * 32), (u32)G::T, tid, q);
+    if (wide) a_reduce_all(x, qinv, q);
+    const double psc = D(job.post_scalar), psu = D(job.post_scalar_h);
+    if constexpr (InvGeoA<LOGN>::STREAM_EPILOGUE) {
+        // N <= 8192: transpose once more so that the psi^-i N^-1 pairs are read and the words written 16 contiguous bytes per lane
+        exchange<LOGN, LAY_A, LAY_S, true>(x, lds, ad);
+        if (!active) return;
+        const size_t off = (((size_t)(tid >> 6)) << 11) + ((tid & 63u) << 1);
+        const BTab sc(lp->inv_ref + G::N);
+        u64 *d = it.dst + off;
+#pragma unroll
+        for (int s0 = 0; s0 < 16; s0 += 2) {
+            u64x2 f[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[e] = sc.at((u32)(s0 + (e >> 1)), 128u, (u32)off + (u32)(e & 1));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 2 * s0 + e;
+                double v = a_modmul(D(x[r]), D(f[e].x), D(f[e].y), q);      // ntt.cpp:214-222 as a residue
+                if (PSCAL) v = a_modmul(v, psc, psu, q);                    // mod_switch.cpp:49
+                x[r] = to_word(a_nonneg(v, q));
+            }
+            st_stream(d + ((size_t)s0 << 7), V2{x[2 * s0], x[2 * s0 + 1]});
+            st_stream(d + ((size_t)(s0 + 1) << 7), V2{x[2 * s0 + 2], x[2 * s0 + 3]});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
+    {
+        const BTab sc(lp->inv_ref + G::N);
+        u64 *d = it.dst + ((size_t)tid << G::PB);
+#pragma unroll
+        for (int r0 = 0; r0 < 32; r0 += 4) {
+            u64x2 f[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = r0 + e, kk = r >> G::PB, pp = r & ((1 << G::PB) - 1);
+                f[e] = sc.at((u32)kk, 1024u, (tid << G::PB) + (u32)pp);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = r0 + e;
+                double v = a_modmul(D(x[r]), D(f[e].x), D(f[e].y), q);
+                if (PSCAL) v = a_modmul(v, psc, psu, q);
+                x[r] = to_word(a_nonneg(v, q));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!active) return;
+        if (G::PB == 0) {
+            const bool odd = (tid & 1u) != 0;
+            u64 *dp = it.dst + (tid & ~1u);
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const u64 recv = from_pair_lane(odd ? x[2 * p] : x[2 * p + 1]);
+                V2 v;
+                v.x = odd ? recv : x[2 * p];
+                v.y = odd ? x[2 * p + 1] : recv;
+                st_stream(dp + ((size_t)(2 * p + (odd ? 1 : 0)) << 10), v);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < (G::PB == 0 ? 0 : (1 << G::A)); ++kk) {
+            if (G::PB == 0) {
+            } else {
+#pragma unroll
+                for (int pp = 0; pp < (1 << G::PB); pp += 2) {
+                    V2 v{x[(kk << G::PB) | pp], x[(kk << G::PB) | pp | 1]};
+                    st_stream(d + ((size_t)kk << 10) + pp, v);
+                }
+            }
+        }
+    }
+}
+
+template <int LOGN> hipError_t launch_a(const HpNttJob &job, hipStream_t stream) {
+    if (!job.inverse) {
+        if (job.mode != HP_NTT_BATCH && job.mode != HP_NTT_SPREAD) return hipErrorNotSupported;
+        k_ntt_fwd_a<LOGN><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
+        return hipGetLastError();
+    }
+    constexpr int LPW = InvGeoA<LOGN>::LPW, TT = InvGeoA<LOGN>::TT;
+    if (job.mode != HP_NTT_BATCH || job.pair_moduli) return hipErrorNotSupported;
+    const u32 grid = LPW == 1 ? job.W : job.L * ((job.P + LPW - 1) / LPW);
+    if (job.use_post_scalar) k_ntt_inv_a<LOGN, true><<<grid, TT, 0, stream>>>(job);
+    else k_ntt_inv_a<LOGN, false><<<grid, TT, 0, stream>>>(job);
+    return hipGetLastError();
+}
+
+template <int LOGN> hipError_t launch_drop_a(const HpNttJob &job, const HpDropArgs &da, hipStream_t stream) {
+    if (da.fin_on || da.raw_input || da.comb) return hipErrorNotSupported;
+    int flav = 0;
+    if (!da.addend || da.add_mask == 0) flav = 1;
+    else if (da.add_mask == 3u) flav = 2;
+    else if (da.add_mask == 1u && !da.dc.bgv) flav = 5;
+    if (flav && flav != 5 && da.dc.bgv) flav += 2;
+#define HP_DROP_A(F) k_ntt_fwd_drop_a<LOGN, F><<<job.W, Geo<LOGN>::T, 0, stream>>>(job, da)
+    if (flav == 1) HP_DROP_A(1);
+    else if (flav == 2) HP_DROP_A(2);
+    else if (flav == 3) HP_DROP_A(3);
+    else if (flav == 4) HP_DROP_A(4);
+    else if (flav == 5) HP_DROP_A(5);
+    else return hipErrorNotSupported;
+#undef HP_DROP_A
+    return hipGetLastError();
+}
+
+} // namespace
+
+hipError_t hp_launch_ntt_a(const HpNttJob &job, hipStream_t stream) {
+    if (job.W == 0) return hipSuccess;
+    if (!job.limbs_a) return hipErrorInvalidValue;
+    switch (job.logn) {
+    case 11: return launch_a<11>(job, stream);
+    case 12: return launch_a<12>(job, stream);
+    case 13: return launch_a<13>(job, stream);
+    case 14: return launch_a<14>(job, stream);
+    case 15: return launch_a<15>(job, stream);
+    default: return hipErrorNotSupported;
+    }
+}
+
+hipError_t hp_launch_ntt_a_drop(const HpNttJob &job, const HpDropArgs &da, hipStream_t stream) {
+    if (job.W == 0) return hipSuccess;
+    if (!job.limbs_a) return hipErrorInvalidValue;
+    switch (job.logn) {
+    case 11: return launch_drop_a<11>(job, da, stream);
+    case 12: return launch_drop_a<12>(job, da, stream);
+    case 13: return launch_drop_a<13>(job, da, stream);
+    case 14: return launch_drop_a<14>(job, da, stream);
+    case 15: return launch_drop_a<15>(job, da, stream);
+    default: return hipErrorNotSupported;
+    }
+}

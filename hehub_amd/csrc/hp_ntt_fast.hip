@@ -43,23 +43,6 @@ namespace {
 // instead of after all sixteen:
 //   SwapPre  N = 32768: registers still hold the loads as they arrived; the lane-pair swap sorts them into columns (load_flight)
 //   DropPre  fused drop-last-prime: that swap, then the Barrett / centring / [* t] prologue of rescaling.cpp:54-69, mod_switch.cpp:52-70
-HP_DEV u64 from_pair_lane(u64 v);
-HP_DEV void lazy_swap(u64 (&x)[32], int r) {
-    const bool odd = (threadIdx.x & 1u) != 0;
-    const u64 vx = x[r], vy = x[r + 1];
-    const u64 keep = odd ? vy : vx, send = odd ? vx : vy;
-    const u64 recv = from_pair_lane(send);
-    x[r] = odd ? recv : keep;
-    x[r + 1] = odd ? keep : recv;
-}
-struct NoPre {
-    static constexpr bool on = false;
-    HP_DEV void operator()(u64 (&)[32], int) const {}
-};
-struct SwapPre {
-    static constexpr bool on = true;
-    HP_DEV void operator()(u64 (&x)[32], int r) const { lazy_swap(x, r); }
-};
 template <bool SWAP, bool BGV, bool SMALL> struct DropPre {
     static constexpr bool on = true;
     u64 q, bc, bump, half, tk, tkh;

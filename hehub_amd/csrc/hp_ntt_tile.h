@@ -283,6 +283,24 @@ HP_DEV u64 from_pair_lane(u64 v) {
     return ((u64)hi << 32) | lo;
 }
 
+// load-side work deferred into the first stage of a forward pass (see pass_slots): the lane-pair swap of N = 32768
+HP_DEV void lazy_swap(u64 (&x)[32], int r) {
+    const bool odd = (threadIdx.x & 1u) != 0;
+    const u64 vx = x[r], vy = x[r + 1];
+    const u64 keep = odd ? vy : vx, send = odd ? vx : vy;
+    const u64 recv = from_pair_lane(send);
+    x[r] = odd ? recv : keep;
+    x[r + 1] = odd ? keep : recv;
+}
+struct NoPre {
+    static constexpr bool on = false;
+    HP_DEV void operator()(u64 (&)[32], int) const {}
+};
+struct SwapPre {
+    static constexpr bool on = true;
+    HP_DEV void operator()(u64 (&x)[32], int r) const { lazy_swap(x, r); }
+};
+
 // ---- forward kernel ----------------------------------------------------------------------------
 #define HP_LOAD_ORDER(t) (((t) >> 1) | (((t) & 1) << 3))
 // load, layout A: thread reads 2^PB consecutive coefficients at 2^A places 1024 apart

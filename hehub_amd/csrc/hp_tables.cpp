@@ -1,5 +1,6 @@
 // hp_tables.cpp -- see hp_tables.h
 #include "hp_tables.h"
+#include <cstring>
 
 #include <cmath>
 
@@ -179,6 +180,23 @@ void build_inv_fast(const std::vector<Pair> &inv_ref, size_t logn, std::vector<P
                 }
             }
         }
+    }
+}
+
+
+u64 f64_bits(double v) {
+    u64 b;
+    static_assert(sizeof(b) == sizeof(v), "IEEE double");
+    memcpy(&b, &v, sizeof(b));
+    return b;
+}
+
+void pairs_to_f64(const std::vector<Pair> &in, u64 q, std::vector<Pair> &out) {
+    out.resize(in.size());
+    const double qd = (double)q;
+    for (size_t i = 0; i < in.size(); i++) {
+        const double w = (double)in[i].w;   // exact: w < q < 2^50
+        out[i] = Pair{f64_bits(w), f64_bits(w / qd)};
     }
 }
 

@@ -52,4 +52,9 @@ void build_inv_ref(u64 q, size_t logn, std::vector<Pair> &out);   // 2N entries
 void build_fwd_fast(const std::vector<Pair> &fwd_ref, size_t logn, std::vector<Pair> &out);
 void build_inv_fast(const std::vector<Pair> &inv_ref, size_t logn, std::vector<Pair> &out);
 
+// Parity level A (hp_ntt_a.hip): any of the tables above with every pair (w, w') replaced by the bit patterns of the IEEE doubles
+// (w, RN(w / q)); same layout.  q < 2^50 (every w < q is a double exactly).
+void pairs_to_f64(const std::vector<Pair> &in, u64 q, std::vector<Pair> &out);
+u64 f64_bits(double v);
+
 } // namespace hp

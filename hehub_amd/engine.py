@@ -85,6 +85,14 @@ class Engine:
     def force_generic(self, on: bool):
         self._chk(self.lib.hp_ctx_set_force_generic(self.h, int(on)))
 
+    def set_parity_level(self, level: str):
+        """"B" (default): raw words identical to hehub's.  "A": the scheme-level pipelines return canonical residues through
+        the FP64 transforms (include/hehub_amd.h: hp_ctx_set_parity_level); the NTT / mod-arith primitives are never affected."""
+        self._chk(self.lib.hp_ctx_set_parity_level(self.h, {"B": 0, "A": 1}[level.upper()]))
+
+    def parity_level(self) -> str:
+        return "BA"[self.lib.hp_ctx_get_parity_level(self.h)]
+
     def to_device(self, a: np.ndarray):
         assert a.dtype == np.uint64
         return self.torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(f"cuda:{self.device}")

@@ -60,6 +60,21 @@ typedef enum {
 /* ---- engine ------------------------------------------------------------ */
 int hp_ctx_create(int device, hp_ctx **out);
 void hp_ctx_destroy(hp_ctx *ctx);
+/* Parity level of the scheme-level pipelines ("Parity levels").
+ *   HP_PARITY_B (default): every output word is the raw lazy u64 word hehub's CPU code produces, bit for bit.
+ *   HP_PARITY_A (opt-in; HP_PARITY_LEVEL=A in the environment at hp_ctx_create): the key switch, drop-last-prime, relinearisation,
+ *     rotation and fused mult entry points (hp_dev_ckks_rescale*, hp_dev_bgv_mod_switch, hp_dev_*_relinearize*,
+ *     hp_dev_ckks_rotate* / conjugate*, hp_dev_*_mult_relin_*) return the CANONICAL residue in [0, q) of every word: congruent
+ *     to hehub's word modulo its q and equal to reduce_strict (mod_arith.h:58-72) of it -- the contract of
+ *     intt_negacyclic_inplace (ntt.h:88-92) extended to the whole pipeline.  hp_dev_ext_prod_montgomery* returns lazy words
+ *     (< 2q, rgsw.cpp:151) with hehub's residues.  Their transforms then run on error-free FP64
+ *     products (hp_ntt_a.hip: 8 instead of 16 instructions per butterfly).  Needs every modulus of the chain below 2^50, a ring
+ *     degree of 2^11 .. 2^15 and ciphertext words below 2^51 (any lazy word hehub produces is below 2q); a call whose chain does
+ *     not qualify runs at level B.  The NTT / mod-arith primitives (hp_ntt_*, hp_dev_ntt_*, hp_dev_poly_*, hp_batched_*) are
+ *     never affected: they stay bit-exact with ntt.cpp:145-223 / mod_arith.cpp. */
+typedef enum { HP_PARITY_B = 0, HP_PARITY_A = 1 } hp_parity_level;
+int hp_ctx_set_parity_level(hp_ctx *ctx, int level);
+int hp_ctx_get_parity_level(hp_ctx *ctx);
 const char *hp_last_error(hp_ctx *ctx);
 const char *hp_version(void);
 /* enqueue on an existing hipStream_t (e.g. torch's current stream); NULL = the HIP default stream.

@@ -1,0 +1,174 @@
+"""Parity level A (opt-in: hp_ctx_set_parity_level / HP_PARITY_LEVEL=A, include/hehub_amd.h): the scheme-level pipelines on the
+FP64 residue transforms of hp_ntt_a.hip.  Contract ("Parity levels"): every output word is congruent to
+the reference's word modulo its q -- here: EQUAL to reduce_strict (mod_arith.h:58-72) of the oracle's raw word, since every
+entry point that ends in a drop-last-prime returns canonical residues; the key switch alone returns lazy words (< 2q) with the
+reference's residues.  Reference contracts: ntt.cpp:155-175, :178-223, rgsw.cpp:98-153, rescaling.cpp:46-75,
+mod_switch.cpp:45-77.  The NTT / mod-arith primitives must stay bit-exact (level B) whatever the context's level."""
+import numpy as np
+import pytest
+
+import params as P
+from oracle.pyoracle import SplitMix
+from test_gpu_full_batch import PERIOD, all_equal_classes, tile
+from test_gpu_parity import _ntt_primes
+
+pytestmark = pytest.mark.gpu
+U = np.uint64
+
+
+@pytest.fixture(scope="module")
+def enga():
+    from hehub_amd.engine import Engine
+
+    e = Engine(0)
+    e.set_parity_level("A")
+    assert e.parity_level() == "A"
+    yield e
+    e.release_workspace()
+    e.close()
+
+
+def strict(moduli, a):
+    """reduce_strict per limb: a [..., L, n] of lazy words below 2q"""
+    q = np.array(moduli, dtype=U)[:, None]
+    return np.where(a >= q, a - q, a)
+
+
+def canon(moduli, a):
+    """the canonical residue of any u64 word"""
+    return a % np.array(moduli, dtype=U)[:, None]
+
+
+CASES = [
+    (11, P.P40[:3] + [P.P50[0]], 2),                      # narrow limbs + a wide special prime
+    (12, [P.P50[1]] + P.P40[:4] + [P.P50[0]], 3),         # the C3 chain's shape: wide q0, narrow q1.., wide p
+    (P.C5_LOGN, P.C5_MODULI_EXT, 2),                      # C5: all narrow
+    (14, P.P50[1:4] + [P.P50[0]], 2),                     # all wide (50-bit)
+    (15, [P.P50[1]] + P.P40[:2] + [P.P50[0]], 1),         # N = 32768 (lane-pair swap + padded exchange)
+    (13, _ntt_primes(2, 13, 44) + _ntt_primes(2, 13, 45) + _ntt_primes(1, 13, 49), 2),   # either side of the wide threshold 2^44
+    (3, [1099510054913, 1073479681, 1072496641, 1099507695617], 2),   # no tiled kernels at this degree: runs at level B
+]
+
+
+@pytest.mark.parametrize("logn,mext,B", CASES)
+def test_scheme_level_residues(enga, orc, logn, mext, B):
+    eng = enga
+    n, L = 1 << logn, len(mext) - 1
+    q = mext[:L]
+    tiled = 11 <= logn <= 15
+    rng = SplitMix(7000 + logn)
+    ct1 = rng.poly((B, 2, L, n), q)
+    ct2 = rng.poly((B, 2, L, n), q)
+    key = rng.poly((L, 2, L + 1, n), mext)
+    # worst-case magnitudes: the largest canonical word and the largest lazy word in some coefficients
+    ct1[0, 0, :, :7] = (np.array(q, dtype=U) - U(1))[:, None]
+    ct2[0, 1, :, :5] = (U(2) * np.array(q, dtype=U) - U(1))[:, None]
+    d1, d2, dk = eng.to_device(ct1), eng.to_device(ct2), eng.to_device(key)
+    exp = lambda f: np.stack([f(i) for i in range(B)])
+    fin = (lambda m, a: strict(m, a)) if tiled else (lambda m, a: a)          # what a drop returns at level A / B
+    quad = eng.mult_low_level(q, d1, d2)
+    quad_h = eng.to_host(quad)
+    assert np.array_equal(quad_h, exp(lambda i: orc.mult_low_level(q, ct1[i], ct2[i])))    # not a transform: level B words
+    ext = eng.ext_prod(mext, quad[:, 2].contiguous(), dk)
+    ext_h = eng.to_host(ext)
+    ext_o = exp(lambda i: orc.ext_prod(mext, quad_h[i, 2], key))
+    assert np.array_equal(canon(mext, ext_h), canon(mext, ext_o))
+    assert (ext_h < U(2) * np.array(mext, dtype=U)[:, None]).all()
+    if not tiled:
+        assert np.array_equal(ext_h, ext_o)
+    # drops of engine-made and of caller-made ciphertexts
+    assert np.array_equal(eng.to_host(eng.ckks_rescale(mext, ext)), fin(q, exp(lambda i: orc.ckks_rescale(mext, ext_o[i]))))
+    assert np.array_equal(eng.to_host(eng.ckks_rescale(q, d1)), fin(q[:-1], exp(lambda i: orc.ckks_rescale(q, ct1[i]))))
+    for t in (65537, 2, 1):
+        assert np.array_equal(eng.to_host(eng.bgv_mod_switch(q, t, d2)), fin(q[:-1], exp(lambda i: orc.bgv_mod_drop(q, t, ct2[i]))))
+    assert np.array_equal(eng.to_host(eng.ckks_relinearize(mext, quad, dk)), fin(q, exp(lambda i: orc.ckks_relinearize(mext, quad_h[i], key))))
+    assert np.array_equal(eng.to_host(eng.bgv_relinearize(mext, quad, dk)), fin(q, exp(lambda i: orc.bgv_relinearize(mext, quad_h[i], key))))
+    for step in (1, 3):
+        assert np.array_equal(eng.to_host(eng.ckks_rotate(mext, d1, dk, step)), fin(q, exp(lambda i: orc.ckks_rotate(mext, ct1[i], key, step))))
+    assert np.array_equal(eng.to_host(eng.ckks_conjugate(mext, d2, dk)), fin(q, exp(lambda i: orc.ckks_conjugate(mext, ct2[i], key))))
+    assert np.array_equal(eng.to_host(eng.ckks_mult(mext, d1, d2, dk)), fin(q[:-1], exp(lambda i: orc.ckks_mult(mext, ct1[i], ct2[i], key))))
+    assert np.array_equal(eng.to_host(eng.bgv_mult(mext, P.C5_T, d1, d2, dk)),
+                          fin(q[:-1], exp(lambda i: orc.bgv_mult(mext, P.C5_T, ct1[i], ct2[i], key))))
+
+
+def test_primitives_stay_level_b(enga, orc):
+    """hp_dev_ntt / hp_dev_intt / the host primitives are bit-exact with ntt.cpp:145-223 whatever the context's level"""
+    eng = enga
+    for logn, moduli in ((12, P.P40[:2]), (15, [P.C3_P, P.P40[0]])):
+        rng = SplitMix(77 + logn)
+        a = rng.poly((2, len(moduli), 1 << logn), moduli)
+        y = eng.to_host(eng.ntt_(moduli, eng.to_device(a)))
+        assert np.array_equal(y, np.stack([orc.poly_ntt(moduli, a[i]) for i in range(2)]))
+        z = eng.to_host(eng.intt_(moduli, eng.to_device(y)))
+        assert np.array_equal(z, np.stack([orc.poly_intt(moduli, y[i]) for i in range(2)]))
+    x = SplitMix(5).words(1 << 15, P.C3_P)
+    assert np.array_equal(eng.host_ntt(15, P.C3_P, x), orc.ntt(15, P.C3_P, x))
+
+
+def test_chain_with_a_59_bit_modulus_runs_at_level_b(enga, orc):
+    """a modulus >= 2^50 has no FP64 kernels: the call silently keeps level B (raw words)"""
+    eng = enga
+    logn, mext, B = 11, _ntt_primes(2, 11, 40) + _ntt_primes(1, 11, 59), 1
+    n, L = 1 << logn, len(mext) - 1
+    rng = SplitMix(4)
+    ct1, ct2, key = rng.poly((B, 2, L, n), mext[:L]), rng.poly((B, 2, L, n), mext[:L]), rng.poly((L, 2, L + 1, n), mext)
+    out = eng.to_host(eng.ckks_mult(mext, eng.to_device(ct1), eng.to_device(ct2), eng.to_device(key)))
+    assert np.array_equal(out[0], orc.ckks_mult(mext, ct1[0], ct2[0], key))
+
+
+def test_c3_batch_256_residues(enga, orc):
+    """BASELINE config 3 (= C4 per GPU) at level A: all 256 outputs are the strict residues of the oracle's outputs; rotation too"""
+    eng = enga
+    logn, mext, B = P.C3_LOGN, P.C3_MODULI_EXT, P.C3_BATCH
+    n, L = 1 << logn, len(mext) - 1
+    rng = SplitMix(3)
+    b1 = rng.poly((PERIOD, 2, L, n), mext[:L])
+    b2 = rng.poly((PERIOD, 2, L, n), mext[:L])
+    key = rng.poly((L, 2, L + 1, n), mext)
+    ct1, ct2, dk = tile(eng, b1, B), tile(eng, b2, B), eng.to_device(key)
+    out = eng.ckks_mult(mext, ct1, ct2, dk)
+    exp = np.stack([strict(mext[:L - 1], orc.ckks_mult(mext, b1[c], b2[c], key)) for c in range(PERIOD)])
+    assert all_equal_classes(eng, out, exp)
+    out.fill_(-1)
+    eng.ckks_mult(mext, ct1, ct2, dk, out=out)
+    assert all_equal_classes(eng, out, exp)
+    rot = eng.ckks_rotate(mext, ct1, dk, 5)
+    assert all_equal_classes(eng, rot, np.stack([strict(mext[:L], orc.ckks_rotate(mext, b1[c], key, 5)) for c in range(PERIOD)]))
+
+
+def test_c5_batch_512_residues(enga, orc):
+    """BASELINE config 5 per GPU at level A: bgv mult_low_level + relinearize (plain_modulus == 1 quirk) + mod_switch, 512 pairs"""
+    eng = enga
+    logn, mext, t, B = P.C5_LOGN, P.C5_MODULI_EXT, P.C5_T, 512
+    n, L = 1 << logn, len(mext) - 1
+    rng = SplitMix(5)
+    b1 = rng.poly((PERIOD, 2, L, n), mext[:L])
+    b2 = rng.poly((PERIOD, 2, L, n), mext[:L])
+    key = rng.poly((L, 2, L + 1, n), mext)
+    ct1, ct2, dk = tile(eng, b1, B), tile(eng, b2, B), eng.to_device(key)
+    out = eng.bgv_mult(mext, t, ct1, ct2, dk)
+    exp = np.stack([strict(mext[:L - 1], orc.bgv_mult(mext, t, b1[c], b2[c], key)) for c in range(PERIOD)])
+    assert all_equal_classes(eng, out, exp)
+
+
+def test_level_a_equals_strict_of_level_b_on_distinct_inputs(enga):
+    """all-distinct random C3 ciphertexts (no periodic classes): level A == reduce_strict(level B) word for word on the device"""
+    import torch
+
+    from hehub_amd.engine import Engine
+    from test_gpu_full_batch import rand_dev
+
+    logn, mext, B = P.C3_LOGN, P.C3_MODULI_EXT, 64
+    n, L = 1 << logn, len(mext) - 1
+    eb = Engine(0)
+    try:
+        ct1 = rand_dev(eb, (B, 2, L, n), mext[:L], 131)
+        ct2 = rand_dev(eb, (B, 2, L, n), mext[:L], 132)
+        key = rand_dev(eb, (L, 2, L + 1, n), mext, 133)
+        ob = eb.ckks_mult(mext, ct1, ct2, key)
+        eb.poly_reduce_strict_(mext[:L - 1], ob.view(B * 2, L - 1, n))
+        oa = enga.ckks_mult(mext, ct1, ct2, key)
+        assert torch.equal(oa, ob)
+    finally:
+        eb.release_workspace()
+        eb.close()
