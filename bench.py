@@ -87,6 +87,11 @@ def parse(argv=None):
                          "(backend nccl = RCCL, world size 1), so that the barrier, the MAX / MIN all-reduces on device tensors and "
                          "the communicator set-up of an N-GPU job run on a one-GPU box; a failure there is recorded in the line "
                          "(`rccl.error`) and the run goes on without a group")
+    ap.add_argument("--parity-level", default=None, choices=["A", "B"],
+                    help="parity level of the scheme-level pipelines of the timed workload (include/hehub_amd.h: hp_ctx_set_parity_level): "
+                         "B (default) = hehub's raw lazy words; A = canonical residues through the FP64 transforms, verified as "
+                         "reduce_strict of the checker's words.  The default line is always level B and reports level A in its own "
+                         "`level_a` section; this switch exists for profiling one level alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU budget of the cpu_baseline sample")
     ap.add_argument("--cpu-procs", type=int, default=-1,
@@ -260,6 +265,9 @@ def extra_sections(run, res, wl, value, lib, cpu_budget):
                                    "A_step_frac_of_hbm_peak": res["pipeline_roofline"]["frac_of_hbm_peak"],
                                    "verified": res.get("verified"), "verified_outputs": wl.B}
     res["bgv"] = S.bgv_section(run, lib)
+    res["level_a"] = S.level_a_section(run, lib, wl)
+    res["level_a"]["ckks"]["speedup_vs_level_b"] = res["level_a"]["ckks"]["per_s"] / value
+    res["level_a"]["bgv"]["speedup_vs_level_b"] = res["level_a"]["bgv"]["per_s"] / res["bgv"]["per_s"]
     copy = S.hbm_copy_ceiling(run)
     res["hbm_copy_ceiling_GBps"] = copy["hbm_copy_ceiling_GBps"]
     res["hbm_copy"] = copy
@@ -273,7 +281,8 @@ def extra_sections(run, res, wl, value, lib, cpu_budget):
                     cb = {"error": repr(e)}
                 (sect if key is None else sect[key])["cpu_baseline"] = cb
     checks = list(by_n.values()) + list(res["ckks_by_N"].values()) + [steady, res["coeffwise"]["mul"], res["coeffwise"]["add"],
-                                                                        res["c2"], res["bgv"]]
+                                                                        res["c2"], res["bgv"], res["level_a"]["ckks"],
+                                                                        res["level_a"]["bgv"]]
     bad = any(s.get("verified") is False for s in checks) or not copy["engine_copy_verified"]
     return bad
 
@@ -332,6 +341,8 @@ def main() -> int:
     run = Run(torch=torch, hd=hd, eng=Engine(local), P=P, args=args, world=world, rank=rank, dev=dev,
               cdev="cpu" if share_gpu else dev)
     extras = not args.roofline_only
+    level = (args.parity_level or ("A" if os.environ.get("HP_PARITY_LEVEL", "B")[:1] in "Aa1" else "B"))
+    run.eng.set_parity_level(level)
     wl = workloads.make(run, args.workload)
 
     # ---- the timed region --------------------------------------------------------------------------------------------
@@ -353,7 +364,7 @@ def main() -> int:
         "metric": wl.metric, "value": value, "unit": wl.unit, "n_gpus": world, "dist_ranks": dist_ranks, "rccl_ranks": rccl_ranks, "rccl": rccl_info,
         "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": wl.scaling,
-        "vs_baseline": None, "dtype": "u64", "data": "synthetic", "config": wl.cfg,
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic", "config": wl.cfg, "parity_level": level,
     }
     if share_gpu:
         res["data"] = "synthetic (TEST MODE: the ranks share ONE GPU over gloo; exercises the multi-rank path, not a scaling number)"
@@ -370,7 +381,7 @@ def main() -> int:
             kind = f"error: {e!r}"
     if extras and not args.no_verify and wl.verifiable:
         try:
-            ok, compared, classes = wl.verify(lib)
+            ok, compared, classes = wl.verify(lib, strict=True) if (level == "A" and isinstance(wl, workloads.Scheme)) else wl.verify(lib)
         except Exception as e:
             ok, compared, classes, kind = False, 0, 0, f"error: {e!r}"
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=run.cdev)
@@ -385,7 +396,7 @@ def main() -> int:
         res["roofline"] = roofline_entry(wl.family, wl.alg_bytes_per_step, args.steps, launches, kern_ms, elapsed, wl.logn, wl.spread)
     if wl.a_limbs is not None:
         res["pipeline_roofline"] = wl.pipeline_roofline(value / world, HBM_PEAK_GBS)
-    if args.workload == "ckks" and extras and not args.no_rates and not args.logn and not args.batch:
+    if args.workload == "ckks" and extras and not args.no_rates and not args.logn and not args.batch and level == "B":
         # BASELINE.json's metric names both rates ("NTT/s and CKKS hom-mult/s ... N=32768"), the north star the coefficient-wise
         # kernels, and configs 2 and 5 their own shapes: the default line carries them all (timed after the hom-mult region)
         if extra_sections(run, res, wl, value, lib, 0.0 if args.no_cpu_baseline else args.cpu_section_seconds):

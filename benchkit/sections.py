@@ -143,6 +143,38 @@ def bgv_section(run: Run, lib):
     return ent
 
 
+def level_a_section(run: Run, lib, wl):
+    """The opt-in parity level A (hp_ctx_set_parity_level; SURVEY.md section 8 "Parity levels"): the SAME C3 and C5 buffers and
+    calls as the headline / the bgv section with the transforms of the pipelines on the FP64 residue kernels (hp_ntt_a.hip).
+    Every output word must equal reduce_strict of the checker's raw word.  The headline `value` is never taken from here."""
+    eng = run.eng
+    out = {"what": "ckks::mult + relinearize + rescale_inplace (C3) and bgv mult + relinearize + mod_switch (C5 per GPU) with "
+                   "hp_ctx_set_parity_level(HP_PARITY_A): canonical residues instead of hehub's lazy representatives; NTT / "
+                   "mod-arith primitives unaffected"}
+    eng.set_parity_level("A")
+    try:
+        for key, w, steps in (("ckks", wl, run.args.steps), ("bgv", Scheme(run, "bgv", 0, 0, 3, seed=5), max(run.args.steps, 20))):
+            dt, launches, kern_ms = timed_launches(run, w.step, w.family, steps, warm=3)
+            per_gpu = w.B * steps / dt
+            ent = {"workload": w.cfg["workload"], "per_s": per_gpu * run.world, "unit": "hom-mult/s", "steps": steps,
+                   "ms_per_step": 1e3 * dt / steps, "pipeline_roofline": w.pipeline_roofline(per_gpu, HBM_PEAK_GBS)}
+            if launches:
+                r = roofline_entry(w.family, w.alg_bytes_per_step, steps, launches, kern_ms, dt, w.logn, True)
+                r["kernel"] = "k_ntt_fwd_a (register/LDS-tiled forward NTT, FP64 residue butterflies), digit-spread launch"
+                r["traffic"] = None
+                r.pop("valu_busy", None)
+                r.pop("traffic_source", None)
+                ent["roofline"] = r
+            if lib is not None:
+                ok, cnt, classes = w.verify(lib, strict=True)
+                ent.update({"verified": bool(ok), "verified_outputs": cnt, "checker_evaluations": classes,
+                            "verify_what": "every output word == reduce_strict(checker's raw word)"})
+            out[key] = ent
+    finally:
+        eng.set_parity_level("B")
+    return out
+
+
 def hbm_copy_ceiling(run: Run):
     """The measured stream ceiling beside the 8 TB/s spec peak: 1 GiB -> 1 GiB device-to-device, read + write
     bytes over the kernel time, (a) the engine's own copy kernel (hp_dev_copy: 16 bytes per lane, non-temporal -- the access

@@ -252,8 +252,9 @@ class Scheme(Workload):
             return lib.bgv_mult(self.mext, self.t, c1, c2, k)
         return lib.ckks_mult(self.mext, c1, c2, k)
 
-    def verify(self, lib):
-        # the buffer the LAST timed step wrote, every ciphertext of it
+    def verify(self, lib, strict=False):
+        # the buffer the LAST timed step wrote, every ciphertext of it; strict: the engine ran at parity level A, whose outputs are
+        # reduce_strict (mod_arith.h:58-72) of the checker's raw words
         import numpy as np
 
         B = self.B
@@ -262,6 +263,9 @@ class Scheme(Workload):
         _, h2 = self.b2.classes(sample)
         hk = self.key.cpu().numpy().view(np.uint64)
         exp = np.stack([self._check(lib, h1[c], h2[c], hk) for c in range(len(idx))])
+        if strict:
+            q = np.array(self.mext[:exp.shape[-2]], dtype=np.uint64)[:, None]
+            exp = np.where(exp >= q, exp - q, exp)
         res = self.result
         if res.shape[0] != B:
             return False, 0, len(idx)

@@ -26,6 +26,9 @@
 namespace {
 
 typedef const HpLimbA __attribute__((address_space(4))) * cptr_limba;
+#ifdef HP_TRACE
+__device__ u64 g_trace[2 * 2048 * 16 * HP_TRACE_SLOTS];
+#endif
 
 HP_DEV double D(u64 v) { return __builtin_bit_cast(double, v); }
 HP_DEV u64 U(double d) { return __builtin_bit_cast(u64, d); }
@@ -141,6 +144,7 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
     using AD = Addr<LOGN, LOGN == 15>;
     __shared__ u32 lds[AD::WORDS];
     __shared__ u64v2 lds_tw[31 * (1 << G::A)];
+    TRACE_ENTRY
     const u32 w = hp_xcd_remap(blockIdx.x, job.W);
     HpItem it;
     if (!hp_decode_item(job, w, it)) return;
@@ -152,11 +156,17 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
     ad.init(tid);
     u64v2 stg = {0, 0};
     if (tid < 31u * (1u << G::A)) stg = ((gptr_u64x2)lp->fwd_k)[tid];
+    TRACE_DECL
+    TRACE_MARK();   // 0: decoded, staging load issued
     u64 x[32];
     constexpr bool SW = G::PB == 0;   // N = 32768: registers left as loaded, sorted into columns by the lane-pair swap of the first stage
     load_flight<LOGN, SW>(it.src, tid, x);
     if (tid < 31u * (1u << G::A)) lds_tw[tid] = stg;
     constexpr bool BGV = FLAV == 3 || FLAV == 4;
+#ifdef HP_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    TRACE_MARK();   // 1: coefficients have arrived
     // pass A: global stages 1..A, wave-uniform twiddles seq[1 .. 2^A - 1]
     if constexpr (DROP) {
         const u32 k = it.limb;
@@ -166,13 +176,18 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
         fwd_pass_a<G::PB, STab>(x, STab(lp->fwd_ref + 1), 1u, 0u, q, ConvPre<SW>());
     }
     if (wide) a_reduce_all(x, qinv, q);
+    TRACE_MARK();   // 2
     exchange<LOGN, LAY_A, LAY_B, true>(x, lds, ad);
+    TRACE_MARK();   // 3
     // pass B: global stages A+1..A+5, twiddles depend on the 1024-block
     fwd_pass_a<0>(x, LTab(lds_tw), 1u << G::A, tid >> 5, q);
     if (wide) a_reduce_all(x, qinv, q);
+    TRACE_MARK();   // 4
     exchange<LOGN, LAY_B, LAY_C, false>(x, lds, ad);
+    TRACE_MARK();   // 5
     // pass C: global stages A+6..logN, per-thread twiddles
     fwd_pass_a<0>(x, BTab(lp->fwd_k + 31 * (1 << G::A)), (u32)G::T, tid, q);
+    TRACE_MARK();   // 6
     if (!DROP) {
         // canonical residues, as words
 #pragma unroll
@@ -180,7 +195,9 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
     } else if (wide) {
         a_reduce_all(x, qinv, q);
     }
+    TRACE_MARK();   // 7: canonical
     exchange<LOGN, LAY_C, LAY_S, false>(x, lds, ad);
+    TRACE_MARK();   // 8
     if (!DROP) {
         const size_t off = (((size_t)(tid >> 6)) << 11) + ((tid & 63u) << 1);
         if (job.mode == HP_NTT_SPREAD && ((job.pack_mask >> it.limb) & 1u)) {
@@ -250,6 +267,8 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
         else if (has_add) rows(std::true_type{});
         else rows(std::false_type{});
     }
+    TRACE_MARK();   // 9: stores issued
+    TRACE_FLUSH();
 }
 
 template <int LOGN>
@@ -442,6 +461,12 @@ template <int LOGN> hipError_t launch_drop_a(const HpNttJob &job, const HpDropAr
 }
 
 } // namespace
+
+#ifdef HP_TRACE
+extern "C" int hp_debug_trace_a(u64 *out, size_t words) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), words * sizeof(u64));
+}
+#endif
 
 hipError_t hp_launch_ntt_a(const HpNttJob &job, hipStream_t stream) {
     if (job.W == 0) return hipSuccess;

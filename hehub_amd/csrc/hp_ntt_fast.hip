@@ -118,28 +118,8 @@ HP_DEV void inv_pass(u64 (&x)[32], const Tab tbl, u32 ncls, u32 cls, u64 nq, u64
     run_pass<false, (1 << BLO) - 1, 31, Tab::depth>(x, tbl, ncls, cls, nq, two_q);
 }
 
-// Phase tracing for kernel tuning (variant builds only, -DHP_TRACE): shader-clock stamps of wave 0
-// of every 16th workgroup at the phase boundaries, read back with hp_debug_trace().
 #ifdef HP_TRACE
-#ifdef HP_TRACE_ALL
-#define HP_TRACE_SEL (blockIdx.x < 2048 * 16)
-#define HP_TRACE_IDX (blockIdx.x)
-#else
-#define HP_TRACE_SEL ((blockIdx.x & 15) == 0 && (blockIdx.x >> 4) < 2048)
-#define HP_TRACE_IDX (blockIdx.x >> 4)
-#endif
-#define HP_TRACE_SLOTS 12
 __device__ u64 g_trace[2 * 2048 * 16 * HP_TRACE_SLOTS];
-#define TRACE_DECL u64 tr__[HP_TRACE_SLOTS]; int tri__ = 0; tr__[10] = ((u64)__builtin_amdgcn_s_getreg(63492) << 32) | (u32)__builtin_amdgcn_s_getreg((31 << 11) | 20); tr__[11] = t_entry__;
-#define TRACE_ENTRY __builtin_amdgcn_sched_barrier(0); const u64 t_entry__ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
-#define TRACE_MARK() do { __builtin_amdgcn_sched_barrier(0); tr__[tri__++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define TRACE_FLUSH() do { if ((threadIdx.x == 0 || threadIdx.x == blockDim.x - 64) && HP_TRACE_SEL) { \
-        for (int i__ = 0; i__ < HP_TRACE_SLOTS; i__++) g_trace[(HP_TRACE_IDX * 2 + (threadIdx.x != 0)) * HP_TRACE_SLOTS + i__] = (i__ < tri__ || i__ >= 10) ? tr__[i__] : 0; } } while (0)
-#else
-#define TRACE_DECL
-#define TRACE_ENTRY
-#define TRACE_MARK() do { } while (0)
-#define TRACE_FLUSH() do { } while (0)
 #endif
 
 // FLAV (fused drop only): 0 = every option decided at run time; 1..5 = the shapes of the CKKS / BGV pipelines with the options

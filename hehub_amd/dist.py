@@ -38,9 +38,14 @@ class _StdoutToStderr:
         return self
 
     def __exit__(self, *exc):
+        import ctypes
         import sys
 
         sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)   # the banner is a C printf: it sits in libc's buffer when fd 1 is a pipe
+        except Exception:
+            pass
         os.dup2(self.saved, 1)
         os.close(self.saved)
         return False
