@@ -251,29 +251,40 @@ def extra_sections(run, res, wl, value, lib, cpu_budget):
     from benchkit import sections as S
 
     P = run.P
-    by_n = S.transform_rates(run, lib)
+    sec = run.chip.section
+    with sec("ntt"):
+        by_n = S.transform_rates(run, lib)
     top = by_n[str(1 << P.C3_LOGN)]
     steady = by_n.pop("steady_32768")
     res["ntt"] = {"N": top["N"], "limbs_per_launch": top["limbs_per_launch"],
                   "forward_limb_ntt_per_s": top["forward"]["per_s"], "inverse_limb_ntt_per_s": top["inverse"]["per_s"],
                   "forward": top["forward"], "inverse": top["inverse"], "verified": top.get("verified"),
                   "steady_state": steady, "by_N": by_n}
-    res["c2"] = S.c2_section(run, lib)
-    res["coeffwise"] = S.coeffwise_rates(run, lib)
-    res["ckks_by_N"] = S.ckks_rates(run, lib)
+    with sec("c2"):
+        res["c2"] = S.c2_section(run, lib)
+    with sec("coeffwise"):
+        res["coeffwise"] = S.coeffwise_rates(run, lib)
+    with sec("ckks_by_N"):
+        res["ckks_by_N"] = S.ckks_rates(run, lib)
     res["ckks_by_N"][str(wl.n)] = {"N": wl.n, "L": wl.L, "batch_per_gpu": wl.B, "per_s": value, "unit": "hom-mult/s",
                                    "A_step_frac_of_hbm_peak": res["pipeline_roofline"]["frac_of_hbm_peak"],
                                    "verified": res.get("verified"), "verified_outputs": wl.B}
-    res["bgv"] = S.bgv_section(run, lib)
-    res["level_a"] = S.level_a_section(run, lib, wl)
+    with sec("bgv"):
+        res["bgv"] = S.bgv_section(run, lib)
+    with sec("level_a"):
+        res["level_a"] = S.level_a_section(run, lib, wl)
     res["level_a"]["ckks"]["speedup_vs_level_b"] = res["level_a"]["ckks"]["per_s"] / value
     res["level_a"]["bgv"]["speedup_vs_level_b"] = res["level_a"]["bgv"]["per_s"] / res["bgv"]["per_s"]
-    copy = S.hbm_copy_ceiling(run)
+    with sec("hbm_copy"):
+        copy = S.hbm_copy_ceiling(run)
     res["hbm_copy_ceiling_GBps"] = copy["hbm_copy_ceiling_GBps"]
+    res["hbm_stream_ceiling_GBps"] = copy["hbm_stream_ceiling_GBps"]
     res["hbm_copy"] = copy
     if run.rank == 0 and run.world == 1 and cpu_budget > 0 and lib is not None:
         # the CPU path beside the two BASELINE configs that are not the headline (bounded samples, one core)
-        for sect, names in ((res["c2"], (("forward", "ntt"), ("inverse", "intt"))), (res["bgv"], ((None, "bgv"),))):
+        # (... and beside the N = 32768 limb-transform rates, the other half of BASELINE's metric)
+        for sect, names in ((res["ntt"], (("forward", "ntt15"), ("inverse", "intt15"))),
+                            (res["c2"], (("forward", "ntt"), ("inverse", "intt"))), (res["bgv"], ((None, "bgv"),))):
             for key, name in names:
                 try:
                     cb = cpu_baseline(name, P, cpu_budget)
@@ -340,6 +351,10 @@ def main() -> int:
     dev = f"cuda:{local}"
     run = Run(torch=torch, hd=hd, eng=Engine(local), P=P, args=args, world=world, rank=rank, dev=dev,
               cdev="cpu" if share_gpu else dev)
+    from benchkit.chip import ChipSampler, cpu_model
+
+    chip = ChipSampler(torch, local)
+    run.chip = chip
     extras = not args.roofline_only
     level = (args.parity_level or ("A" if os.environ.get("HP_PARITY_LEVEL", "B")[:1] in "Aa1" else "B"))
     run.eng.set_parity_level(level)
@@ -355,6 +370,7 @@ def main() -> int:
         wl.step()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    chip.sections["timed_region"] = chip.summarize(t0, t1)
     launches, kern_ms = run.eng.prof_end()
     elapsed = hd.max_over_ranks(t1 - t0, device=run.cdev)
     hd.barrier()
@@ -401,6 +417,11 @@ def main() -> int:
         # kernels, and configs 2 and 5 their own shapes: the default line carries them all (timed after the hom-mult region)
         if extra_sections(run, res, wl, value, lib, 0.0 if args.no_cpu_baseline else args.cpu_section_seconds):
             failed = True
+    # shader clock and socket power of this rank's GPU while each section ran (amdgpu hwmon: freq1_input, power1_input)
+    res["chip"] = dict(chip.sections, source="amdgpu hwmon sysfs (sclk freq1_input, socket power1_input), sampled every 4 ms by a thread of this process"
+                       if chip.dir else "no amdgpu hwmon files visible: not sampled")
+    res["cpu_model"] = cpu_model()
+    chip.close()
     if rank == 0:
         if world == 1 and extras and not args.no_cpu_baseline:
             cwl = wl.cpu_name

@@ -24,6 +24,7 @@ class Run:
     rank: int
     dev: str       # "cuda:<local>"
     cdev: str      # where the tensors of the few collectives live ("cpu" in the shared-GPU test mode)
+    chip: Any = None   # benchkit.chip.ChipSampler of this rank's GPU
 
 
 def timed_launches(run: Run, fn, family, steps, warm=1):

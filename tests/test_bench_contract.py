@@ -75,6 +75,22 @@ def test_default_line_carries_both_halves_of_the_metric():
     assert 0.3 < bgv["pipeline_roofline"]["frac_of_hbm_peak"] < 1 and 0.05 < bgv["roofline"]["frac"] < 1
     assert bgv["cpu_baseline"]["value"] > 0 and bgv["per_s"] > 2 * r["value"]
     assert 2000 < r["hbm_copy_ceiling_GBps"] < 8000 and r["hbm_copy"]["engine_copy_verified"] is True
+    # round 4: the stream rate of every read : write mix the engine's streaming kernels have, the chip state per section, the CPU model,
+    # a one-core CPU sample beside the N = 32768 transform rates, the RCCL communicator, and the opt-in parity level A in its own section
+    mix = r["hbm_copy"]["stream_mix_GBps"]
+    assert set(mix) == {"1R:1W", "2R:1W", "4R:3W"} and all(2000 < v < 8000 for v in mix.values())
+    assert r["hbm_stream_ceiling_GBps"] >= r["hbm_copy_ceiling_GBps"]
+    chip = r["chip"]
+    assert {"timed_region", "ntt", "c2", "coeffwise", "bgv", "level_a"} <= set(chip)
+    assert chip["timed_region"]["samples"] >= 3 and 500 < chip["timed_region"]["sclk_MHz"] <= 2500 and chip["timed_region"]["socket_power_W"] > 100
+    assert isinstance(r["cpu_model"], str) and r["cpu_model"] != "unknown"
+    for d in ("forward", "inverse"):
+        assert ntt[d]["cpu_baseline"]["value"] > 0 and "N=32768" in ntt[d]["cpu_baseline"]["sample"]
+    la = r["level_a"]
+    assert r["parity_level"] == "B"
+    for k, outs in (("ckks", 256), ("bgv", 512)):
+        assert la[k]["verified"] is True and la[k]["verified_outputs"] == outs and la[k]["speedup_vs_level_b"] > 1.0
+    assert la["ckks"]["roofline"]["frac"] > r["roofline"]["frac"]
 
 
 @pytest.mark.gpu
