@@ -202,10 +202,10 @@ struct ProfScope {
 };
 
 // ---- transforms -------------------------------------------------------------------------------------------
-inline bool logn_ok(size_t logn) { return logn >= 1 && logn <= 15; }
+inline bool logn_ok(size_t logn) { return logn >= 1 && logn <= 16; }   // (ntt.cpp:26-29 takes any degree with 2N | q - 1; the reference's bit reversal is 16 bits wide, permutation.h:41-55)
 inline bool tiled_ok(const hp_ctx *ctx, size_t logn) { return !ctx->force_generic && logn >= 11 && logn <= 15; }
 inline bool fused_drop_ok(const hp_ctx *ctx, size_t logn) { return tiled_ok(ctx, logn) && !ctx->no_fused_drop; }
-#define HP_LOGN_MSG "ring degrees 2^1 .. 2^15 are supported"
+#define HP_LOGN_MSG "ring degrees 2^1 .. 2^16 are supported"
 int run_ntt(hp_ctx *ctx, const HpNttJob &job);
 HpNttJob batch_job(const Plan *plan, size_t logn, size_t L, size_t P, const u64 *src, u64 *dst, size_t src_ps, size_t dst_ps,
                    int inverse, int strict);

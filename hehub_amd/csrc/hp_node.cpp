@@ -317,7 +317,7 @@ int hp_node_dev_bgv_mult_relin_modswitch(hp_node *node, size_t logn, size_t L, c
 static int node_host_mult(hp_node *node, bool bgv, size_t logn, size_t L, const uint64_t *mext, uint64_t t, size_t batch,
                           const uint64_t *h_ct1, const uint64_t *h_ct2, uint64_t *const *d_key, uint64_t *h_out) {
     if (!node || !mext || !h_ct1 || !h_ct2 || !d_key || !h_out) return HP_EINVAL;
-    if (logn < 1 || logn > 15 || L < 2) return node_fail(node, HP_EINVAL, "invalid shape");
+    if (logn < 1 || logn > 16 || L < 2) return node_fail(node, HP_EINVAL, "invalid shape");
     std::lock_guard<std::mutex> lk(node->mu);
     std::vector<Staging> &st = node->staging;
     const size_t n = (size_t)1 << logn, in_words = 2 * L * n, out_words = 2 * (L - 1) * n;
@@ -353,7 +353,7 @@ int hp_node_bgv_mult_relin_modswitch(hp_node *node, size_t logn, size_t L, const
 // ntt.h:41-51 / :72-92 on a host-resident batch u64[batch][L][N], in place, sliced over the ranks
 int hp_node_ntt(hp_node *node, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *h_x, int inverse, int strict) {
     if (!node || !moduli || !h_x) return HP_EINVAL;
-    if (logn < 1 || logn > 15 || L < 1) return node_fail(node, HP_EINVAL, "invalid shape");
+    if (logn < 1 || logn > 16 || L < 1) return node_fail(node, HP_EINVAL, "invalid shape");
     std::lock_guard<std::mutex> lk(node->mu);
     std::vector<Staging> &st = node->staging;
     const size_t words = L * ((size_t)1 << logn);
@@ -585,7 +585,7 @@ void hp_node_sharded_destroy(hp_node_sharded *plan) { free_plan(plan); }
 int hp_node_sharded_create(hp_node *node, size_t logn, size_t L, const uint64_t *moduli_ext, uint64_t plain_modulus, size_t batch,
                            hp_node_sharded **out) {
     if (!node || !moduli_ext || !out) return HP_EINVAL;
-    if (logn < 1 || logn > 15 || L < 2 || L + 1 > HP_MAX_LIMBS || batch == 0) return node_fail(node, HP_EINVAL, "invalid shape");
+    if (logn < 1 || logn > 16 || L < 2 || L + 1 > HP_MAX_LIMBS || batch == 0) return node_fail(node, HP_EINVAL, "invalid shape");
     std::lock_guard<std::mutex> lk(node->mu);
     hp_node_sharded *p = new (std::nothrow) hp_node_sharded();
     if (!p) return HP_ENOMEM;

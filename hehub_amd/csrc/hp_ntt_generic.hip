@@ -1,7 +1,7 @@
-// hp_ntt_generic.hip -- simple one-stage-at-a-time negacyclic transforms for any logN in [1,15].
+// hp_ntt_generic.hip -- simple one-stage-at-a-time negacyclic transforms for any logN in [1,16].
 //
 // These kernels exist for (a) sizes the tiled kernels do not cover (N < 2048: the reference's
-// own tests use N = 8, 16, 128) and (b) as an on-device cross-check of the tiled kernels
+// own tests use N = 8, 16, 128; N = 65536: the largest degree the reference's 16-bit bit reversal allows) and (b) as an on-device cross-check of the tiled kernels
 // (hp_ctx_set_force_generic).  One workgroup owns one limb; the limb lives in LDS when it fits
 // (N <= 8192) and in the destination buffer otherwise.  Every butterfly is exactly the
 // reference's (ntt.cpp:160-166), scheduled by stage with a barrier in between.

@@ -39,7 +39,7 @@ uint64_t get64(const unsigned char *p) { uint64_t v = 0; for (int i = 0; i < 8; 
 
 bool desc_ok(const hp_wire_desc *d) {
     if (!d || d->kind < HP_WIRE_POLY || d->kind > HP_WIRE_KSK) return false;
-    if (d->log_dimension < 1 || d->log_dimension > 15 || d->limbs < 1 || d->limbs > 32 || d->polys < 1) return false;
+    if (d->log_dimension < 1 || d->log_dimension > 16 || d->limbs < 1 || d->limbs > 32 || d->polys < 1) return false;
     if (d->kind == HP_WIRE_POLY && d->polys != 1) return false;
     if (d->kind == HP_WIRE_CT && d->polys != 2) return false;
     if (d->kind == HP_WIRE_QUAD_CT && d->polys != 3) return false;

@@ -77,7 +77,9 @@ def _run_cases(lib, big: bool) -> dict:
             out[f"montgomery128_q{q}"] = summary(lib.montgomery_128_lazy(q, np.stack([a, b % U(q)], axis=1)))
 
     # ---- single-limb transforms (tests/ntt_t.cpp grid + config primes) -----------
-    grid = [(q, l) for q in P.NTT_TEST_Q for l in (4, 7, 11, 12, 13, 14, 15)]
+    grid = [(q, l) for q in P.NTT_TEST_Q for l in (4, 7, 11, 12, 13, 14, 15, 16)]   # (16: the largest degree the reference's 16-bit
+    # bit reversal allows, permutation.h:41-55; needs 2^17 | q - 1)
+    grid += [(P.P50[1], 16), (P.P40[0], 16)]
     grid += [(q, 14) for q in P.C2_MODULI] + [(q, 15) for q in P.C3_MODULI_EXT] + [(q, 13) for q in P.C5_MODULI_EXT]
     for q, logn in grid:
         if (q - 1) % (2 << logn):

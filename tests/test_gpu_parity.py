@@ -41,7 +41,7 @@ def test_host_mod_arith(eng, orc, q):
     assert eng.host_barrett(q, np.zeros(0, dtype=U)).size == 0
 
 
-@pytest.mark.parametrize("logn", [1, 2, 4, 7, 10, 11, 12, 13, 14, 15])
+@pytest.mark.parametrize("logn", [1, 2, 4, 7, 10, 11, 12, 13, 14, 15, 16])
 @pytest.mark.parametrize("q", P.NTT_TEST_Q + [P.P50[0], P.P40[0]])
 def test_host_ntt_round_trip(eng, orc, logn, q):
     from hehub_amd.engine import InvalidArgument
@@ -122,6 +122,7 @@ SCHEME_CASES = [
     (12, [P.P50[1]] + P.P40[:4] + [P.P50[0]], 3),
     (P.C5_LOGN, P.C5_MODULI_EXT, 2),
     (14, P.P50[1:4] + [P.P50[0]], 2),     # C2 ring degree, fused drop-last-prime path
+    (16, [P.P40[0], 1125899902124033, P.P50[1]], 1),   # N = 65536 (primes = 1 mod 2^17): the largest degree the reference takes
 ]
 
 
@@ -230,7 +231,7 @@ def test_abi_rejects_bad_arguments(eng):
     buf = eng.empty((2, 2, 3, 1 << 11))
     ptr = eng._ptr(buf)
     # ring degree out of range, zero / too many limbs
-    assert lib.hp_dev_ntt(h, 16, 1, _u64arr(q40[:1]), 1, ptr) == capi.HP_EUNSUPPORTED   # N = 65536: beyond the kernels
+    assert lib.hp_dev_ntt(h, 17, 1, _u64arr(q40[:1]), 1, ptr) == capi.HP_EUNSUPPORTED   # N = 131072: beyond the reference's 16-bit bit reversal (permutation.h:41-55)
     assert lib.hp_dev_ntt(h, 0, 1, _u64arr(q40[:1]), 1, ptr) == capi.HP_EUNSUPPORTED
     assert lib.hp_dev_ckks_mult_relin_rescale(h, 11, 1, _u64arr(q40[:2]), 1, ptr, ptr, ptr, ptr) == capi.HP_EINVAL   # only one prime
     assert lib.hp_dev_ext_prod_montgomery(h, 11, 40, _u64arr(q40[:1] * 41), 1, ptr, ptr, ptr) == capi.HP_EINVAL
