@@ -39,6 +39,12 @@ SIGNATURES = {
     "hp_host_free": (INT, [P, P]),
     "hp_memcpy_h2d": (INT, [P, P, P, szt]),
     "hp_memcpy_d2h": (INT, [P, P, P, szt]),
+    "hp_host_register": (INT, [P, P, szt]),
+    "hp_host_unregister": (INT, [P, P]),
+    "hp_memcpy_h2d_async": (INT, [P, P, P, szt]),
+    "hp_memcpy_d2h_async": (INT, [P, P, P, szt]),
+    "hp_dev_store_host_rows": (INT, [P, szt, szt, P, P]),
+    "hp_dev_load_host_rows": (INT, [P, szt, szt, P, P]),
     "hp_ctx_set_force_generic": (INT, [P, INT]),
     "hp_ctx_set_parity_level": (INT, [P, INT]),
     "hp_ctx_get_parity_level": (INT, [P]),

@@ -470,6 +470,67 @@ int hp_memcpy_d2h(hp_ctx *ctx, void *dst, const void *src, size_t bytes) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return HP_OK;
 }
+// Host memory the CALLER owns, made DMA-able in place (hipHostRegister): transfers from / to it then run at the link rate and
+// asynchronously, without the runtime's internal staging of pageable memory.
+int hp_host_register(hp_ctx *ctx, void *hptr, size_t bytes) {
+    HP_ENTER(ctx);
+    HP_REQUIRE(ctx, hptr);
+    hipError_t e = hipHostRegister(hptr, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ctx, HP_EHIP, std::string("hipHostRegister: ") + hipGetErrorString(e));
+    }
+    return HP_OK;
+}
+int hp_host_unregister(hp_ctx *ctx, void *hptr) {
+    HP_ENTER(ctx);
+    HP_REQUIRE(ctx, hptr);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipHostUnregister(hptr));
+    return HP_OK;
+}
+// enqueue only: the host buffer must stay untouched (h2d: unmodified; d2h: unread) until hp_sync() or a synchronous call returns
+int hp_memcpy_h2d_async(hp_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    HP_ENTER(ctx);
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return HP_OK;
+}
+int hp_memcpy_d2h_async(hp_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    HP_ENTER(ctx);
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return HP_OK;
+}
+// One polynomial between contiguous device rows and separate registered host blocks, by ONE kernel over PCIe (enqueue only).
+static int host_rows(hp_ctx *ctx, bool to_host, size_t rows, size_t words, u64 *dev, void *const *h_rows) {
+    HP_ENTER(ctx);
+    HP_REQUIRE(ctx, dev, h_rows);
+    HP_ALIGNED(ctx, dev);
+    if (words & 1) return fail(ctx, HP_EINVAL, "host rows: an even number of words per row");
+    for (size_t r0 = 0; r0 < rows; r0 += HP_HOST_ROWS_MAX) {
+        const size_t cnt = rows - r0 < HP_HOST_ROWS_MAX ? rows - r0 : HP_HOST_ROWS_MAX;
+        HpHostRows hr;
+        for (size_t r = 0; r < cnt; r++) {
+            if (!h_rows[r0 + r] || ((uintptr_t)h_rows[r0 + r] & 15u)) return fail(ctx, HP_EINVAL, "host rows: NULL or misaligned row");
+            void *d = nullptr;
+            hipError_t e = hipHostGetDevicePointer(&d, h_rows[r0 + r], 0);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(ctx, HP_EINVAL, "host rows: a row is not registered host memory (hp_host_register / hp_host_alloc)");
+            }
+            hr.p[r] = (u64 *)d;
+        }
+        ProfScope ps(ctx, "copy");
+        int rc = chk(ctx, hp_launch_host_rows(to_host, hr, (u32)cnt, words, dev + r0 * words, ctx->stream), "host rows");
+        if (rc) return rc;
+    }
+    return HP_OK;
+}
+int hp_dev_store_host_rows(hp_ctx *ctx, size_t rows, size_t words, const uint64_t *d_src, uint64_t *const *h_rows) {
+    return host_rows(ctx, true, rows, words, const_cast<u64 *>(d_src), (void *const *)h_rows);
+}
+int hp_dev_load_host_rows(hp_ctx *ctx, size_t rows, size_t words, uint64_t *d_dst, const uint64_t *const *h_rows) {
+    return host_rows(ctx, false, rows, words, d_dst, (void *const *)h_rows);
+}
 int hp_ctx_set_force_generic(hp_ctx *ctx, int on) {
     HP_ENTER(ctx);
     ctx->force_generic = on != 0;

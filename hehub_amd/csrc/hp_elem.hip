@@ -171,6 +171,27 @@ hipError_t hp_launch_copy(size_t words, const u64 *in, u64 *out, hipStream_t str
     return hipSuccess;
 }
 
+// ---- rows that live in separate blocks of registered HOST memory (hehub's SmartArray limbs, allocator.h:105-223) ------------------
+// One kernel moves a whole polynomial between its contiguous device rows and its scattered host blocks through their device-visible
+// addresses: 47-49 GB/s over PCIe either way against 11-17 GB/s for one DMA command per 256 KiB block (tools/ubench_pcie.hip).
+template <bool TO_HOST> __global__ void __launch_bounds__(256) k_host_rows(HpHostRows rows, u64 *dev, size_t pairs) {
+    typedef u64 __attribute__((ext_vector_type(2))) vv;
+    vv *d = reinterpret_cast<vv *>(dev) + (size_t)blockIdx.y * pairs;
+    vv *h = reinterpret_cast<vv *>(rows.p[blockIdx.y]);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {
+        if (TO_HOST) h[i] = d[i];
+        else d[i] = h[i];
+    }
+}
+hipError_t hp_launch_host_rows(bool to_host, const HpHostRows &rows, u32 count, size_t words, u64 *dev, hipStream_t stream) {
+    if (count == 0 || words == 0) return hipSuccess;
+    const size_t pairs = words >> 1;
+    const unsigned gx = (unsigned)((pairs + 256 * 16 - 1) / (256 * 16));   // 16 pairs per thread
+    if (to_host) k_host_rows<true><<<dim3(gx ? gx : 1, count), 256, 0, stream>>>(rows, dev, pairs);
+    else k_host_rows<false><<<dim3(gx ? gx : 1, count), 256, 0, stream>>>(rows, dev, pairs);
+    return hipGetLastError();
+}
+
 // ---- gathers: permutation.cpp:28-75 -------------------------------------------------
 __global__ void __launch_bounds__(ELEM_THREADS) k_gather(const u32 *__restrict__ perm, u32 n, u32 chunks,
                                                         const u64 *__restrict__ in, u64 *__restrict__ out) {

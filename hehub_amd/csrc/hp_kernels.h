@@ -69,6 +69,12 @@ hipError_t hp_launch_poly_scalar_mul(const HpLimb *limbs, const HpScalars &sc, u
 hipError_t hp_launch_poly_strict(const HpLimb *limbs, u32 L, u32 n, u32 rows, u64 *x, hipStream_t stream);
 // out = in, `words` u64 (16-byte aligned rows; an odd last word goes through hipMemcpyAsync)
 hipError_t hp_launch_copy(size_t words, const u64 *in, u64 *out, hipStream_t stream);
+// rows of a polynomial in separate blocks of registered host memory (device-visible addresses), moved by one kernel
+#define HP_HOST_ROWS_MAX 64
+struct HpHostRows {
+    u64 *p[HP_HOST_ROWS_MAX];
+};
+hipError_t hp_launch_host_rows(bool to_host, const HpHostRows &rows, u32 count, size_t words, u64 *dev, hipStream_t stream);
 hipError_t hp_launch_gather(const u32 *perm, u32 n, u32 rows, const u64 *in, u64 *out, hipStream_t stream);
 hipError_t hp_launch_reverse(u32 n, u32 rows, const u64 *in, u64 *out, hipStream_t stream);
 

@@ -28,7 +28,7 @@ struct hp_ctx;
 namespace hehub { namespace amd {
 hp_ctx *engine();
 struct TransferStats {
-    unsigned long long h2d_bytes = 0, d2h_bytes = 0, h2d_copies = 0, d2h_copies = 0, engine_calls = 0;
+    unsigned long long h2d_bytes = 0, d2h_bytes = 0, h2d_copies = 0, d2h_copies = 0, engine_calls = 0, host_blocks_registered = 0;
 };
 } }
 #else
@@ -37,6 +37,7 @@ struct TransferStats {
 
 #include "../../include/hehub_amd.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -46,6 +47,7 @@ struct TransferStats {
 #include <memory>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 
 namespace hehub {
 
@@ -86,6 +88,8 @@ void check(int rc) {
     g_stats.engine_calls++;
     if (rc == HP_OK) return;
     std::string msg = hp_last_error(engine());   // the calling thread's own last failure (hp_ctx.cpp)
+    (void)hp_sync(engine());   // operands may have been enqueued for upload from the caller's memory (limb_copy_h2d): let them finish
+                               // before the exception hands that memory back
     if (rc == HP_EINVAL) throw std::invalid_argument(msg);
     if (rc == HP_ELOGIC) throw std::logic_error(msg);
     throw std::runtime_error("hehub_amd: " + msg);
@@ -96,9 +100,10 @@ void check(int rc) {
 struct Report {
     ~Report() {
         if (std::getenv("HEHUB_AMD_VERBOSE"))
-            std::fprintf(stderr, "hehub_amd: %llu engine calls (%s); PCIe: %llu copies / %.1f MiB to the device, %llu copies / %.1f MiB back\n",
+            std::fprintf(stderr, "hehub_amd: %llu engine calls (%s); PCIe: %llu copies / %.1f MiB to the device, %llu copies / %.1f MiB back; "
+                                 "%llu host blocks registered for DMA\n",
                          g_stats.engine_calls, hp_version(), g_stats.h2d_copies, g_stats.h2d_bytes / 1048576.0, g_stats.d2h_copies,
-                         g_stats.d2h_bytes / 1048576.0);
+                         g_stats.d2h_bytes / 1048576.0, g_stats.host_blocks_registered);
     }
 } g_report;
 
@@ -169,6 +174,135 @@ void d2h(u64 *dst, const u64 *src, size_t words) {
 }
 
 TransferStats transfer_stats() { return g_stats; }
+
+// ---- limbs that live in host memory the CALLER owns (hehub's SmartArray blocks, allocator.h:105-223) ---------------------
+// hehub's pool recycles its blocks and never gives one back to the OS (allocator.h:19-22,45-49,204-210), so a block can be
+// registered with the driver ONCE (hipHostRegister) and from then on crosses PCIe by DMA at the link rate, asynchronously, instead
+// of through the runtime's staging copy of pageable memory (4-5 x slower at 256 KiB).  Only blocks of at least 128 KiB are
+// registered: glibc maps those on their own pages, smaller ones share pages with other heap objects.  HEHUB_AMD_PIN_HOST=0
+// turns it off.  limb_copy_* only ENQUEUE; limb_copies_wait() is called once per engine call, after the last download.
+namespace {
+struct PinSet {
+    std::mutex mu;
+    std::unordered_map<const void *, bool> seen;   // block -> registered (false: the driver refused, do not ask again)
+    bool on = true;
+};
+PinSet &pins() {
+    static PinSet &p = *[] {
+        PinSet *q = new PinSet;
+        if (const char *e = std::getenv("HEHUB_AMD_PIN_HOST")) q->on = std::atoi(e) != 0;
+        return q;
+    }();
+    return p;
+}
+bool pinned_block(const u64 *p, size_t words) {
+#ifndef HEHUB_AMD_BIND_REFERENCE
+    // own mirror: limbs are std::vector buffers, which DO go back to the OS when they die -- a registration would outlive the
+    // mapping.  (The mirror keeps its words on the device anyway and stages through its own page-locked buffer.)
+    (void)p; (void)words;
+    return false;
+#endif
+    PinSet &P = pins();
+    if (!P.on || words * sizeof(u64) < (128u << 10)) return false;
+    std::lock_guard<std::mutex> lk(P.mu);
+    auto it = P.seen.find(p);
+    if (it != P.seen.end()) return it->second;
+    const bool ok = hp_host_register(engine(), const_cast<u64 *>(p), words * sizeof(u64)) == HP_OK;
+    if (ok) g_stats.host_blocks_registered++;
+    P.seen.emplace(p, ok);
+    return ok;
+}
+} // namespace
+void limb_copy_h2d(u64 *dst, const u64 *src, size_t words) {
+    if (!pinned_block(src, words)) return h2d(dst, src, words);
+    check(hp_memcpy_h2d_async(engine(), dst, src, words * sizeof(u64)));
+    g_stats.h2d_bytes += words * 8;
+    g_stats.h2d_copies++;
+}
+void limb_copy_d2h(u64 *dst, const u64 *src, size_t words) {
+    if (!pinned_block(dst, words)) return d2h(dst, src, words);
+    check(hp_memcpy_d2h_async(engine(), dst, src, words * sizeof(u64)));
+    g_stats.d2h_bytes += words * 8;
+    g_stats.d2h_copies++;
+}
+// Limbs that cannot be registered (smaller than 128 KiB: they share pages with other heap objects) cross PCIe through a page-locked
+// arena instead, a whole polynomial per DMA: packed by memcpy on the way up, unpacked after the wait on the way down.
+namespace {
+struct Arena {
+    u64 *buf = nullptr;
+    size_t cap = 0, used = 0;
+    struct Pending { std::vector<u64 *> rows; const u64 *st; size_t n; };
+    std::vector<Pending> down;
+};
+Arena &arena() { static Arena &a = *new Arena; return a; }
+void arena_flush() {   // everything enqueued so far has happened; hand the downloaded words to their limbs
+    Arena &A = arena();
+    check(hp_sync(engine()));
+    for (auto &p : A.down)
+        for (size_t k = 0; k < p.rows.size(); k++) std::memcpy(p.rows[k], p.st + k * p.n, p.n * sizeof(u64));
+    A.down.clear();
+    A.used = 0;
+}
+u64 *arena_take(size_t words) {
+    Arena &A = arena();
+    if (A.used + words > A.cap) {
+        arena_flush();
+        if (words > A.cap) {
+            if (A.buf) (void)hp_host_free(engine(), A.buf);
+            void *p = nullptr;
+            const size_t want = std::max(words, (size_t)1 << 20);   // at least 8 MiB
+            check(hp_host_alloc(engine(), want * sizeof(u64), &p));
+            A.buf = (u64 *)p;
+            A.cap = want;
+        }
+    }
+    u64 *r = A.buf + A.used;
+    A.used += (words + 1) & ~(size_t)1;
+    return r;
+}
+} // namespace
+void limb_copies_wait() { arena_flush(); }
+// a whole polynomial at once: when every limb is a registered block, ONE kernel moves all of them over PCIe (47-49 GB/s against
+// 11-17 GB/s for a DMA command per block); otherwise one DMA through the page-locked arena
+template <class Vec> void poly_copy_h2d(u64 *dst, const Vec &v, size_t limbs, size_t n) {
+    if (limbs == 0 || n == 0) return;
+    bool all = limbs >= 2;
+    for (size_t k = 0; k < limbs && all; k++) all = pinned_block(v[(int)k].data(), n);
+    if (all) {
+        std::vector<const u64 *> rows(limbs);
+        for (size_t k = 0; k < limbs; k++) rows[k] = v[(int)k].data();
+        check(hp_dev_load_host_rows(engine(), limbs, n, dst, rows.data()));
+    } else if (limbs == 1 && pinned_block(v[0].data(), n)) {
+        check(hp_memcpy_h2d_async(engine(), dst, v[0].data(), n * sizeof(u64)));
+    } else {
+        u64 *st = arena_take(limbs * n);
+        for (size_t k = 0; k < limbs; k++) std::memcpy(st + k * n, v[(int)k].data(), n * sizeof(u64));
+        check(hp_memcpy_h2d_async(engine(), dst, st, limbs * n * sizeof(u64)));
+    }
+    g_stats.h2d_bytes += limbs * n * 8;
+    g_stats.h2d_copies++;
+}
+template <class Vec> void poly_copy_d2h(Vec &v, const u64 *src, size_t limbs, size_t n) {
+    if (limbs == 0 || n == 0) return;
+    bool all = limbs >= 2;
+    for (size_t k = 0; k < limbs && all; k++) all = pinned_block(v[(int)k].data(), n);
+    if (all) {
+        std::vector<u64 *> rows(limbs);
+        for (size_t k = 0; k < limbs; k++) rows[k] = v[(int)k].data();
+        check(hp_dev_store_host_rows(engine(), limbs, n, src, rows.data()));
+    } else if (limbs == 1 && pinned_block(v[0].data(), n)) {
+        check(hp_memcpy_d2h_async(engine(), v[0].data(), src, n * sizeof(u64)));
+    } else {
+        u64 *st = arena_take(limbs * n);
+        check(hp_memcpy_d2h_async(engine(), st, src, limbs * n * sizeof(u64)));
+        Arena::Pending p;
+        p.st = st; p.n = n;
+        for (size_t k = 0; k < limbs; k++) p.rows.push_back(v[(int)k].data());
+        arena().down.push_back(std::move(p));
+    }
+    g_stats.d2h_bytes += limbs * n * 8;
+    g_stats.d2h_copies++;
+}
 
 #ifndef HEHUB_AMD_BIND_REFERENCE
 // A polynomial's limbs are separate host vectors but one contiguous device view: they cross PCIe as ONE copy through a
@@ -406,18 +540,22 @@ struct Access {
         if (cache_get(v, limbs, blk, off)) return Src{blk->p + off, blk};
         const size_t n = v.dimension();
         blk = alloc_block(limbs * n);
-        for (size_t k = 0; k < limbs; k++) h2d(blk->p + k * n, v[(int)k].data(), n);
+        // (enqueued; the call that consumes the block ends with the download of its result and limb_copies_wait())
+        poly_copy_h2d(blk->p, v, limbs, n);
         cache_put(v, limbs, blk, 0);
         return Src{blk->p, blk};
     }
     static void shape(RnsIntVec &v, size_t n, size_t limbs, const std::vector<u64> &moduli) {
         v = RnsIntVec(RnsIntVec::Params{n, limbs, std::vector<u64>(moduli.begin(), moduli.begin() + limbs)});
     }
-    // hehub's object is host memory: the result comes back now; the device copy is remembered for the next consumer
+    // hehub's object is host memory: the result comes back now; the device copy is remembered for the next consumer.
+    // Several polynomials of one result (the halves of a ciphertext) are enqueued together and waited for once.
+    static void bind_enqueue(RnsIntVec &v, const Dst &d, size_t off, size_t limbs) { poly_copy_d2h(v, d.p + off, limbs, v.dimension()); }
+    static void bind_finish(RnsIntVec &v, const Dst &d, size_t off, size_t limbs) { cache_put(v, limbs, d.blk, off); }
     static void bind(RnsIntVec &v, const Dst &d, size_t off, size_t limbs) {
-        const size_t n = v.dimension();
-        for (size_t k = 0; k < limbs; k++) d2h(v[(int)k].data(), d.p + off + k * n, n);
-        cache_put(v, limbs, d.blk, off);
+        bind_enqueue(v, d, off, limbs);
+        limb_copies_wait();   // hehub's object is host memory the caller may read as soon as we return
+        bind_finish(v, d, off, limbs);
     }
     static bool adjacent(const RnsIntVec &a, const RnsIntVec &b, size_t limbs) {
         BlockRef ba, bb;
@@ -688,7 +826,7 @@ private:
                 check(hp_dev_copy(amd::engine(), (L + 1) * n, s.p, row));
                 Access::drop_device_copy(rgsw[j][h]);     // the assembled block is the key's device form: no second 55 MiB
 #else
-                for (size_t k = 0; k <= L; k++) amd::h2d(row + k * n, rgsw[j][h][(int)k].data(), n);
+                amd::poly_copy_h2d(row, rgsw[j][h], L + 1, n);
 #endif
             }
     }
@@ -698,7 +836,13 @@ private:
 // the two polynomials of a result ciphertext as views of the block an engine call filled: [2][L][N]
 RlweCt make_ct(size_t n, size_t L, const std::vector<u64> &moduli, const Dst &d) {
     RlweCt ct{result_poly(n, L, moduli, PolyRepForm::value), result_poly(n, L, moduli, PolyRepForm::value)};
+#ifdef HEHUB_AMD_BIND_REFERENCE
+    for (int h = 0; h < 2; h++) Access::bind_enqueue(ct[h], d, (size_t)h * L * n, L);
+    amd::limb_copies_wait();
+    for (int h = 0; h < 2; h++) Access::bind_finish(ct[h], d, (size_t)h * L * n, L);
+#else
     for (int h = 0; h < 2; h++) Access::bind(ct[h], d, (size_t)h * L * n, L);
+#endif
     return ct;
 }
 
@@ -735,10 +879,19 @@ template <class Quad, class Ct> Quad mult_low_level_common(const Ct &ct1, const 
     Dst dq(3 * L * n);
     check(hp_dev_mult_low_level(amd::engine(), ct1[0].log_dimension(), L, m1.data(), 1, d1.p, d2.p, dq.p));
     Quad quad;
+#ifdef HEHUB_AMD_BIND_REFERENCE
+    for (int h = 0; h < 3; h++) {
+        quad[h] = result_poly(n, L, m1, PolyRepForm::value);
+        Access::bind_enqueue(quad[h], dq, (size_t)h * L * n, L);
+    }
+    amd::limb_copies_wait();
+    for (int h = 0; h < 3; h++) Access::bind_finish(quad[h], dq, (size_t)h * L * n, L);
+#else
     for (int h = 0; h < 3; h++) {
         quad[h] = result_poly(n, L, m1, PolyRepForm::value);
         Access::bind(quad[h], dq, (size_t)h * L * n, L);
     }
+#endif
     return quad;
 }
 
@@ -750,10 +903,24 @@ void drop_last_prime(RlweCt &ct, bool bgv, u64 t) {
     const std::vector<u64> m(ct[0].modulus_vec());
     if (bgv) check(hp_dev_bgv_mod_switch(amd::engine(), logn, L, m.data(), t, 1, din.p, dout.p));
     else check(hp_dev_ckks_rescale(amd::engine(), logn, L, m.data(), 1, din.p, dout.p));
+#ifdef HEHUB_AMD_BIND_REFERENCE
+    // remove_components hands the last limb's block back to hehub's pool, whose free list writes its link into the block's first
+    // word (allocator.h:67-71): the (asynchronous) upload of that limb must have happened by then
+    amd::limb_copies_wait();
+#endif
+#ifdef HEHUB_AMD_BIND_REFERENCE
+    for (int h = 0; h < 2; h++) {
+        ct[h].remove_components();
+        Access::bind_enqueue(ct[h], dout, (size_t)h * (L - 1) * n, L - 1);
+    }
+    amd::limb_copies_wait();
+    for (int h = 0; h < 2; h++) Access::bind_finish(ct[h], dout, (size_t)h * (L - 1) * n, L - 1);
+#else
     for (int h = 0; h < 2; h++) {
         ct[h].remove_components();
         Access::bind(ct[h], dout, (size_t)h * (L - 1) * n, L - 1);
     }
+#endif
 }
 
 } // namespace

@@ -58,7 +58,7 @@ struct DevBlock;   // a pooled device allocation (hehub.cpp)
 struct Access;     // the binding's view of a vector's two copies (hehub.cpp)
 /// bytes and calls that crossed PCIe through this layer since the process started, and engine calls made
 struct TransferStats {
-    unsigned long long h2d_bytes = 0, d2h_bytes = 0, h2d_copies = 0, d2h_copies = 0, engine_calls = 0;
+    unsigned long long h2d_bytes = 0, d2h_bytes = 0, h2d_copies = 0, d2h_copies = 0, engine_calls = 0, host_blocks_registered = 0;
 };
 TransferStats transfer_stats();
 } // namespace amd

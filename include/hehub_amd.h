@@ -104,6 +104,20 @@ int hp_host_alloc(hp_ctx *ctx, size_t bytes, void **hptr);
 int hp_host_free(hp_ctx *ctx, void *hptr);
 int hp_memcpy_h2d(hp_ctx *ctx, void *dst, const void *src, size_t bytes);
 int hp_memcpy_d2h(hp_ctx *ctx, void *dst, const void *src, size_t bytes);
+/* Host memory the caller owns, made DMA-able in place (hipHostRegister) -- the limbs of hehub's SmartArray pool
+ * (allocator.h:19-22: blocks are recycled, never returned to the OS) can be registered once and then cross PCIe at the link rate
+ * without the runtime's staging of pageable memory.  The *_async copies only enqueue on the ctx stream: the host buffer must stay
+ * untouched until hp_sync() (or any synchronous hp_* call on the ctx) returns. */
+int hp_host_register(hp_ctx *ctx, void *hptr, size_t bytes);
+int hp_host_unregister(hp_ctx *ctx, void *hptr);
+int hp_memcpy_h2d_async(hp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int hp_memcpy_d2h_async(hp_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+/* A polynomial whose limbs are SEPARATE registered host blocks (rns.h:15-156: one SmartArray per limb) <-> its contiguous device rows
+ * u64[rows][words], by ONE kernel that reads / writes the host blocks over PCIe: 47-49 GB/s either way on an MI355X against
+ * 11-17 GB/s for one DMA command per 256 KiB block (tools/ubench_pcie.hip, profiles/r04_ubench_pcie.txt).  Every h_rows[r] must be
+ * 16-byte aligned memory from hp_host_alloc or registered with hp_host_register; words even.  Enqueue only (see above). */
+int hp_dev_store_host_rows(hp_ctx *ctx, size_t rows, size_t words, const uint64_t *d_src, uint64_t *const *h_rows);
+int hp_dev_load_host_rows(hp_ctx *ctx, size_t rows, size_t words, uint64_t *d_dst, const uint64_t *const *h_rows);
 /* force the simple one-stage-at-a-time transform kernels (debug / cross-check) */
 int hp_ctx_set_force_generic(hp_ctx *ctx, int on);
 /* timing of the last profiled launch group: see hp_prof_* below */

@@ -8,5 +8,9 @@ for a in "15 10 24" "13 6 24"; do
   [ -x oracle/_ref/ref_chain_cpu ] && { echo "== hehub on the CPU (oracle/_ref/ref_chain_cpu $a)"; oracle/_ref/ref_chain_cpu $a; }
   [ -x oracle/_ref/ref_chain_amd ] && { echo "== hehub's headers over the binding, HEHUB_AMD_CT_CACHE=64 HEHUB_AMD_KEY_CACHE=4"
                                         HEHUB_AMD_CT_CACHE=64 HEHUB_AMD_KEY_CACHE=4 HEHUB_AMD_VERBOSE=1 oracle/_ref/ref_chain_amd $a 2>&1
+                                        echo "== hehub's headers over the binding, HEHUB_AMD_KEY_CACHE=4 only"
+                                        HEHUB_AMD_KEY_CACHE=4 HEHUB_AMD_VERBOSE=1 oracle/_ref/ref_chain_amd $a 2>&1
+                                        echo "== hehub's headers over the binding, no caches, HEHUB_AMD_PIN_HOST=0 (round-3 transfers: one pageable copy per limb)"
+                                        HEHUB_AMD_PIN_HOST=0 HEHUB_AMD_VERBOSE=1 oracle/_ref/ref_chain_amd $a 2>&1
                                         echo "== hehub's headers over the binding, no caches"; HEHUB_AMD_VERBOSE=1 oracle/_ref/ref_chain_amd $a 2>&1; }
 done
