@@ -85,6 +85,7 @@ SIGNATURES = {
     "hp_dev_ks_inner_range": (INT, [P, szt, szt, P, szt, szt, szt, P, P, szt, P, P]),
     "hp_dev_drop_coeffs": (INT, [P, szt, szt, P, u64, szt, P, P]),
     "hp_dev_drop_apply_range": (INT, [P, szt, szt, P, u64, szt, szt, szt, P, P, P, szt, szt, C.c_uint, P]),
+    "hp_dev_drop_apply_range_strict": (INT, [P, szt, szt, P, u64, szt, szt, szt, P, P, P, szt, szt, C.c_uint, P]),
     "hp_node_create": (INT, [P, szt, C.POINTER(P)]),
     "hp_node_destroy": (None, [P]),
     "hp_node_size": (szt, [P]),

@@ -586,8 +586,8 @@ int hp_dev_drop_coeffs(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *modul
     return drop_coeffs(ctx, plan, logn, L, P2, plain_modulus != 0, plain_modulus, x, clast);
 }
 
-int hp_dev_drop_apply_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, uint64_t plain_modulus, size_t P2,
-                            size_t k0, size_t k1, const uint64_t *x, const uint64_t *clast, const uint64_t *addend,
+static int drop_apply_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, uint64_t plain_modulus, size_t P2,
+                            size_t k0, size_t k1, const uint64_t *x, const uint64_t *clast, bool clast_strict, const uint64_t *addend,
                             size_t add_poly_stride, size_t add_ct_stride, unsigned add_mask, uint64_t *out) {
     HP_ENTER(ctx);
     HP_REQUIRE(ctx, moduli, x, clast, out);
@@ -605,7 +605,18 @@ int hp_dev_drop_apply_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *
     u64 *rem = cv.take(P2 * (k1 - k0) * n);
     HpDropConsts dc;
     make_drop_consts(plan, L, plain_modulus != 0, plain_modulus, dc);
-    return drop_apply(ctx, plan, logn, L, P2, k0, k1, dc, x, clast, false, addend, add_poly_stride, add_ct_stride, add_mask, out, rem);
+    return drop_apply(ctx, plan, logn, L, P2, k0, k1, dc, x, clast, clast_strict, addend, add_poly_stride, add_ct_stride, add_mask, out, rem);
+}
+
+int hp_dev_drop_apply_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, uint64_t plain_modulus, size_t P2,
+                            size_t k0, size_t k1, const uint64_t *x, const uint64_t *clast, const uint64_t *addend,
+                            size_t add_poly_stride, size_t add_ct_stride, unsigned add_mask, uint64_t *out) {
+    return drop_apply_range(ctx, logn, L, moduli, plain_modulus, P2, k0, k1, x, clast, false, addend, add_poly_stride, add_ct_stride, add_mask, out);
+}
+int hp_dev_drop_apply_range_strict(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, uint64_t plain_modulus, size_t P2,
+                                   size_t k0, size_t k1, const uint64_t *x, const uint64_t *clast, const uint64_t *addend,
+                                   size_t add_poly_stride, size_t add_ct_stride, unsigned add_mask, uint64_t *out) {
+    return drop_apply_range(ctx, logn, L, moduli, plain_modulus, P2, k0, k1, x, clast, true, addend, add_poly_stride, add_ct_stride, add_mask, out);
 }
 
 } // extern "C"

@@ -547,7 +547,7 @@ int sharded_run(hp_node_sharded *p, const uint64_t *h_ct1, const uint64_t *h_ct2
         if (all_ok() && !rc && r != own_p) step(recv_block(p, r, 1, s, own_p, R.c_p));
         // stage 3: drop p on the owned limbs (+= d0, d1); the owner of q_{L-1} prepares that limb's coefficients
         if (!rc && all_ok())
-            step(hp_dev_drop_apply_range(c, logn, L + 1, mext, inner_t, 2 * B, a0, a1, R.ks, R.c_p, R.quad, L, 3 * L, 3, R.relin));
+            step(hp_dev_drop_apply_range_strict(c, logn, L + 1, mext, inner_t, 2 * B, a0, a1, R.ks, R.c_p, R.quad, L, 3 * L, 3, R.relin));
         if (!rc && all_ok() && r == own_q) {
             step(hp_dev_drop_coeffs(c, logn, L, mext, p->t, 2 * B, R.relin, R.c_q));
             if (!rc) step(send_block(p, r, 2, s, R.c_q, [&](size_t d) { return p->rk[d].c_q; }, everyone));
@@ -557,7 +557,7 @@ int sharded_run(hp_node_sharded *p, const uint64_t *h_ct1, const uint64_t *h_ct2
         if (all_ok() && !rc && r != own_q) step(recv_block(p, r, 2, s, own_q, R.c_q));
         // stage 4: drop q_{L-1} on the owned limbs; result limbs go to rank 0 (and to the caller's per-rank buffers)
         uint64_t *out = d_out ? d_out[r] : R.out;
-        if (!rc && all_ok()) step(hp_dev_drop_apply_range(c, logn, L, mext, p->t, 2 * B, b0, b1, R.relin, R.c_q, nullptr, 0, 0, 0, out));
+        if (!rc && all_ok()) step(hp_dev_drop_apply_range_strict(c, logn, L, mext, p->t, 2 * B, b0, b1, R.relin, R.c_q, nullptr, 0, 0, 0, out));
         if (!rc && all_ok()) {
             if (d_out) step(send_block(p, r, 3, s, out, [&](size_t d) { return d_out[d]; }, everyone));   // every rank ends up with the whole result
             else if (r != 0) step(send_block(p, r, 3, s, out, [&](size_t d) { return p->rk[d].out; }, [](size_t d) { return d == 0; }));

@@ -211,6 +211,12 @@ class Engine:
     def copy(self, src, out=None):
         """deep copy of device words (hp_dev_copy)"""
         out = self.empty(src.shape) if out is None else out
+        # the kernel writes src.numel() words at out's address: a short, strided or foreign `out` would be written past its end
+        for t in (src, out):
+            if t.element_size() != 8 or not t.is_contiguous() or t.device.type != "cuda" or t.device.index != self.device:
+                raise InvalidArgument(capi.HP_EINVAL, "copy: contiguous 8-byte tensors on the engine's device")
+        if out.numel() != src.numel():
+            raise InvalidArgument(capi.HP_EINVAL, f"copy: out holds {out.numel()} words, src {src.numel()}")
         self._chk(self.lib.hp_dev_copy(self.h, src.numel(), self._ptr(src), self._ptr(out)))
         return out
 

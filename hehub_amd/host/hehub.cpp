@@ -28,7 +28,8 @@ struct hp_ctx;
 namespace hehub { namespace amd {
 hp_ctx *engine();
 struct TransferStats {
-    unsigned long long h2d_bytes = 0, d2h_bytes = 0, h2d_copies = 0, d2h_copies = 0, engine_calls = 0, host_blocks_registered = 0;
+    unsigned long long h2d_bytes = 0, d2h_bytes = 0, h2d_copies = 0, d2h_copies = 0, engine_calls = 0, host_blocks_registered = 0,
+                       device_copies_invalidated = 0;
 };
 } }
 #else
@@ -431,6 +432,7 @@ struct Access {
     }
     static void host_written(RnsIntVec &v) {
         sync_host(v);
+        if (v.dev_ok_) g_stats.device_copies_invalidated++;   // a non-const access: the next engine call uploads the vector again
         v.dev_ok_ = false;
         v.stamp_ = next_stamp();
     }

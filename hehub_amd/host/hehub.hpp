@@ -59,6 +59,10 @@ struct Access;     // the binding's view of a vector's two copies (hehub.cpp)
 /// bytes and calls that crossed PCIe through this layer since the process started, and engine calls made
 struct TransferStats {
     unsigned long long h2d_bytes = 0, d2h_bytes = 0, h2d_copies = 0, d2h_copies = 0, engine_calls = 0, host_blocks_registered = 0;
+    // device copies thrown away because host words were handed out WRITABLE (operator[], components(), begin() / end() / last() on a
+    // non-const vector): each one costs a re-upload at the next engine call (and a key-cache miss for a key polynomial).  Code that
+    // only reads should go through view() / a const reference; this counter shows when it does not.
+    unsigned long long device_copies_invalidated = 0;
 };
 TransferStats transfer_stats();
 } // namespace amd
@@ -94,6 +98,10 @@ public:
     // words as of that moment: after the next engine call on the vector, ask again.
     ComponentData &operator[](int k) { return host_rw()[k]; }
     const ComponentData &operator[](int k) const { return host_ro()[k]; }
+    /// read-only words of limb k / of all limbs WITHOUT giving up the device copy, also on a non-const vector (`ct[0].view(k)[i]`):
+    /// what a caller that only looks at a result should use -- operator[] on a non-const vector must assume a write
+    const ComponentData &view(int k) const { return host_ro()[k]; }
+    const std::vector<ComponentData> &view() const { return host_ro(); }
     std::vector<ComponentData> &components() { return host_rw(); }
     const std::vector<ComponentData> &components() const { return host_ro(); }
     auto begin() { return host_rw().begin(); }

@@ -213,14 +213,14 @@ class ShardedMult:
             e._chk(lib.hp_dev_drop_coeffs(h, logn, L + 1, m_ext, inner_t, 2 * B, P(ks), P(c_p)))
         yield ("broadcast", c_p, own_p)
 
-        e._chk(lib.hp_dev_drop_apply_range(h, logn, L + 1, m_ext, inner_t, 2 * B, a0, a1, P(ks), P(c_p), P(quad), L, 3 * L, 3,
+        e._chk(lib.hp_dev_drop_apply_range_strict(h, logn, L + 1, m_ext, inner_t, 2 * B, a0, a1, P(ks), P(c_p), P(quad), L, 3 * L, 3,
                                            P(relin)))
         own_q = owner_of(L - 1, self.ranges)
         if rank == own_q:
             e._chk(lib.hp_dev_drop_coeffs(h, logn, L, m_ct, t, 2 * B, P(relin), P(c_q)))
         yield ("broadcast", c_q, own_q)
 
-        e._chk(lib.hp_dev_drop_apply_range(h, logn, L, m_ct, t, 2 * B, b0, b1, P(relin), P(c_q), None, 0, 0, 0, P(out)))
+        e._chk(lib.hp_dev_drop_apply_range_strict(h, logn, L, m_ct, t, 2 * B, b0, b1, P(relin), P(c_q), None, 0, 0, 0, P(out)))
         if gather_out:
             yield ("all_gather", out.view(2 * B, L - 1, n), clip(self.ranges, L - 1))
 

@@ -276,6 +276,13 @@ int hp_dev_drop_apply_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *
                             size_t P2, size_t k0, size_t k1, const uint64_t *d_x, const uint64_t *d_clast,
                             const uint64_t *d_addend, size_t add_poly_stride, size_t add_ct_stride, unsigned add_mask,
                             uint64_t *d_out);
+/* The same when the caller vouches that every word of clast is below q_last (the rows were written by hp_dev_drop_coeffs):
+ * where q_last <= 2 q_k the remainder of rescaling.cpp:54-58 is then one conditional subtraction instead of a Barrett quotient --
+ * the canonical residue either way, so the words are identical.  hp_dev_drop_apply_range makes no such assumption. */
+int hp_dev_drop_apply_range_strict(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, uint64_t plain_modulus,
+                                   size_t P2, size_t k0, size_t k1, const uint64_t *d_x, const uint64_t *d_clast,
+                                   const uint64_t *d_addend, size_t add_poly_stride, size_t add_ct_stride, unsigned add_mask,
+                                   uint64_t *d_out);
 
 /* ---- node: several GPUs behind one handle (hehub_amd/csrc/hp_node.cpp) ------------------------------------------
  * hehub is a single-threaded CPU library; an application that holds a BATCH of ciphertexts uses all GPUs of a node through

@@ -475,6 +475,16 @@ static void test_device_residency() {
     c += a;
     auto s4 = amd::transfer_stats();
     REQUIRE(s4.h2d_bytes == s3.h2d_bytes);
+    // view(): the same read-only look on a NON-const vector -- no invalidation, no upload at the next call
+    const u64 w2 = c.view(1)[17] + c.view()[0][0];
+    (void)w2;
+    c += a;
+    auto s4b = amd::transfer_stats();
+    REQUIRE(s4b.h2d_bytes == s3.h2d_bytes && s4b.device_copies_invalidated == s4.device_copies_invalidated);
+    // ... while operator[] on a non-const vector has to assume a write: counted, and the next call uploads the vector again
+    { RnsPolynomial g(c); (void)g.view(0)[0]; g += a; auto t0 = amd::transfer_stats(); const u64 r = g[0][0]; (void)r; g += a;
+      auto t1 = amd::transfer_stats();
+      REQUIRE(t1.device_copies_invalidated == t0.device_copies_invalidated + 1 && t1.h2d_bytes - t0.h2d_bytes == 3 * N * 8); }
     // a writable look makes the host copy the current one: the next engine call uploads it, and sees the change
     RnsPolynomial e(c);
     e[1][17] = (w + 1) % q[1];

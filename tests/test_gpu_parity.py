@@ -505,3 +505,58 @@ def test_dev_copy(eng):
     with pytest.raises(InvalidArgument, match="aligned"):
         eng._chk(eng.lib.hp_dev_copy(eng.h, 8, eng._ptr(buf), eng._ptr(buf[1:])))
     eng._chk(eng.lib.hp_dev_copy(eng.h, 0, eng._ptr(buf), eng._ptr(buf)))
+    # the Python wrapper refuses an `out` the kernel would overrun or misread: short, strided, 4-byte words, host memory
+    src = torch.arange(64, dtype=torch.int64, device="cuda:0")
+    for bad in (torch.zeros(32, dtype=torch.int64, device="cuda:0"), torch.zeros(128, dtype=torch.int64, device="cuda:0")[::2],
+                torch.zeros(64, dtype=torch.int32, device="cuda:0"), torch.zeros(64, dtype=torch.int64)):
+        with pytest.raises(InvalidArgument, match="copy:"):
+            eng.copy(src, out=bad)
+    assert torch.equal(eng.copy(src), src)
+
+
+def test_host_rows_over_pcie(eng):
+    """hp_host_register + hp_dev_store_host_rows / hp_dev_load_host_rows: a polynomial whose limbs are separate blocks of
+    caller-owned host memory (rns.h:15-156: one SmartArray per limb, allocator.h:105-223) crosses PCIe by one kernel"""
+    import ctypes as C
+
+    import torch
+
+    from hehub_amd import capi
+    from hehub_amd.engine import HpError, InvalidArgument
+
+    lib, h = eng.lib, eng.h
+    rows, n = 7, 32768
+    blocks = [np.zeros(n + 512, dtype=U) for _ in range(rows)]          # separate allocations, 256 KiB + slack each
+    views = []
+    for b in blocks:
+        off = (-b.ctypes.data // 8) % 2                                  # 16-byte aligned start
+        views.append(b[off:off + n])
+        assert lib.hp_host_register(h, C.c_void_p(b.ctypes.data), b.nbytes) == capi.HP_OK
+    ptrs = (C.c_void_p * rows)(*[v.ctypes.data for v in views])
+    src = torch.randint(-2**62, 2**62, (rows, n), dtype=torch.int64, device="cuda:0")
+    eng._chk(lib.hp_dev_store_host_rows(h, rows, n, eng._ptr(src), ptrs))
+    eng.sync()
+    host = src.cpu().numpy().view(U)
+    for r in range(rows):
+        assert np.array_equal(views[r], host[r])
+        views[r][:] = views[r] ^ U(0x5555)                                # the host changes its words ...
+    back = torch.zeros_like(src)
+    eng._chk(lib.hp_dev_load_host_rows(h, rows, n, eng._ptr(back), ptrs))
+    eng.sync()
+    assert np.array_equal(back.cpu().numpy().view(U), host ^ U(0x5555))  # ... and the device reads them
+    # a row that is plain pageable memory is refused, not read through a wild pointer
+    loose = np.zeros(n, dtype=U)
+    bad = (C.c_void_p * 1)(loose.ctypes.data)
+    with pytest.raises(InvalidArgument, match="not registered"):
+        eng._chk(lib.hp_dev_store_host_rows(h, 1, n, eng._ptr(src), bad))
+    with pytest.raises(InvalidArgument, match="even"):
+        eng._chk(lib.hp_dev_store_host_rows(h, rows, n - 1, eng._ptr(src), ptrs))
+    # asynchronous copies from / to a registered block
+    eng._chk(lib.hp_memcpy_d2h_async(h, C.c_void_p(views[0].ctypes.data), eng._ptr(src), n * 8))
+    eng.sync()
+    assert np.array_equal(views[0], host[0])
+    eng._chk(lib.hp_memcpy_h2d_async(h, eng._ptr(back), C.c_void_p(views[0].ctypes.data), n * 8))
+    eng.sync()
+    assert np.array_equal(back[0].cpu().numpy().view(U), host[0])
+    for b in blocks:
+        assert lib.hp_host_unregister(h, C.c_void_p(b.ctypes.data)) == capi.HP_OK
