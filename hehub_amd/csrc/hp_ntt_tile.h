@@ -358,8 +358,13 @@ HP_DEV void load_flight(const u64 *src, u32 tid, u64 (&x)[32]) {
 #define TRACE_DECL u64 tr__[HP_TRACE_SLOTS]; int tri__ = 0; tr__[10] = ((u64)__builtin_amdgcn_s_getreg(63492) << 32) | (u32)__builtin_amdgcn_s_getreg((31 << 11) | 20); tr__[11] = t_entry__;
 #define TRACE_ENTRY __builtin_amdgcn_sched_barrier(0); const u64 t_entry__ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
 #define TRACE_MARK() do { __builtin_amdgcn_sched_barrier(0); tr__[tri__++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#ifdef HP_TRACE_WAVES   // every wave of every 16th workgroup: record (blockIdx >> 4) * 16 + wave
+#define TRACE_FLUSH() do { if ((threadIdx.x & 63u) == 0 && HP_TRACE_SEL && (threadIdx.x >> 6) < 16) { \
+        for (int i__ = 0; i__ < HP_TRACE_SLOTS; i__++) g_trace[(HP_TRACE_IDX * 16 + (threadIdx.x >> 6)) * HP_TRACE_SLOTS + i__] = (i__ < tri__ || i__ >= 10) ? tr__[i__] : 0; } } while (0)
+#else
 #define TRACE_FLUSH() do { if ((threadIdx.x == 0 || threadIdx.x == blockDim.x - 64) && HP_TRACE_SEL) { \
         for (int i__ = 0; i__ < HP_TRACE_SLOTS; i__++) g_trace[(HP_TRACE_IDX * 2 + (threadIdx.x != 0)) * HP_TRACE_SLOTS + i__] = (i__ < tri__ || i__ >= 10) ? tr__[i__] : 0; } } while (0)
+#endif
 #else
 #define TRACE_DECL
 #define TRACE_ENTRY
