@@ -161,9 +161,19 @@ def level_a_section(run: Run, lib, wl):
             if launches:
                 r = roofline_entry(w.family, w.alg_bytes_per_step, steps, launches, kern_ms, dt, w.logn, True)
                 r["kernel"] = "k_ntt_fwd_a (register/LDS-tiled forward NTT, FP64 residue butterflies), digit-spread launch"
-                r["traffic"] = None
-                r.pop("valu_busy", None)
-                r.pop("traffic_source", None)
+                r["traffic"], _src, _vb = None, r.pop("traffic_source", None), r.pop("valu_busy", None)
+                try:   # the level-A kernel's own PMC entry (tools/traffic_from_pmc.py), never the integer kernel's
+                    import json as _json
+
+                    from .timing import TRAFFIC_FILE
+                    tr = _json.load(open(TRAFFIC_FILE)).get(f"k_ntt_fwd_a_logn{w.logn}_spread")
+                    if tr:
+                        r["traffic"] = tr["bytes_per_limb"] * r["algorithmic_bytes_per_launch"] / (16.0 * (1 << w.logn))
+                        r["traffic_source"] = f"rocprofv3 PMC per-limb measurement x limbs per launch (profiles/traffic.json: {tr.get('source')})"
+                        if "valu_busy" in tr:
+                            r["valu_busy"] = tr["valu_busy"]
+                except (OSError, ValueError, KeyError):
+                    pass
                 ent["roofline"] = r
             if lib is not None:
                 ok, cnt, classes = w.verify(lib, strict=True)

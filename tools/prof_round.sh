@@ -18,6 +18,7 @@ kt() {   # kt <name> <bench args...>
 }
 kt default --roofline-only
 kt default_full --cpu-seconds 1 --cpu-procs 0
+kt level_a --roofline-only --parity-level A          # the C3 step at the opt-in parity level A (FP64 residue transforms)
 for wl in ntt intt ntt15 intt15 bgv rotate mul add encdec; do kt $wl --workload $wl --steps 3 --warmup 1 --roofline-only; done
 cd $R
 tools/prof_pmc.sh ${TAG}_ntt --workload ntt --steps 3 --warmup 1
@@ -29,5 +30,7 @@ tools/prof_pmc.sh ${TAG}_intt12 --workload intt15 --logn 12 --batch 3724 --steps
 tools/prof_pmc.sh ${TAG}_mul --workload mul --steps 3 --warmup 1
 tools/prof_pmc.sh ${TAG}_ckks --workload ckks --steps 2 --warmup 1 --batch 64
 tools/prof_pmc.sh ${TAG}_bgv --workload bgv --steps 2 --warmup 1 --batch 128
+tools/prof_pmc.sh ${TAG}_ckks_a --workload ckks --steps 2 --warmup 1 --batch 64 --parity-level A
+tools/prof_pmc.sh ${TAG}_bgv_a --workload bgv --steps 2 --warmup 1 --batch 128 --parity-level A
 # device residency behind hehub's object API: the same program as hehub on the CPU, over the binding, and over the own mirror
 tools/prof_resident.sh > gpurun_out/${TAG}_resident_chain.txt 2>&1

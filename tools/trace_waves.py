@@ -12,12 +12,12 @@ logn, mods = 15, P.C3_MODULI_EXT
 n = 1 << logn; L = len(mods) - 1
 lib = capi.load()
 names = "entry decoded loaded passA exch1 passB exch2 passC canon exch3 stored".split()
-def dump(fn, label):
+def dump(fn, label, lo=200, hi=1500):
     f = getattr(lib, fn); f.argtypes = [C.c_void_p, C.c_size_t]; f.restype = C.c_int
     buf = np.zeros(2048 * 16 * 12, dtype=np.uint64)
     f(buf.ctypes.data_as(C.c_void_p), buf.size)
     t = buf.reshape(2048, 16, 12).astype(np.int64)
-    t = t[200:1500]                                   # workgroups 3200 .. 24000 of 25600: away from the ramp and the tail
+    t = t[lo:hi]                                      # (spread launch: workgroups 3200 .. 24000 of 25600: away from the ramp and the tail)
     stamps = np.concatenate([t[:, :, 11:12], t[:, :, :10]], axis=2)   # entry first
     ok = (stamps > 0).all(axis=(1, 2))
     stamps = stamps[ok]
@@ -36,7 +36,10 @@ def dump(fn, label):
 B = 256
 pt = torch.randint(0, 1 << 40, (B, L, n), dtype=torch.int64, device="cuda")
 key = torch.randint(0, 1 << 40, (L, 2, L + 1, n), dtype=torch.int64, device="cuda")
+ct = torch.randint(0, 1 << 40, (B, 2, L, n), dtype=torch.int64, device="cuda")
 for lvl, fn in (("B", "hp_debug_trace"), ("A", "hp_debug_trace_a")):
     e.set_parity_level(lvl)
     for _ in range(2): e.ext_prod(mods, pt, key)
     torch.cuda.synchronize(); dump(fn, "digit-spread launch, level " + lvl)
+    for _ in range(2): e.ckks_rescale(mods[:L], ct)            # 2 * 256 * 9 = 4608 items: the fused drop (rescale flavour)
+    torch.cuda.synchronize(); dump(fn, "fused drop launch (rescale flavour; 'canon' = fold, 'stored' = epilogue incl. its loads), level " + lvl, 60, 240)

@@ -11,7 +11,9 @@ tag, d = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, 
 SPECS = [("ntt15", r"k_ntt_fwdILi15", "k_ntt_fwd_logn15", 256 * 11), ("intt15", r"k_ntt_invILi15", "k_ntt_inv_logn15", 256 * 11),
          ("ntt", r"k_ntt_fwdILi14", "k_ntt_fwd_logn14", 1024 * 4), ("intt", r"k_ntt_invILi14", "k_ntt_inv_logn14", 1024 * 4),
          ("ntt12", r"k_ntt_fwdILi12", "k_ntt_fwd_logn12", 3724 * 11), ("intt12", r"k_ntt_invILi12", "k_ntt_inv_logn12", 3724 * 11),
-         ("ckks", r"k_ntt_fwdILi15", "k_ntt_fwd_logn15_spread", 64 * 100), ("bgv", r"k_ntt_fwdILi13", "k_ntt_fwd_logn13_spread", 128 * 36)]
+         ("ckks", r"k_ntt_fwdILi15", "k_ntt_fwd_logn15_spread", 64 * 100), ("bgv", r"k_ntt_fwdILi13", "k_ntt_fwd_logn13_spread", 128 * 36),
+         # parity level A (hp_ntt_a.hip): the same launches on the FP64 residue kernels
+         ("ckks_a", r"k_ntt_fwd_aILi15", "k_ntt_fwd_a_logn15_spread", 64 * 100), ("bgv_a", r"k_ntt_fwd_aILi13", "k_ntt_fwd_a_logn13_spread", 128 * 36)]
 out_path = os.path.join(ROOT, "profiles", "traffic.json")
 tr = json.load(open(out_path)) if os.path.exists(out_path) else {}
 for name, kre, entry, limbs in SPECS:
