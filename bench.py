@@ -293,7 +293,8 @@ def extra_sections(run, res, wl, value, lib, cpu_budget):
                 (sect if key is None else sect[key])["cpu_baseline"] = cb
     checks = list(by_n.values()) + list(res["ckks_by_N"].values()) + [steady, res["coeffwise"]["mul"], res["coeffwise"]["add"],
                                                                         res["c2"], res["bgv"], res["level_a"]["ckks"],
-                                                                        res["level_a"]["bgv"]]
+                                                                        res["level_a"]["bgv"]] + [v for v in res["level_a"]["ntt"].values()
+                                                                                                  if isinstance(v, dict)]
     bad = any(s.get("verified") is False for s in checks) or not copy["engine_copy_verified"]
     return bad
 

@@ -182,6 +182,40 @@ def level_a_section(run: Run, lib, wl):
             out[key] = ent
     finally:
         eng.set_parity_level("B")
+    out["ntt"] = residue_transform_rates(run, lib)
+    return out
+
+
+def residue_transform_rates(run: Run, lib):
+    """the limb transforms as residues (hp_dev_ntt_residues / hp_dev_intt_residues: canonical words through the FP64 kernels) at the
+    shapes of the `ntt` and `c2` sections: N = 32768 over the C3 ciphertext moduli (one 50-bit, nine 40-bit) at the C3 batch's limb
+    count and in steady state, and BASELINE config 2 exactly (four 50-bit moduli: every limb takes the extra range reductions)"""
+    import numpy as np
+
+    P, eng, steps = run.P, run.eng, run.args.steps
+    out = {"what": "forward: every word == the reference's lazy word modulo q; inverse: the words of intt_negacyclic_inplace (ntt.h:88-92)"}
+    for key, logn, moduli, B in (("32768", 15, P.C3_Q, 512), ("steady_32768", 15, P.C3_Q, 2560), ("c2", P.C2_LOGN, P.C2_MODULI, P.C2_BATCH)):
+        n, L = 1 << logn, len(moduli)
+        xb = Batch(run.torch, B, (L, n), moduli, run.dev, 140 + logn + 100 * run.rank, 3)
+        x = xb.full
+        ent = {"N": n, "limbs_per_launch": B * L, "moduli_bits": sorted({int(q).bit_length() for q in moduli})}
+        for name, fam, fn in (("forward", "ntt", lambda: eng.ntt_residues_(moduli, x)), ("inverse", "intt", lambda: eng.intt_residues_(moduli, x))):
+            dt, launches, kern_ms = timed_launches(run, fn, fam, steps, warm=2)
+            ent[name] = rate_entry(B * L, 16.0 * n, steps, run.world, dt, launches, kern_ms)
+            ent[name]["unit"] = "limb-NTT/s"
+        if lib is not None:
+            idx, host = xb.classes()
+            qcol = np.array(moduli, dtype=np.uint64)[:, None]
+            y = xb.fresh()
+            eng.ntt_residues_(moduli, y)
+            fwd = np.stack([lib.poly_ntt(moduli, host[c]) for c in range(len(idx))])
+            ok1, cnt = compare_classes(run.torch, y, fwd % qcol, xb.period, idx)
+            eng.intt_residues_(moduli, y)                                   # (input: the canonical forward words)
+            inv = np.stack([lib.poly_reduce_strict(moduli, lib.poly_intt(moduli, fwd[c] % qcol)) for c in range(len(idx))])
+            ok2, _ = compare_classes(run.torch, y, inv, xb.period, idx)
+            ent["verified"], ent["verified_polynomials"] = bool(ok1 and ok2), cnt
+        out[key] = ent
+        del x, xb
     return out
 
 

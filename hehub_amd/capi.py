@@ -59,6 +59,8 @@ SIGNATURES = {
     "hp_batched_montgomery_128_lazy": (INT, [P, u64, szt, P, P]),
     "hp_dev_ntt": (INT, [P, szt, szt, P, szt, P]),
     "hp_dev_intt": (INT, [P, szt, szt, P, szt, P, INT]),
+    "hp_dev_ntt_residues": (INT, [P, szt, szt, P, szt, P]),
+    "hp_dev_intt_residues": (INT, [P, szt, szt, P, szt, P]),
     "hp_dev_poly_add": (INT, [P, szt, szt, P, szt, P, P, P]),
     "hp_dev_poly_sub": (INT, [P, szt, szt, P, szt, P, P, P]),
     "hp_dev_poly_mul": (INT, [P, szt, szt, P, szt, P, P, P]),

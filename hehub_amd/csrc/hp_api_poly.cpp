@@ -125,6 +125,32 @@ int hp_dev_intt(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size
     return run_ntt(ctx, batch_job(plan, logn, L, batch, d_x, d_x, L, L, 1, strict));
 }
 
+// The transforms as RESIDUES (parity level A as an explicit entry point, whatever the context's level): canonical words through the
+// FP64 kernels of hp_ntt_a.hip.  Forward: every output word == ntt.cpp:145-176's word modulo q, in [0, q).  Inverse: the words of
+// intt_negacyclic_inplace (ntt.h:88-92 = lazy inverse + reduce_strict).  Input words below 2^52; N = 2^11 .. 2^15; every q < 2^50.
+static int dev_ntt_residues(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *d_x, int inverse) {
+    HP_ENTER(ctx);
+    HP_REQUIRE(ctx, moduli, d_x);
+    HP_ALIGNED(ctx, d_x);
+    if (!logn_ok(logn)) return fail(ctx, HP_EUNSUPPORTED, HP_LOGN_MSG);
+    if (batch == 0) return HP_OK;
+    const Plan *plan;
+    int rc = get_plan(ctx, logn, moduli, L, true, &plan);
+    if (rc) return rc;
+    bool ok = false;
+    if ((rc = ensure_plan_a(ctx, plan, &ok))) return rc;
+    if (!ok) return fail(ctx, HP_EUNSUPPORTED, "residue transforms need a ring degree of 2^11 .. 2^15 and every modulus below 2^50");
+    HpNttJob j = batch_job(plan, logn, L, batch, d_x, d_x, L, L, inverse, inverse);
+    j.limbs_a = plan->d_limbs_a;
+    return run_ntt(ctx, j);
+}
+int hp_dev_ntt_residues(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *d_x) {
+    return dev_ntt_residues(ctx, logn, L, moduli, batch, d_x, 0);
+}
+int hp_dev_intt_residues(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *d_x) {
+    return dev_ntt_residues(ctx, logn, L, moduli, batch, d_x, 1);
+}
+
 static int dev_binary(hp_ctx *ctx, int op, size_t n, size_t L, const uint64_t *moduli, size_t batch,
                       const uint64_t *a, const uint64_t *b, uint64_t *out) {
     HP_ENTER(ctx);

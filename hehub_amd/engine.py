@@ -177,6 +177,18 @@ class Engine:
         self._chk(self.lib.hp_dev_intt(self.h, n.bit_length() - 1, L, _u64arr(moduli), B, self._ptr(x), int(strict)))
         return x
 
+    def ntt_residues_(self, moduli, x):
+        """forward transforms in place to CANONICAL residues (hp_dev_ntt_residues: the FP64 kernels; == oracle ntt words mod q)"""
+        B, L, n = x.shape
+        self._chk(self.lib.hp_dev_ntt_residues(self.h, n.bit_length() - 1, L, _u64arr(moduli), B, self._ptr(x)))
+        return x
+
+    def intt_residues_(self, moduli, x):
+        """inverse transforms in place, strict (hp_dev_intt_residues: the words of intt_negacyclic_inplace)"""
+        B, L, n = x.shape
+        self._chk(self.lib.hp_dev_intt_residues(self.h, n.bit_length() - 1, L, _u64arr(moduli), B, self._ptr(x)))
+        return x
+
     def _binary(self, fn, moduli, a, b, out=None):
         B, L, n = a.shape
         out = self.empty(a.shape) if out is None else out

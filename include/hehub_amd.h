@@ -151,6 +151,14 @@ int hp_batched_montgomery_128_lazy(hp_ctx *ctx, uint64_t modulus, size_t len, co
 int hp_dev_ntt(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *d_x);
 int hp_dev_intt(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *d_x,
                 int strict);
+/* The same transforms as RESIDUES (parity level A as explicit entry points, whatever the context's level; hp_ntt_a.hip: error-free
+ * FP64 butterflies, 8 instead of 16 instructions each): in place, every output word is the canonical residue in [0, q).
+ *   hp_dev_ntt_residues:  word == (ntt.cpp:145-176's lazy word) mod q, i.e. reduce_strict of it where that one is below 2q
+ *   hp_dev_intt_residues: the words of intt_negacyclic_inplace (ntt.h:88-92 = lazy inverse + reduce_strict), bit for bit
+ * Input words must be below 2^52 (any lazy word hehub produces is below 2q); N = 2^11 .. 2^15 and every modulus below 2^50, else
+ * HP_EUNSUPPORTED.  hp_dev_ntt / hp_dev_intt above stay bit-exact with the reference's lazy words. */
+int hp_dev_ntt_residues(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *d_x);
+int hp_dev_intt_residues(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *d_x);
 /* rns.cpp:58-87 / :89-118 / :120-140 / :142-171 on u64[batch][L][N].  d_self may alias d_out. */
 int hp_dev_poly_add(hp_ctx *ctx, size_t n, size_t L, const uint64_t *moduli, size_t batch,
                     const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out);

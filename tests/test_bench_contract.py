@@ -91,6 +91,10 @@ def test_default_line_carries_both_halves_of_the_metric():
     for k, outs in (("ckks", 256), ("bgv", 512)):
         assert la[k]["verified"] is True and la[k]["verified_outputs"] == outs and la[k]["speedup_vs_level_b"] > 1.0
     assert la["ckks"]["roofline"]["frac"] > r["roofline"]["frac"]
+    for key in ("32768", "steady_32768", "c2"):     # the limb transforms as residues (hp_dev_ntt_residues / hp_dev_intt_residues)
+        assert la["ntt"][key]["verified"] is True
+        assert la["ntt"][key]["forward"]["frac_of_hbm_peak"] > 0.3 and la["ntt"][key]["inverse"]["frac_of_hbm_peak"] > 0.3
+    assert la["ntt"]["steady_32768"]["forward"]["frac_of_hbm_peak"] > ntt["steady_state"]["forward"]["frac_of_hbm_peak"]
 
 
 @pytest.mark.gpu

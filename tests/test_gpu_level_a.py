@@ -172,3 +172,34 @@ def test_level_a_equals_strict_of_level_b_on_distinct_inputs(enga):
     finally:
         eb.release_workspace()
         eb.close()
+
+
+@pytest.mark.parametrize("logn", [11, 12, 13, 14, 15])
+def test_residue_transforms(enga, orc, logn):
+    """hp_dev_ntt_residues / hp_dev_intt_residues: the FP64 transforms as explicit entry points.  Forward == the oracle's lazy words
+    modulo q (ntt.cpp:145-176); inverse == the words of intt_negacyclic_inplace (ntt.h:88-92), bit for bit; round trip == input."""
+    from hehub_amd.engine import Engine, HpError
+
+    moduli = [P.P50[1], P.P40[0], P.P40[3], P.P50[0]] + (_ntt_primes(1, logn, 44) + _ntt_primes(1, logn, 45))
+    n, B = 1 << logn, 3
+    rng = SplitMix(900 + logn)
+    a = rng.poly((B, len(moduli), n), moduli)
+    a[0, :, :9] = (np.array(moduli, dtype=U) - U(1))[:, None]                 # largest canonical words
+    lazy = a.copy()
+    lazy[1, :, :9] = (U(2) * np.array(moduli, dtype=U) - U(1))[:, None]       # largest lazy words hehub hands over
+    for eng in (enga, Engine(0)):                                             # whatever the context's level
+        y = eng.to_host(eng.ntt_residues_(moduli, eng.to_device(lazy)))
+        exp = np.stack([orc.poly_ntt(moduli, lazy[i]) for i in range(B)])
+        assert np.array_equal(y, canon(moduli, exp))
+        yl = np.stack([orc.poly_ntt(moduli, a[i]) for i in range(B)])          # the reference's lazy forward words as inverse input
+        z = eng.to_host(eng.intt_residues_(moduli, eng.to_device(yl)))
+        assert np.array_equal(z, np.stack([orc.poly_reduce_strict(moduli, orc.poly_intt(moduli, yl[i])) for i in range(B)]))
+        assert np.array_equal(z, a)
+        rt = eng.to_host(eng.intt_residues_(moduli, eng.ntt_residues_(moduli, eng.to_device(a))))
+        assert np.array_equal(rt, a)
+        if eng is not enga:
+            with pytest.raises(HpError, match="below 2\\^50"):
+                eng.ntt_residues_([P.C1_Q], eng.empty((1, 1, 1 << 12)))
+            with pytest.raises(HpError, match="2\\^11"):
+                eng.ntt_residues_([P.P40[0]], eng.empty((1, 1, 1 << 8)))
+            eng.close()
