@@ -248,6 +248,17 @@ void hp_node_destroy(hp_node *node) {
 size_t hp_node_size(const hp_node *node) { return node ? node->ctx.size() : 0; }
 hp_ctx *hp_node_ctx(hp_node *node, size_t rank) { return (node && rank < node->ctx.size()) ? node->ctx[rank] : nullptr; }
 const char *hp_node_last_error(hp_node *node) { return node ? node->err.c_str() : "null node"; }
+// parity level of every rank's context (hp_ctx_set_parity_level): the batch-sharded entry points then return canonical residues;
+// the limb-sharded mode exchanges caller-visible coefficient rows between ranks and stays at level B whatever the setting
+int hp_node_set_parity_level(hp_node *node, int level) {
+    if (!node) return HP_EINVAL;
+    std::lock_guard<std::mutex> lk(node->mu);
+    for (hp_ctx *c : node->ctx) {
+        int rc = hp_ctx_set_parity_level(c, level);
+        if (rc) return node_fail(node, rc, hp_last_error(c));
+    }
+    return HP_OK;
+}
 
 int hp_node_peer_matrix(const hp_node *node, int *matrix) {
     if (!node || !matrix) return HP_EINVAL;

@@ -45,6 +45,10 @@ class Node:
         msg = self.lib.hp_node_last_error(self.h).decode()
         raise (InvalidArgument if rc == capi.HP_EINVAL else HpError)(rc, msg)
 
+    def set_parity_level(self, level: str):
+        """"B" (default) or "A" on every rank's context (include/hehub_amd.h: hp_ctx_set_parity_level)"""
+        self._chk(self.lib.hp_node_set_parity_level(self.h, {"B": 0, "A": 1}[level.upper()]))
+
     def peer_matrix(self) -> np.ndarray:
         """[a][b] = 1 when rank a writes rank b's device memory directly (hp_node_peer_matrix)"""
         m = (C.c_int * (self.world * self.world))()

@@ -305,6 +305,9 @@ int hp_node_create(const int *devices, size_t count, hp_node **out);
 void hp_node_destroy(hp_node *node);
 size_t hp_node_size(const hp_node *node);
 hp_ctx *hp_node_ctx(hp_node *node, size_t rank);      /* the rank's engine context, for the hp_dev_* entry points */
+/* hp_ctx_set_parity_level on every rank's context: the batch-sharded entry points below then return canonical residues (level A);
+ * the limb-sharded mode passes coefficient rows between ranks and runs at level B whatever the setting */
+int hp_node_set_parity_level(hp_node *node, int level);
 const char *hp_node_last_error(hp_node *node);   /* "rank r: <message of that rank's failing call>"; the first rank with a failure of its own */
 /* matrix[a * size + b] = 1 when rank a can write rank b's device memory directly (same device, or hipDeviceEnablePeerAccess
  * succeeded at hp_node_create), else 0.  The limb-sharded plan below writes peers directly where it can and stages through

@@ -61,6 +61,42 @@ def test_batch_sharded_host_batches(orc, world):
         node.close()
 
 
+@pytest.mark.parametrize("world", [1, 3])
+def test_batch_sharded_at_parity_level_a(orc, world):
+    """hp_node_set_parity_level(A): the batch slices come back as canonical residues = reduce_strict of the oracle's words; the
+    limb-sharded mode stays at level B (raw words) whatever the node's setting"""
+    from hehub_amd.node import ShardedPlan
+
+    node = make_node(world)
+    try:
+        node.set_parity_level("A")
+        logn, mext, B = 12, [P.P50[1]] + P.P40[:3] + [P.P50[0]], 5
+        L = len(mext) - 1
+        ct1, ct2, key = case(logn, mext, B, 1700 + world)
+        dk = node.replicate(key)
+        q = np.array(mext[:L - 1], dtype=np.uint64)[:, None]
+        strict = lambda a: np.where(a >= q, a - q, a)
+        out = node.ckks_mult(mext, ct1, ct2, dk)
+        for i in range(B):
+            assert np.array_equal(out[i], strict(orc.ckks_mult(mext, ct1[i], ct2[i], key))), (world, i)
+        out = node.bgv_mult(mext, P.C5_T, ct1, ct2, dk)
+        for i in range(B):
+            assert np.array_equal(out[i], strict(orc.bgv_mult(mext, P.C5_T, ct1[i], ct2[i], key))), (world, i)
+        plan = ShardedPlan(node, logn, mext, 2)
+        try:
+            res = plan.mult(ct1[:2], ct2[:2], dk)
+            for i in range(2):
+                assert np.array_equal(res[i], orc.ckks_mult(mext, ct1[i], ct2[i], key))
+        finally:
+            plan.close()
+        node.free_replicas(dk)
+        node.set_parity_level("B")
+        out = node.ckks_mult(mext, ct1, ct2, node.replicate(key))
+        assert np.array_equal(out[0], orc.ckks_mult(mext, ct1[0], ct2[0], key))
+    finally:
+        node.close()
+
+
 @pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
 @pytest.mark.parametrize("logn,mext,B", [(12, [P.P50[1]] + P.P40[:4] + [P.P50[0]], 3), (7, [P.P40[0], P.P40[1], P.P50[0]], 2)])
 def test_limb_sharded_matches_the_oracle(orc, world, logn, mext, B):

@@ -16,14 +16,25 @@ from oracle.pyoracle import Oracle, SplitMix  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 HKS = len(sys.argv) > 3 and sys.argv[3] == "hks"   # third argument "hks": only the hybrid key switch against its exact integer model
+LEVELA = len(sys.argv) > 3 and sys.argv[3] == "levela"   # "levela": the pipelines at parity level A (expected = the oracle's words mod q
+                                                         # where the ring degree has tiled kernels, the raw words elsewhere) + residue transforms
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 orc, eng = Oracle("orc"), Engine(0)
+if LEVELA:
+    eng.set_parity_level("A")
 pool = P.P40 + P.P50          # every list prime supports 2N | q-1 up to N = 32768
 t0, cases, rs = time.time(), 0, np.random.RandomState(seed0)
 hist = {}
 
 
+def canon(moduli, a):
+    """level A: canonical residue of every word of a [..., L', n] array whose limbs are the first L' of `moduli`"""
+    return a % np.array(moduli[:a.shape[-2]], dtype=np.uint64)[:, None]
+
+
 def check(name, got, exp, **kw):
+    if LEVELA and name not in ("ntt", "intt") and 11 <= kw.get("logn", 0) <= 15:
+        exp = canon(kw["mext"], exp)
     if not np.array_equal(got, exp):
         print("MISMATCH", name, kw, "first bad index", np.argwhere(got != exp)[:3].tolist())
         sys.exit(1)
@@ -40,7 +51,18 @@ while time.time() - t0 < budget:
     rng = SplitMix(int(rs.randint(1, 1 << 30)))
     kw = dict(logn=logn, L=L, B=B, mext=mext)
     op = rs.choice(["ntt", "elem", "perm", "base", "mult", "bgv", "rot", "drop", "encdec", "sharded", "hks"], p=[.1] * 10 + [0.0]) if not HKS else "hks"
-    if op == "ntt":
+    if LEVELA:
+        op = rs.choice(["resid", "mult", "bgv", "rot", "drop"], p=[.2, .25, .2, .2, .15])
+    if op == "resid":
+        if not 11 <= logn <= 15:
+            continue
+        x = np.stack([rng.poly((L, n), [2 * m for m in q]) for _ in range(B)])        # lazy input words
+        d = eng.to_device(x); eng.ntt_residues_(q, d)
+        y = np.stack([orc.poly_ntt(q, x[i]) for i in range(B)])
+        check("ntt", eng.to_host(d), canon(q, y), **kw)
+        d = eng.to_device(y); eng.intt_residues_(q, d)                                # the reference's lazy forward words back
+        check("intt", eng.to_host(d), np.stack([orc.poly_reduce_strict(q, orc.poly_intt(q, y[i])) for i in range(B)]), **kw)
+    elif op == "ntt":
         x = np.stack([rng.poly((L, n), q) for _ in range(B)])
         d = eng.to_device(x); eng.ntt_(q, d)
         y = np.stack([orc.poly_ntt(q, x[i]) for i in range(B)])
