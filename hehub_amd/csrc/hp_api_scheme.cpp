@@ -36,7 +36,7 @@ namespace {
 // transform's input is a strict coefficient row (< max_j q_j) and grows by at most 2q per stage, which bounds m.  Only the tiled
 // kernels and the multi-ciphertext inner-product kernels know the format.
 static u32 spread_pack_mask(const hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P, size_t k0, size_t k1) {
-    // measured (tools/ab_pack.sh): -13..-16 % on the inner product at every tiled ring degree, -1.5 % on the spread launch at
+    // measured (tools/ab/ab_pack.sh): -13..-16 % on the inner product at every tiled ring degree, -1.5 % on the spread launch at
     // N = 32768.  (While the inner product computed 64-bit row addresses per load the extra loads of the two planes ate the
     // gain below N = 32768; with buffer addressing they cost nothing.)
     if (!tiled_ok(ctx, logn) || (int)logn < ctx->pack48_min_logn || P < 2 || ctx->no_pack48) return 0;

@@ -344,7 +344,7 @@ int hp_ctx_create(int device, hp_ctx **out) {
     c->hks_two_step = getenv("HP_HKS_TWO_STEP") != nullptr;
     c->hks_combine_kernel = getenv("HP_HKS_COMBINE_KERNEL") != nullptr;
     if (const char *e = getenv("HP_DROP_GROUP")) c->drop_group = (int)clampi(atol(e), 0, HP_MAX_LIMBS);
-    if (const char *e = getenv("HP_SPREAD_GROUP")) c->spread_group = (int)clampi(atol(e), 0, HP_MAX_LIMBS);   // measured (tools/ab_groups.sh): 4..8 beat 2 by 2-3 % on the launch since the rows are packed; 11 (all moduli) loses it again
+    if (const char *e = getenv("HP_SPREAD_GROUP")) c->spread_group = (int)clampi(atol(e), 0, HP_MAX_LIMBS);   // measured (tools/ab/ab_groups.sh): 4..8 beat 2 by 2-3 % on the launch since the rows are packed; 11 (all moduli) loses it again
     if (const char *e = getenv("HP_MULT_STREAMS")) c->mult_streams = atoi(e) >= 2 ? 2 : 1;
     if (const char *e = getenv("HP_MULT_CHUNK")) c->mult_chunk = (size_t)clampi(atol(e), 0, 1l << 30);
     if (const char *e = getenv("HP_PARITY_LEVEL")) c->parity_level = (e[0] == 'A' || e[0] == 'a' || e[0] == '1') ? 1 : 0;

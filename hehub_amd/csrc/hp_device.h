@@ -5,7 +5,7 @@
 // words are identical to the reference.  gfx950 has no
 // 64x64->128 multiply: a wide product is built from v_mad_u64_u32 /
 // v_mul_hi_u32 (measured half rate, ~4 cycles per wave64 instruction, see
-// tools/ubench_valu.hip), so the helpers below are written to minimise the
+// tools/ubench/ubench_valu.hip), so the helpers below are written to minimise the
 // number of 32-bit multiplies and to keep 64-bit additions on v_lshl_add_u64.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -136,7 +136,7 @@ HP_DEV void hp_butterfly_nq(u64 &lo, u64 &hi, u64 w, u64 wh, u64 two_q, u32 n0, 
 // Two independent butterflies with their instruction streams interleaved by hand.  A single wave
 // can start a dependent v_mad_u64_u32 only every ~9 cycles and the SIMD holds just four waves of
 // this kernel, so two independent chains per wave are what keeps the half-rate multiplier busy:
-// 61 instead of 73 cycles per wave-butterfly per SIMD (tools/ubench_bfly.hip).
+// 61 instead of 73 cycles per wave-butterfly per SIMD (tools/ubench/ubench_bfly.hip).
 // (wa, wha) and (wb, whb) may be the same twiddle.
 HP_DEV void hp_butterfly2_nq(u64 &lo_a, u64 &hi_a, u64 &lo_b, u64 &hi_b, u64 wa, u64 wha, u64 wb, u64 whb, u64 two_q,
                              u32 n0, u32 n1) {

@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_poly_binary(const HpLimb *__re
     const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
     if ((chunk + 1) * ELEM_CHUNK <= n) {
         // a full chunk (every chunk of the tiled ring degrees): the eight 16-byte loads of a thread are issued together, then
-        // the arithmetic and the four stores -- the launch shape a plain copy streams fastest with (tools/ubench_copy.hip)
+        // the arithmetic and the four stores -- the launch shape a plain copy streams fastest with (tools/ubench/ubench_copy.hip)
         constexpr int IT = ELEM_CHUNK / (ELEM_THREADS * 2);
         const size_t o = base + (size_t)chunk * ELEM_CHUNK + threadIdx.x * 2;
         U2 va[IT], vb[IT];
@@ -173,7 +173,7 @@ hipError_t hp_launch_copy(size_t words, const u64 *in, u64 *out, hipStream_t str
 
 // ---- rows that live in separate blocks of registered HOST memory (hehub's SmartArray limbs, allocator.h:105-223) ------------------
 // One kernel moves a whole polynomial between its contiguous device rows and its scattered host blocks through their device-visible
-// addresses: 47-49 GB/s over PCIe either way against 11-17 GB/s for one DMA command per 256 KiB block (tools/ubench_pcie.hip).
+// addresses: 47-49 GB/s over PCIe either way against 11-17 GB/s for one DMA command per 256 KiB block (tools/ubench/ubench_pcie.hip).
 template <bool TO_HOST> __global__ void __launch_bounds__(256) k_host_rows(HpHostRows rows, u64 *dev, size_t pairs) {
     typedef u64 __attribute__((ext_vector_type(2))) vv;
     vv *d = reinterpret_cast<vv *>(dev) + (size_t)blockIdx.y * pairs;

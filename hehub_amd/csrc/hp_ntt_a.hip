@@ -6,7 +6,7 @@
 //
 // Why: the level-B butterfly is 16 integer VALU instructions (10 of them 32-bit multiplies) = 62 cycles per wave-butterfly and the
 // transforms are bound by exactly that.  For q < 2^50 the residue of x w needs 8 FP64 instructions
-// (tools/ubench_bfly_f64.hip: 31.5 cycles, exact on 2 x 10^9 random and edge cases):
+// (tools/ubench/ubench_bfly_f64.hip: 31.5 cycles, exact on 2 x 10^9 random and edge cases):
 //     h = RN(x w)            l = fma(x, w, -h)             x w = h + l exactly (error-free product)
 //     k = rint(x u)          u = RN(w / q), precomputed    |k - x w / q| <= 1/2 + |x| 2^-52
 //     t = fma(-k, q, h) + l                                 = x w - k q exactly, |t| <= q (1/2 + |x| 2^-52)

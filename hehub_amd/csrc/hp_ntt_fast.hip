@@ -27,7 +27,7 @@
 //     modulus-major and handed to XCDs in contiguous slices (hp_xcd_remap) to keep them there.
 //
 // The kernel is bound by the integer ALUs, not by HBM: 10 multiply-type instructions of 16 per butterfly
-// (tools/ubench_*.hip), 88 % VALUBusy in the PMC passes at 35-44 % of HBM peak; see DESIGN.md 4.1.
+// (tools/ubench/*.hip), 88 % VALUBusy in the PMC passes at 35-44 % of HBM peak; see DESIGN.md 4.1.
 #include "hp_kernels.h"
 #include "hp_ntt_job.h"
 #include <type_traits>

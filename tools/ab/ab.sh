@@ -1,7 +1,7 @@
 #!/bin/bash
-# A/B of engine variants with interleaved repetitions: tools/ab.sh <reps> <variant> <variant> ...   (GPU box)
+# A/B of engine variants with interleaved repetitions: tools/ab/ab.sh <reps> <variant> <variant> ...   (GPU box)
 # prints per variant the sorted per-run times of the C3 digit-spread and in-place transform launches and the hom-mult/s
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 REPS=$1; shift
 for i in $(seq $REPS); do
   for v in "$@"; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # hom-mult/s (and the digit-spread roofline fraction seen by the library's events) of variants x sub-batch sizes with two
-# software-pipelined streams: tools/ab_chunks.sh <reps> "<variants>" "<chunks>"      (GPU box)
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+# software-pipelined streams: tools/ab/ab_chunks.sh <reps> "<variants>" "<chunks>"      (GPU box)
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 REPS=$1; VARS=$2; CHUNKS=$3
 for i in $(seq $REPS); do
 for v in $VARS; do for c in $CHUNKS; do

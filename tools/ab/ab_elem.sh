@@ -1,6 +1,6 @@
 #!/bin/bash
-# interleaved A/B of the coefficient-wise kernels (C3 limb shape, 3 x 512 MiB per launch): tools/ab_elem.sh <reps> <variant> ...
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+# interleaved A/B of the coefficient-wise kernels (C3 limb shape, 3 x 512 MiB per launch): tools/ab/ab_elem.sh <reps> <variant> ...
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 REPS=$1; shift
 for i in $(seq $REPS); do
   for v in "$@"; do

@@ -1,6 +1,6 @@
 #!/bin/bash
-# A/B of one environment knob with interleaved repetitions (GPU box): tools/ab_env.sh <reps> <VAR> <value> <value> ...   ("-" = unset)
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+# A/B of one environment knob with interleaved repetitions (GPU box): tools/ab/ab_env.sh <reps> <VAR> <value> <value> ...   ("-" = unset)
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 REPS=$1; VAR=$2; shift 2
 for i in $(seq $REPS); do
   for v in "$@"; do

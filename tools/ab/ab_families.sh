@@ -1,7 +1,7 @@
 #!/bin/bash
-# interleaved A/B of engine variants per kernel family (GPU box): tools/ab_families.sh <reps> <variant> <variant> ...   ("main" = hehub_amd/lib)
+# interleaved A/B of engine variants per kernel family (GPU box): tools/ab/ab_families.sh <reps> <variant> <variant> ...   ("main" = hehub_amd/lib)
 # extra arguments for bench_families.py through FAM_ARGS, e.g. FAM_ARGS="--workload bgv"
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 REPS=$1; shift
 for i in $(seq $REPS); do
   for v in "$@"; do

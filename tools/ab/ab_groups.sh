@@ -1,6 +1,6 @@
 #!/bin/bash
-# digit-spread / fused-drop item numbering by groups of G moduli (GPU box): tools/ab_groups.sh "<spread Gs>" "<drop Gs>" [reps]
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+# digit-spread / fused-drop item numbering by groups of G moduli (GPU box): tools/ab/ab_groups.sh "<spread Gs>" "<drop Gs>" [reps]
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 SG=${1:-"2 4"}; DG=${2:-""}; REPS=${3:-3}
 for i in $(seq $REPS); do
   for g in $SG; do echo "spread$g $(HP_SPREAD_GROUP=$g python $R/tools/bench_families.py $FAM_ARGS 2>/dev/null)"; done

@@ -1,5 +1,5 @@
 #!/bin/bash
-# interleaved A/B of the inverse transform at several sizes (GPU box): VARIANTS="base main" tools/ab_inverse.sh
+# interleaved A/B of the inverse transform at several sizes (GPU box): VARIANTS="base main" tools/ab/ab_inverse.sh
 R=$GRAFT_REPO_ROOT
 cd $R; python -m pytest tests/test_gpu_parity.py tests/test_gpu_full_batch.py tests/test_gpu_golden.py tests/test_extensions.py -m gpu -x -q 2>&1 | tail -1
 for i in 1 2 3; do for v in ${VARIANTS:-base main}; do

@@ -1,6 +1,6 @@
 #!/bin/bash
-# interleaved A/B of the hom-mult step at both parity levels: tools/ab_level_a.sh <reps> <variant> ...   ("main" = hehub_amd/lib)
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+# interleaved A/B of the hom-mult step at both parity levels: tools/ab/ab_level_a.sh <reps> <variant> ...   ("main" = hehub_amd/lib)
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 REPS=$1; shift
 for i in $(seq $REPS); do
   for v in "$@"; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # packed digit rows per ring degree (GPU box): interleaved HP_PACK48_MIN_LOGN=15 (N = 32768 only, the round-2 setting until the
 # inner product got buffer addressing) vs 11 (every tiled size, the default)
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 for i in 1 2 3; do for m in 15 11; do
   echo "bgv8192 min$m $(HP_PACK48_MIN_LOGN=$m python $R/tools/bench_families.py --workload bgv)"
   for l in 11 12 13 14; do echo "ckks_logn$l min$m $(HP_PACK48_MIN_LOGN=$m python $R/tools/bench_families.py --logn $l)"; done

@@ -1,12 +1,12 @@
 #!/bin/bash
-# interleaved A/B of the plain transforms at N = 32768 (C3 moduli): forward / inverse, C3-batch-sized (5120 limbs) and steady (25600) launches,
-# plus the per-family times of the C3 step.  tools/ab_transforms.sh <reps> <variant> <variant> ...   ("main" = hehub_amd/lib)
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+# interleaved A/B of the rotation workload + drop families: tools/ab/ab_rotate.sh <reps> <variant> <variant> ...  ("main" = hehub_amd/lib)
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 REPS=$1; shift
 for i in $(seq $REPS); do
   for v in "$@"; do
     if [ "$v" = main ]; then unset HEHUB_AMD_LIB; else export HEHUB_AMD_LIB=$R/hehub_amd/lib_variants/libhehub_amd_$v.so; fi
-    echo "$v $(python $R/tools/bench_transforms.py 2>/dev/null) $(python $R/tools/bench_families.py $FAM_ARGS 2>/dev/null)"
+    rot=$(python $R/bench.py --workload rotate --steps 10 --warmup 3 --roofline-only 2>/dev/null | python3 -c "import sys,json; print(round(json.loads(sys.stdin.read())['value']))")
+    echo "$v rot=$rot $(python $R/tools/bench_families.py 2>/dev/null) $(FAM=1 python $R/tools/bench_families.py --workload bgv 2>/dev/null | sed 's/\([a-z_]*\)=/bgv_\1=/g')"
   done
 done | python3 -c "
 import sys, collections, statistics

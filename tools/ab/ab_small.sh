@@ -1,6 +1,6 @@
 #!/bin/bash
-# A/B of engine variants on the smaller rings: tools/ab_small.sh <reps> <variant> ...   (GPU box)
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+# A/B of engine variants on the smaller rings: tools/ab/ab_small.sh <reps> <variant> ...   (GPU box)
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 REPS=$1; shift
 for i in $(seq $REPS); do
   for v in "$@"; do

@@ -1,6 +1,6 @@
 #!/bin/bash
-# interleaved A/B of the inverse (and forward) transforms at N = 2048 .. 16384: tools/ab_small_inv.sh <reps> <variant> ...  ("main" = hehub_amd/lib)
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+# interleaved A/B of the inverse (and forward) transforms at N = 2048 .. 16384: tools/ab/ab_small_inv.sh <reps> <variant> ...  ("main" = hehub_amd/lib)
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 REPS=$1; shift
 for i in $(seq $REPS); do
   for v in "$@"; do

@@ -1,6 +1,6 @@
 #!/bin/bash
-# hom-mult/s of engine variants x HP_MULT_STREAMS settings, interleaved: tools/ab_streams.sh <reps> <variant> ...
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+# hom-mult/s of engine variants x HP_MULT_STREAMS settings, interleaved: tools/ab/ab_streams.sh <reps> <variant> ...
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 REPS=$1; shift
 for i in $(seq $REPS); do
   for v in "$@"; do

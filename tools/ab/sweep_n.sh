@@ -1,6 +1,6 @@
 #!/bin/bash
-# Ring-degree sweep: tools/sweep_n.sh > gpurun_out/<tag>_sweep_N.txt   (GPU box)
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+# Ring-degree sweep: tools/ab/sweep_n.sh > gpurun_out/<tag>_sweep_N.txt   (GPU box)
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 echo "# bench.py --workload {ntt15,intt15,ckks} --logn {12..15} --steps 10 --warmup 2 on one MI355X (batch 256 polynomials x 11"
 echo "# limbs for the transforms; 256 ciphertext pairs, L = 10 moduli + special prime for CKKS mult+relin+rescale)."
 echo "# columns: workload, log2 N, GPU value, unit, forward/inverse-NTT roofline GB/s and fraction of 8 TB/s,"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # launch time of the plain forward transform at N = 32768 against the number of rounds (256 limbs each): what a launch costs beyond
-# rounds x steady-state time.  tools/sweep_small_launches.sh [variant ...]   ("main" = hehub_amd/lib)
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+# rounds x steady-state time.  tools/ab/sweep_small_launches.sh [variant ...]   ("main" = hehub_amd/lib)
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 for v in "${@:-main}"; do
   if [ "$v" = main ]; then unset HEHUB_AMD_LIB; else export HEHUB_AMD_LIB=$R/hehub_amd/lib_variants/libhehub_amd_$v.so; fi
   for B in 93 186 256 419 512; do

@@ -1,6 +1,6 @@
 // VALU cost of the lazy Harvey butterfly on gfx950, isolated from memory: every thread keeps 32
 // coefficients in registers and runs 5-stage passes on them in a loop.
-// Build: hipcc --offload-arch=gfx950 -O3 -I../hehub_amd/csrc -o ubench_bfly ubench_bfly.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -I../../hehub_amd/csrc -o ubench_bfly ubench_bfly.hip
 #include "hp_device.h"
 #include <cstdio>
 

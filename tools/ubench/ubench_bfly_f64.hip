@@ -6,7 +6,7 @@
 //   hi = lo - t, lo = lo + t                 8 FP64 instructions
 // Same harness as ubench_bfly.hip (32 coefficients per thread, 5-stage passes in a loop) + an exactness check of t against
 // 128-bit integer arithmetic on the device.
-// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I../hehub_amd/csrc -o ubench_bfly_f64 ubench_bfly_f64.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I../../hehub_amd/csrc -o ubench_bfly_f64 ubench_bfly_f64.hip
 #include "hp_device.h"
 #include <cstdio>
 #include <cmath>

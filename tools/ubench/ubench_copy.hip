@@ -1,5 +1,5 @@
 // Which launch shape gives a plain device-to-device copy the highest rate on gfx950?  (sets COPY_UNROLL / threads of k_copy in hp_elem.hip
-// = the engine's measured stream ceiling).   hipcc --offload-arch=gfx950 -O3 tools/ubench_copy.hip -o tools/ubench_copy
+// = the engine's measured stream ceiling).   hipcc --offload-arch=gfx950 -O3 tools/ubench/ubench_copy.hip -o tools/ubench/ubench_copy
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

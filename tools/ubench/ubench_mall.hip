@@ -1,6 +1,6 @@
 // Does a buffer written by one kernel come back from the 256 MiB Infinity Cache when the next kernel reads it?
 // write W bytes (kernel A), read them (kernel B), for W = 16 MiB .. 1 GiB; prints the read rate of B.
-// hipcc --offload-arch=gfx950 -O3 tools/ubench_mall.hip -o tools/ubench_mall
+// hipcc --offload-arch=gfx950 -O3 tools/ubench/ubench_mall.hip -o tools/ubench/ubench_mall
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

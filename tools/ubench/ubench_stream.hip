@@ -1,6 +1,6 @@
 // What HBM gives a read-dominated streaming kernel on gfx950: S concurrent row streams read with non-temporal 16-byte loads,
 // W rows written, the access pattern of the key-switch inner product (per (ciphertext, modulus): L digit rows in, 2 rows out;
-// 16 KiB of each row per workgroup).  Build: hipcc --offload-arch=gfx950 -O3 tools/ubench_stream.hip -o /tmp/ubench_stream
+// 16 KiB of each row per workgroup).  Build: hipcc --offload-arch=gfx950 -O3 tools/ubench/ubench_stream.hip -o /tmp/ubench_stream
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
