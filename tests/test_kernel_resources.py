@@ -128,3 +128,35 @@ def test_vcc_carry_wait_states():
         if dist is None or dist < 3:
             bad.append((i, dist, lines[max(0, i - 4):i + 1]))
     assert not bad, bad[:2]
+
+
+def test_level_a_kernels(meta):
+    """hp_ntt_a.hip (FP64 residue butterflies): every tiled size and flavour is built, four waves per SIMD, no spills in anything
+    the C3 / C5 pipelines launch (the BGV-with-addend flavour and the smallest inverse keep 2-4 spilled registers)"""
+    for logn in range(11, 16):
+        pick(meta, rf"k_ntt_fwd_a<{logn}>")
+        for ps in ("false", "true"):
+            pick(meta, rf"k_ntt_inv_a<{logn}, {ps}>")
+        for flav in range(1, 6):
+            pick(meta, rf"k_ntt_fwd_drop_a<{logn}, {flav}>")
+    for name, r in pick(meta, r"k_ntt_(fwd|inv|fwd_drop)_a<").items():
+        assert r["vgpr_count"] <= 128 and r["sgpr_spill_count"] == 0, (name, r)
+        assert r["vgpr_spill_count"] <= 4, (name, r)
+    for name, r in pick(meta, r"k_ntt_fwd_a<\d+>|k_ntt_inv_a<1[2-5], |k_ntt_fwd_drop_a<\d+, [1235]>").items():
+        assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, (name, r)
+    for name, r in pick(meta, r"k_ntt_(fwd|inv|fwd_drop)_a<15").items():
+        assert 140 * 1024 <= r["group_segment_fixed_size"] <= 160 * 1024, (name, r)
+
+
+def test_level_a_butterfly_is_not_contracted():
+    """the error-free product needs h = RN(x w) and l = fma(x, w, -h) as TWO roundings: the shipped code object of hp_ntt_a.hip must hold
+    as many v_mul_f64 as v_fma_f64-pairs of the butterfly (a contracted build would have turned multiplies into FMAs)"""
+    from kernel_meta import disassembly
+
+    text = disassembly()
+    body = text[text.index("k_ntt_fwd_aILi15E"):]
+    body = body[:body.index("s_endpgm")]
+    mul, fma, rnd = body.count("v_mul_f64"), body.count("v_fma_f64"), body.count("v_rndne_f64")
+    # per butterfly: 2 multiplies (x w, x u), 2 fused multiply-adds, 1 rint; 240 butterflies, the same again per reduction / canonicalisation
+    assert mul >= 480 and fma >= 480 and rnd >= 240, (mul, fma, rnd)
+    assert abs(mul - fma) <= 8, (mul, fma)
