@@ -84,3 +84,19 @@ def test_bench_line_reports_an_initialised_rccl_communicator():
     assert [l for l in out.stdout.splitlines() if l.strip()] == lines, out.stdout[-2000:]
     r = json.loads(lines[0])
     assert r["rccl_ranks"] == 1 and r["rccl"]["initialised"] is True and r["rccl"]["backend"] == "nccl" and r["verified"] is True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["p2p", "allgather"])
+def test_limb_sharded_mode_through_rccl_one_rank(transport):
+    """bench.py --workload ckks-limb on ONE rank with the exchanges forced through the RCCL communicator (all_gather of the key-switch
+    coefficient rows and of the result, broadcast of the dropped limbs' coefficients): the code an N-GPU latency-mode job runs, every
+    output verified against the checker"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HP_SHARDED_FORCE_COLLECTIVES"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "ckks-limb", "--limb-transport", transport, "--steps", "2",
+                          "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.stdout[-2000:], out.stderr[-3000:])
+    r = json.loads(lines[0])
+    assert r["rccl_ranks"] == 1 and r["verified"] is True and r["config"]["digit_exchange"] == transport and r["scaling"] == "strong"
