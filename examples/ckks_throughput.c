@@ -4,7 +4,7 @@
  *
  *   gcc -O2 -std=c99 examples/ckks_throughput.c -Iinclude -Lhehub_amd/lib -lhehub_amd \
  *       -Wl,-rpath,$PWD/hehub_amd/lib -o examples/ckks_throughput
- *   examples/ckks_throughput [log2 N = 15] [batch = 64] [steps = 5]
+ *   examples/ckks_throughput [log2 N = 15] [batch = 64] [steps = 5] [parity level: B (default) | A]
  * Moduli: CKKS parameters {50, 40 x 9} bits + one 50-bit special prime (the BASELINE config 3 chain). */
 #define _POSIX_C_SOURCE 199309L
 #include "hehub_amd.h"
@@ -50,9 +50,12 @@ int main(int argc, char **argv) {
     const size_t logn = argc > 1 ? (size_t)atoi(argv[1]) : 15, batch = argc > 2 ? (size_t)atoi(argv[2]) : 64;
     const int steps = argc > 3 ? atoi(argv[3]) : 5;
     const size_t n = (size_t)1 << logn, L = 10;
+    const int level_a = argc > 4 && (argv[4][0] == 'A' || argv[4][0] == 'a');
     hp_ctx *ctx = NULL;
     CHECK(hp_ctx_create(0, &ctx));
-    printf("%s: N=%zu, L=%zu moduli + special prime, batch %zu\n", hp_version(), n, L, batch);
+    /* level B: every word is hehub's lazy word; level A: its canonical residue (reduce_strict of it), through the FP64 transforms */
+    CHECK(hp_ctx_set_parity_level(ctx, level_a ? HP_PARITY_A : HP_PARITY_B));
+    printf("%s: N=%zu, L=%zu moduli + special prime, batch %zu, parity level %c\n", hp_version(), n, L, batch, level_a ? 'A' : 'B');
 
     uint64_t *ct1, *ct2, *key, *out;
     CHECK(upload_random(ctx, &ct1, batch * 2 * L, n, MODULI_EXT, L, 1));           /* u64[batch][2][L][N]   */
