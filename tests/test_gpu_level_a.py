@@ -35,8 +35,8 @@ def strict(moduli, a):
 
 
 def canon(moduli, a):
-    """the canonical residue of any u64 word"""
-    return a % np.array(moduli, dtype=U)[:, None]
+    """the canonical residue of any u64 word of a [..., L', n] array whose limbs are the first L' of `moduli`"""
+    return a % np.array(moduli[:a.shape[-2]], dtype=U)[:, None]
 
 
 CASES = [
@@ -203,3 +203,66 @@ def test_residue_transforms(enga, orc, logn):
             with pytest.raises(HpError, match="2\\^11"):
                 eng.ntt_residues_([P.P40[0]], eng.empty((1, 1, 1 << 8)))
             eng.close()
+
+
+@pytest.mark.parametrize("logn,L0,L", [(11, 5, 3), (13, 6, 5)])
+def test_extensions_at_level_a(enga, orc, logn, L0, L):
+    """keys of a higher level (hp_dev_*_at) and rescale by several primes (hp_dev_ckks_rescale_n) at parity level A: the residues of what
+    the oracle gives for the extracted sub-key / for successive single drops (tests/test_extensions.py pins the words at level B)"""
+    eng = enga
+    n, B = 1 << logn, 2
+    q_full, p = P.P40[:L0], P.P50[0]
+    rng = SplitMix(1900 + logn)
+    key_full = rng.poly((L0, 2, L0 + 1, n), q_full + [p])
+    sub = np.ascontiguousarray(key_full[:L][:, :, list(range(L)) + [L0], :])
+    mext = q_full[:L] + [p]
+    ct1 = np.stack([rng.poly((2, L, n), mext[:L]) for _ in range(B)])
+    ct2 = np.stack([rng.poly((2, L, n), mext[:L]) for _ in range(B)])
+    d1, d2, dk = eng.to_device(ct1), eng.to_device(ct2), eng.to_device(key_full)
+    exp = np.stack([orc.ckks_mult(mext, ct1[i], ct2[i], sub) for i in range(B)])
+    assert np.array_equal(eng.to_host(eng.ckks_mult_at(mext, L0, d1, d2, dk)), canon(mext, exp))
+    exp = np.stack([orc.ckks_rotate(mext, ct1[i], sub, 3) for i in range(B)])
+    assert np.array_equal(eng.to_host(eng.ckks_rotate_at(mext, L0, d1, dk, 3)), canon(mext, exp))
+    drops = 2
+    q = mext[:L]
+    exp = ct1
+    for d in range(drops):
+        exp = np.stack([orc.ckks_rescale(q[:L - d], exp[i]) for i in range(B)])
+    # (the second drop consumes the first one's canonical words: the same residues as the oracle's chain of lazy words)
+    assert np.array_equal(eng.to_host(eng.ckks_rescale_n(q, d1, drops)), canon(q, exp))
+
+
+def test_level_a_pipeline_in_a_hip_graph(enga, orc):
+    """after one warm-up call (which builds the FP64 tables) a level-A entry point only enqueues kernels: capturable and replayable"""
+    import torch
+
+    eng = enga
+    logn, L = 12, 3
+    mext = [P.P50[1]] + P.P40[:L - 1] + [P.P50[0]]
+    n, B = 1 << logn, 2
+    rng = SplitMix(2777)
+    ct1 = np.stack([rng.poly((2, L, n), mext[:L]) for _ in range(B)]); ct2 = np.stack([rng.poly((2, L, n), mext[:L]) for _ in range(B)])
+    key = rng.poly((L, 2, L + 1, n), mext)
+    d1, d2, dk = eng.to_device(ct1), eng.to_device(ct2), eng.to_device(key)
+    out = eng.empty((B, 2, L - 1, n))
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    try:
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            eng.use_stream(side)
+            eng.ckks_mult(mext, d1, d2, dk, out=out)
+            side.synchronize()
+            with torch.cuda.graph(g, stream=side):
+                eng.ckks_mult(mext, d1, d2, dk, out=out)
+        torch.cuda.current_stream().wait_stream(side)
+        exp = lambda a, b: canon(mext, np.stack([orc.ckks_mult(mext, a[i], b[i], key) for i in range(B)]))
+        out.zero_()
+        g.replay(); torch.cuda.synchronize()
+        assert np.array_equal(eng.to_host(out), exp(ct1, ct2))
+        d1.copy_(eng.to_device(ct2)); d2.copy_(eng.to_device(ct1))
+        out.zero_()
+        g.replay(); torch.cuda.synchronize()
+        assert np.array_equal(eng.to_host(out), exp(ct2, ct1))
+    finally:
+        eng.use_stream(torch.cuda.current_stream())
