@@ -139,7 +139,8 @@ static int dev_ntt_residues(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *
     if (rc) return rc;
     bool ok = false;
     if ((rc = ensure_plan_a(ctx, plan, &ok))) return rc;
-    if (!ok) return fail(ctx, HP_EUNSUPPORTED, "residue transforms need a ring degree of 2^11 .. 2^15 and every modulus below 2^50");
+    if (!ok || ctx->force_generic)
+        return fail(ctx, HP_EUNSUPPORTED, "residue transforms need a ring degree of 2^11 .. 2^15 and every modulus below 2^50 (and the tiled kernels enabled)");
     HpNttJob j = batch_job(plan, logn, L, batch, d_x, d_x, L, L, inverse, inverse);
     j.limbs_a = plan->d_limbs_a;
     return run_ntt(ctx, j);

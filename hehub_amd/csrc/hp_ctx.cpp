@@ -120,7 +120,7 @@ static int ensure_plan_a_impl(hp_ctx *ctx, const Plan *plan, bool *ok) {
     if (plan->a_state == 1) { *ok = true; return HP_OK; }
     if (plan->a_state < 0) return HP_OK;
     const size_t logn = plan->logn;
-    bool can = logn >= 11 && logn <= 15 && !ctx->force_generic;
+    bool can = logn >= 11 && logn <= 15;   // (the debug switches that bypass the tiled kernels are looked at per call: LevelScope)
     for (const hp::ModConsts &c : plan->consts)
         if (c.q >= ((u64)1 << 50) || c.q < 3) can = false;
     if (!can) { plan->a_state = -1; return HP_OK; }

@@ -165,7 +165,9 @@ struct LevelScope {
     int rc = 0;
     LevelScope(hp_ctx *c, const Plan *plan) : ctx(c) {
         c->cur_a = false;
-        if (c->parity_level == 1 && plan) {
+        // (level A is the tiled FP64 kernels end to end: not with the debug switches that route a call through the simple
+        // kernels or the unfused drop -- a mix of representatives would satisfy neither level's contract)
+        if (c->parity_level == 1 && plan && !c->force_generic && !c->no_fused_drop) {
             bool ok = false;
             rc = ensure_plan_a(c, plan, &ok);
             c->cur_a = (rc == 0) && ok;

@@ -266,3 +266,27 @@ def test_level_a_pipeline_in_a_hip_graph(enga, orc):
         assert np.array_equal(eng.to_host(out), exp(ct2, ct1))
     finally:
         eng.use_stream(torch.cuda.current_stream())
+
+
+def test_debug_switches_keep_a_call_at_level_b(orc):
+    """hp_ctx_set_force_generic (the simple kernels as cross-check) with the context at level A: the call runs at level B as a whole --
+    never a mix of canonical and lazy representatives -- and goes back to level A when the switch is released"""
+    from hehub_amd.engine import Engine
+
+    eng = Engine(0)
+    try:
+        eng.set_parity_level("A")
+        logn, mext, B = 11, P.P40[:3] + [P.P50[0]], 2
+        n, L = 1 << logn, 3
+        rng = SplitMix(31337)
+        ct1, ct2 = rng.poly((B, 2, L, n), mext[:L]), rng.poly((B, 2, L, n), mext[:L])
+        key = rng.poly((L, 2, L + 1, n), mext)
+        d1, d2, dk = eng.to_device(ct1), eng.to_device(ct2), eng.to_device(key)
+        raw = np.stack([orc.ckks_mult(mext, ct1[i], ct2[i], key) for i in range(B)])
+        assert np.array_equal(eng.to_host(eng.ckks_mult(mext, d1, d2, dk)), canon(mext, raw))
+        eng.force_generic(True)
+        assert np.array_equal(eng.to_host(eng.ckks_mult(mext, d1, d2, dk)), raw)
+        eng.force_generic(False)
+        assert np.array_equal(eng.to_host(eng.ckks_mult(mext, d1, d2, dk)), canon(mext, raw))
+    finally:
+        eng.close()
