@@ -53,3 +53,32 @@ def test_knob_settings_give_the_same_words(cases, monkeypatch, env):
             assert np.array_equal(eng.to_host(eng.ckks_rotate(mext, d1, dk, 3)), exp["rot"]), env
     finally:
         eng.close()
+
+
+KNOBS_A = [{}, {"HP_SPREAD_GROUP": "0"}, {"HP_SPREAD_GROUP": "3"}, {"HP_DROP_GROUP": "0"}, {"HP_DROP_GROUP": "7"}, {"HP_NO_PACK48": "1"},
+           {"HP_PACK48_MIN_LOGN": "15"}, {"HP_MULT_STREAMS": "2", "HP_MULT_CHUNK": "3"}, {"HP_MULT_CHUNK": "1"}, {"HP_NO_FUSED_DROP": "1"}]
+
+
+@pytest.mark.parametrize("env", KNOBS_A, ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()) or "defaults")
+def test_knob_settings_at_parity_level_a(cases, monkeypatch, env):
+    """the same with HP_PARITY_LEVEL=A in the environment: every schedule knob gives the canonical residues of the oracle's words;
+    HP_NO_FUSED_DROP (a debug path through the unfused level-B drop kernels) keeps the whole call at level B"""
+    from hehub_amd.engine import Engine
+
+    for k in ("HP_SPREAD_GROUP", "HP_DROP_GROUP", "HP_NO_PACK48", "HP_PACK48_MIN_LOGN", "HP_NO_FUSED_DROP", "HP_MULT_STREAMS",
+              "HP_MULT_CHUNK"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("HP_PARITY_LEVEL", "A")
+    eng = Engine(0)
+    try:
+        assert eng.parity_level() == "A"
+        for mext, ct1, ct2, key, exp in cases:
+            fin = (lambda a: a) if "HP_NO_FUSED_DROP" in env else (lambda a: a % np.array(mext[:a.shape[-2]], dtype=np.uint64)[:, None])
+            d1, d2, dk = eng.to_device(ct1), eng.to_device(ct2), eng.to_device(key)
+            assert np.array_equal(eng.to_host(eng.ckks_mult(mext, d1, d2, dk)), fin(exp["ckks"])), env
+            assert np.array_equal(eng.to_host(eng.bgv_mult(mext, P.C5_T, d1, d2, dk)), fin(exp["bgv"])), env
+            assert np.array_equal(eng.to_host(eng.ckks_rotate(mext, d1, dk, 3)), fin(exp["rot"])), env
+    finally:
+        eng.close()
