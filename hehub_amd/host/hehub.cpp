@@ -27,6 +27,8 @@
 struct hp_ctx;
 namespace hehub { namespace amd {
 hp_ctx *engine();
+void set_parity_level_a(bool on);
+bool parity_level_a();
 struct TransferStats {
     unsigned long long h2d_bytes = 0, d2h_bytes = 0, h2d_copies = 0, d2h_copies = 0, engine_calls = 0, host_blocks_registered = 0,
                        device_copies_invalidated = 0;
@@ -65,6 +67,13 @@ hp_ctx *engine() {
     if (!ctx) throw std::runtime_error("hehub_amd: no MI355X engine available (hp_ctx_create failed); there is no CPU fallback");
     return ctx;
 }
+
+// parity level of the process-wide engine (include/hehub_amd.h: hp_ctx_set_parity_level): false = B, hehub's raw lazy words (default);
+// true = A, the scheme-level calls return canonical residues (reduce_strict of hehub's words) through the FP64 transforms
+void set_parity_level_a(bool on) {
+    if (hp_ctx_set_parity_level(engine(), on ? HP_PARITY_A : HP_PARITY_B) != HP_OK) throw std::runtime_error(hp_last_error(engine()));
+}
+bool parity_level_a() { return hp_ctx_get_parity_level(engine()) == HP_PARITY_A; }
 
 } // namespace amd
 

@@ -39,6 +39,12 @@ namespace amd {
 /// reference's lazily filled global caches (ntt.cpp:107-143).  Throws std::runtime_error when no GPU
 /// or no engine library is available -- there is no CPU fallback.
 hp_ctx *engine();
+/// Parity level of the process-wide engine (include/hehub_amd.h: hp_ctx_set_parity_level; also HP_PARITY_LEVEL=A in the environment).
+/// false = B (default): every word is hehub's raw lazy word.  true = A: ckks / bgv mult, relinearize, rotate, rescale, mod_switch return
+/// the canonical residue of every word (reduce_strict of hehub's word; decryptions are identical) through the FP64 transforms -- 20 % more
+/// hom-mult/s at N = 32768.  The NTT / mod-arith primitives and the operators are never affected.
+void set_parity_level_a(bool on);
+bool parity_level_a();
 } // namespace amd
 
 // Stand-alone mirror of hehub's RNS vector (rns.h:15-115): the public names a caller of hehub uses.  Only built when hehub's own

@@ -433,6 +433,36 @@ static void test_ragged_operands() {   // rns.cpp:59-72 (+= on the first self.co
 
 // Device residency of the mirror's vectors (hehub.hpp; allocator.h:105-220 is what hehub does on the host): value semantics
 // and host access must behave exactly as if the words had never left the host, while PCIe is crossed only when somebody looks.
+// amd::set_parity_level_a: the scheme-level calls of the object API return canonical residues = reduce_strict of the level-B words
+static void test_parity_level_a() {
+    const size_t N = 4096;
+    const std::vector<u64> q{1125899903827969ull, 1099510054913ull, 1099507695617ull};   // a 50-bit (wide) and two 40-bit moduli
+    auto fill = [&](RnsPolynomial &p, u64 seed) {
+        for (size_t k = 0; k < p.component_count(); k++)
+            for (size_t i = 0; i < N; i++) p[(int)k][i] = (seed * 1000003ull + k * 7919ull + i * 104729ull) % q[k];
+        p.rep_form = PolyRepForm::value;
+    };
+    ckks::CkksCt ct;
+    for (int h = 0; h < 2; h++) { ct[h] = RnsPolynomial(N, 3, q); fill(ct[h], 11 + h); }
+    ct.scaling_factor = std::pow(2.0, 80);
+    REQUIRE(!amd::parity_level_a());
+    ckks::CkksCt b = ct;
+    ckks::rescale_inplace(b);
+    amd::set_parity_level_a(true);
+    REQUIRE(amd::parity_level_a());
+    ckks::CkksCt a = ct;
+    ckks::rescale_inplace(a);
+    amd::set_parity_level_a(false);
+    bool same = true;
+    for (int h = 0; h < 2; h++)
+        for (size_t k = 0; k < 2; k++)
+            for (size_t i = 0; i < N; i++) {
+                const u64 wb = b[h].view((int)k)[i], wa = a[h].view((int)k)[i];
+                same = same && wa == (wb >= q[k] ? wb - q[k] : wb) && wa < q[k];
+            }
+    REQUIRE(same);   // (a Harvey product lands in [q, 2q) only rarely, so most words coincide; tests/test_gpu_level_a.py has inputs where they do not)
+}
+
 static void test_device_residency() {
     const size_t N = 4096;
     const std::vector<u64> q{1099510054913ull, 1099507695617ull, 1099506515969ull};
@@ -563,6 +593,7 @@ int main() {
     test_plain_ops_and_decrypt_core();
     test_ragged_operands();
     test_device_residency();
+    test_parity_level_a();
     std::printf("%s: %d checks, %d failures\n", g_fail ? "FAILED" : "All tests passed", g_checks, g_fail);
     return g_fail ? 1 : 0;
 }
