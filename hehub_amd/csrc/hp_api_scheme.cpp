@@ -131,15 +131,16 @@ void make_drop_consts(const Plan *plan, size_t L, bool bgv, u64 t, HpDropConsts 
 
 // clast[p2] = strict(INTT_{q_last}(x[p2][last]))  (BGV: times t^-1 before the strict reduction):
 // a one-limb batch whose rows are the last limbs of the P2 polynomials
-int drop_coeffs(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, bool bgv, u64 t, const u64 *x, u64 *clast) {
-    const size_t n = (size_t)1 << logn;
-    const u64 q_last = plan->consts[L - 1].q;
+// rows: the limbs of modulus number `limb` of the P2 polynomials, row_pstride limbs apart
+int limb_coeffs(hp_ctx *ctx, const Plan *plan, size_t logn, size_t limb, size_t P2, bool bgv, u64 t, const u64 *rows, size_t row_pstride,
+                u64 *clast) {
+    const u64 q_last = plan->consts[limb].q;
     HpNttJob lj;
     memset(&lj, 0, sizeof(lj));
-    lj.limbs = plan->d_limbs + (L - 1); lj.src = x + (L - 1) * n; lj.dst = clast; lj.logn = (u32)logn; lj.L = 1;
-    lj.P = (u32)P2; lj.src_pstride = (u32)L; lj.dst_pstride = 1; lj.src_kstride = 1; lj.W = (u32)P2; lj.mode = HP_NTT_BATCH;
+    lj.limbs = plan->d_limbs + limb; lj.src = rows; lj.dst = clast; lj.logn = (u32)logn; lj.L = 1;
+    lj.P = (u32)P2; lj.src_pstride = (u32)row_pstride; lj.dst_pstride = 1; lj.src_kstride = 1; lj.W = (u32)P2; lj.mode = HP_NTT_BATCH;
     lj.inverse = 1; lj.strict = 1;
-    if (ctx->cur_a) lj.limbs_a = plan->d_limbs_a + (L - 1);
+    if (ctx->cur_a) lj.limbs_a = plan->d_limbs_a + limb;
     if (bgv) {
         const u64 s = hp::inverse_mod_prime(t, q_last) % q_last;
         lj.post_scalar = s;
@@ -152,12 +153,17 @@ int drop_coeffs(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2,
     }
     return run_ntt(ctx, lj);
 }
+int drop_coeffs(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, bool bgv, u64 t, const u64 *x, u64 *clast) {
+    return limb_coeffs(ctx, plan, logn, L - 1, P2, bgv, t, x + ((L - 1) << logn), L, clast);
+}
 
 // out[k] = ((x[k] - NTT_k(centre(barrett_k(clast)))) * inv_k) [* (q_last mod t)] [+ addend[k]] for the limbs k in [k0, k1)
 // of the L-1 that remain.  rem: workspace of P2*(k1-k0)*n words (unused by the fused tiled path).
 int drop_apply(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, size_t k0, size_t k1, const HpDropConsts &dc0,
                const u64 *x, const u64 *clast, bool clast_strict, const u64 *addend, size_t add_poly_stride, size_t add_ct_stride,
-               u32 add_mask, u64 *out, u64 *rem) {
+               u32 add_mask, u64 *out, u64 *rem, size_t out_stride = 0) {
+    // out_stride: limbs between consecutive polynomials of out (0: L - 1, with the range's first limb at out + k0 limbs; otherwise out
+    // points at the first limb of the range itself)
     // clast_strict: the caller vouches that every word of clast is below q_last (drop_last: it has just been written by a
     // strict inverse transform).  Rows handed in over the C ABI get the full Barrett reduction, which is right for any u64.
     const size_t n = (size_t)1 << logn, kc = k1 - k0;
@@ -170,10 +176,11 @@ int drop_apply(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, 
     }
     const HpLimb *limbs = plan->d_limbs + k0;
     x += k0 * n;
-    out += k0 * n;
+    if (out_stride == 0) out += k0 * n;
     if (addend) addend += k0 * n;
     int rc;
     // tiled sizes: Barrett + centring fused into the remainder NTT's loads, (x - rem)*inv [+ addend] into its stores
+    if (out_stride && !fused_drop_ok(ctx, logn)) return fail(ctx, HP_ELOGIC, "compact drop rows need the fused kernels");
     if (fused_drop_ok(ctx, logn)) {
         HpNttJob fj = batch_job(plan, logn, kc, P2, clast, nullptr, 1, 0, 0, 0);
         fj.limbs = limbs;
@@ -183,7 +190,7 @@ int drop_apply(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, 
         HpDropArgs da;
         memset(&da, 0, sizeof(da));
         da.dc = dc; da.x = x; da.L = (u32)L; da.addend = addend; da.add_poly_stride = (u32)add_poly_stride;
-        da.add_ct_stride = (u32)add_ct_stride; da.add_mask = add_mask; da.out = out; da.out_stride = (u32)(L - 1);
+        da.add_ct_stride = (u32)add_ct_stride; da.add_mask = add_mask; da.out = out; da.out_stride = (u32)(out_stride ? out_stride : L - 1);
         da.small_rem = clast_strict ? 1 : 0;   // rescaling.cpp:54-58: strict_barrett_{q_k}(c), c < q_last -- one conditional subtraction when q_last <= 2 q_k
         for (size_t k = k0; k < k1; k++)
             if (plan->consts[L - 1].q > 2 * plan->consts[k].q) da.small_rem = 0;
@@ -218,6 +225,65 @@ int drop_apply(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, 
                                          (u32)add_ct_stride, add_mask, out, ctx->stream), "drop_fin");
     }
     return rc;
+}
+
+// Level A only: relinearize's mod-down (drop p = q_L, addend on both polynomials: rgsw.cpp / ckks/arith.cpp:64-71) and the rescale / mod
+// switch that follows it in a mult (drop q' = q_{L-1}: rescaling.cpp:46-75, mod_switch.cpp:45-77) as ONE transform per output limb:
+// ext [P2][L+1] -> out [P2][L-1].  Residues only (hp_ntt_a.hip: DropPre2A has the algebra): the intermediate rows are never formed
+// for the limbs k < L - 1; the limb L - 1, whose coefficients the second drop needs, goes through the ordinary single drop.
+bool two_drops_ok(const hp_ctx *ctx, size_t logn, size_t L) { return ctx->cur_a && !ctx->no_double_drop && fused_drop_ok(ctx, logn) && L >= 2; }
+size_t two_drops_ws_words(size_t n, size_t P2) { return 3 * (padded(P2 * n) / 8); }
+int drop_two_last_a(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, bool bgv, u64 t1, u64 t2, const u64 *ext,
+                    const u64 *addend, size_t add_poly_stride, size_t add_ct_stride, u64 *out, Carver &cv) {
+    const size_t n = (size_t)1 << logn;
+    HpDropConsts dc1, dc2;
+    make_drop_consts(plan, L + 1, bgv, t1, dc1);
+    make_drop_consts(plan, L, bgv, t2, dc2);
+    u64 *cp = cv.take(P2 * n), *ylast = cv.take(P2 * n), *cq = cv.take(P2 * n);
+    int rc;
+    if ((rc = drop_coeffs(ctx, plan, logn, L + 1, P2, bgv, t1, ext, cp))) return rc;
+    // y_{L-1} = ((ext_{L-1} - NTT(cp)) p^-1 ...) + addend_{L-1}, compact rows; then its strict coefficients modulo q'
+    if ((rc = drop_apply(ctx, plan, logn, L + 1, P2, L - 1, L, dc1, ext, cp, true, addend, add_poly_stride, add_ct_stride, 3, ylast,
+                         nullptr, 1)))
+        return rc;
+    if ((rc = limb_coeffs(ctx, plan, logn, L - 1, P2, bgv, t2, ylast, 1, cq))) return rc;
+    const size_t kc = L - 1;
+    if (kc == 0) return HP_OK;
+    HpNttJob fj = batch_job(plan, logn, kc, P2, cp, nullptr, 1, 0, 0, 0);
+    fj.limbs = plan->d_limbs;
+    fj.limbs_a = plan->d_limbs_a;
+    fj.src_kstride = 0;
+    fj.pair_moduli = (u32)ctx->drop_group;
+    if (fj.pair_moduli > kc) fj.pair_moduli = (u32)kc;
+    HpDropArgs da;
+    memset(&da, 0, sizeof(da));
+    da.x = ext; da.L = (u32)(L + 1); da.addend = addend; da.add_poly_stride = (u32)add_poly_stride; da.add_ct_stride = (u32)add_ct_stride;
+    da.add_mask = 3; da.out = out; da.out_stride = (u32)(L - 1);
+    da.comb = cq;
+    da.dc.bgv = bgv ? 1 : 0;
+    da.dc.q_last = hp::f64_bits((double)dc1.q_last);
+    da.dc.half_q_last = hp::f64_bits((double)dc1.half_q_last);
+    da.q2_last = hp::f64_bits((double)dc2.q_last);
+    da.half_q2_last = hp::f64_bits((double)dc2.half_q_last);
+    auto mulmod = [](u64 a, u64 b, u64 q) { return (u64)(((unsigned __int128)a * b) % q); };
+    for (size_t k = 0; k < kc; k++) {
+        const u64 q = plan->consts[k].q;
+        const double qd = (double)q;
+        // A = p^-1 [(p mod t1)], m = A [t1], m2 = 1 [t2], B = q'^-1 [(q' mod t2)]     (bracketed factors: BGV)
+        u64 A = dc1.inv[k], m = A, m2 = 1 % q, B = dc2.inv[k];
+        if (bgv) {
+            A = mulmod(A, dc1.qlt[k], q);
+            m = mulmod(A, dc1.t[k], q);
+            m2 = dc2.t[k];
+            B = mulmod(B, dc2.qlt[k], q);
+        }
+        da.dc.inv[k] = hp::f64_bits((double)A); da.dc.inv_h[k] = hp::f64_bits((double)A / qd);
+        da.dc.t[k] = hp::f64_bits((double)m); da.dc.t_h[k] = hp::f64_bits((double)m / qd);
+        da.comb_mul[k] = hp::f64_bits((double)m2); da.comb_mul_h[k] = hp::f64_bits((double)m2 / qd);
+        da.dc.qlt[k] = hp::f64_bits((double)B); da.dc.qlt_h[k] = hp::f64_bits((double)B / qd);
+    }
+    ProfScope ps(ctx, "ntt_drop");
+    return chk(ctx, hp_launch_ntt_a_drop(fj, da, ctx->stream), "fused double drop NTT (level A)");
 }
 
 } // namespace
@@ -471,6 +537,14 @@ static int dev_mult(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uin
                                            ct2 + b0 * 2 * L * n, quad, ctx->stream), "tensor");
         }
         // the reference's bgv::relinearize runs its inner mod switch with plain_modulus == 1 (bgv.h:32): inner_t = 1
+        if (!rc && two_drops_ok(ctx, logn, L)) {
+            // level A: relinearize's mod-down and the rescale / mod switch in one transform per output limb (drop_two_last_a)
+            u64 *ext = cv.take(P * 2 * (L + 1) * n);
+            rc = ext_prod(ctx, plan, logn, L, P, quad + 2 * L * n, 3 * L, key, key_L0, ext, cv);
+            if (!rc) rc = drop_two_last_a(ctx, plan, logn, L, 2 * P, bgv, inner_t, t, ext, quad, L, 3 * L, out + b0 * 2 * (L - 1) * n, cv);
+            if (rc) break;
+            continue;
+        }
         if (!rc) rc = relin_core(ctx, plan, logn, L, P, bgv, inner_t, quad, key, key_L0, lin, cv);
         if (!rc) rc = drop_last(ctx, plan, logn, L, 2 * P, bgv, t, lin, nullptr, 0, 0, 0, out + b0 * 2 * (L - 1) * n, cv);
         if (rc) break;

@@ -130,6 +130,9 @@ struct HpDropArgs {
     u64 fin[HP_MAX_LIMBS], fin_h[HP_MAX_LIMBS];
     const u64 *comb;       // non-NULL (with raw_input): input = src + comb_mul[k] * centre_k(comb[p2]), comb [P2][N] strict modulo 2*comb_half+1
     u64 comb_half, comb_r[HP_MAX_LIMBS], comb_mul[HP_MAX_LIMBS], comb_mul_h[HP_MAX_LIMBS];
+    u64 q2_last, half_q2_last;   // level A, two drops in one launch (hp_ntt_a.hip: DropPre2A): the second modulus dropped; comb = its
+                                 // strict coefficient rows [P2][N]; per limb (t, t_h) = m_k, (comb_mul, comb_mul_h) = m2_k, (inv, inv_h) = A_k,
+                                 // (qlt, qlt_h) = B_k, all as bit patterns of doubles (v, RN(v / q_k))
     const u64 *x;          // [P2][L][n]: polynomial p2 at x + p2*L*n, limb k at + k*n
     u32 L;                 // limbs of x (the last one is being dropped)
     const u64 *addend;     // optional [.][.][n]: row (p2>>1)*add_ct_stride + (p2&1)*add_poly_stride + k

@@ -84,6 +84,59 @@ template <bool SWAP, bool BGV> struct DropPreA {
     }
 };
 
+// Two drops in one transform (level A only: residues, not representatives).  Dropping p and then q' from rows x with addend a,
+//     y_k = (x_k - NTT_k(cp)) p^-1 + a_k            cp = centred INTT_p(x_p)                  (rescaling.cpp:46-75, first call)
+//     z_k = (y_k - NTT_k(cq)) q'^-1                 cq = centred INTT_q'(y_q')                (second call)
+// is, by linearity of the transform modulo q_k,
+//     z_k = ((A_k x_k + a_k) - NTT_k(m_k cp + m2_k cq)) B_k
+// with A_k = m_k = p^-1, m2_k = 1, B_k = q'^-1 for CKKS; BGV (mod_switch.cpp:45-77) carries the plain-modulus factors:
+// A_k = p^-1 (p mod t1), m_k = A_k t1, m2_k = t2, B_k = q'^-1 (q' mod t2).  One transform per output limb instead of two and no
+// intermediate rows y_k for k < L - 1 in HBM; the limb y_q' that cq needs is produced by the ordinary single drop.
+// The second coefficient row arrives through a ring of DEPTH 16-byte loads that follows the order in which the first stage touches
+// the registers (0, 16, 2, 18, ...: load_flight's issue order).
+template <int LOGN, bool SWAP, bool SCALE2> struct DropPre2A {
+    static constexpr bool on = true;
+    static constexpr int DEPTH = 8;
+    using G = Geo<LOGN>;
+    double q, p_last, p_half, q2_last, q2_half, m, mu, m2, m2u;
+    const u64 *row;   // the thread's part of the second coefficient row
+    bool odd;
+    mutable V2 ring[DEPTH];
+    static constexpr int reg_of(int j) { return (j & 1) ? 16 + (j - 1) : j; }
+    HP_DEV V2 fetch(int r) const {
+        const u64 *a = (G::PB == 0) ? row + ((size_t)(r + (odd ? 1 : 0)) << 10) : row + ((size_t)(r >> G::PB) << 10) + (r & ((1 << G::PB) - 1));
+        typedef u64 __attribute__((ext_vector_type(2))) vv;
+        const vv v = *reinterpret_cast<const vv *>(a);
+        return V2{v.x, v.y};
+    }
+    HP_DEV void prime(const u64 *crow, u32 tid) {
+        odd = (tid & 1u) != 0;
+        row = (G::PB == 0) ? crow + (tid & ~1u) : crow + ((size_t)tid << G::PB);
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) ring[j] = fetch(reg_of(j));
+    }
+    HP_DEV void operator()(u64 (&x)[32], int r) const {
+        const int j = (r & 14) | (r >> 4);
+        V2 c2 = ring[j % DEPTH];
+        if (j + DEPTH < 16) ring[j % DEPTH] = fetch(reg_of(j + DEPTH));
+        if (SWAP) {
+            lazy_swap(x, r);
+            const u64 keep = odd ? c2.y : c2.x, send = odd ? c2.x : c2.y;
+            const u64 recv = from_pair_lane(send);
+            c2 = odd ? V2{recv, keep} : V2{keep, recv};
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            double c = from_word(x[r + e]);
+            c = (c >= p_half) ? c - p_last : c;
+            double d = from_word(e ? c2.y : c2.x);
+            d = (d >= q2_half) ? d - q2_last : d;
+            if (SCALE2) d = a_modmul(d, m2, m2u, q);
+            x[r + e] = U(a_modmul(c, m, mu, q) + d);
+        }
+    }
+};
+
 // ---- passes: the slot schedule of hp_ntt_fast.hip (pass_slots) with the FP64 butterfly ---------------------------------------
 template <bool FWD, int S, int S0, int S1, int DEP, class Tab, class Pre = NoPre>
 HP_DEV void pass_slots_a(u64 (&x)[32], u64x2 (&ring)[DEP], const Tab &tbl, u32 ncls, u32 cls, double q, const Pre &pre = Pre()) {
@@ -137,7 +190,8 @@ template <int BLO, class Tab> HP_DEV void inv_pass_a(u64 (&x)[32], const Tab tbl
 
 // ---- forward ---------------------------------------------------------------------------------------------------------------
 // FLAV (fused drop): 1 CKKS, no addend; 2 CKKS, addend on both polynomials (relinearize's +=, ckks/arith.cpp:70-71); 3 / 4 the
-// same with the BGV factors (mod_switch.cpp:70,76); 5 CKKS, addend on polynomial 0 only (rotations, ckks/arith.cpp:75-93)
+// same with the BGV factors (mod_switch.cpp:70,76); 5 CKKS, addend on polynomial 0 only (rotations, ckks/arith.cpp:75-93);
+// 6 / 7 two drops at once (DropPre2A), CKKS / BGV, addend of the first drop on both polynomials
 template <int LOGN, bool DROP, int FLAV>
 HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
     using G = Geo<LOGN>;
@@ -160,6 +214,9 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
     TRACE_MARK();   // 0: decoded, staging load issued
     u64 x[32];
     constexpr bool SW = G::PB == 0;   // N = 32768: registers left as loaded, sorted into columns by the lane-pair swap of the first stage
+    constexpr bool TWO = FLAV == 6 || FLAV == 7;
+    DropPre2A<LOGN, SW, FLAV == 7> pre2;
+    if constexpr (TWO) pre2.prime(da->comb + (size_t)it.poly * G::N, tid);
     load_flight<LOGN, SW>(it.src, tid, x);
     if (tid < 31u * (1u << G::A)) lds_tw[tid] = stg;
     constexpr bool BGV = FLAV == 3 || FLAV == 4;
@@ -168,7 +225,13 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
 #endif
     TRACE_MARK();   // 1: coefficients have arrived
     // pass A: global stages 1..A, wave-uniform twiddles seq[1 .. 2^A - 1]
-    if constexpr (DROP) {
+    if constexpr (TWO) {
+        const u32 k = it.limb;
+        pre2.q = q; pre2.p_last = D(da->dc.q_last); pre2.p_half = D(da->dc.half_q_last);
+        pre2.q2_last = D(da->q2_last); pre2.q2_half = D(da->half_q2_last);
+        pre2.m = D(da->dc.t[k]); pre2.mu = D(da->dc.t_h[k]); pre2.m2 = D(da->comb_mul[k]); pre2.m2u = D(da->comb_mul_h[k]);
+        fwd_pass_a<G::PB, STab>(x, STab(lp->fwd_ref + 1), 1u, 0u, q, pre2);
+    } else if constexpr (DROP) {
         const u32 k = it.limb;
         const DropPreA<SW, BGV> pre{q, D(da->dc.q_last), D(da->dc.half_q_last), D(da->dc.t[k]), D(da->dc.t_h[k])};
         fwd_pass_a<G::PB, STab>(x, STab(lp->fwd_ref + 1), 1u, 0u, q, pre);
@@ -223,7 +286,7 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
         // as a residue: x and the addend are lazy words of the caller's rows (below 2^51), the result is canonical
         const u32 k = it.limb, p2 = it.poly;
         const u32 voff = ((((tid >> 6)) << 11) + ((tid & 63u) << 1)) << 3;
-        const bool has_add = FLAV == 2 || FLAV == 4 || (FLAV == 5 && __builtin_amdgcn_readfirstlane((p2 & 1u) == 0 ? 1 : 0) != 0);
+        const bool has_add = FLAV == 2 || FLAV == 4 || TWO || (FLAV == 5 && __builtin_amdgcn_readfirstlane((p2 & 1u) == 0 ? 1 : 0) != 0);
         const StreamBuf xs(da->x + ((size_t)p2 * da->L + k) * G::N);
         const StreamBuf as(has_add ? da->addend + ((size_t)(p2 >> 1) * da->add_ct_stride + (size_t)(p2 & 1) * da->add_poly_stride + k) * G::N
                                    : da->x);
@@ -249,8 +312,16 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
                     if (ADD) ar[s % EPI_DEPTH] = as.load(voff, (u32)(s + EPI_DEPTH) << 10);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                double v0 = a_modmul(from_word(xv.x) - D(x[2 * s]), inv, invu, q);
-                double v1 = a_modmul(from_word(xv.y) - D(x[2 * s + 1]), inv, invu, q);
+                double v0, v1;
+                if constexpr (TWO) {
+                    // ((A x + a) - NTT(...)) B: |A x| <= q/2 (1 + 2^-1), a < 2^51, |NTT| < 1.12 * 2^50 (narrow limbs; q/2 for wide ones): below 2^52
+                    v0 = a_modmul(a_modmul(from_word(xv.x), inv, invu, q) + from_word(av.x) - D(x[2 * s]), ql, qlu, q);
+                    v1 = a_modmul(a_modmul(from_word(xv.y), inv, invu, q) + from_word(av.y) - D(x[2 * s + 1]), ql, qlu, q);
+                    d.store(voff + ((u32)s << 10), V2{a_canon(v0, qinv, q), a_canon(v1, qinv, q)});
+                    continue;
+                }
+                v0 = a_modmul(from_word(xv.x) - D(x[2 * s]), inv, invu, q);
+                v1 = a_modmul(from_word(xv.y) - D(x[2 * s + 1]), inv, invu, q);
                 if (BGV) {
                     v0 = a_modmul(v0, ql, qlu, q);
                     v1 = a_modmul(v1, ql, qlu, q);
@@ -262,7 +333,7 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
                 d.store(voff + ((u32)s << 10), V2{a_canon(v0, qinv, q), a_canon(v1, qinv, q)});
             }
         };
-        if constexpr (FLAV == 2 || FLAV == 4) rows(std::true_type{});
+        if constexpr (FLAV == 2 || FLAV == 4 || TWO) rows(std::true_type{});
         else if constexpr (FLAV == 1 || FLAV == 3) rows(std::false_type{});
         else if (has_add) rows(std::true_type{});
         else rows(std::false_type{});
@@ -443,18 +514,21 @@ template <int LOGN> hipError_t launch_a(const HpNttJob &job, hipStream_t stream)
 }
 
 template <int LOGN> hipError_t launch_drop_a(const HpNttJob &job, const HpDropArgs &da, hipStream_t stream) {
-    if (da.fin_on || da.raw_input || da.comb) return hipErrorNotSupported;
+    if (da.fin_on || da.raw_input) return hipErrorNotSupported;
     int flav = 0;
-    if (!da.addend || da.add_mask == 0) flav = 1;
+    if (da.comb) flav = (da.addend && da.add_mask == 3u) ? (da.dc.bgv ? 7 : 6) : 0;   // two drops at once
+    else if (!da.addend || da.add_mask == 0) flav = 1;
     else if (da.add_mask == 3u) flav = 2;
     else if (da.add_mask == 1u && !da.dc.bgv) flav = 5;
-    if (flav && flav != 5 && da.dc.bgv) flav += 2;
+    if (flav && flav < 5 && da.dc.bgv) flav += 2;
 #define HP_DROP_A(F) k_ntt_fwd_drop_a<LOGN, F><<<job.W, Geo<LOGN>::T, 0, stream>>>(job, da)
     if (flav == 1) HP_DROP_A(1);
     else if (flav == 2) HP_DROP_A(2);
     else if (flav == 3) HP_DROP_A(3);
     else if (flav == 4) HP_DROP_A(4);
     else if (flav == 5) HP_DROP_A(5);
+    else if (flav == 6) HP_DROP_A(6);
+    else if (flav == 7) HP_DROP_A(7);
     else return hipErrorNotSupported;
 #undef HP_DROP_A
     return hipGetLastError();
