@@ -232,6 +232,48 @@ def test_extensions_at_level_a(enga, orc, logn, L0, L):
     assert np.array_equal(eng.to_host(eng.ckks_rescale_n(q, d1, drops)), canon(q, exp))
 
 
+@pytest.mark.parametrize("logn,mext", [
+    (11, [P.P50[1], P.P40[0], P.P50[0]]),          # L = 2: one output limb (wide), narrow q', wide p
+    (12, P.P40[:2] + [P.P40[6]]),                   # L = 2, all narrow
+    (13, [P.P40[0], P.P50[1], P.P50[2]]),           # L = 2, wide q' and p
+    (15, [P.P50[1], P.P40[0], P.P40[1], P.P50[0]]),  # N = 32768 (no spills there), L = 3
+    (14, P.P50[1:4] + P.P40[:2] + [P.P50[0]]),      # L = 5, wide limbs first
+])
+def test_two_drops_in_one_transform(orc, monkeypatch, logn, mext):
+    """hp_dev_*_mult_relin_* at level A drops the special prime and the last prime in one transform per output limb
+    (hp_api_scheme.cpp: drop_two_last_a): the oracle's residues, the same words as with HP_NO_DOUBLE_DROP (two launches), for CKKS,
+    BGV (rescaling.cpp:46-75, mod_switch.cpp:45-77) and the inner_t extension"""
+    from hehub_amd.engine import Engine
+
+    n, L, B, t = 1 << logn, len(mext) - 1, 3, P.C5_T
+    q = mext[:L]
+    rng = SplitMix(4400 + logn)
+    ct1, ct2 = rng.poly((B, 2, L, n), q), rng.poly((B, 2, L, n), q)
+    key = rng.poly((L, 2, L + 1, n), mext)
+    ct1[0, 0, :, :7] = (np.array(q, dtype=U) - U(1))[:, None]
+    ct2[0, 1, :, :5] = (U(2) * np.array(q, dtype=U) - U(1))[:, None]
+    exp = {"ckks": np.stack([orc.ckks_mult(mext, ct1[i], ct2[i], key) for i in range(B)]),
+           "bgv": np.stack([orc.bgv_mult(mext, t, ct1[i], ct2[i], key) for i in range(B)]),
+           "bgv_t": np.stack([orc.bgv_mod_drop(q, t, orc.bgv_relinearize(mext, orc.mult_low_level(q, ct1[i], ct2[i]), key, inner_t=t))
+                              for i in range(B)])}
+    got = {}
+    for off in (False, True):
+        monkeypatch.delenv("HP_NO_DOUBLE_DROP", raising=False)
+        if off:
+            monkeypatch.setenv("HP_NO_DOUBLE_DROP", "1")
+        eng = Engine(0)
+        try:
+            eng.set_parity_level("A")
+            d1, d2, dk = eng.to_device(ct1), eng.to_device(ct2), eng.to_device(key)
+            got[off] = {"ckks": eng.to_host(eng.ckks_mult(mext, d1, d2, dk)), "bgv": eng.to_host(eng.bgv_mult(mext, t, d1, d2, dk)),
+                        "bgv_t": eng.to_host(eng.bgv_mult(mext, t, d1, d2, dk, inner_t=True))}
+        finally:
+            eng.close()
+    for name in exp:
+        assert np.array_equal(got[False][name], canon(mext, exp[name])), name
+        assert np.array_equal(got[True][name], got[False][name]), name
+
+
 def test_level_a_pipeline_in_a_hip_graph(enga, orc):
     """after one warm-up call (which builds the FP64 tables) a level-A entry point only enqueues kernels: capturable and replayable"""
     import torch
