@@ -16,12 +16,14 @@ namespace hpi {
 size_t ext_prod_ws_words(size_t n, size_t L, size_t P) { return padded(P * L * n) / 8 + padded(P * L * (L + 1) * n) / 8; }
 
 // (i) c[j] = strict(INTT(pt[j])) for the digits j in [j0, j1)                          rgsw.cpp:103-105
+// for_spread_a: the rows go to the level-A digit-spread launch of the same call and nowhere else: written as doubles
 int ks_coef(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P, size_t j0, size_t j1, const u64 *pt,
-            size_t pt_pstride, u64 *coef) {
+            size_t pt_pstride, u64 *coef, bool for_spread_a) {
     const size_t n = (size_t)1 << logn;
     HpNttJob j = batch_job(plan, logn, j1 - j0, P, pt + j0 * n, coef + j0 * n, pt_pstride, L, 1, 1);
     j.limbs = plan->d_limbs + j0;
     if (ctx->cur_a) j.limbs_a = plan->d_limbs_a + j0;   // strict either way: the same words at both levels
+    j.dst_f64 = (ctx->cur_a && for_spread_a) ? 1u : 0u;
     return run_ntt(ctx, j);
 }
 
@@ -75,7 +77,7 @@ int ks_digits_inner(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t
     if (sj.pair_moduli > L) sj.pair_moduli = (u32)L;
     // digit rows of the output moduli whose words are provably below 2^48 cross HBM as 6 bytes per word (HP_PACK48)
     sj.pack_mask = strict_coef ? spread_pack_mask(ctx, plan, logn, L, P, k0, k1) : 0u;
-    // level A: digit rows as canonical residues (the inner product below is the same integer kernel: its u128 sums then differ
+    // level A: digit rows as residues in [q/2, 3q/2] (the inner product below is the same integer kernel: its u128 sums then differ
     // from rgsw.cpp:126-149's by multiples of q_k, its Montgomery outputs are congruent to the reference's and below 2 q_k).
     // Caller-supplied coefficient rows (limb-range stages) are not known to be below 2^50: level B.
     if (ctx->cur_a && strict_coef) sj.limbs_a = plan->d_limbs_a;
@@ -95,7 +97,7 @@ int ext_prod(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P, con
     u64 *coef = cv.take(P * L * n);
     u64 *digits = cv.take(P * L * (L + 1) * n);
     int rc;
-    if ((rc = ks_coef(ctx, plan, logn, L, P, 0, L, pt, pt_pstride, coef))) return rc;
+    if ((rc = ks_coef(ctx, plan, logn, L, P, 0, L, pt, pt_pstride, coef, true))) return rc;
     return ks_digits_inner(ctx, plan, logn, L, P, 0, L + 1, coef, pt, pt_pstride, key, key_L0, out, digits, true);
 }
 

@@ -217,7 +217,7 @@ HpNttJob batch_job(const Plan *plan, size_t logn, size_t L, size_t P, const u64 
 size_t ext_prod_ws_words(size_t n, size_t L, size_t P);
 size_t drop_ws_words(size_t n, size_t L, size_t P2);
 int ks_coef(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P, size_t j0, size_t j1, const u64 *pt, size_t pt_pstride,
-            u64 *coef);
+            u64 *coef, bool for_spread_a = false);
 int drop_last(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, bool bgv, u64 t, const u64 *x, const u64 *addend,
               size_t add_poly_stride, size_t add_ct_stride, u32 add_mask, u64 *out, Carver &cv);
 

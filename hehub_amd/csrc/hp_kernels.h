@@ -48,6 +48,8 @@ struct HpNttJob {
     // which return CANONICAL residues (equal to reduce_strict of the level-B words); post_scalar / post_scalar_h then hold the
     // bit patterns of the doubles (s, RN(s / q))
     const HpLimbA *limbs_a;
+    u32 dst_f64;    // level A, inverse: the output rows are the doubles themselves, not words -- only for rows that feed a level-A
+                    // HP_NTT_SPREAD launch (k_ntt_fwd_a<., true> reads doubles), never for rows a caller sees
 };
 
 hipError_t hp_launch_ntt_generic(const HpNttJob &job, hipStream_t stream);

@@ -59,12 +59,15 @@ HP_DEV void a_reduce_all(u64 (&x)[32], double qinv, double q) {
 }
 
 // ---- load-side work of the forward kernels, done per 16-byte load right before the first butterfly that touches it ----------
-template <bool SWAP> struct ConvPre {
-    static constexpr bool on = true;
+// F64: the row already holds doubles (the strict coefficient rows of the key switch, written by k_ntt_inv_a with job.dst_f64)
+template <bool SWAP, bool F64> struct ConvPre {
+    static constexpr bool on = SWAP || !F64;
     HP_DEV void operator()(u64 (&x)[32], int r) const {
         if (SWAP) lazy_swap(x, r);
-        x[r] = U(from_word(x[r]));
-        x[r + 1] = U(from_word(x[r + 1]));
+        if (!F64) {
+            x[r] = U(from_word(x[r]));
+            x[r + 1] = U(from_word(x[r + 1]));
+        }
     }
 };
 // fused drop-last-prime: c (strict modulo q_last) -> the centred representative c - [c >= q_last / 2] q_last, which is congruent
@@ -96,7 +99,7 @@ template <bool SWAP, bool BGV> struct DropPreA {
 // the registers (0, 16, 2, 18, ...: load_flight's issue order).
 template <int LOGN, bool SWAP, bool SCALE2> struct DropPre2A {
     static constexpr bool on = true;
-    static constexpr int DEPTH = 8;
+    static constexpr int DEPTH = 8;   // (four spill the same four registers below N = 32768, where the epilogue is the tight spot)
     using G = Geo<LOGN>;
     double q, p_last, p_half, q2_last, q2_half, m, mu, m2, m2u;
     const u64 *row;   // the thread's part of the second coefficient row
@@ -192,7 +195,7 @@ template <int BLO, class Tab> HP_DEV void inv_pass_a(u64 (&x)[32], const Tab tbl
 // FLAV (fused drop): 1 CKKS, no addend; 2 CKKS, addend on both polynomials (relinearize's +=, ckks/arith.cpp:70-71); 3 / 4 the
 // same with the BGV factors (mod_switch.cpp:70,76); 5 CKKS, addend on polynomial 0 only (rotations, ckks/arith.cpp:75-93);
 // 6 / 7 two drops at once (DropPre2A), CKKS / BGV, addend of the first drop on both polynomials
-template <int LOGN, bool DROP, int FLAV>
+template <int LOGN, bool DROP, int FLAV, bool SPREAD = false>
 HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
     using G = Geo<LOGN>;
     using AD = Addr<LOGN, LOGN == 15>;
@@ -236,7 +239,7 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
         const DropPreA<SW, BGV> pre{q, D(da->dc.q_last), D(da->dc.half_q_last), D(da->dc.t[k]), D(da->dc.t_h[k])};
         fwd_pass_a<G::PB, STab>(x, STab(lp->fwd_ref + 1), 1u, 0u, q, pre);
     } else {
-        fwd_pass_a<G::PB, STab>(x, STab(lp->fwd_ref + 1), 1u, 0u, q, ConvPre<SW>());
+        fwd_pass_a<G::PB, STab>(x, STab(lp->fwd_ref + 1), 1u, 0u, q, ConvPre<SW, SPREAD>());
     }
     if (wide) a_reduce_all(x, qinv, q);
     TRACE_MARK();   // 2
@@ -252,9 +255,17 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
     fwd_pass_a<0>(x, BTab(lp->fwd_k + 31 * (1 << G::A)), (u32)G::T, tid, q);
     TRACE_MARK();   // 6
     if (!DROP) {
-        // canonical residues, as words
+        if constexpr (SPREAD) {
+            // digit rows (workspace read by the inner product alone, which takes any word below 2^51 -- level B hands it lazy ones):
+            // the centred residue + q, in [q/2, 3q/2], needs no sign fix-up; q and the 2^52 of the conversion are one addend
+            const double bias = q + TWO52;
 #pragma unroll
-        for (int r = 0; r < 32; ++r) x[r] = a_canon(D(x[r]), qinv, q);
+            for (int r = 0; r < 32; ++r) x[r] = U(a_reduce(D(x[r]), qinv, q) + bias) & 0x000FFFFFFFFFFFFFull;
+        } else {
+            // canonical residues, as words
+#pragma unroll
+            for (int r = 0; r < 32; ++r) x[r] = a_canon(D(x[r]), qinv, q);
+        }
     } else if (wide) {
         a_reduce_all(x, qinv, q);
     }
@@ -263,8 +274,8 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
     TRACE_MARK();   // 8
     if (!DROP) {
         const size_t off = (((size_t)(tid >> 6)) << 11) + ((tid & 63u) << 1);
-        if (job.mode == HP_NTT_SPREAD && ((job.pack_mask >> it.limb) & 1u)) {
-            // HP_PACK48 (hp_device.h): canonical residues of a modulus below 2^47 always fit
+        if (SPREAD && ((job.pack_mask >> it.limb) & 1u)) {
+            // HP_PACK48 (hp_device.h): words below 3q/2 of a modulus below 2^47 always fit
             typedef u32 __attribute__((ext_vector_type(2))) v2u;
             u32 *lo = reinterpret_cast<u32 *>(it.dst) + off;
             u32 *hi = reinterpret_cast<u32 *>(it.dst) + G::N + (off >> 1);
@@ -342,9 +353,9 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
     TRACE_FLUSH();
 }
 
-template <int LOGN>
+template <int LOGN, bool SPREAD>
 __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd_a(HpNttJob job) {
-    ntt_fwd_a_body<LOGN, false, 0>(job, nullptr);
+    ntt_fwd_a_body<LOGN, false, 0, SPREAD>(job, nullptr);
 }
 template <int LOGN, int FLAV>
 __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd_drop_a(HpNttJob job, HpDropArgs da) {
@@ -427,6 +438,9 @@ __global__ void __launch_bounds__(InvGeoA<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv_
     inv_pass_a<G::PB>(x, BTab(lp->inv_k + 31 + 31 * 32), (u32)G::T, tid, q);
     if (wide) a_reduce_all(x, qinv, q);
     const double psc = D(job.post_scalar), psu = D(job.post_scalar_h);
+    // rows for a caller: words; rows for the digit-spread launch of the same key switch (job.dst_f64): the doubles themselves
+    const double wbias = job.dst_f64 ? 0.0 : TWO52;
+    const u64 wmask = job.dst_f64 ? ~0ull : 0x000FFFFFFFFFFFFFull;
     if constexpr (InvGeoA<LOGN>::STREAM_EPILOGUE) {
         // N <= 8192: transpose once more so that the psi^-i N^-1 pairs are read and the words written 16 contiguous bytes per lane
         exchange<LOGN, LAY_A, LAY_S, true>(x, lds, ad);
@@ -444,7 +458,7 @@ __global__ void __launch_bounds__(InvGeoA<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv_
                 const int r = 2 * s0 + e;
                 double v = a_modmul(D(x[r]), D(f[e].x), D(f[e].y), q);      // ntt.cpp:214-222 as a residue
                 if (PSCAL) v = a_modmul(v, psc, psu, q);                    // mod_switch.cpp:49
-                x[r] = to_word(a_nonneg(v, q));
+                x[r] = U(a_nonneg(v, q) + wbias) & wmask;
             }
             st_stream(d + ((size_t)s0 << 7), V2{x[2 * s0], x[2 * s0 + 1]});
             st_stream(d + ((size_t)(s0 + 1) << 7), V2{x[2 * s0 + 2], x[2 * s0 + 3]});
@@ -468,7 +482,7 @@ __global__ void __launch_bounds__(InvGeoA<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv_
                 const int r = r0 + e;
                 double v = a_modmul(D(x[r]), D(f[e].x), D(f[e].y), q);
                 if (PSCAL) v = a_modmul(v, psc, psu, q);
-                x[r] = to_word(a_nonneg(v, q));
+                x[r] = U(a_nonneg(v, q) + wbias) & wmask;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -502,7 +516,8 @@ __global__ void __launch_bounds__(InvGeoA<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv_
 template <int LOGN> hipError_t launch_a(const HpNttJob &job, hipStream_t stream) {
     if (!job.inverse) {
         if (job.mode != HP_NTT_BATCH && job.mode != HP_NTT_SPREAD) return hipErrorNotSupported;
-        k_ntt_fwd_a<LOGN><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
+        if (job.mode == HP_NTT_SPREAD) k_ntt_fwd_a<LOGN, true><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
+        else k_ntt_fwd_a<LOGN, false><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
         return hipGetLastError();
     }
     constexpr int LPW = InvGeoA<LOGN>::LPW, TT = InvGeoA<LOGN>::TT;

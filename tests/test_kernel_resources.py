@@ -132,17 +132,19 @@ def test_vcc_carry_wait_states():
 
 def test_level_a_kernels(meta):
     """hp_ntt_a.hip (FP64 residue butterflies): every tiled size and flavour is built, four waves per SIMD, no spills in anything
-    the C3 / C5 pipelines launch (the BGV-with-addend flavour and the smallest inverse keep 2-4 spilled registers)"""
+    the C3 pipeline and the single drops launch (the BGV-with-addend flavour, the two-drops flavours below N = 32768 and the smallest
+    inverse keep 2-4 spilled registers)"""
     for logn in range(11, 16):
-        pick(meta, rf"k_ntt_fwd_a<{logn}>")
+        for spread in ("false", "true"):
+            pick(meta, rf"k_ntt_fwd_a<{logn}, {spread}>")
         for ps in ("false", "true"):
             pick(meta, rf"k_ntt_inv_a<{logn}, {ps}>")
-        for flav in range(1, 6):
+        for flav in range(1, 8):
             pick(meta, rf"k_ntt_fwd_drop_a<{logn}, {flav}>")
     for name, r in pick(meta, r"k_ntt_(fwd|inv|fwd_drop)_a<").items():
         assert r["vgpr_count"] <= 128 and r["sgpr_spill_count"] == 0, (name, r)
         assert r["vgpr_spill_count"] <= 4, (name, r)
-    for name, r in pick(meta, r"k_ntt_fwd_a<\d+>|k_ntt_inv_a<1[2-5], |k_ntt_fwd_drop_a<\d+, [1235]>").items():
+    for name, r in pick(meta, r"k_ntt_fwd_a<\d+, |k_ntt_inv_a<1[2-5], |k_ntt_fwd_drop_a<\d+, [1235]>|k_ntt_fwd_drop_a<15, [67]>").items():
         assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, (name, r)
     for name, r in pick(meta, r"k_ntt_(fwd|inv|fwd_drop)_a<15").items():
         assert 140 * 1024 <= r["group_segment_fixed_size"] <= 160 * 1024, (name, r)
