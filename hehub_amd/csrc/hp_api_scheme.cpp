@@ -133,16 +133,15 @@ void make_drop_consts(const Plan *plan, size_t L, bool bgv, u64 t, HpDropConsts 
 
 // clast[p2] = strict(INTT_{q_last}(x[p2][last]))  (BGV: times t^-1 before the strict reduction):
 // a one-limb batch whose rows are the last limbs of the P2 polynomials
-// rows: the limbs of modulus number `limb` of the P2 polynomials, row_pstride limbs apart
-int limb_coeffs(hp_ctx *ctx, const Plan *plan, size_t logn, size_t limb, size_t P2, bool bgv, u64 t, const u64 *rows, size_t row_pstride,
-                u64 *clast) {
-    const u64 q_last = plan->consts[limb].q;
+int drop_coeffs(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, bool bgv, u64 t, const u64 *x, u64 *clast) {
+    const size_t n = (size_t)1 << logn;
+    const u64 q_last = plan->consts[L - 1].q;
     HpNttJob lj;
     memset(&lj, 0, sizeof(lj));
-    lj.limbs = plan->d_limbs + limb; lj.src = rows; lj.dst = clast; lj.logn = (u32)logn; lj.L = 1;
-    lj.P = (u32)P2; lj.src_pstride = (u32)row_pstride; lj.dst_pstride = 1; lj.src_kstride = 1; lj.W = (u32)P2; lj.mode = HP_NTT_BATCH;
+    lj.limbs = plan->d_limbs + (L - 1); lj.src = x + (L - 1) * n; lj.dst = clast; lj.logn = (u32)logn; lj.L = 1;
+    lj.P = (u32)P2; lj.src_pstride = (u32)L; lj.dst_pstride = 1; lj.src_kstride = 1; lj.W = (u32)P2; lj.mode = HP_NTT_BATCH;
     lj.inverse = 1; lj.strict = 1;
-    if (ctx->cur_a) lj.limbs_a = plan->d_limbs_a + limb;
+    if (ctx->cur_a) lj.limbs_a = plan->d_limbs_a + (L - 1);
     if (bgv) {
         const u64 s = hp::inverse_mod_prime(t, q_last) % q_last;
         lj.post_scalar = s;
@@ -155,17 +154,12 @@ int limb_coeffs(hp_ctx *ctx, const Plan *plan, size_t logn, size_t limb, size_t 
     }
     return run_ntt(ctx, lj);
 }
-int drop_coeffs(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, bool bgv, u64 t, const u64 *x, u64 *clast) {
-    return limb_coeffs(ctx, plan, logn, L - 1, P2, bgv, t, x + ((L - 1) << logn), L, clast);
-}
 
 // out[k] = ((x[k] - NTT_k(centre(barrett_k(clast)))) * inv_k) [* (q_last mod t)] [+ addend[k]] for the limbs k in [k0, k1)
 // of the L-1 that remain.  rem: workspace of P2*(k1-k0)*n words (unused by the fused tiled path).
 int drop_apply(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, size_t k0, size_t k1, const HpDropConsts &dc0,
                const u64 *x, const u64 *clast, bool clast_strict, const u64 *addend, size_t add_poly_stride, size_t add_ct_stride,
-               u32 add_mask, u64 *out, u64 *rem, size_t out_stride = 0) {
-    // out_stride: limbs between consecutive polynomials of out (0: L - 1, with the range's first limb at out + k0 limbs; otherwise out
-    // points at the first limb of the range itself)
+               u32 add_mask, u64 *out, u64 *rem) {
     // clast_strict: the caller vouches that every word of clast is below q_last (drop_last: it has just been written by a
     // strict inverse transform).  Rows handed in over the C ABI get the full Barrett reduction, which is right for any u64.
     const size_t n = (size_t)1 << logn, kc = k1 - k0;
@@ -178,11 +172,10 @@ int drop_apply(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, 
     }
     const HpLimb *limbs = plan->d_limbs + k0;
     x += k0 * n;
-    if (out_stride == 0) out += k0 * n;
+    out += k0 * n;
     if (addend) addend += k0 * n;
     int rc;
     // tiled sizes: Barrett + centring fused into the remainder NTT's loads, (x - rem)*inv [+ addend] into its stores
-    if (out_stride && !fused_drop_ok(ctx, logn)) return fail(ctx, HP_ELOGIC, "compact drop rows need the fused kernels");
     if (fused_drop_ok(ctx, logn)) {
         HpNttJob fj = batch_job(plan, logn, kc, P2, clast, nullptr, 1, 0, 0, 0);
         fj.limbs = limbs;
@@ -192,7 +185,7 @@ int drop_apply(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, 
         HpDropArgs da;
         memset(&da, 0, sizeof(da));
         da.dc = dc; da.x = x; da.L = (u32)L; da.addend = addend; da.add_poly_stride = (u32)add_poly_stride;
-        da.add_ct_stride = (u32)add_ct_stride; da.add_mask = add_mask; da.out = out; da.out_stride = (u32)(out_stride ? out_stride : L - 1);
+        da.add_ct_stride = (u32)add_ct_stride; da.add_mask = add_mask; da.out = out; da.out_stride = (u32)(L - 1);
         da.small_rem = clast_strict ? 1 : 0;   // rescaling.cpp:54-58: strict_barrett_{q_k}(c), c < q_last -- one conditional subtraction when q_last <= 2 q_k
         for (size_t k = k0; k < k1; k++)
             if (plan->consts[L - 1].q > 2 * plan->consts[k].q) da.small_rem = 0;
@@ -232,23 +225,48 @@ int drop_apply(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, 
 // Level A only: relinearize's mod-down (drop p = q_L, addend on both polynomials: rgsw.cpp / ckks/arith.cpp:64-71) and the rescale / mod
 // switch that follows it in a mult (drop q' = q_{L-1}: rescaling.cpp:46-75, mod_switch.cpp:45-77) as ONE transform per output limb:
 // ext [P2][L+1] -> out [P2][L-1].  Residues only (hp_ntt_a.hip: DropPre2A has the algebra): the intermediate rows are never formed
-// for the limbs k < L - 1; the limb L - 1, whose coefficients the second drop needs, goes through the ordinary single drop.
+// for the limbs k < L - 1, and of the limb L - 1 only the coefficients the second drop needs (one inverse launch, also by linearity).
 bool two_drops_ok(const hp_ctx *ctx, size_t logn, size_t L) { return ctx->cur_a && !ctx->no_double_drop && fused_drop_ok(ctx, logn) && L >= 2; }
-size_t two_drops_ws_words(size_t n, size_t P2) { return 3 * (padded(P2 * n) / 8); }
 int drop_two_last_a(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, bool bgv, u64 t1, u64 t2, const u64 *ext,
                     const u64 *addend, size_t add_poly_stride, size_t add_ct_stride, u64 *out, Carver &cv) {
     const size_t n = (size_t)1 << logn;
     HpDropConsts dc1, dc2;
     make_drop_consts(plan, L + 1, bgv, t1, dc1);
     make_drop_consts(plan, L, bgv, t2, dc2);
-    u64 *cp = cv.take(P2 * n), *ylast = cv.take(P2 * n), *cq = cv.take(P2 * n);
+    u64 *cp = cv.take(P2 * n), *cq = cv.take(P2 * n);
     int rc;
+    auto mulmod = [](u64 a, u64 b, u64 q) { return (u64)(((unsigned __int128)a * b) % q); };
     if ((rc = drop_coeffs(ctx, plan, logn, L + 1, P2, bgv, t1, ext, cp))) return rc;
-    // y_{L-1} = ((ext_{L-1} - NTT(cp)) p^-1 ...) + addend_{L-1}, compact rows; then its strict coefficients modulo q'
-    if ((rc = drop_apply(ctx, plan, logn, L + 1, P2, L - 1, L, dc1, ext, cp, true, addend, add_poly_stride, add_ct_stride, 3, ylast,
-                         nullptr, 1)))
-        return rc;
-    if ((rc = limb_coeffs(ctx, plan, logn, L - 1, P2, bgv, t2, ylast, 1, cq))) return rc;
+    {
+        // cq: the strict coefficients modulo q' of y_{L-1} = A' ext_{L-1} + addend_{L-1} - NTT(K cp) [times t2^-1], which are
+        // INTT(A' ext_{L-1} + addend_{L-1}) - K cp: one inverse launch (k_ntt_inv_mix_a), y_{L-1} itself is never formed
+        const size_t kl = L - 1;
+        const u64 q2 = plan->consts[kl].q;
+        u64 A = dc1.inv[kl], K = A;
+        if (bgv) {
+            A = mulmod(A, dc1.qlt[kl], q2);
+            K = mulmod(A, dc1.t[kl], q2);
+        }
+        HpNttJob lj;
+        memset(&lj, 0, sizeof(lj));
+        lj.limbs = plan->d_limbs + kl; lj.limbs_a = plan->d_limbs_a + kl; lj.src = ext + kl * n; lj.dst = cq; lj.logn = (u32)logn; lj.L = 1;
+        lj.P = (u32)P2; lj.src_pstride = (u32)(L + 1); lj.dst_pstride = 1; lj.src_kstride = 1; lj.W = (u32)P2; lj.mode = HP_NTT_BATCH;
+        lj.inverse = 1; lj.strict = 1;
+        if (bgv) {
+            const u64 s = hp::inverse_mod_prime(t2, q2) % q2;
+            lj.post_scalar = hp::f64_bits((double)s);
+            lj.post_scalar_h = hp::f64_bits((double)s / (double)q2);
+            lj.use_post_scalar = 1;
+        }
+        HpInvMixArgs mx;
+        memset(&mx, 0, sizeof(mx));
+        mx.add = addend + kl * n; mx.add_poly_stride = (u32)add_poly_stride; mx.add_ct_stride = (u32)add_ct_stride;
+        mx.A = hp::f64_bits((double)A); mx.A_h = hp::f64_bits((double)A / (double)q2);
+        mx.K = hp::f64_bits((double)K); mx.K_h = hp::f64_bits((double)K / (double)q2);
+        mx.cprev = cp; mx.prev_q = hp::f64_bits((double)dc1.q_last); mx.prev_half = hp::f64_bits((double)dc1.half_q_last);
+        ProfScope ps(ctx, "intt");
+        if ((rc = chk(ctx, hp_launch_ntt_a_inv_mix(lj, mx, ctx->stream), "inverse NTT of the combined limb (level A)"))) return rc;
+    }
     const size_t kc = L - 1;
     if (kc == 0) return HP_OK;
     HpNttJob fj = batch_job(plan, logn, kc, P2, cp, nullptr, 1, 0, 0, 0);
@@ -267,7 +285,6 @@ int drop_two_last_a(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t
     da.dc.half_q_last = hp::f64_bits((double)dc1.half_q_last);
     da.q2_last = hp::f64_bits((double)dc2.q_last);
     da.half_q2_last = hp::f64_bits((double)dc2.half_q_last);
-    auto mulmod = [](u64 a, u64 b, u64 q) { return (u64)(((unsigned __int128)a * b) % q); };
     for (size_t k = 0; k < kc; k++) {
         const u64 q = plan->consts[k].q;
         const double qd = (double)q;

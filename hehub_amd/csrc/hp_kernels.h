@@ -147,6 +147,17 @@ hipError_t hp_launch_ntt_fast_drop(const HpNttJob &job, const HpDropArgs &da, hi
 // level A: dc.q_last / half_q_last and the pairs (inv, inv_h), (t, t_h), (qlt, qlt_h) hold bit patterns of doubles (v, RN(v / q_k));
 // r, small_rem, raw_input, fin, comb are not used; output rows are canonical residues
 hipError_t hp_launch_ntt_a_drop(const HpNttJob &job, const HpDropArgs &da, hipStream_t stream);
+// level A, inverse of ONE limb (job.L == 1) whose input is A * src + add and whose output has K * centre(cprev) subtracted
+// (hp_ntt_a.hip: ntt_inv_a_body MIX); every constant as the bit pattern of a double, (v, RN(v / q)) for the multipliers
+struct HpInvMixArgs {
+    const u64 *add;            // addend rows already at the limb: polynomial p at (p >> 1) * add_ct_stride + (p & 1) * add_poly_stride limbs
+    u32 add_poly_stride, add_ct_stride;
+    u64 A, A_h;
+    const u64 *cprev;          // [P][N] strict coefficients modulo prev_q
+    u64 prev_q, prev_half;
+    u64 K, K_h;
+};
+hipError_t hp_launch_ntt_a_inv_mix(const HpNttJob &job, const HpInvMixArgs &mx, hipStream_t stream);
 
 // clast [P2][n] (strict coefficients of the last limb) -> rem [P2][L-1][n]
 hipError_t hp_launch_drop_rem(const HpLimb *limbs, const HpDropConsts &dc, u32 Lm1, u32 n, u32 P2,

@@ -369,8 +369,11 @@ template <int LOGN> struct InvGeoA {
     static constexpr bool STREAM_EPILOGUE = LOGN <= 13;
 };
 
-template <int LOGN, bool PSCAL>
-__global__ void __launch_bounds__(InvGeoA<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv_a(HpNttJob job) {
+// MIX (the second coefficient row of drop_two_last_a in ONE launch): the coefficients modulo q' of y = A x + a - NTT(K cp), the row the
+// first drop would leave in the limb of q', are INTT(A x + a) - K cp by linearity: the input is combined from the row x and the addend
+// row a while loading, K times the centred coefficients of the previous drop is subtracted from the output
+template <int LOGN, bool PSCAL, bool MIX>
+HP_DEV void ntt_inv_a_body(const HpNttJob &job, const HpInvMixArgs *mx) {
     using G = Geo<LOGN>;
     constexpr int LPW = InvGeoA<LOGN>::LPW, TT = InvGeoA<LOGN>::TT;
     __shared__ u32 lds_all[Addr<LOGN>::WORDS * LPW];
@@ -424,8 +427,25 @@ __global__ void __launch_bounds__(InvGeoA<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv_
         const u32 e = threadIdx.x + (u32)i * TT;
         if (e < 31u * 32u) lds_tw[e] = stg[i];
     }
+    if constexpr (MIX) {
+        const u64 *as = mx->add + ((size_t)(it.poly >> 1) * mx->add_ct_stride + (size_t)(it.poly & 1) * mx->add_poly_stride) * G::N +
+                        (((size_t)(tid >> 6)) << 11) + ((tid & 63u) << 1);
+        const double A = D(mx->A), Au = D(mx->A_h);
+        V2 ar[4];
 #pragma unroll
-    for (int r = 0; r < 32; ++r) x[r] = U(from_word(x[r]));
+        for (int r = 0; r < 4; ++r) ar[r] = ld_stream(as + ((size_t)r << 7));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const V2 av = ar[r % 4];
+            if (r + 4 < 16) ar[r % 4] = ld_stream(as + ((size_t)(r + 4) << 7));
+            // |A x| <= q (1/2 + 2^-1), a < 2^51: narrow limbs take lazy words below 2^45 (sum < 2^50), wide ones are reduced right below
+            x[2 * r] = U(a_modmul(from_word(x[2 * r]), A, Au, q) + from_word(av.x));
+            x[2 * r + 1] = U(a_modmul(from_word(x[2 * r + 1]), A, Au, q) + from_word(av.y));
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) x[r] = U(from_word(x[r]));
+    }
     if (wide) a_reduce_all(x, qinv, q);   // lazy words up to 2 q
     exchange<LOGN, LAY_S, LAY_C, false>(x, lds, ad);
     inv_pass_a<0>(x, STab(lp->inv_k), 1u, 0u, q);
@@ -441,6 +461,15 @@ __global__ void __launch_bounds__(InvGeoA<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv_
     // rows for a caller: words; rows for the digit-spread launch of the same key switch (job.dst_f64): the doubles themselves
     const double wbias = job.dst_f64 ? 0.0 : TWO52;
     const u64 wmask = job.dst_f64 ? ~0ull : 0x000FFFFFFFFFFFFFull;
+    // MIX: v - K centre(c), back into (-q, q) unless the post-scalar multiplication does that anyway
+    const u64 *cprow = MIX ? mx->cprev + (size_t)it.poly * G::N : nullptr;
+    const double mK = MIX ? D(mx->K) : 0.0, mKu = MIX ? D(mx->K_h) : 0.0, mpq = MIX ? D(mx->prev_q) : 0.0, mph = MIX ? D(mx->prev_half) : 0.0;
+    auto mix = [&](double v, u64 cw) {
+        double c = from_word(cw);
+        c = (c >= mph) ? c - mpq : c;
+        v -= a_modmul(c, mK, mKu, q);
+        return PSCAL ? v : a_reduce(v, qinv, q);
+    };
     if constexpr (InvGeoA<LOGN>::STREAM_EPILOGUE) {
         // N <= 8192: transpose once more so that the psi^-i N^-1 pairs are read and the words written 16 contiguous bytes per lane
         exchange<LOGN, LAY_A, LAY_S, true>(x, lds, ad);
@@ -453,10 +482,16 @@ __global__ void __launch_bounds__(InvGeoA<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv_
             u64x2 f[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) f[e] = sc.at((u32)(s0 + (e >> 1)), 128u, (u32)off + (u32)(e & 1));
+            V2 cw[2] = {{0, 0}, {0, 0}};
+            if constexpr (MIX) {
+                cw[0] = ld_stream(cprow + off + ((size_t)s0 << 7));
+                cw[1] = ld_stream(cprow + off + ((size_t)(s0 + 1) << 7));
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = 2 * s0 + e;
                 double v = a_modmul(D(x[r]), D(f[e].x), D(f[e].y), q);      // ntt.cpp:214-222 as a residue
+                if constexpr (MIX) v = mix(v, (e & 1) ? cw[e >> 1].y : cw[e >> 1].x);
                 if (PSCAL) v = a_modmul(v, psc, psu, q);                    // mod_switch.cpp:49
                 x[r] = U(a_nonneg(v, q) + wbias) & wmask;
             }
@@ -477,10 +512,19 @@ __global__ void __launch_bounds__(InvGeoA<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv_
                 const int r = r0 + e, kk = r >> G::PB, pp = r & ((1 << G::PB) - 1);
                 f[e] = sc.at((u32)kk, 1024u, (tid << G::PB) + (u32)pp);
             }
+            u64 cw[4] = {0, 0, 0, 0};
+            if constexpr (MIX) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = r0 + e, kk = r >> G::PB, pp = r & ((1 << G::PB) - 1);
+                    cw[e] = cprow[((size_t)kk << 10) + ((size_t)tid << G::PB) + pp];
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = r0 + e;
                 double v = a_modmul(D(x[r]), D(f[e].x), D(f[e].y), q);
+                if constexpr (MIX) v = mix(v, cw[e]);
                 if (PSCAL) v = a_modmul(v, psc, psu, q);
                 x[r] = U(a_nonneg(v, q) + wbias) & wmask;
             }
@@ -511,6 +555,24 @@ __global__ void __launch_bounds__(InvGeoA<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv_
             }
         }
     }
+}
+
+template <int LOGN, bool PSCAL>
+__global__ void __launch_bounds__(InvGeoA<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv_a(HpNttJob job) {
+    ntt_inv_a_body<LOGN, PSCAL, false>(job, nullptr);
+}
+template <int LOGN, bool PSCAL>
+__global__ void __launch_bounds__(InvGeoA<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv_mix_a(HpNttJob job, HpInvMixArgs mx) {
+    ntt_inv_a_body<LOGN, PSCAL, true>(job, &mx);
+}
+
+template <int LOGN> hipError_t launch_inv_mix_a(const HpNttJob &job, const HpInvMixArgs &mx, hipStream_t stream) {
+    constexpr int LPW = InvGeoA<LOGN>::LPW, TT = InvGeoA<LOGN>::TT;
+    if (!job.inverse || job.mode != HP_NTT_BATCH || job.pair_moduli || job.L != 1) return hipErrorNotSupported;
+    const u32 grid = LPW == 1 ? job.W : job.L * ((job.P + LPW - 1) / LPW);
+    if (job.use_post_scalar) k_ntt_inv_mix_a<LOGN, true><<<grid, TT, 0, stream>>>(job, mx);
+    else k_ntt_inv_mix_a<LOGN, false><<<grid, TT, 0, stream>>>(job, mx);
+    return hipGetLastError();
 }
 
 template <int LOGN> hipError_t launch_a(const HpNttJob &job, hipStream_t stream) {
@@ -566,6 +628,19 @@ hipError_t hp_launch_ntt_a(const HpNttJob &job, hipStream_t stream) {
     case 13: return launch_a<13>(job, stream);
     case 14: return launch_a<14>(job, stream);
     case 15: return launch_a<15>(job, stream);
+    default: return hipErrorNotSupported;
+    }
+}
+
+hipError_t hp_launch_ntt_a_inv_mix(const HpNttJob &job, const HpInvMixArgs &mx, hipStream_t stream) {
+    if (job.W == 0) return hipSuccess;
+    if (!job.limbs_a) return hipErrorInvalidValue;
+    switch (job.logn) {
+    case 11: return launch_inv_mix_a<11>(job, mx, stream);
+    case 12: return launch_inv_mix_a<12>(job, mx, stream);
+    case 13: return launch_inv_mix_a<13>(job, mx, stream);
+    case 14: return launch_inv_mix_a<14>(job, mx, stream);
+    case 15: return launch_inv_mix_a<15>(job, mx, stream);
     default: return hipErrorNotSupported;
     }
 }
