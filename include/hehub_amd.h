@@ -70,7 +70,9 @@ void hp_ctx_destroy(hp_ctx *ctx);
  *     (< 2q, rgsw.cpp:151) with hehub's residues.  Their transforms then run on error-free FP64
  *     products (hp_ntt_a.hip: 8 instead of 16 instructions per butterfly).  Needs every modulus of the chain below 2^50, a ring
  *     degree of 2^11 .. 2^15 and ciphertext words below 2^51 (any lazy word hehub produces is below 2q); a call whose chain does
- *     not qualify runs at level B.  The NTT / mod-arith primitives (hp_ntt_*, hp_dev_ntt_*, hp_dev_poly_*, hp_batched_*) are
+ *     not qualify runs at level B.  At this level the fused mult entry points (hp_dev_*_mult_relin_*) also merge relinearize's
+ *     mod-down with the rescale / mod switch into one transform per output limb (same residues; HP_NO_DOUBLE_DROP=1 at
+ *     hp_ctx_create keeps the two launches).  The NTT / mod-arith primitives (hp_ntt_*, hp_dev_ntt_*, hp_dev_poly_*, hp_batched_*) are
  *     never affected: they stay bit-exact with ntt.cpp:145-223 / mod_arith.cpp. */
 typedef enum { HP_PARITY_B = 0, HP_PARITY_A = 1 } hp_parity_level;
 int hp_ctx_set_parity_level(hp_ctx *ctx, int level);
