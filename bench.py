@@ -48,6 +48,9 @@ import time
 
 # the host driver of these boxes only supports dmabuf IPC: RCCL needs this before the HIP runtime starts
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# pageable numpy <-> device copies (inputs, the verify pass) through the runtime's staging buffers, not by pinning numpy's pages in
+# place: tests/conftest.py has the why
+os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1048576")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

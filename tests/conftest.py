@@ -13,6 +13,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Host <-> device copies of numpy arrays through torch (the tests' to_device / to_host): by default the HIP runtime pins the
+# pageable numpy pages in place for every copy of 1 MiB or more (hsa_amd_memory_lock on memory numpy frees and re-maps all the
+# time) -- about one run in eight of this suite died of a GPU page fault inside such a copy (rocgdb: VMFaultHandler while the main
+# thread sat in DmaBlitManager::hsaCopyStagedOrPinned -> addPinnedMem; NOTES.md).  The staging path has no such window.  Read when
+# the runtime starts, inherited by the subprocesses the tests spawn; the engine's own transfers use memory it registers itself.
+os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1048576")   # MiB
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")

@@ -9,6 +9,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1048576")   # numpy <-> device copies through staging buffers (tests/conftest.py)
 import params as P  # noqa: E402
 from hehub_amd.engine import Engine  # noqa: E402
 from hehub_amd.sharded import ShardedMult  # noqa: E402
