@@ -80,13 +80,19 @@ int ks_digits_inner(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t
     // level A: digit rows as residues in [q/2, 3q/2] (the inner product below is the same integer kernel: its u128 sums then differ
     // from rgsw.cpp:126-149's by multiples of q_k, its Montgomery outputs are congruent to the reference's and below 2 q_k).
     // Caller-supplied coefficient rows (limb-range stages) are not known to be below 2^50: level B.
-    if (ctx->cur_a && strict_coef) sj.limbs_a = plan->d_limbs_a;
+    if (ctx->cur_a && strict_coef) {
+        sj.limbs_a = plan->d_limbs_a;
+        // ... and, where q_k + 2 <= 2^40, as 5 bytes per word (HP_PACK40, hp_device.h): same preconditions as the 48-bit rows
+        if (!ctx->no_pack40)
+            for (size_t k = k0; k < k1; k++)
+                if (((sj.pack_mask >> k) & 1u) && plan->consts[k].q + 2 <= ((u64)1 << 40)) sj.pack40_mask |= 1u << k;
+    }
     if ((rc = run_ntt(ctx, sj))) return rc;
     // (iii) u128 inner product + Montgomery                         rgsw.cpp:121-153
     {
         ProfScope ps(ctx, "ks_inner");
         rc = chk(ctx, hp_launch_ks_inner(plan->d_limbs, (u32)L, (u32)k0, (u32)(k1 - k0), (u32)(key_L0 + 1), (u32)n, (u32)P, digits, pt,
-                                         (u32)pt_pstride, key, out, sj.pack_mask, ctx->stream), "ks_inner");
+                                         (u32)pt_pstride, key, out, sj.pack_mask, sj.pack40_mask, ctx->stream), "ks_inner");
     }
     return rc;
 }

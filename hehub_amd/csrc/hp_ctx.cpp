@@ -339,6 +339,7 @@ int hp_ctx_create(int device, hp_ctx **out) {
     c->no_fused_drop = getenv("HP_NO_FUSED_DROP") != nullptr;
     c->no_pack48 = getenv("HP_NO_PACK48") != nullptr;
     c->no_double_drop = getenv("HP_NO_DOUBLE_DROP") != nullptr;
+    c->no_pack40 = getenv("HP_NO_PACK40") != nullptr;
     // (every numeric knob is clamped to the range its code path is written for; tests/test_gpu_knobs.py runs the extremes)
     auto clampi = [](long v, long lo, long hi) { return v < lo ? lo : v > hi ? hi : v; };
     if (const char *e = getenv("HP_PACK48_MIN_LOGN")) c->pack48_min_logn = (int)clampi(atol(e), 11, 16);

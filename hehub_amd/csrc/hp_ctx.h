@@ -83,6 +83,7 @@ struct hp_ctx {
     bool hks_combine_kernel = false;   // HP_HKS_COMBINE_KERNEL: the merged ModDown + rescale combination as its own kernel
     bool no_fused_drop = false;   // HP_NO_FUSED_DROP: separate drop_rem / NTT / drop_fin launches
     bool no_pack48 = false;       // HP_NO_PACK48: digit workspace always as plain u64 rows
+    bool no_pack40 = false;       // HP_NO_PACK40: level A keeps 48-bit digit rows for the moduli below 2^40
     bool no_double_drop = false;  // HP_NO_DOUBLE_DROP: level A keeps relinearize's mod-down and the rescale / mod switch of a mult as two launches
     int pack48_min_logn = 11;     // HP_PACK48_MIN_LOGN: smallest ring degree whose digit rows are packed
     int mult_streams = 1;         // HP_MULT_STREAMS=2: software-pipeline two sub-batches in dev_mult

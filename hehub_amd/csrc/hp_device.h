@@ -321,6 +321,10 @@ HP_DEV u64 hp_sub_lazy(u64 a, u64 b, u64 two_q) {
 // (One 12-byte record per pair of words, moved with dwordx3 accesses, measured no faster than plain rows: the accesses straddle
 // cache lines.  Two planes: -13..-16 % on the inner product at every tiled ring degree once that kernel addressed its rows through
 // buffer descriptors, -1.5 % on the spread launch at N = 32768.)
+// HP_PACK40 (parity level A only, where a digit row may hold any representative): for a modulus with q + 2 <= 2^40 the row keeps
+// r + (q - 1)/2 + 1 with r the centred residue (|r| <= (q - 1)/2 + 1 after x - rint(x / q) q), a value in [0, 2^40):
+// [u32 lo[N]] [u8 hi[N]] [3N bytes unused], 5 of 8 bytes cross HBM.  The inner product adds (q - 1)/2 times the sum of the key words
+// it multiplied the rows by: sum (w + (q - 1)/2) key = sum (r + q) key.
 // XCD-aware work-item remap: consecutive blockIdx values land on different XCDs
 // (block b -> XCD b % 8, observed placement; used for L2 locality only).  Work
 // items are numbered so that neighbours share a modulus (twiddle table); this

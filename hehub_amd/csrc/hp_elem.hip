@@ -425,11 +425,12 @@ template <int PT> HP_DEV void ks_mac(const KsRow<PT> &r, HpAcc (&acc)[PT][2][2])
         for (int h = 0; h < 2; h++) hp_mac2(acc[c][h][0], r.d[c].x, kw[h][0], acc[c][h][1], r.d[c].y, kw[h][1]);
 }
 
-// PACKED: the digit rows of this output modulus are in the HP_PACK48 format (hp_device.h)
-template <int PT, bool PACKED>
+// PACK: 48 / 40 = the digit rows of this output modulus are in the HP_PACK48 / HP_PACK40 format (hp_device.h); 0 = plain words
+template <int PT, int PACK>
 HP_DEV void ks_sweep(const __amdgpu_buffer_rsrc_t (&rd)[PT], const __amdgpu_buffer_rsrc_t (&rp)[PT], __amdgpu_buffer_rsrc_t rk,
-                     u32 i, u32 n, u32 L, u32 k, u32 d_stride, u32 k_stride, u32 k_half, HpAcc (&acc)[PT][2][2]) {
-    const u32 v16 = i << 3, v8 = i << 2, v4 = i << 1;   // lane byte offsets: plain words / low planes / high planes
+                     u32 i, u32 n, u32 L, u32 k, u32 d_stride, u32 k_stride, u32 k_half, u64 q, HpAcc (&acc)[PT][2][2]) {
+    const u32 v16 = i << 3, v8 = i << 2, v4 = i << 1;   // lane byte offsets: plain words / low planes / high planes (48-bit rows)
+    u64 ksum[2][2] = {{0, 0}, {0, 0}};                   // HP_PACK40: sum of the key words the offset rows were multiplied by
     const bool diag = k < L;
     const u32 T = diag ? L - 1 : L;                     // digit rows besides the diagonal
     auto load_key = [&](KsRow<PT> &r, u32 j) {
@@ -443,11 +444,16 @@ HP_DEV void ks_sweep(const __amdgpu_buffer_rsrc_t (&rd)[PT], const __amdgpu_buff
         const u32 so = __builtin_amdgcn_readfirstlane(j * d_stride);
 #pragma unroll
         for (int c = 0; c < PT; c++) {
-            if (PACKED) {
+            if (PACK == 48) {
                 const v2u lo = __builtin_amdgcn_raw_buffer_load_b64(rd[c], v8, so, KS_NT);
                 const u32 hi = __builtin_amdgcn_raw_buffer_load_b32(rd[c], v4, so + (n << 2), KS_NT);
                 r.d[c].x = lo.x | ((u64)(hi & 0xffffu) << 32);
                 r.d[c].y = lo.y | ((u64)(hi >> 16) << 32);
+            } else if (PACK == 40) {
+                const v2u lo = __builtin_amdgcn_raw_buffer_load_b64(rd[c], v8, so, KS_NT);
+                const u32 hi = (u32)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rd[c], i, so + (n << 2), KS_NT);
+                r.d[c].x = lo.x | ((u64)(hi & 0xffu) << 32);
+                r.d[c].y = lo.y | ((u64)(hi >> 8) << 32);
             } else {
                 r.d[c] = ks_u2(__builtin_amdgcn_raw_buffer_load_b128(rd[c], v16, so, KS_NT));
             }
@@ -459,31 +465,43 @@ HP_DEV void ks_sweep(const __amdgpu_buffer_rsrc_t (&rd)[PT], const __amdgpu_buff
 #pragma unroll
         for (int c = 0; c < PT; c++) rb.d[c] = ks_u2(__builtin_amdgcn_raw_buffer_load_b128(rp[c], v16, 0, KS_NT));
     }
+    auto mac_digit = [&](const KsRow<PT> &r) {
+        ks_mac<PT>(r, acc);
+        if (PACK == 40) { ksum[0][0] += r.g0.x; ksum[0][1] += r.g0.y; ksum[1][0] += r.g1.x; ksum[1][1] += r.g1.y; }
+    };
     if (T) load_digit(ra, 0);
     if (diag) ks_mac<PT>(rb, acc);
     if (!T) return;
     u32 t = 0;
     for (; t + 2 <= T; t += 2) {
         load_digit(rb, t + 1);
-        ks_mac<PT>(ra, acc);
+        mac_digit(ra);
         load_digit(ra, min(t + 2, T - 1));   // last: harmless re-read
-        ks_mac<PT>(rb, acc);
+        mac_digit(rb);
     }
-    if (t < T) ks_mac<PT>(ra, acc);
+    if (t < T) mac_digit(ra);
+    if (PACK == 40) {
+        const u64 qc = (q - 1) >> 1;
+#pragma unroll
+        for (int c = 0; c < PT; c++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) hp_mac2(acc[c][h][0], qc, ksum[h][0], acc[c][h][1], qc, ksum[h][1]);
+    }
 }
 
-template <int PT>
+template <int PT, bool P40 = false>
 __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner_blk(const HpLimb *__restrict__ limbs, u32 L, u32 k_first, u32 P,
                                                               u32 key_Le, u32 n, u32 chunks, const u64 *__restrict__ digits,
                                                               const u64 *__restrict__ pt, u32 pt_pstride,
-                                                              const u64 *__restrict__ key, u64 *__restrict__ out, u32 pack_mask) {
+                                                              const u64 *__restrict__ key, u64 *__restrict__ out, u32 pack_mask,
+                                                              u32 pack40_mask) {
     const u32 Le = L + 1;
     const u32 PG = (P + PT - 1) / PT;
     const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
     const u32 k = k_first + row / PG, p0 = (row % PG) * PT;
     const u64 q = limbs[k].q, mqinv = limbs[k].mqinv;
     const u32 kcol = (k == L) ? key_Le - 1 : k;   // key made for more moduli (extension): special prime = its last column
-    const bool packed = ((pack_mask >> k) & 1u) != 0;
+    const bool packed = ((pack_mask >> k) & 1u) != 0, packed40 = P40 && ((pack40_mask >> k) & 1u) != 0;   // (P40: its own kernel, so that the level-B one keeps its registers)
     // descriptors: digit row (p, j = 0, k) -- the digit index adds j * Le * 8n bytes; the caller's limb (p, k); the key column
     // (j = 0, half 0, kcol) -- j adds 2 * key_Le * 8n bytes, the second half key_Le * 8n.  (32-bit offsets: L (L + 1) * 8n and
     // 2 L key_Le * 8n stay below 2^30 bytes at N = 32768 with the 32 limbs the engine allows.)
@@ -503,8 +521,9 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner_blk(const HpLimb *__r
         for (int c = 0; c < PT; c++)
 #pragma unroll
             for (int h = 0; h < 2; h++) { hp_acc_zero(acc[c][h][0]); hp_acc_zero(acc[c][h][1]); }
-        if (packed) ks_sweep<PT, true>(rd, rp, rk, i, n, L, k, d_stride, k_stride, k_half, acc);
-        else ks_sweep<PT, false>(rd, rp, rk, i, n, L, k, d_stride, k_stride, k_half, acc);
+        if (P40 && packed40) ks_sweep<PT, 40>(rd, rp, rk, i, n, L, k, d_stride, k_stride, k_half, q, acc);
+        else if (packed) ks_sweep<PT, 48>(rd, rp, rk, i, n, L, k, d_stride, k_stride, k_half, q, acc);
+        else ks_sweep<PT, 0>(rd, rp, rk, i, n, L, k, d_stride, k_stride, k_half, q, acc);
 #pragma unroll
         for (int c = 0; c < PT; c++) {
             const u32 p = p0 + c;
@@ -525,9 +544,10 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner_blk(const HpLimb *__r
 }
 
 hipError_t hp_launch_ks_inner(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32 key_Le, u32 n, u32 P, const u64 *digits,
-                              const u64 *pt, u32 pt_pstride, const u64 *key, u64 *out, u32 pack_mask, hipStream_t stream) {
+                              const u64 *pt, u32 pt_pstride, const u64 *key, u64 *out, u32 pack_mask, u32 pack40_mask,
+                              hipStream_t stream) {
     if (kc == 0) return hipSuccess;
-    if (pack_mask && !(n >= 2 && P >= 2)) return hipErrorInvalidValue;   // the one-ciphertext kernel reads plain rows only
+    if ((pack_mask | pack40_mask) && !(n >= 2 && P >= 2)) return hipErrorInvalidValue;   // the one-ciphertext kernel reads plain rows only
     // the blocked kernels address digit rows and key columns through buffer descriptors with 32-bit byte offsets
     // (j * (L+1) * 8n and j * 2 key_Le * 8n + key_Le * 8n, j < L): an offset past 2^31 would read zeros, not fault
     if ((u64)L * (L + 1) * 8u * n >= (1ull << 31) || 2ull * L * key_Le * 8u * n >= (1ull << 31)) return hipErrorInvalidValue;
@@ -536,10 +556,12 @@ hipError_t hp_launch_ks_inner(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u
     const int PT = (n >= 2 && P >= 4) ? 4 : (n >= 2 && P >= 2) ? 2 : 1;
     if (PT >= 4) {
         elem_grid(n, ((P + 3) / 4) * kc, chunks, grid);
-        k_ks_inner_blk<4><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, key_Le, n, chunks, digits, pt, pt_pstride, key, out, pack_mask);
+        if (pack40_mask) k_ks_inner_blk<4, true><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, key_Le, n, chunks, digits, pt, pt_pstride, key, out, pack_mask, pack40_mask);
+        else k_ks_inner_blk<4><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, key_Le, n, chunks, digits, pt, pt_pstride, key, out, pack_mask, 0u);
     } else if (PT >= 2) {
         elem_grid(n, ((P + 1) / 2) * kc, chunks, grid);
-        k_ks_inner_blk<2><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, key_Le, n, chunks, digits, pt, pt_pstride, key, out, pack_mask);
+        if (pack40_mask) k_ks_inner_blk<2, true><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, key_Le, n, chunks, digits, pt, pt_pstride, key, out, pack_mask, pack40_mask);
+        else k_ks_inner_blk<2><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, key_Le, n, chunks, digits, pt, pt_pstride, key, out, pack_mask, 0u);
     } else {
         elem_grid(n, P * kc, chunks, grid);
         k_ks_inner<<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, key_Le, n, chunks, digits, pt, pt_pstride, key, out);

@@ -37,6 +37,7 @@ struct HpNttJob {
     u32 pack_mask;    // HP_NTT_SPREAD, tiled kernels: bit k set = the digit rows of output modulus k are written in the 48-bit
                       // packed row format (hp_device.h: HP_PACK48) that the inner-product kernel reads back; set by the engine only
                       // when every word of those rows is provably below 2^48 (hp_api_scheme.cpp: spread_pack_mask)
+    u32 pack40_mask;  // level A only (hp_ntt_a.hip): bit k set = those rows in the 40-bit packed format HP_PACK40 instead (hp_device.h)
     int mode;
     int inverse;
     int strict;     // inverse only: reduce_strict epilogue (ntt.h:88-92)
@@ -105,8 +106,10 @@ hipError_t hp_launch_tensor(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32
 // only output moduli [k_first, k_first + kc) of the L+1 are computed (kc = L+1: all)
 // key_Le: limbs per key polynomial (L+1, or more for a key generated at a higher level: its last column is the special prime)
 // pack_mask: bit k set = the digit rows of output modulus k are in the 48-bit packed row format (needs P >= 2)
+// pack40_mask: bit k set = in the 40-bit offset format of parity level A (HP_PACK40; takes precedence)
 hipError_t hp_launch_ks_inner(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32 key_Le, u32 n, u32 P, const u64 *digits,
-                              const u64 *pt, u32 pt_pstride, const u64 *key, u64 *out, u32 pack_mask, hipStream_t stream);
+                              const u64 *pt, u32 pt_pstride, const u64 *key, u64 *out, u32 pack_mask, u32 pack40_mask,
+                              hipStream_t stream);
 
 // drop-last-prime helpers (rescaling.cpp:46-75 / mod_switch.cpp:45-77)
 struct HpDropConsts {

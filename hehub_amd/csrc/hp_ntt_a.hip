@@ -258,7 +258,9 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
         if constexpr (SPREAD) {
             // digit rows (workspace read by the inner product alone, which takes any word below 2^51 -- level B hands it lazy ones):
             // the centred residue + q, in [q/2, 3q/2], needs no sign fix-up; q and the 2^52 of the conversion are one addend
-            const double bias = q + TWO52;
+            // (HP_PACK40 rows: + (q - 1)/2 + 1 instead of + q, hp_device.h)
+            const bool p40 = ((job.pack40_mask >> it.limb) & 1u) != 0;
+            const double bias = (p40 ? __builtin_floor(q * 0.5) + 1.0 : q) + TWO52;
 #pragma unroll
             for (int r = 0; r < 32; ++r) x[r] = U(a_reduce(D(x[r]), qinv, q) + bias) & 0x000FFFFFFFFFFFFFull;
         } else {
@@ -274,7 +276,16 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
     TRACE_MARK();   // 8
     if (!DROP) {
         const size_t off = (((size_t)(tid >> 6)) << 11) + ((tid & 63u) << 1);
-        if (SPREAD && ((job.pack_mask >> it.limb) & 1u)) {
+        if (SPREAD && ((job.pack40_mask >> it.limb) & 1u)) {
+            typedef u32 __attribute__((ext_vector_type(2))) v2u;
+            u32 *lo = reinterpret_cast<u32 *>(it.dst) + off;
+            unsigned short *hi = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(it.dst) + 4 * (size_t)G::N + off);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                __builtin_nontemporal_store(v2u{lo32(x[2 * s]), lo32(x[2 * s + 1])}, reinterpret_cast<v2u *>(lo + ((size_t)s << 7)));
+                __builtin_nontemporal_store((unsigned short)((hi32(x[2 * s]) & 0xffu) | ((hi32(x[2 * s + 1]) & 0xffu) << 8)), hi + ((size_t)s << 6));
+            }
+        } else if (SPREAD && ((job.pack_mask >> it.limb) & 1u)) {
             // HP_PACK48 (hp_device.h): words below 3q/2 of a modulus below 2^47 always fit
             typedef u32 __attribute__((ext_vector_type(2))) v2u;
             u32 *lo = reinterpret_cast<u32 *>(it.dst) + off;

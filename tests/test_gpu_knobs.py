@@ -56,7 +56,7 @@ def test_knob_settings_give_the_same_words(cases, monkeypatch, env):
 
 
 KNOBS_A = [{}, {"HP_SPREAD_GROUP": "0"}, {"HP_SPREAD_GROUP": "3"}, {"HP_DROP_GROUP": "0"}, {"HP_DROP_GROUP": "7"}, {"HP_NO_PACK48": "1"},
-           {"HP_PACK48_MIN_LOGN": "15"}, {"HP_MULT_STREAMS": "2", "HP_MULT_CHUNK": "3"}, {"HP_MULT_CHUNK": "1"}, {"HP_NO_FUSED_DROP": "1"}, {"HP_NO_DOUBLE_DROP": "1"}, {"HP_NO_DOUBLE_DROP": "1", "HP_DROP_GROUP": "0"}]
+           {"HP_PACK48_MIN_LOGN": "15"}, {"HP_MULT_STREAMS": "2", "HP_MULT_CHUNK": "3"}, {"HP_MULT_CHUNK": "1"}, {"HP_NO_FUSED_DROP": "1"}, {"HP_NO_DOUBLE_DROP": "1"}, {"HP_NO_DOUBLE_DROP": "1", "HP_DROP_GROUP": "0"}, {"HP_NO_PACK40": "1"}]
 
 
 @pytest.mark.parametrize("env", KNOBS_A, ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()) or "defaults")
@@ -66,7 +66,7 @@ def test_knob_settings_at_parity_level_a(cases, monkeypatch, env):
     from hehub_amd.engine import Engine
 
     for k in ("HP_SPREAD_GROUP", "HP_DROP_GROUP", "HP_NO_PACK48", "HP_PACK48_MIN_LOGN", "HP_NO_FUSED_DROP", "HP_MULT_STREAMS",
-              "HP_MULT_CHUNK", "HP_NO_DOUBLE_DROP"):
+              "HP_MULT_CHUNK", "HP_NO_DOUBLE_DROP", "HP_NO_PACK40"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)

@@ -274,6 +274,49 @@ def test_two_drops_in_one_transform(orc, monkeypatch, logn, mext):
         assert np.array_equal(got[True][name], got[False][name]), name
 
 
+@pytest.mark.parametrize("logn", [11, 13, 15])
+def test_forty_bit_digit_rows(orc, monkeypatch, logn):
+    """HP_PACK40 (hp_device.h): at level A the digit rows of a modulus with q + 2 <= 2^40 cross HBM as 5 bytes per word in an offset
+    representation.  The largest NTT prime below 2^40 (the offset words reach q + 1), a 30-bit one, one just above 2^40 (stays on 48-bit
+    rows) and a 50-bit one in one chain: the oracle's residues for the key switch, rotation and both mult pipelines
+    (rgsw.cpp:98-153), and the same words as with HP_NO_PACK40"""
+    from hehub_amd.engine import Engine
+
+    top40, bit30, over40 = P.ntt_primes(1, logn, 40)[0], P.ntt_primes(1, logn, 30)[0], P.ntt_primes(1, logn, 41)[0]
+    assert top40 + 2 <= 1 << 40 < over40
+    mext = [top40, bit30, over40, P.P40[1], P.P50[0]]
+    n, L, B = 1 << logn, len(mext) - 1, 2 if logn == 15 else 3
+    q = mext[:L]
+    rng = SplitMix(5100 + logn)
+    ct1, ct2 = rng.poly((B, 2, L, n), q), rng.poly((B, 2, L, n), q)
+    key = rng.poly((L, 2, L + 1, n), mext)
+    ct1[0, 1, :, :9] = (np.array(q, dtype=U) - U(1))[:, None]
+    exp = {"ext": np.stack([orc.ext_prod(mext, ct1[i, 1], key) for i in range(B)]),
+           "rot": np.stack([orc.ckks_rotate(mext, ct1[i], key, 5) for i in range(B)]),
+           "ckks": np.stack([orc.ckks_mult(mext, ct1[i], ct2[i], key) for i in range(B)]),
+           "bgv": np.stack([orc.bgv_mult(mext, P.C5_T, ct1[i], ct2[i], key) for i in range(B)])}
+    got = {}
+    for off in (False, True):
+        monkeypatch.delenv("HP_NO_PACK40", raising=False)
+        if off:
+            monkeypatch.setenv("HP_NO_PACK40", "1")
+        eng = Engine(0)
+        try:
+            eng.set_parity_level("A")
+            d1, d2, dk = eng.to_device(ct1), eng.to_device(ct2), eng.to_device(key)
+            got[off] = {"ext": eng.to_host(eng.ext_prod(mext, d1[:, 1].contiguous(), dk)), "rot": eng.to_host(eng.ckks_rotate(mext, d1, dk, 5)),
+                        "ckks": eng.to_host(eng.ckks_mult(mext, d1, d2, dk)), "bgv": eng.to_host(eng.bgv_mult(mext, P.C5_T, d1, d2, dk))}
+        finally:
+            eng.close()
+    for name in exp:
+        assert np.array_equal(canon(mext, got[False][name]), canon(mext, exp[name])), name
+        if name != "ext":   # everything that ends in a drop is canonical; the key switch alone returns lazy words
+            assert np.array_equal(got[False][name], canon(mext, exp[name])), name
+            assert np.array_equal(got[True][name], got[False][name]), name
+        else:
+            assert np.array_equal(canon(mext, got[True][name]), canon(mext, got[False][name])), name
+
+
 def test_level_a_pipeline_in_a_hip_graph(enga, orc):
     """after one warm-up call (which builds the FP64 tables) a level-A entry point only enqueues kernels: capturable and replayable"""
     import torch
