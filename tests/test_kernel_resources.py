@@ -69,10 +69,12 @@ def test_inverse_small_sizes_budget(meta):
 
 
 def test_inner_product_occupancy(meta):
-    (name, r), = pick(meta, r"k_ks_inner_blk<4>").items()
-    assert r["vgpr_spill_count"] == 0 and r["vgpr_count"] <= 256, (name, r)     # two waves per SIMD
-    (name, r), = pick(meta, r"k_ks_inner_blk<2>").items()
-    assert r["vgpr_spill_count"] == 0 and r["vgpr_count"] <= 128, (name, r)     # four
+    # (<PT, false>: the kernel of parity level B and of 48-bit rows; <PT, true>: level A with 40-bit rows, its own instantiation)
+    for p40 in ("false", "true"):
+        (name, r), = pick(meta, rf"k_ks_inner_blk<4, {p40}>").items()
+        assert r["vgpr_spill_count"] == 0 and r["vgpr_count"] <= 256, (name, r)     # two waves per SIMD
+        (name, r), = pick(meta, rf"k_ks_inner_blk<2, {p40}>").items()
+        assert r["vgpr_spill_count"] == 0 and r["vgpr_count"] <= 128, (name, r)     # four
 
 
 def test_no_kernel_spills_scalars_or_exceeds_lds(meta):
