@@ -112,10 +112,10 @@ HP_DEV void fwd_pass(u64 (&x)[32], const Tab tbl, u32 ncls, u32 cls, u64 nq, u64
 }
 
 // inverse: stages on register bits BLO..BHI (ascending)
-template <int BLO, int BHI, class Tab>
+template <int BLO, int BHI, class Tab, int D = Tab::depth>
 HP_DEV void inv_pass(u64 (&x)[32], const Tab tbl, u32 ncls, u32 cls, u64 nq, u64 two_q) {
     static_assert(BHI == 4, "inverse passes end at register bit 4");
-    run_pass<false, (1 << BLO) - 1, 31, Tab::depth>(x, tbl, ncls, cls, nq, two_q);
+    run_pass<false, (1 << BLO) - 1, 31, D>(x, tbl, ncls, cls, nq, two_q);
 }
 
 #ifdef HP_TRACE
@@ -462,7 +462,10 @@ __global__ void __launch_bounds__(InvGeo<LOGN>::TT, Geo<LOGN>::MINW) k_ntt_inv(H
     exchange<LOGN, LAY_B, LAY_A, true>(x, lds, ad);
     TRACE_MARK();   // 6
     // pass C': levels 10..logN-1, per-thread twiddles
-    inv_pass<G::PB, 4>(x, BTab(lp->inv_k + 31 + 31 * 32), (u32)G::T, tid, nq, two_q);
+    // (twiddle ring of the last pass: 4 slots at N = 32768 / 8192; 3 at N = 16384 and 2 at N <= 4096, where the fourth costs spilled
+    // registers -- 9 -> 4 and 19 -> 8 -- and buys nothing: +0.5 % / +3 % on the launch, less scratch traffic in WRITE_SIZE)
+    constexpr int RING = LOGN == 14 ? 3 : LOGN <= 12 ? 2 : BTab::depth;
+    inv_pass<G::PB, 4, BTab, RING>(x, BTab(lp->inv_k + 31 + 31 * 32), (u32)G::T, tid, nq, two_q);
     TRACE_MARK();   // 7
     if constexpr (InvGeo<LOGN>::STREAM_EPILOGUE) {
         // N <= 8192: in layout A a thread owns 2^PB >= 4 consecutive coefficients, so a 16-byte store instruction would write
