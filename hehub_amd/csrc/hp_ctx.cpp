@@ -130,22 +130,24 @@ static int ensure_plan_a_impl(hp_ctx *ctx, const Plan *plan, bool *ok) {
         auto key = std::make_pair(q, logn);
         auto it = ctx->tables_a.find(key);
         if (it == ctx->tables_a.end()) {
+            // (inserted first and filled in place: tables that were uploaded before a later upload failed stay owned by the cache
+            // -- hp_ctx_destroy frees them, the retry fills the rest)
+            it = ctx->tables_a.emplace(key, DevTables()).first;
+        }
+        DevTables &d = it->second;
+        if (!d.fwd_ref || !d.inv_ref || !d.fwd_k || !d.inv_k) {
             std::vector<hp::Pair> fwd, inv, fk, ik, t;
             hp::build_fwd_ref(q, logn, fwd);
             hp::build_inv_ref(q, logn, inv);
             hp::build_fwd_fast(fwd, logn, fk);
             hp::build_inv_fast(inv, logn, ik);
-            DevTables d;
             int rc;
-            hp::pairs_to_f64(fwd, q, t);
-            if ((rc = upload(ctx, t.data(), t.size() * sizeof(hp::Pair), (void **)&d.fwd_ref))) return rc;
-            hp::pairs_to_f64(inv, q, t);
-            if ((rc = upload(ctx, t.data(), t.size() * sizeof(hp::Pair), (void **)&d.inv_ref))) return rc;
-            hp::pairs_to_f64(fk, q, t);
-            if ((rc = upload(ctx, t.data(), t.size() * sizeof(hp::Pair), (void **)&d.fwd_k))) return rc;
-            hp::pairs_to_f64(ik, q, t);
-            if ((rc = upload(ctx, t.data(), t.size() * sizeof(hp::Pair), (void **)&d.inv_k))) return rc;
-            it = ctx->tables_a.emplace(key, d).first;
+            struct { const std::vector<hp::Pair> *src; u64x2 **dst; } parts[4] = {{&fwd, &d.fwd_ref}, {&inv, &d.inv_ref}, {&fk, &d.fwd_k}, {&ik, &d.inv_k}};
+            for (auto &pt : parts) {
+                if (*pt.dst) continue;
+                hp::pairs_to_f64(*pt.src, q, t);
+                if ((rc = upload(ctx, t.data(), t.size() * sizeof(hp::Pair), (void **)pt.dst))) return rc;
+            }
         }
         HpLimbA &l = limbs[k];
         memset(&l, 0, sizeof(l));
@@ -319,14 +321,12 @@ extern "C" {
 
 const char *hp_version(void) { return "hehub_amd 0.2 (gfx950)"; }
 
-int hp_ctx_create(int device, hp_ctx **out) {
-    if (!out) return HP_EINVAL;
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return HP_EHIP;
+// a context on `device` that belongs to the family `sh` (a fresh one for hp_ctx_create, the parent's for hp_ctx_fork)
+static int make_ctx(int device, hpi::Shared *sh, hp_ctx **out) {
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (hipSetDevice(device) != hipSuccess) return HP_EHIP;
-    hp_ctx *c = new (std::nothrow) hp_ctx();
+    hp_ctx *c = new (std::nothrow) hp_ctx(sh);
     if (!c) return HP_ENOMEM;
     c->device = device;
     const hipError_t es = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
@@ -336,6 +336,22 @@ int hp_ctx_create(int device, hp_ctx **out) {
         return HP_EHIP;
     }
     c->stream = c->own_stream;
+    *out = c;
+    return HP_OK;
+}
+
+int hp_ctx_create(int device, hp_ctx **out) {
+    if (!out) return HP_EINVAL;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return HP_EHIP;
+    hpi::Shared *sh = new (std::nothrow) hpi::Shared();
+    if (!sh) return HP_ENOMEM;
+    hp_ctx *c = nullptr;
+    const int rc = make_ctx(device, sh, &c);
+    if (rc) {
+        delete sh;
+        return rc;
+    }
     c->no_fused_drop = getenv("HP_NO_FUSED_DROP") != nullptr;
     c->no_pack48 = getenv("HP_NO_PACK48") != nullptr;
     c->no_double_drop = getenv("HP_NO_DOUBLE_DROP") != nullptr;
@@ -354,6 +370,46 @@ int hp_ctx_create(int device, hp_ctx **out) {
     return HP_OK;
 }
 
+// A second LANE on the parent's GPU: its own stream and scratch workspace, so that its calls overlap on the device with the calls
+// of the other members of the family; the twiddle tables, per-chain constants and gather maps are the family's (one copy in HBM and
+// in the caches whatever the number of lanes).  Knobs and parity level start as the parent's are now.
+int hp_ctx_fork(hp_ctx *parent, hp_ctx **out) {
+    if (!parent) return HP_EINVAL;
+    hpi::Guard guard__(parent);
+    HP_REQUIRE(parent, out);
+    hp_ctx *c = nullptr;
+    const int rc = make_ctx(parent->device, parent->sh, &c);
+    if (rc) return fail(parent, rc, "hp_ctx_fork: could not create the lane's stream");
+    parent->sh->refs++;
+    c->force_generic = parent->force_generic; c->parity_level = parent->parity_level;
+    c->drop_group = parent->drop_group; c->spread_group = parent->spread_group; c->hks_two_step = parent->hks_two_step;
+    c->hks_combine_kernel = parent->hks_combine_kernel; c->no_fused_drop = parent->no_fused_drop; c->no_pack48 = parent->no_pack48;
+    c->no_pack40 = parent->no_pack40; c->no_double_drop = parent->no_double_drop; c->pack48_min_logn = parent->pack48_min_logn;
+    c->mult_streams = parent->mult_streams; c->mult_chunk = parent->mult_chunk;
+    *out = c;
+    return HP_OK;
+}
+
+// Device-side ordering between two contexts (normally two lanes of a family, any two contexts of one process work): everything `ctx`
+// enqueues from now on runs after everything `other` has enqueued so far.  One event, no host synchronisation.
+int hp_ctx_wait_for(hp_ctx *ctx, hp_ctx *other) {
+    if (!other) return HP_EINVAL;
+    if (ctx == other) return ctx ? HP_OK : HP_EINVAL;
+    hipEvent_t ev;
+    hipStream_t from;
+    {
+        HP_ENTER(other);
+        if (!other->ev_tail) HIP_TRY(other, hipEventCreateWithFlags(&other->ev_tail, hipEventDisableTiming));
+        HIP_TRY(other, hipEventRecord(other->ev_tail, other->stream));
+        ev = other->ev_tail;
+        from = other->stream;
+    }
+    HP_ENTER(ctx);
+    if (from == ctx->stream) return HP_OK;   // both contexts were pointed at one stream: already ordered
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ev, 0));
+    return HP_OK;
+}
+
 int hp_ctx_set_parity_level(hp_ctx *ctx, int level) {
     HP_ENTER(ctx);
     if (level != HP_PARITY_B && level != HP_PARITY_A) return fail(ctx, HP_EINVAL, "parity level: HP_PARITY_B (0) or HP_PARITY_A (1)");
@@ -367,31 +423,41 @@ void hp_ctx_destroy(hp_ctx *ctx) {
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev};
-    (void)hipSetDevice(ctx->device);
-    (void)hipDeviceSynchronize();
-    for (auto &kv : ctx->tables) {
-        (void)hipFree(kv.second.fwd_ref); (void)hipFree(kv.second.inv_ref);
-        (void)hipFree(kv.second.fwd_k); (void)hipFree(kv.second.inv_k);
+    hpi::Shared *sh = ctx->sh;
+    bool last;
+    {
+        std::lock_guard<std::mutex> lk(sh->mu);
+        (void)hipSetDevice(ctx->device);
+        (void)hipDeviceSynchronize();
+        last = --sh->refs == 0;
+        if (last) {   // the family's caches go with its last member
+            for (auto &kv : sh->tables) {
+                (void)hipFree(kv.second.fwd_ref); (void)hipFree(kv.second.inv_ref);
+                (void)hipFree(kv.second.fwd_k); (void)hipFree(kv.second.inv_k);
+            }
+            for (auto &kv : sh->tables_a) {
+                (void)hipFree(kv.second.fwd_ref); (void)hipFree(kv.second.inv_ref);
+                (void)hipFree(kv.second.fwd_k); (void)hipFree(kv.second.inv_k);
+            }
+            for (auto &kv : sh->plans) { (void)hipFree(kv.second.d_limbs); if (kv.second.d_limbs_a) (void)hipFree(kv.second.d_limbs_a); }
+            for (auto &kv : sh->perms) (void)hipFree(kv.second);
+            for (auto &kv : sh->crt) (void)hipFree(kv.second);
+            for (auto &kv : sh->hks) (void)hipFree(kv.second);
+        }
+        if (ctx->ws) (void)hipFree(ctx->ws);
+        for (auto &ev : ctx->prof_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+        for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+        for (int i = 0; i < 2; i++) {
+            if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]);
+            if (ctx->ev_done[i]) (void)hipEventDestroy(ctx->ev_done[i]);
+        }
+        if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+        if (ctx->ev_switch) (void)hipEventDestroy(ctx->ev_switch);
+        if (ctx->ev_tail) (void)hipEventDestroy(ctx->ev_tail);
+        (void)hipStreamDestroy(ctx->own_stream);
     }
-    for (auto &kv : ctx->tables_a) {
-        (void)hipFree(kv.second.fwd_ref); (void)hipFree(kv.second.inv_ref);
-        (void)hipFree(kv.second.fwd_k); (void)hipFree(kv.second.inv_k);
-    }
-    for (auto &kv : ctx->plans) { (void)hipFree(kv.second.d_limbs); if (kv.second.d_limbs_a) (void)hipFree(kv.second.d_limbs_a); }
-    for (auto &kv : ctx->perms) (void)hipFree(kv.second);
-    for (auto &kv : ctx->crt) (void)hipFree(kv.second);
-    for (auto &kv : ctx->hks) (void)hipFree(kv.second);
-    if (ctx->ws) (void)hipFree(ctx->ws);
-    for (auto &ev : ctx->prof_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
-    for (int i = 0; i < 2; i++) {
-        if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]);
-        if (ctx->ev_done[i]) (void)hipEventDestroy(ctx->ev_done[i]);
-    }
-    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
-    if (ctx->ev_switch) (void)hipEventDestroy(ctx->ev_switch);
-    (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
+    if (last) delete sh;
 }
 
 // The calling thread's last failure on this context if it had one, else the context's last failure.  The pointer
@@ -532,6 +598,32 @@ int hp_dev_store_host_rows(hp_ctx *ctx, size_t rows, size_t words, const uint64_
 }
 int hp_dev_load_host_rows(hp_ctx *ctx, size_t rows, size_t words, uint64_t *d_dst, const uint64_t *const *h_rows) {
     return host_rows(ctx, false, rows, words, d_dst, (void *const *)h_rows);
+}
+// Rows that lie anywhere in device memory <-> one packed block u64[rows][words]: the batch entry points want [batch][2][L][N], the
+// ciphertexts of an application are separate objects.  One kernel per 64 rows (the row pointers travel as kernel arguments).
+static int dev_rows(hp_ctx *ctx, bool scatter, size_t rows, size_t words, u64 *packed, void *const *d_rows) {
+    HP_ENTER(ctx);
+    HP_REQUIRE(ctx, packed, d_rows);
+    HP_ALIGNED(ctx, packed);
+    if (words & 1) return fail(ctx, HP_EINVAL, "device rows: an even number of words per row");
+    for (size_t r0 = 0; r0 < rows; r0 += HP_HOST_ROWS_MAX) {
+        const size_t cnt = rows - r0 < HP_HOST_ROWS_MAX ? rows - r0 : HP_HOST_ROWS_MAX;
+        HpHostRows hr;
+        for (size_t r = 0; r < cnt; r++) {
+            if (!d_rows[r0 + r] || ((uintptr_t)d_rows[r0 + r] & 15u)) return fail(ctx, HP_EINVAL, "device rows: NULL or misaligned row");
+            hr.p[r] = (u64 *)d_rows[r0 + r];
+        }
+        ProfScope ps(ctx, "copy");
+        int rc = chk(ctx, hp_launch_host_rows(scatter, hr, (u32)cnt, words, packed + r0 * words, ctx->stream), "device rows");
+        if (rc) return rc;
+    }
+    return HP_OK;
+}
+int hp_dev_gather_rows(hp_ctx *ctx, size_t rows, size_t words, const uint64_t *const *d_rows, uint64_t *d_dst) {
+    return dev_rows(ctx, false, rows, words, d_dst, (void *const *)d_rows);
+}
+int hp_dev_scatter_rows(hp_ctx *ctx, size_t rows, size_t words, const uint64_t *d_src, uint64_t *const *d_rows) {
+    return dev_rows(ctx, true, rows, words, const_cast<u64 *>(d_src), (void *const *)d_rows);
 }
 int hp_ctx_set_force_generic(hp_ctx *ctx, int on) {
     HP_ENTER(ctx);

@@ -47,24 +47,46 @@ constexpr size_t MAX_PERMS = 64, MAX_CRT = 128, MAX_HKS = 16;
 
 } // namespace hpi
 
+namespace hpi {
+// What the contexts of one FAMILY have in common (hp_ctx_create makes a family of one, hp_ctx_fork adds a lane to it): the device,
+// ONE lock -- every entry point of every member runs under it, so the host side of a family is serialised exactly as a single
+// context's always was, while the members' streams overlap on the device -- and the caches of immutable device objects (twiddle
+// tables, per-chain constants, gather maps), which all members read.
+struct Shared {
+    std::mutex mu;
+    int refs = 1;
+    std::map<std::pair<u64, size_t>, DevTables> tables;          // (q, logn)
+    std::map<std::pair<u64, size_t>, DevTables> tables_a;        // (q, logn): the same tables as (w, w / q) doubles (parity level A)
+    std::map<std::pair<size_t, std::vector<u64>>, Plan> plans;   // (logn, moduli); logn == 0: no transforms needed
+    std::map<std::pair<size_t, size_t>, u32 *> perms;                 // (logn, step mod N/2) -> gather map
+    std::map<std::pair<std::vector<u64>, u64>, HpCrtConsts *> crt;    // (old moduli, new modulus) -> CRT-branch constants
+    std::map<std::pair<std::vector<u64>, std::pair<size_t, size_t>>, HpHksConsts *> hks;   // (extended moduli, (k, alpha))
+};
+} // namespace hpi
+
 struct hp_ctx {
+    hpi::Shared *sh;
+    explicit hp_ctx(hpi::Shared *s)
+        : sh(s), mu(s->mu), tables(s->tables), tables_a(s->tables_a), plans(s->plans), perms(s->perms), crt(s->crt), hks(s->hks) {}
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev_switch = nullptr;   // orders a newly selected stream after the work already enqueued on the previous one
-    std::mutex mu;
+    hipEvent_t ev_tail = nullptr;     // hp_ctx_wait_for: marks "everything this context has enqueued so far" for another one to wait on
+    std::mutex &mu;                   // the family's lock
     std::string err;
     bool force_generic = false;
     // parity level of the scheme-level pipelines (hp_ctx_set_parity_level; HP_PARITY_LEVEL=A): 0 = B, raw words identical to
     // hehub's (default); 1 = A, canonical residues through the FP64 transforms of hp_ntt_a.hip where the chain allows
     int parity_level = 0;
     bool cur_a = false;           // set for the duration of one entry point (under the context lock): this call runs at level A
-    std::map<std::pair<u64, size_t>, hpi::DevTables> tables;          // (q, logn)
-    std::map<std::pair<u64, size_t>, hpi::DevTables> tables_a;        // (q, logn): the same tables as (w, w / q) doubles (parity level A)
-    std::map<std::pair<size_t, std::vector<u64>>, hpi::Plan> plans;   // (logn, moduli); logn == 0: no transforms needed
-    std::map<std::pair<size_t, size_t>, u32 *> perms;                 // (logn, step mod N/2) -> gather map
-    std::map<std::pair<std::vector<u64>, u64>, HpCrtConsts *> crt;    // (old moduli, new modulus) -> CRT-branch constants
-    std::map<std::pair<std::vector<u64>, std::pair<size_t, size_t>>, HpHksConsts *> hks;   // (extended moduli, (k, alpha))
+    // the family's caches (hpi::Shared)
+    std::map<std::pair<u64, size_t>, hpi::DevTables> &tables;
+    std::map<std::pair<u64, size_t>, hpi::DevTables> &tables_a;
+    std::map<std::pair<size_t, std::vector<u64>>, hpi::Plan> &plans;
+    std::map<std::pair<size_t, size_t>, u32 *> &perms;
+    std::map<std::pair<std::vector<u64>, u64>, HpCrtConsts *> &crt;
+    std::map<std::pair<std::vector<u64>, std::pair<size_t, size_t>>, HpHksConsts *> &hks;
     void *ws = nullptr;
     size_t ws_bytes = 0;
     unsigned long ws_generation = 0;   // bumped whenever the workspace is reallocated or released (captured graphs go stale)

@@ -24,16 +24,7 @@
 #include "fhe/primitives/keys.h"
 #include "fhe/primitives/rgsw.h"
 #include "fhe/primitives/rlwe.h"
-struct hp_ctx;
-namespace hehub { namespace amd {
-hp_ctx *engine();
-void set_parity_level_a(bool on);
-bool parity_level_a();
-struct TransferStats {
-    unsigned long long h2d_bytes = 0, d2h_bytes = 0, h2d_copies = 0, d2h_copies = 0, engine_calls = 0, host_blocks_registered = 0,
-                       device_copies_invalidated = 0;
-};
-} }
+#include "hehub_amd_ext.hpp"
 #else
 #include "hehub.hpp"
 #endif
@@ -56,22 +47,96 @@ namespace hehub {
 
 namespace amd {
 
+// ---- lanes ------------------------------------------------------------------------------------------------------
+// hehub's interface is one ciphertext per call and its callers are loops of INDEPENDENT calls (src/circuits/linear_algebra.h:
+// 109-133: two rotations with different keys per diagonal; examples/ckks_example.cpp:15-26; bench/benchmarks.cpp:24-35), and one
+// C3 ciphertext fills 10 .. 100 of the 256 CUs.  The own-mirror build therefore spreads the calls over a few LANES of the engine
+// (hp_ctx_fork: own stream + scratch, shared tables) and keeps the book on every device block -- which lane wrote it last, which
+// lanes read it since -- so that a call waits (on the device: hp_ctx_wait_for, one event) for exactly the calls it depends on:
+//   * a call goes to the lane whose most recent call produced one of its operands (a dependent chain stays on one stream and
+//     needs no event at all), otherwise to the next lane round robin;
+//   * a reader waits for the block's writers on other lanes, a writer (a fresh block out of the pool included) for its readers too;
+//   * uploads and downloads are synchronous on their lane, so they leave no debt behind.
+// One lane (HEHUB_AMD_LANES=1) is the round-4 behaviour: everything on one stream.  The binding build always has one lane: hehub's
+// objects are host memory, every call ends with the download of its result.
+constexpr int MAX_LANES = 8;
+struct Lane {
+    hp_ctx *ctx = nullptr;
+    unsigned long long ticket = 0;            // number of the lane's current / most recent call
+    unsigned long long seen[MAX_LANES] = {};  // seen[l]: this lane is ordered behind lane l's calls up to that ticket
+};
+struct LaneSet {
+    Lane v[MAX_LANES];
+    int count = 1, cur = 0, rr = 0, depth = 0;
+    bool level_a = false;
+};
+namespace {
+LaneSet &lane_set() {
+    static LaneSet &S = *new LaneSet;   // (never destroyed: see Pool)
+    return S;
+}
+} // namespace
+
 hp_ctx *engine() {
-    static hp_ctx *ctx = nullptr;
     static std::once_flag once;
-    std::call_once(once, [] {
+    LaneSet &S = lane_set();
+    std::call_once(once, [&S] {
         int dev = 0;
         if (const char *e = std::getenv("HEHUB_AMD_DEVICE")) dev = std::atoi(e);
-        if (hp_ctx_create(dev, &ctx) != HP_OK) ctx = nullptr;
+        if (hp_ctx_create(dev, &S.v[0].ctx) != HP_OK) S.v[0].ctx = nullptr;
+#ifndef HEHUB_AMD_BIND_REFERENCE
+        S.count = 4;
+        if (const char *e = std::getenv("HEHUB_AMD_LANES")) S.count = std::max(1, std::min(MAX_LANES, std::atoi(e)));
+#endif
+        if (S.v[0].ctx) S.level_a = hp_ctx_get_parity_level(S.v[0].ctx) == HP_PARITY_A;
     });
-    if (!ctx) throw std::runtime_error("hehub_amd: no MI355X engine available (hp_ctx_create failed); there is no CPU fallback");
-    return ctx;
+    if (!S.v[0].ctx) throw std::runtime_error("hehub_amd: no MI355X engine available (hp_ctx_create failed); there is no CPU fallback");
+    return S.v[0].ctx;
+}
+
+// the context of the lane the current call runs on
+static hp_ctx *cur() {
+    hp_ctx *root = engine();
+    LaneSet &S = lane_set();
+    Lane &L = S.v[S.cur];
+    if (!L.ctx) {
+        if (hp_ctx_fork(root, &L.ctx) != HP_OK) throw std::runtime_error(std::string("hehub_amd: ") + hp_last_error(root));
+        (void)hp_ctx_set_parity_level(L.ctx, S.level_a ? HP_PARITY_A : HP_PARITY_B);
+    }
+    return L.ctx;
+}
+
+int lanes() {
+    (void)engine();
+    return lane_set().count;
+}
+void synchronize() {
+    (void)engine();
+    LaneSet &S = lane_set();
+    for (int l = 0; l < MAX_LANES; l++)
+        if (S.v[l].ctx && hp_sync(S.v[l].ctx) != HP_OK) throw std::runtime_error(std::string("hehub_amd: ") + hp_last_error(S.v[l].ctx));
+}
+void set_lanes(int n) {
+#ifdef HEHUB_AMD_BIND_REFERENCE
+    (void)n;
+#else
+    synchronize();   // (a lane that goes out of use must not owe anybody anything)
+    LaneSet &S = lane_set();
+    S.count = std::max(1, std::min(MAX_LANES, n));
+    S.cur = 0;
+    S.rr = 0;
+#endif
 }
 
 // parity level of the process-wide engine (include/hehub_amd.h: hp_ctx_set_parity_level): false = B, hehub's raw lazy words (default);
 // true = A, the scheme-level calls return canonical residues (reduce_strict of hehub's words) through the FP64 transforms
 void set_parity_level_a(bool on) {
-    if (hp_ctx_set_parity_level(engine(), on ? HP_PARITY_A : HP_PARITY_B) != HP_OK) throw std::runtime_error(hp_last_error(engine()));
+    (void)engine();
+    LaneSet &S = lane_set();
+    for (int l = 0; l < MAX_LANES; l++)
+        if (S.v[l].ctx && hp_ctx_set_parity_level(S.v[l].ctx, on ? HP_PARITY_A : HP_PARITY_B) != HP_OK)
+            throw std::runtime_error(hp_last_error(S.v[l].ctx));
+    S.level_a = on;
 }
 bool parity_level_a() { return hp_ctx_get_parity_level(engine()) == HP_PARITY_A; }
 
@@ -83,11 +148,12 @@ bool parity_level_a() { return hp_ctx_get_parity_level(engine()) == HP_PARITY_A;
 namespace amd {
 
 // A device allocation out of a per-size free list (hehub pools its host blocks the same way and never gives them back to
-// the OS, allocator.h:19-49).  Everything this layer enqueues goes to ONE stream, so a block that returns to the pool can be
-// handed out again at once: the next user's kernels are ordered behind the last user's.
+// the OS, allocator.h:19-49).  A block carries the tickets of the last call that wrote it and of the last call that read it, per
+// lane; the record stays with the block through the pool, so whoever gets it next is ordered behind its previous users.
 struct DevBlock {
     u64 *p = nullptr;
     size_t words = 0;
+    unsigned long long rd[MAX_LANES] = {}, wr[MAX_LANES] = {};
 };
 
 namespace {
@@ -97,9 +163,9 @@ TransferStats g_stats;
 void check(int rc) {
     g_stats.engine_calls++;
     if (rc == HP_OK) return;
-    std::string msg = hp_last_error(engine());   // the calling thread's own last failure (hp_ctx.cpp)
-    (void)hp_sync(engine());   // operands may have been enqueued for upload from the caller's memory (limb_copy_h2d): let them finish
-                               // before the exception hands that memory back
+    std::string msg = hp_last_error(cur());   // the calling thread's own last failure (hp_ctx.cpp)
+    (void)hp_sync(cur());   // operands may have been enqueued for upload from the caller's memory (limb_copy_h2d): let them finish
+                            // before the exception hands that memory back
     if (rc == HP_EINVAL) throw std::invalid_argument(msg);
     if (rc == HP_ELOGIC) throw std::logic_error(msg);
     throw std::runtime_error("hehub_amd: " + msg);
@@ -111,9 +177,9 @@ struct Report {
     ~Report() {
         if (std::getenv("HEHUB_AMD_VERBOSE"))
             std::fprintf(stderr, "hehub_amd: %llu engine calls (%s); PCIe: %llu copies / %.1f MiB to the device, %llu copies / %.1f MiB back; "
-                                 "%llu host blocks registered for DMA\n",
+                                 "%llu host blocks registered for DMA; %llu waits between lanes\n",
                          g_stats.engine_calls, hp_version(), g_stats.h2d_copies, g_stats.h2d_bytes / 1048576.0, g_stats.d2h_copies,
-                         g_stats.d2h_bytes / 1048576.0, g_stats.host_blocks_registered);
+                         g_stats.d2h_bytes / 1048576.0, g_stats.host_blocks_registered, g_stats.lane_waits);
     }
 } g_report;
 
@@ -121,7 +187,7 @@ struct Report {
 // process exit, when the HIP runtime may already be gone (crash or hang at exit).  Pooled blocks go back with the process.
 struct Pool {
     std::mutex mu;
-    std::map<size_t, std::vector<u64 *>> free;
+    std::map<size_t, std::vector<DevBlock *>> free;
     size_t free_bytes = 0;
     size_t cap_bytes = (size_t)8 << 30;   // beyond this a returned block goes back to the device (HEHUB_AMD_POOL_MIB)
 };
@@ -134,51 +200,127 @@ Pool &pool() {
     return p;
 }
 
+// the current lane is ordered behind every call lane l has enqueued so far
+void order_after(int l) {
+    LaneSet &S = lane_set();
+    Lane &me = S.v[S.cur];
+    hp_ctx *mine = cur();
+    if (hp_ctx_wait_for(mine, S.v[l].ctx) != HP_OK) throw std::runtime_error(std::string("hehub_amd: ") + hp_last_error(mine));
+    me.seen[l] = S.v[l].ticket;
+    g_stats.lane_waits++;
+}
+
 } // namespace
 
 using BlockRef = std::shared_ptr<DevBlock>;
 
+// the current call reads / writes the block: wait for whoever it depends on, leave the call's ticket
+void track_read(DevBlock &b) {
+    LaneSet &S = lane_set();
+    if (S.count == 1) return;
+    Lane &me = S.v[S.cur];
+    for (int l = 0; l < MAX_LANES; l++)
+        if (l != S.cur && b.wr[l] > me.seen[l]) order_after(l);
+    b.rd[S.cur] = me.ticket;
+}
+void track_write(DevBlock &b) {
+    LaneSet &S = lane_set();
+    if (S.count == 1) return;
+    Lane &me = S.v[S.cur];
+    for (int l = 0; l < MAX_LANES; l++)
+        if (l != S.cur && std::max(b.wr[l], b.rd[l]) > me.seen[l]) order_after(l);
+    b.wr[S.cur] = me.ticket;
+}
+// after a host synchronisation of the current lane that followed track_write: every earlier user of the block has finished
+void settled(DevBlock &b) {
+    for (int l = 0; l < MAX_LANES; l++) b.rd[l] = b.wr[l] = 0;
+}
+
 BlockRef alloc_block(size_t words) {
     if (words == 0) words = 2;
     Pool &P = pool();
-    u64 *p = nullptr;
+    DevBlock *blk = nullptr;
     {
         std::lock_guard<std::mutex> lk(P.mu);
+        // a pooled block whose previous users are all on the current lane (or have been waited for): taking one that another lane
+        // still reads or writes would make this call wait for that lane -- a dependency the program does not have.  (Each lane
+        // so ends up recycling its own working set; a block nobody can take yet stays pooled.)
         auto it = P.free.find(words);
-        if (it != P.free.end() && !it->second.empty()) {
-            p = it->second.back();
-            it->second.pop_back();
-            P.free_bytes -= words * 8;
+        if (it != P.free.end()) {
+            LaneSet &S = lane_set();
+            const Lane &me = S.v[S.cur];
+            auto &list = it->second;
+            for (size_t i = list.size(); i-- > 0;) {
+                bool clean = true;
+                for (int l = 0; l < MAX_LANES && clean; l++)
+                    clean = l == S.cur || S.count == 1 || std::max(list[i]->wr[l], list[i]->rd[l]) <= me.seen[l];
+                if (!clean) continue;
+                blk = list[i];
+                list.erase(list.begin() + i);
+                P.free_bytes -= words * 8;
+                break;
+            }
         }
     }
-    if (!p) {
+    if (!blk) {
         void *d = nullptr;
-        check(hp_dev_alloc(engine(), words * sizeof(u64), &d));
-        p = (u64 *)d;
+        check(hp_dev_alloc(cur(), words * sizeof(u64), &d));
+        blk = new DevBlock;
+        blk->p = (u64 *)d;
+        blk->words = words;
     }
-    return BlockRef(new DevBlock{p, words}, [](DevBlock *b) {
+    return BlockRef(blk, [](DevBlock *b) {
         Pool &Q = pool();
         bool keep;
         {
             std::lock_guard<std::mutex> lk(Q.mu);
             keep = Q.free_bytes + b->words * 8 <= Q.cap_bytes;
             if (keep) {
-                Q.free[b->words].push_back(b->p);
+                Q.free[b->words].push_back(b);   // (with its record: the next owner waits for this one's readers and writers)
                 Q.free_bytes += b->words * 8;
             }
         }
-        if (!keep) (void)hp_dev_free(engine(), b->p);
-        delete b;
+        if (!keep) {
+            LaneSet &S = lane_set();
+            for (int l = 0; l < MAX_LANES; l++)
+                if (S.v[l].ctx) (void)hp_sync(S.v[l].ctx);
+            (void)hp_dev_free(S.v[0].ctx, b->p);
+            delete b;
+        }
     });
 }
 
+// One call of the public interface: picks the lane (see "lanes" above) and opens a new ticket on it.  Calls nest (ckks::add ->
+// add -> operator+=): the outermost scope decides.
+struct OpScope {
+    explicit OpScope(std::initializer_list<const BlockRef *> operands, int force_lane = -1) {
+        (void)engine();
+        LaneSet &S = lane_set();
+        if (S.depth++ > 0) return;
+        int lane = force_lane;
+        if (S.count == 1) lane = 0;
+        for (const BlockRef *r : operands) {
+            if (lane >= 0) break;
+            if (!r || !*r) continue;
+            for (int l = 0; l < S.count; l++)
+                if ((*r)->wr[l] && (*r)->wr[l] == S.v[l].ticket) { lane = l; break; }
+        }
+        if (lane < 0) lane = S.rr = (S.rr + 1) % S.count;
+        S.cur = lane;
+        (void)cur();
+        S.v[lane].ticket++;
+    }
+    ~OpScope() { lane_set().depth--; }
+    OpScope(const OpScope &) = delete;
+};
+
 void h2d(u64 *dst, const u64 *src, size_t words) {
-    check(hp_memcpy_h2d(engine(), dst, src, words * sizeof(u64)));
+    check(hp_memcpy_h2d(cur(), dst, src, words * sizeof(u64)));
     g_stats.h2d_bytes += words * 8;
     g_stats.h2d_copies++;
 }
 void d2h(u64 *dst, const u64 *src, size_t words) {
-    check(hp_memcpy_d2h(engine(), dst, src, words * sizeof(u64)));
+    check(hp_memcpy_d2h(cur(), dst, src, words * sizeof(u64)));
     g_stats.d2h_bytes += words * 8;
     g_stats.d2h_copies++;
 }
@@ -217,7 +359,7 @@ bool pinned_block(const u64 *p, size_t words) {
     std::lock_guard<std::mutex> lk(P.mu);
     auto it = P.seen.find(p);
     if (it != P.seen.end()) return it->second;
-    const bool ok = hp_host_register(engine(), const_cast<u64 *>(p), words * sizeof(u64)) == HP_OK;
+    const bool ok = hp_host_register(cur(), const_cast<u64 *>(p), words * sizeof(u64)) == HP_OK;
     if (ok) g_stats.host_blocks_registered++;
     P.seen.emplace(p, ok);
     return ok;
@@ -225,13 +367,13 @@ bool pinned_block(const u64 *p, size_t words) {
 } // namespace
 void limb_copy_h2d(u64 *dst, const u64 *src, size_t words) {
     if (!pinned_block(src, words)) return h2d(dst, src, words);
-    check(hp_memcpy_h2d_async(engine(), dst, src, words * sizeof(u64)));
+    check(hp_memcpy_h2d_async(cur(), dst, src, words * sizeof(u64)));
     g_stats.h2d_bytes += words * 8;
     g_stats.h2d_copies++;
 }
 void limb_copy_d2h(u64 *dst, const u64 *src, size_t words) {
     if (!pinned_block(dst, words)) return d2h(dst, src, words);
-    check(hp_memcpy_d2h_async(engine(), dst, src, words * sizeof(u64)));
+    check(hp_memcpy_d2h_async(cur(), dst, src, words * sizeof(u64)));
     g_stats.d2h_bytes += words * 8;
     g_stats.d2h_copies++;
 }
@@ -247,7 +389,7 @@ struct Arena {
 Arena &arena() { static Arena &a = *new Arena; return a; }
 void arena_flush() {   // everything enqueued so far has happened; hand the downloaded words to their limbs
     Arena &A = arena();
-    check(hp_sync(engine()));
+    check(hp_sync(cur()));
     for (auto &p : A.down)
         for (size_t k = 0; k < p.rows.size(); k++) std::memcpy(p.rows[k], p.st + k * p.n, p.n * sizeof(u64));
     A.down.clear();
@@ -258,10 +400,10 @@ u64 *arena_take(size_t words) {
     if (A.used + words > A.cap) {
         arena_flush();
         if (words > A.cap) {
-            if (A.buf) (void)hp_host_free(engine(), A.buf);
+            if (A.buf) (void)hp_host_free(cur(), A.buf);
             void *p = nullptr;
             const size_t want = std::max(words, (size_t)1 << 20);   // at least 8 MiB
-            check(hp_host_alloc(engine(), want * sizeof(u64), &p));
+            check(hp_host_alloc(cur(), want * sizeof(u64), &p));
             A.buf = (u64 *)p;
             A.cap = want;
         }
@@ -281,13 +423,13 @@ template <class Vec> void poly_copy_h2d(u64 *dst, const Vec &v, size_t limbs, si
     if (all) {
         std::vector<const u64 *> rows(limbs);
         for (size_t k = 0; k < limbs; k++) rows[k] = v[(int)k].data();
-        check(hp_dev_load_host_rows(engine(), limbs, n, dst, rows.data()));
+        check(hp_dev_load_host_rows(cur(), limbs, n, dst, rows.data()));
     } else if (limbs == 1 && pinned_block(v[0].data(), n)) {
-        check(hp_memcpy_h2d_async(engine(), dst, v[0].data(), n * sizeof(u64)));
+        check(hp_memcpy_h2d_async(cur(), dst, v[0].data(), n * sizeof(u64)));
     } else {
         u64 *st = arena_take(limbs * n);
         for (size_t k = 0; k < limbs; k++) std::memcpy(st + k * n, v[(int)k].data(), n * sizeof(u64));
-        check(hp_memcpy_h2d_async(engine(), dst, st, limbs * n * sizeof(u64)));
+        check(hp_memcpy_h2d_async(cur(), dst, st, limbs * n * sizeof(u64)));
     }
     g_stats.h2d_bytes += limbs * n * 8;
     g_stats.h2d_copies++;
@@ -299,12 +441,12 @@ template <class Vec> void poly_copy_d2h(Vec &v, const u64 *src, size_t limbs, si
     if (all) {
         std::vector<u64 *> rows(limbs);
         for (size_t k = 0; k < limbs; k++) rows[k] = v[(int)k].data();
-        check(hp_dev_store_host_rows(engine(), limbs, n, src, rows.data()));
+        check(hp_dev_store_host_rows(cur(), limbs, n, src, rows.data()));
     } else if (limbs == 1 && pinned_block(v[0].data(), n)) {
-        check(hp_memcpy_d2h_async(engine(), v[0].data(), src, n * sizeof(u64)));
+        check(hp_memcpy_d2h_async(cur(), v[0].data(), src, n * sizeof(u64)));
     } else {
         u64 *st = arena_take(limbs * n);
-        check(hp_memcpy_d2h_async(engine(), st, src, limbs * n * sizeof(u64)));
+        check(hp_memcpy_d2h_async(cur(), st, src, limbs * n * sizeof(u64)));
         Arena::Pending p;
         p.st = st; p.n = n;
         for (size_t k = 0; k < limbs; k++) p.rows.push_back(v[(int)k].data());
@@ -323,9 +465,9 @@ u64 *pinned(size_t words) {
     static u64 *buf = nullptr;
     static size_t cap = 0;
     if (words > cap) {
-        if (buf) (void)hp_host_free(engine(), buf);
+        if (buf) (void)hp_host_free(cur(), buf);
         void *p = nullptr;
-        check(hp_host_alloc(engine(), words * sizeof(u64), &p));
+        check(hp_host_alloc(cur(), words * sizeof(u64), &p));
         buf = (u64 *)p;
         cap = words;
     }
@@ -358,7 +500,7 @@ struct Src {
 struct Dst {
     BlockRef blk;
     u64 *p = nullptr;
-    explicit Dst(size_t words) : blk(alloc_block(words)), p(blk->p) {}
+    explicit Dst(size_t words) : blk(alloc_block(words)), p(blk->p) { track_write(*blk); }
 };
 
 #ifndef HEHUB_AMD_BIND_REFERENCE
@@ -380,15 +522,22 @@ struct Access {
                 v.blk_ = alloc_block(v.count_ * n);
                 v.off_ = 0;
             }
-            h2d_limbs(v.blk_->p + v.off_, v.limbs_, v.count_, n);
+            const bool whole = v.off_ == 0 && v.count_ * n == v.blk_->words;
+            track_write(*v.blk_);
+            h2d_limbs(v.blk_->p + v.off_, v.limbs_, v.count_, n);   // (synchronous: the upload leaves no debt on its lane)
+            if (whole) settled(*v.blk_);
             v.dev_ok_ = true;
         }
         (void)limbs;
+        track_read(*v.blk_);
         return Src{v.blk_->p + v.off_, v.blk_};
     }
+    // the block that holds the vector's current device words, if any: what OpScope looks at to keep a dependent chain on one lane
+    static const BlockRef *home(const RnsIntVec &v) { return v.dev_ok_ ? &v.blk_ : nullptr; }
     // the vector's own device words, to be overwritten in place by an engine call that has read them (operator+= ...)
     static u64 *inout(RnsIntVec &v) {
         Src s = in(v, v.count_);
+        track_write(*v.blk_);
         v.host_ok_ = false;
         v.stamp_ = next_stamp();
         return const_cast<u64 *>(s.p);
@@ -436,7 +585,16 @@ struct Access {
         const size_t n = v.dimension();
         v.limbs_.resize(v.count_);   // (vectors that exist are refreshed in place: a reference a caller holds sees the new words)
         for (size_t k = 0; k < v.count_; k++) v.limbs_[k].resize(n);
-        d2h_limbs(v.limbs_, v.blk_->p + v.off_, v.count_, n);
+        {
+            // the download runs on the lane that wrote the words last (no event needed there), behind the block's other writers
+            LaneSet &S = lane_set();
+            int lane = 0;
+            for (int l = 1; l < MAX_LANES; l++)
+                if (v.blk_->wr[l] > v.blk_->wr[lane]) lane = l;
+            OpScope op({}, S.depth ? S.cur : lane);
+            track_read(*v.blk_);
+            d2h_limbs(v.limbs_, v.blk_->p + v.off_, v.count_, n);   // (synchronous)
+        }
         v.host_ok_ = true;
     }
     static void host_written(RnsIntVec &v) {
@@ -451,8 +609,11 @@ struct Access {
         dst.stamp_ = next_stamp();
         if (o.dev_ok_ && o.count_) {   // device-to-device: the host copy (if any) is not duplicated, it can be fetched again
             const size_t w = o.count_ * o.dimension();
+            OpScope op({&o.blk_});
             dst.blk_ = alloc_block(w);
-            check(hp_dev_copy(engine(), w, o.blk_->p + o.off_, dst.blk_->p));
+            track_read(*o.blk_);
+            track_write(*dst.blk_);
+            check(hp_dev_copy(cur(), w, o.blk_->p + o.off_, dst.blk_->p));
             dst.dev_ok_ = true;
             dst.host_ok_ = false;
         } else {
@@ -460,6 +621,38 @@ struct Access {
             dst.host_ok_ = true;
             dst.dev_ok_ = false;
         }
+    }
+    // u64[polys.size()][limbs][N] for a batch entry point: the polynomials' own words when they already lie like that (the result
+    // of an earlier batched call, untouched since), otherwise ONE gather kernel into a block that then becomes their home
+    static Src batch_in(const std::vector<const RnsIntVec *> &polys, size_t limbs) {
+        const RnsIntVec &f = *polys[0];
+        const size_t w = limbs * f.dimension();
+        bool packed = true;
+        for (size_t r = 0; r < polys.size() && packed; r++) {
+            const RnsIntVec &v = *polys[r];
+            packed = v.dev_ok_ && v.blk_ == f.blk_ && v.off_ == f.off_ + r * w && v.count_ == limbs;
+        }
+        if (packed) {
+            track_read(*f.blk_);
+            return Src{f.blk_->p + f.off_, f.blk_};
+        }
+        std::vector<const u64 *> rows(polys.size());
+        std::vector<BlockRef> holds(polys.size());
+        for (size_t r = 0; r < polys.size(); r++) {
+            Src s = in(*polys[r], limbs);
+            rows[r] = s.p;
+            holds[r] = s.hold;
+        }
+        BlockRef tmp = alloc_block(w * polys.size());
+        track_write(*tmp);
+        check(hp_dev_gather_rows(cur(), polys.size(), w, rows.data(), tmp->p));
+        for (size_t r = 0; r < polys.size(); r++)
+            if (polys[r]->count_ == limbs) rehome(*polys[r], tmp, r * w);   // (same words, another place: invisible to the caller)
+        return Src{tmp->p, tmp};
+    }
+    // polynomial r of a batched result is the view [r * limbs * N, (r + 1) * limbs * N) of the block the engine call filled
+    static void bind_many(const std::vector<RnsIntVec *> &polys, const Dst &d, size_t limbs) {
+        for (size_t r = 0; r < polys.size(); r++) bind(*polys[r], d, r * limbs * polys[r]->dimension(), limbs);
     }
     static void steal(RnsIntVec &dst, RnsIntVec &o) {
         dst.logn_ = o.logn_; dst.count_ = o.count_; dst.q_ = std::move(o.q_); dst.limbs_ = std::move(o.limbs_);
@@ -556,6 +749,7 @@ struct Access {
         cache_put(v, limbs, blk, 0);
         return Src{blk->p, blk};
     }
+    static const BlockRef *home(const RnsIntVec &) { return nullptr; }   // (one lane in this build)
     static void shape(RnsIntVec &v, size_t n, size_t limbs, const std::vector<u64> &moduli) {
         v = RnsIntVec(RnsIntVec::Params{n, limbs, std::vector<u64>(moduli.begin(), moduli.begin() + limbs)});
     }
@@ -567,6 +761,29 @@ struct Access {
         bind_enqueue(v, d, off, limbs);
         limb_copies_wait();   // hehub's object is host memory the caller may read as soon as we return
         bind_finish(v, d, off, limbs);
+    }
+    // a batch goes up into ONE block, polynomial by polynomial (each a single kernel over PCIe from its registered limb blocks, or
+    // one DMA through the page-locked arena); a polynomial the ciphertext cache knows is copied on the device instead
+    static Src batch_in(const std::vector<const RnsIntVec *> &polys, size_t limbs) {
+        const size_t n = polys[0]->dimension(), w = limbs * n;
+        BlockRef tmp = alloc_block(w * polys.size());
+        for (size_t r = 0; r < polys.size(); r++) {
+            BlockRef blk;
+            size_t off = 0;
+            if (cache_get(*polys[r], limbs, blk, off)) {
+                check(hp_dev_copy(cur(), w, blk->p + off, tmp->p + r * w));
+            } else {
+                poly_copy_h2d(tmp->p + r * w, *polys[r], limbs, n);
+                cache_put(*polys[r], limbs, tmp, r * w);
+            }
+        }
+        return Src{tmp->p, tmp};
+    }
+    // hehub's objects are host memory: the whole batch is enqueued for download and waited for once
+    static void bind_many(const std::vector<RnsIntVec *> &polys, const Dst &d, size_t limbs) {
+        for (size_t r = 0; r < polys.size(); r++) bind_enqueue(*polys[r], d, r * limbs * polys[r]->dimension(), limbs);
+        limb_copies_wait();
+        for (size_t r = 0; r < polys.size(); r++) bind_finish(*polys[r], d, r * limbs * polys[r]->dimension(), limbs);
     }
     static bool adjacent(const RnsIntVec &a, const RnsIntVec &b, size_t limbs) {
         BlockRef ba, bb;
@@ -589,11 +806,12 @@ Src gather(std::initializer_list<const RnsIntVec *> polys, size_t limbs) {
     if (polys.size() == 1 || adj) return Access::in(*first, limbs);
     const size_t w = Access::words(*first, limbs);
     BlockRef tmp = alloc_block(w * polys.size());
+    track_write(*tmp);
     size_t i = 0;
     bool whole = true;
     for (const RnsIntVec *p : polys) {
         Src s = Access::in(*p, limbs);
-        if (w) check(hp_dev_copy(engine(), w, s.p, tmp->p + i * w));
+        if (w) check(hp_dev_copy(cur(), w, s.p, tmp->p + i * w));
         whole = whole && p->component_count() == limbs;
         i++;
     }
@@ -612,6 +830,7 @@ Src gather(std::initializer_list<const RnsIntVec *> polys, size_t limbs) {
 
 using amd::Access;
 using amd::check;
+using amd::OpScope;
 using amd::Dst;
 using amd::Src;
 
@@ -696,7 +915,7 @@ size_t check_addsub(const RnsIntVec &self, const RnsIntVec &b) {
 enum class Bin { add, sub, mul };
 
 void dev_binary(Bin op, size_t n, size_t L, const u64 *m, size_t batch, const u64 *a, const u64 *b, u64 *out) {
-    auto *ctx = amd::engine();
+    auto *ctx = amd::cur();
     if (op == Bin::add) check(hp_dev_poly_add(ctx, n, L, m, batch, a, b, out));
     if (op == Bin::sub) check(hp_dev_poly_sub(ctx, n, L, m, batch, a, b, out));
     if (op == Bin::mul) check(hp_dev_poly_mul(ctx, n, L, m, batch, a, b, out));
@@ -706,6 +925,7 @@ void dev_binary(Bin op, size_t n, size_t L, const u64 *m, size_t batch, const u6
 void run_inplace(Bin op, RnsIntVec &self, const RnsIntVec &b, size_t L) {
     const size_t n = self.dimension();
     if (L == 0 || n == 0) return;
+    OpScope scope({Access::home(self), Access::home(b)});
     Src sb = Access::in(b, L);
 #ifndef HEHUB_AMD_BIND_REFERENCE
     u64 *p = Access::inout(self);   // the vector's own device words: hp_dev_poly_* allow d_out == d_a
@@ -721,13 +941,14 @@ void run_inplace(Bin op, RnsIntVec &self, const RnsIntVec &b, size_t L) {
 void scalar_mul(RnsIntVec &self, const std::vector<u64> &scalars) {
     const size_t n = self.dimension(), L = self.component_count();
     if (L == 0) return;
+    OpScope op({Access::home(self)});
 #ifndef HEHUB_AMD_BIND_REFERENCE
     u64 *p = Access::inout(self);
-    check(hp_dev_poly_scalar_mul(amd::engine(), n, L, self.modulus_vec().data(), 1, scalars.data(), p, p));
+    check(hp_dev_poly_scalar_mul(amd::cur(), n, L, self.modulus_vec().data(), 1, scalars.data(), p, p));
 #else
     Src s = Access::in(self, L);
     Dst d(L * n);
-    check(hp_dev_poly_scalar_mul(amd::engine(), n, L, self.modulus_vec().data(), 1, scalars.data(), s.p, d.p));
+    check(hp_dev_poly_scalar_mul(amd::cur(), n, L, self.modulus_vec().data(), 1, scalars.data(), s.p, d.p));
     Access::bind(self, d, 0, L);
 #endif
 }
@@ -792,6 +1013,7 @@ public:
         const size_t words = L * 2 * (L + 1) * n;
         if (cap == 0) {
             own_ = amd::alloc_block(words);
+            amd::track_write(*own_);
             assemble(own_->p, rgsw, L, n);
             return;
         }
@@ -818,9 +1040,11 @@ public:
                 cache.erase(cache.begin() + i);
                 cache.push_back(hit);
                 own_ = hit.second;
+                amd::track_read(*own_);
                 return;
             }
         own_ = amd::alloc_block(words);
+        amd::track_write(*own_);
         assemble(own_->p, rgsw, L, n);
         if (cache.size() >= cap) cache.erase(cache.begin());
         cache.emplace_back(std::move(sig), own_);
@@ -834,7 +1058,7 @@ private:
                 u64 *row = dst + ((j * 2 + h) * (L + 1)) * n;
 #ifndef HEHUB_AMD_BIND_REFERENCE
                 Src s = Access::in(rgsw[j][h], L + 1);   // (a key polynomial that lives on the device is copied there)
-                check(hp_dev_copy(amd::engine(), (L + 1) * n, s.p, row));
+                check(hp_dev_copy(amd::cur(), (L + 1) * n, s.p, row));
                 Access::drop_device_copy(rgsw[j][h]);     // the assembled block is the key's device form: no second 55 MiB
 #else
                 amd::poly_copy_h2d(row, rgsw[j][h], L + 1, n);
@@ -863,12 +1087,13 @@ RlweCt relinearize_common(const std::array<RnsPolynomial, 3> &quad, const RlweKs
     const size_t L0 = check_ext_prod(quad[2], key, mext);
     const size_t n = quad[2].dimension(), L = quad[2].component_count();
     if (bgv && L0 != L) throw std::invalid_argument("Inconsistent RGSW ciphertext.");   // no higher-level keys for the BGV quirk path
+    OpScope op({Access::home(quad[0]), Access::home(quad[1]), Access::home(quad[2])});
     DevKey dk(key, L0, n);
     Src dq = amd::gather({&quad[0], &quad[1], &quad[2]}, L);
     Dst dout(2 * L * n);
     const size_t logn = quad[2].log_dimension();
-    if (bgv) check(hp_dev_bgv_relinearize(amd::engine(), logn, L, mext.data(), 1 /* bgv.h:32 */, 1, dq.p, dk.p(), dout.p));
-    else check(hp_dev_ckks_relinearize_at(amd::engine(), logn, L, L0, mext.data(), 1, dq.p, dk.p(), dout.p));
+    if (bgv) check(hp_dev_bgv_relinearize(amd::cur(), logn, L, mext.data(), 1 /* bgv.h:32 */, 1, dq.p, dk.p(), dout.p));
+    else check(hp_dev_ckks_relinearize_at(amd::cur(), logn, L, L0, mext.data(), 1, dq.p, dk.p(), dout.p));
     std::vector<u64> q(mext.begin(), mext.begin() + L);
     return make_ct(n, L, q, dout);
 }
@@ -885,10 +1110,11 @@ template <class Quad, class Ct> Quad mult_low_level_common(const Ct &ct1, const 
     m1.resize(L); m2.resize(L);
     if (m1 != m2) throw std::invalid_argument("Operands' moduli mismatch.");
     // (a ciphertext with more limbs than L does not lie as [2][L][N]: gather() then copies the first L limbs of each half)
+    OpScope op({Access::home(ct1[0]), Access::home(ct1[1]), Access::home(ct2[0]), Access::home(ct2[1])});
     Src d1 = amd::gather({&ct1[0], &ct1[1]}, L);
     Src d2 = amd::gather({&ct2[0], &ct2[1]}, L);
     Dst dq(3 * L * n);
-    check(hp_dev_mult_low_level(amd::engine(), ct1[0].log_dimension(), L, m1.data(), 1, d1.p, d2.p, dq.p));
+    check(hp_dev_mult_low_level(amd::cur(), ct1[0].log_dimension(), L, m1.data(), 1, d1.p, d2.p, dq.p));
     Quad quad;
 #ifdef HEHUB_AMD_BIND_REFERENCE
     for (int h = 0; h < 3; h++) {
@@ -909,11 +1135,12 @@ template <class Quad, class Ct> Quad mult_low_level_common(const Ct &ct1, const 
 void drop_last_prime(RlweCt &ct, bool bgv, u64 t) {
     check_ct_wellformed(ct);
     const size_t n = ct[0].dimension(), L = ct[0].component_count(), logn = ct[0].log_dimension();
+    OpScope op({Access::home(ct[0]), Access::home(ct[1])});
     Src din = amd::gather({&ct[0], &ct[1]}, L);
     Dst dout(2 * (L - 1) * n);
     const std::vector<u64> m(ct[0].modulus_vec());
-    if (bgv) check(hp_dev_bgv_mod_switch(amd::engine(), logn, L, m.data(), t, 1, din.p, dout.p));
-    else check(hp_dev_ckks_rescale(amd::engine(), logn, L, m.data(), 1, din.p, dout.p));
+    if (bgv) check(hp_dev_bgv_mod_switch(amd::cur(), logn, L, m.data(), t, 1, din.p, dout.p));
+    else check(hp_dev_ckks_rescale(amd::cur(), logn, L, m.data(), 1, din.p, dout.p));
 #ifdef HEHUB_AMD_BIND_REFERENCE
     // remove_components hands the last limb's block back to hehub's pool, whose free list writes its link into the block's first
     // word (allocator.h:67-71): the (asynchronous) upload of that limb must have happened by then
@@ -960,6 +1187,7 @@ RnsIntVec operator*(const RnsIntVec &a, const RnsIntVec &b) {
     Access::shape(result, a.dimension(), components, moduli);
     const size_t n = a.dimension();
     if (components == 0 || n == 0) return result;
+    OpScope op({Access::home(a), Access::home(b)});
     Src sa = Access::in(a, components), sb = Access::in(b, components);
     Dst d(components * n);
     dev_binary(Bin::mul, n, components, moduli.data(), 1, sa.p, sb.p, d.p);
@@ -1013,13 +1241,13 @@ const RnsPolynomial &operator*=(RnsPolynomial &self, const std::vector<u64> &s) 
 // =====================================================================================================
 // mod_arith.h
 // =====================================================================================================
-void batched_barrett_lazy(const u64 q, const size_t n, u64 v[]) { check(hp_batched_barrett_lazy(amd::engine(), q, n, v)); }
+void batched_barrett_lazy(const u64 q, const size_t n, u64 v[]) { check(hp_batched_barrett_lazy(amd::cur(), q, n, v)); }
 #ifndef HEHUB_AMD_BIND_REFERENCE   // inline in the reference's mod_arith.h:18-25,58-63
-void batched_barrett(const u64 q, const size_t n, u64 v[]) { check(hp_batched_barrett(amd::engine(), q, n, v)); }
-void batched_reduce_strict(const u64 q, const size_t n, u64 v[]) { check(hp_batched_reduce_strict(amd::engine(), q, n, v)); }
+void batched_barrett(const u64 q, const size_t n, u64 v[]) { check(hp_batched_barrett(amd::cur(), q, n, v)); }
+void batched_reduce_strict(const u64 q, const size_t n, u64 v[]) { check(hp_batched_reduce_strict(amd::cur(), q, n, v)); }
 #endif
 void batched_mul_mod_hybrid_lazy(const u64 q, const size_t n, const u64 a[], const u64 b[], u64 out[]) {
-    check(hp_batched_mul_mod_hybrid_lazy(amd::engine(), q, n, a, b, out));
+    check(hp_batched_mul_mod_hybrid_lazy(amd::cur(), q, n, a, b, out));
 }
 #ifndef HEHUB_AMD_BIND_REFERENCE
 void batched_mul_mod_hybrid(const u64 q, const size_t n, const u64 a[], const u64 b[], u64 out[]) {
@@ -1028,7 +1256,7 @@ void batched_mul_mod_hybrid(const u64 q, const size_t n, const u64 a[], const u6
 }
 #endif
 void batched_mul_mod_barrett_lazy(const u64 q, const size_t n, const u64 a[], const u64 b[], u64 out[]) {
-    check(hp_batched_mul_mod_barrett_lazy(amd::engine(), q, n, a, b, out));
+    check(hp_batched_mul_mod_barrett_lazy(amd::cur(), q, n, a, b, out));
 }
 #ifndef HEHUB_AMD_BIND_REFERENCE
 void batched_mul_mod_barrett(const u64 q, const size_t n, const u64 a[], const u64 b[], u64 out[]) {
@@ -1037,14 +1265,15 @@ void batched_mul_mod_barrett(const u64 q, const size_t n, const u64 a[], const u
 }
 #endif
 void batched_montgomery_128_lazy(const u64 q, const size_t len, const u128 in[], u64 out[]) {
-    check(hp_batched_montgomery_128_lazy(amd::engine(), q, len, reinterpret_cast<const u64 *>(in), out));
+    check(hp_batched_montgomery_128_lazy(amd::cur(), q, len, reinterpret_cast<const u64 *>(in), out));
 }
 
 #ifndef HEHUB_AMD_BIND_REFERENCE   // mod_arith.h:65-72 (inline) and mod_arith.cpp:136-149 stay the reference's
 void reduce_strict(RnsPolynomial &p) {
     const size_t n = p.dimension(), L = p.component_count();
     if (L == 0) return;
-    check(hp_dev_poly_reduce_strict(amd::engine(), n, L, p.modulus_vec().data(), 1, Access::inout(p)));
+    OpScope op({Access::home(p)});
+    check(hp_dev_poly_reduce_strict(amd::cur(), n, L, p.modulus_vec().data(), 1, Access::inout(p)));
 }
 
 // host-side scalar, as in the reference (mod_arith.cpp:136-149): Bezout coefficient lifted to [0, prime)
@@ -1063,10 +1292,10 @@ u64 inverse_mod_prime(const u64 elem, const u64 prime) {
 // ntt.h
 // =====================================================================================================
 void ntt_negacyclic_inplace_lazy(const size_t logn, const u64 q, u64 c[]) {
-    check(hp_ntt_negacyclic_inplace_lazy(amd::engine(), logn, q, c));
+    check(hp_ntt_negacyclic_inplace_lazy(amd::cur(), logn, q, c));
 }
 void intt_negacyclic_inplace_lazy(const size_t logn, const u64 q, u64 v[]) {
-    check(hp_intt_negacyclic_inplace_lazy(amd::engine(), logn, q, v));
+    check(hp_intt_negacyclic_inplace_lazy(amd::cur(), logn, q, v));
 }
 
 #ifndef HEHUB_AMD_BIND_REFERENCE   // ntt.h:41-92 (inline per-limb loops) stay the reference's
@@ -1074,9 +1303,10 @@ static void poly_transform(RnsPolynomial &p, bool inverse, bool strict) {
     const size_t n = p.dimension(), L = p.component_count();
     (void)n;
     if (L) {
+        OpScope op({Access::home(p)});
         u64 *d = Access::inout(p);
-        if (inverse) check(hp_dev_intt(amd::engine(), p.log_dimension(), L, p.modulus_vec().data(), 1, d, strict ? 1 : 0));
-        else check(hp_dev_ntt(amd::engine(), p.log_dimension(), L, p.modulus_vec().data(), 1, d));
+        if (inverse) check(hp_dev_intt(amd::cur(), p.log_dimension(), L, p.modulus_vec().data(), 1, d, strict ? 1 : 0));
+        else check(hp_dev_ntt(amd::cur(), p.log_dimension(), L, p.modulus_vec().data(), 1, d));
     }
     p.rep_form = inverse ? PolyRepForm::coeff : PolyRepForm::value;
 }
@@ -1086,7 +1316,7 @@ void intt_negacyclic_inplace(RnsPolynomial &p) { poly_transform(p, true, true); 
 #endif
 
 void cache_ntt_factors_strict(const u64 logn, const std::vector<u64> &moduli) {
-    check(hp_cache_ntt_factors_strict(amd::engine(), logn, moduli.data(), moduli.size()));
+    check(hp_cache_ntt_factors_strict(amd::cur(), logn, moduli.data(), moduli.size()));
 }
 
 // =====================================================================================================
@@ -1097,10 +1327,11 @@ static RnsPolynomial gather(const RnsPolynomial &p, bool is_cycle, size_t step) 
     const size_t n = p.dimension(), L = p.component_count();
     RnsPolynomial out = result_poly(n, L, p.modulus_vec(), PolyRepForm::value);
     if (L == 0) return out;
+    OpScope op({Access::home(p)});
     Src din = Access::in(p, L);
     Dst dout(L * n);
-    if (is_cycle) check(hp_dev_poly_cycle(amd::engine(), p.log_dimension(), L, 1, step, din.p, dout.p));
-    else check(hp_dev_poly_involution(amd::engine(), p.log_dimension(), L, 1, din.p, dout.p));
+    if (is_cycle) check(hp_dev_poly_cycle(amd::cur(), p.log_dimension(), L, 1, step, din.p, dout.p));
+    else check(hp_dev_poly_involution(amd::cur(), p.log_dimension(), L, 1, din.p, dout.p));
     Access::bind(out, dout, 0, L);
     return out;
 }
@@ -1122,6 +1353,7 @@ static RlweCt addsub(const RlweCt &a, const RlweCt &b, bool sub) {
     const size_t n = a[0].dimension();
     const bool same = L[0] == L[1] && L[0] > 0 && a[1].dimension() == n && a[0].modulus_vec() == a[1].modulus_vec() &&
                       b[0].component_count() == L[0] && b[1].component_count() == L[0];
+    OpScope op({Access::home(a[0]), Access::home(a[1]), Access::home(b[0]), Access::home(b[1])});
     if (!same) return sub ? RlweCt{a[0] - b[0], a[1] - b[1]} : RlweCt{a[0] + b[0], a[1] + b[1]};
     Src sa = amd::gather({&a[0], &a[1]}, L[0]), sb = amd::gather({&b[0], &b[1]}, L[0]);
     Dst d(2 * L[0] * n);
@@ -1141,10 +1373,11 @@ RlweCt ext_prod_montgomery(const RlwePt &pt, const RgswCt &rgsw) {
     std::vector<u64> mext;
     const size_t L0 = check_ext_prod(pt, rgsw, mext);
     const size_t n = pt.dimension(), L = pt.component_count();
+    OpScope op({Access::home(pt)});
     DevKey dk(rgsw, L0, n);
     Src dp = Access::in(pt, L);
     Dst dout(2 * (L + 1) * n);
-    check(hp_dev_ext_prod_montgomery_at(amd::engine(), pt.log_dimension(), L, L0, mext.data(), 1, dp.p, dk.p(), dout.p));
+    check(hp_dev_ext_prod_montgomery_at(amd::cur(), pt.log_dimension(), L, L0, mext.data(), 1, dp.p, dk.p(), dout.p));
     return make_ct(n, L + 1, mext, dout);
 }
 
@@ -1167,9 +1400,10 @@ RlwePt decrypt_core(const RlweCt &ct, const RlweSk &sk) {
     if (c0.modulus_vec() != m1) throw std::invalid_argument("Operands' moduli mismatch.");
     RnsPolynomial pt = result_poly(n, L, m1, PolyRepForm::coeff);
     if (L == 0) return pt;
+    OpScope op({Access::home(c0), Access::home(c1)});
     Src dct = amd::gather({&c0, &c1}, L), dsk = Access::in(sk, L);
     Dst dpt(L * n);
-    check(hp_dev_rlwe_decrypt_core(amd::engine(), c0.log_dimension(), L, m1.data(), 1, dct.p, dsk.p, dpt.p));
+    check(hp_dev_rlwe_decrypt_core(amd::cur(), c0.log_dimension(), L, m1.data(), 1, dct.p, dsk.p, dpt.p));
     Access::bind(pt, dpt, 0, L);
     return pt;
 }
@@ -1180,12 +1414,13 @@ RnsPolynomial rns_base_transform(RnsPolynomial in, const std::vector<u64> &new_m
     if (in.rep_form == PolyRepForm::value)
         throw std::logic_error("Trying to perform RNS base transformation on NTT values.");
     const size_t n = in.dimension(), L = in.component_count();
+    OpScope op({Access::home(in)});
     if (L == 1) {
         RnsPolynomial out = result_poly(n, new_moduli.size(), new_moduli, PolyRepForm::coeff);
         if (new_moduli.empty()) return out;
         Src din = Access::in(in, 1);
         Dst dout(new_moduli.size() * n);
-        check(hp_dev_rns_base_from_single(amd::engine(), n, in.modulus_at(0), new_moduli.size(), new_moduli.data(), 1, din.p, dout.p));
+        check(hp_dev_rns_base_from_single(amd::cur(), n, in.modulus_at(0), new_moduli.size(), new_moduli.data(), 1, din.p, dout.p));
         Access::bind(out, dout, 0, new_moduli.size());
         return out;
     }
@@ -1193,7 +1428,7 @@ RnsPolynomial rns_base_transform(RnsPolynomial in, const std::vector<u64> &new_m
         RnsPolynomial out = result_poly(n, 1, new_moduli, PolyRepForm::coeff);
         Src din = Access::in(in, L);
         Dst dout(n);
-        check(hp_dev_rns_base_to_single(amd::engine(), n, L, in.modulus_vec().data(), new_moduli[0], 1, din.p, dout.p));
+        check(hp_dev_rns_base_to_single(amd::cur(), n, L, in.modulus_vec().data(), new_moduli[0], 1, din.p, dout.p));
         Access::bind(out, dout, 0, 1);
         return out;
     }
@@ -1287,11 +1522,12 @@ static CkksCt key_switched(const CkksCt &ct, const RlweKsk &key, bool conj, size
     const size_t L0 = check_ext_prod(ct[1], key, mext);
     const size_t n = ct[1].dimension(), L = ct[1].component_count(), logn = ct[1].log_dimension();
     if (ct[0].dimension() != n || ct[0].component_count() != L) throw std::invalid_argument("Ill-formed ciphertext.");
+    OpScope op({Access::home(ct[0]), Access::home(ct[1])});
     DevKey dk(key, L0, n);
     Src dct = amd::gather({&ct[0], &ct[1]}, L);
     Dst dout(2 * L * n);
-    if (conj) check(hp_dev_ckks_conjugate_at(amd::engine(), logn, L, L0, mext.data(), 1, dct.p, dk.p(), dout.p));
-    else check(hp_dev_ckks_rotate_at(amd::engine(), logn, L, L0, mext.data(), 1, step, dct.p, dk.p(), dout.p));
+    if (conj) check(hp_dev_ckks_conjugate_at(amd::cur(), logn, L, L0, mext.data(), 1, dct.p, dk.p(), dout.p));
+    else check(hp_dev_ckks_rotate_at(amd::cur(), logn, L, L0, mext.data(), 1, step, dct.p, dk.p(), dout.p));
     std::vector<u64> q(mext.begin(), mext.begin() + L);
     CkksCt r = make_ct(n, L, q, dout);
     r.scaling_factor = ct.scaling_factor;
@@ -1373,5 +1609,257 @@ void mod_switch_inplace(BgvCt &ct, size_t dropping_primes) {   // mod_switch.cpp
 }
 
 } // namespace bgv
+
+
+// =====================================================================================================
+// hehub_amd_ext.hpp: batched forms of the scheme-level calls
+// =====================================================================================================
+namespace amd {
+
+namespace {
+
+// the shape all members of a batch share (both halves of every ciphertext: dimension, limbs, moduli), or false
+template <class Ct> bool uniform_shape(const std::vector<Ct> &cts, size_t &n, size_t &L, std::vector<u64> &q) {
+    if (cts.empty()) return false;
+    n = cts[0][0].dimension();
+    L = cts[0][0].component_count();
+    q = cts[0][0].modulus_vec();
+    q.resize(L);
+    if (L == 0 || n < 2) return false;
+    for (const Ct &ct : cts)
+        for (int h = 0; h < 2; h++) {
+            if (ct[h].dimension() != n || ct[h].component_count() != L) return false;
+            std::vector<u64> m(ct[h].modulus_vec());
+            m.resize(L);
+            if (m != q) return false;
+        }
+    return true;
+}
+template <class Ct> std::vector<const RnsIntVec *> halves(const std::vector<Ct> &cts) {
+    std::vector<const RnsIntVec *> v;
+    v.reserve(2 * cts.size());
+    for (const Ct &ct : cts) { v.push_back(&ct[0]); v.push_back(&ct[1]); }
+    return v;
+}
+// result ciphertexts as views of u64[B][2][L][N]
+template <class Ct> std::vector<Ct> result_batch(size_t B, size_t n, size_t L, const std::vector<u64> &q, const Dst &d) {
+    std::vector<Ct> out;
+    out.reserve(B);
+    std::vector<RnsIntVec *> polys;
+    for (size_t i = 0; i < B; i++)
+        out.emplace_back(RlweCt{result_poly(n, L, q, PolyRepForm::value), result_poly(n, L, q, PolyRepForm::value)});
+    for (Ct &ct : out) { polys.push_back(&ct[0]); polys.push_back(&ct[1]); }
+    Access::bind_many(polys, d, L);
+    return out;
+}
+void same_size(size_t a, size_t b) {
+    if (a != b) throw std::invalid_argument("hehub_amd: the two batches have different sizes.");
+}
+
+// the checks of mult_low_level (ckks/arith.cpp:55-62 -> operator*, rns.h:253-270), member by member; false: not one common shape
+template <class Ct> bool mult_args_ok(const std::vector<Ct> &a, const std::vector<Ct> &b, size_t &n, size_t &L, std::vector<u64> &q) {
+    size_t nb, Lb;
+    std::vector<u64> qb;
+    const bool ua = uniform_shape(a, n, L, q), ub = uniform_shape(b, nb, Lb, qb);
+    if (!ua || !ub || nb != n || Lb != L) return false;
+    for (size_t i = 0; i < a.size(); i++)
+        for (int h = 0; h < 2; h++) {
+            if (a[i][h].rep_form == PolyRepForm::coeff) throw std::invalid_argument("Operand a is in coefficient form.");
+            if (b[i][h].rep_form == PolyRepForm::coeff) throw std::invalid_argument("Operand b is in coefficient form.");
+        }
+    if (q != qb) throw std::invalid_argument("Operands' moduli mismatch.");
+    return true;
+}
+
+// ckks::mult / bgv mult_low_level + relinearize [+ drop of q_last] on a batch; bgv: t = the common plain modulus
+template <class Ct>
+std::vector<Ct> mult_batch(const std::vector<Ct> &a, const std::vector<Ct> &b, const RlweKsk &key, bool drop, bool bgv, u64 t, size_t n, size_t L,
+                           const std::vector<u64> &q) {
+    const size_t B = a.size();
+    size_t logn = 0;
+    while (((size_t)1 << logn) < n) logn++;
+    std::vector<u64> mext;
+    const size_t L0 = check_ext_prod(result_poly(n, L, q, PolyRepForm::value), key, mext);
+    if (bgv && L0 != L) throw std::invalid_argument("Inconsistent RGSW ciphertext.");
+    if (drop && L == 1) throw std::invalid_argument("Unable to drop the only one prime.");
+    OpScope op({}, 0);   // (batches run on lane 0: a batch fills the GPU by itself, and only one lane grows a batch-sized workspace)
+    DevKey dk(key, L0, n);
+    Src d1 = Access::batch_in(halves(a), L), d2 = Access::batch_in(halves(b), L);
+    const size_t Lout = drop ? L - 1 : L;
+    Dst dout(B * 2 * Lout * n);
+    if (drop) {
+        if (bgv) check(hp_dev_bgv_mult_relin_modswitch(cur(), logn, L, mext.data(), t, B, d1.p, d2.p, dk.p(), dout.p));
+        else check(hp_dev_ckks_mult_relin_rescale_at(cur(), logn, L, L0, mext.data(), B, d1.p, d2.p, dk.p(), dout.p));
+    } else {
+        Dst dq(B * 3 * L * n);
+        check(hp_dev_mult_low_level(cur(), logn, L, q.data(), B, d1.p, d2.p, dq.p));
+        if (bgv) check(hp_dev_bgv_relinearize(cur(), logn, L, mext.data(), 1 /* bgv.h:32 */, B, dq.p, dk.p(), dout.p));
+        else check(hp_dev_ckks_relinearize_at(cur(), logn, L, L0, mext.data(), B, dq.p, dk.p(), dout.p));
+    }
+    return result_batch<Ct>(B, n, Lout, q, dout);
+}
+
+// rescale_inplace / mod_switch_inplace by one prime on a batch of one shape
+template <class Ct> void drop_batch(std::vector<Ct> &cts, bool bgv, u64 t, size_t n, size_t L, const std::vector<u64> &q) {
+    const size_t B = cts.size();
+    size_t logn = 0;
+    while (((size_t)1 << logn) < n) logn++;
+    OpScope op({}, 0);
+    Src din = Access::batch_in(halves(cts), L);
+    Dst dout(B * 2 * (L - 1) * n);
+    if (bgv) check(hp_dev_bgv_mod_switch(cur(), logn, L, q.data(), t, B, din.p, dout.p));
+    else check(hp_dev_ckks_rescale(cur(), logn, L, q.data(), B, din.p, dout.p));
+#ifdef HEHUB_AMD_BIND_REFERENCE
+    limb_copies_wait();   // (remove_components hands limb blocks back to hehub's pool: their uploads must have happened, see drop_last_prime)
+#endif
+    std::vector<RnsIntVec *> polys;
+    for (Ct &ct : cts)
+        for (int h = 0; h < 2; h++) {
+            ct[h].remove_components();
+            polys.push_back(&ct[h]);
+        }
+    Access::bind_many(polys, dout, L - 1);
+}
+
+std::vector<ckks::CkksCt> ckks_mult(const std::vector<ckks::CkksCt> &a, const std::vector<ckks::CkksCt> &b, const RlweKsk &key, bool rescale) {
+    same_size(a.size(), b.size());
+    size_t n, L;
+    std::vector<u64> q;
+    std::vector<ckks::CkksCt> out;
+    if (a.empty()) return out;
+    if (!mult_args_ok(a, b, n, L, q)) {   // no common shape: the loop of single calls, with their checks
+        for (size_t i = 0; i < a.size(); i++) {
+            out.push_back(ckks::mult(a[i], b[i], key));
+            if (rescale) ckks::rescale_inplace(out.back());
+        }
+        return out;
+    }
+    out = mult_batch(a, b, key, rescale, false, 0, n, L, q);
+    for (size_t i = 0; i < a.size(); i++) {
+        out[i].scaling_factor = a[i].scaling_factor * b[i].scaling_factor;   // ckks/arith.cpp:61, :68
+        if (rescale) out[i].scaling_factor /= q[L - 1];                      // rescaling.cpp:87
+    }
+    return out;
+}
+
+std::vector<bgv::BgvCt> bgv_mult(const std::vector<bgv::BgvCt> &a, const std::vector<bgv::BgvCt> &b, const RlweKsk &key, bool drop) {
+    same_size(a.size(), b.size());
+    size_t n, L;
+    std::vector<u64> q;
+    std::vector<bgv::BgvCt> out;
+    if (a.empty()) return out;
+    bool one_t = true;
+    for (size_t i = 0; i < a.size(); i++) {
+        if (a[i].plain_modulus != b[i].plain_modulus) throw std::invalid_argument("Plain moduli mismatch.");   // bgv/arith.cpp:60-62
+        one_t = one_t && a[i].plain_modulus == a[0].plain_modulus;
+    }
+    if (!one_t || !mult_args_ok(a, b, n, L, q)) {
+        for (size_t i = 0; i < a.size(); i++) {
+            out.push_back(bgv::relinearize(bgv::mult_low_level(a[i], b[i]), key));
+            if (drop) bgv::mod_switch_inplace(out.back());
+        }
+        return out;
+    }
+    out = mult_batch(a, b, key, drop, true, a[0].plain_modulus, n, L, q);
+    for (auto &ct : out) ct.plain_modulus = a[0].plain_modulus;
+    return out;
+}
+
+std::vector<ckks::CkksCt> ckks_key_switched(const std::vector<ckks::CkksCt> &cts, const RlweKsk &key, bool conj, size_t step) {
+    size_t n, L;
+    std::vector<u64> q;
+    std::vector<ckks::CkksCt> out;
+    if (cts.empty()) return out;
+    if (!uniform_shape(cts, n, L, q)) {
+        for (auto &ct : cts) out.push_back(conj ? ckks::conjugate(ct, key) : ckks::rotate(ct, key, step));
+        return out;
+    }
+    for (auto &ct : cts)
+        for (int h = 0; h < 2; h++)
+            if (ct[h].rep_form != PolyRepForm::value) throw std::invalid_argument("poly_ntt is expected to be in NTT value form");
+    std::vector<u64> mext;
+    const size_t L0 = check_ext_prod(cts[0][1], key, mext);
+    const size_t logn = cts[0][1].log_dimension(), B = cts.size();
+    OpScope op({}, 0);
+    DevKey dk(key, L0, n);
+    Src din = Access::batch_in(halves(cts), L);
+    Dst dout(B * 2 * L * n);
+    if (conj) check(hp_dev_ckks_conjugate_at(cur(), logn, L, L0, mext.data(), B, din.p, dk.p(), dout.p));
+    else check(hp_dev_ckks_rotate_at(cur(), logn, L, L0, mext.data(), B, step, din.p, dk.p(), dout.p));
+    out = result_batch<ckks::CkksCt>(B, n, L, q, dout);
+    for (size_t i = 0; i < B; i++) out[i].scaling_factor = cts[i].scaling_factor;
+    return out;
+}
+
+std::vector<ckks::CkksCt> ckks_addsub(const std::vector<ckks::CkksCt> &a, const std::vector<ckks::CkksCt> &b, bool sub) {
+    same_size(a.size(), b.size());
+    size_t n, L, nb, Lb;
+    std::vector<u64> q, qb;
+    std::vector<ckks::CkksCt> out;
+    if (a.empty()) return out;
+    bool fast = uniform_shape(a, n, L, q) && uniform_shape(b, nb, Lb, qb) && nb == n && Lb >= L;   // (b may carry more limbs: rns.cpp:59-72)
+    if (fast) {
+        qb.resize(L);
+        fast = qb == q;
+    }
+    for (size_t i = 0; i < a.size() && fast; i++)
+        for (int h = 0; h < 2; h++) fast = a[i][h].rep_form == b[i][h].rep_form && a[i][h].rep_form == a[0][0].rep_form;
+    for (size_t i = 0; i < a.size() && fast; i++) fast = std::abs(a[i].scaling_factor - b[i].scaling_factor) <= std::pow(2.0, -50);
+    if (!fast) {   // the loop of single calls throws what hehub throws, where hehub throws it
+        for (size_t i = 0; i < a.size(); i++) out.push_back(sub ? ckks::sub(a[i], b[i]) : ckks::add(a[i], b[i]));
+        return out;
+    }
+    const size_t B = a.size();
+    OpScope op({}, 0);
+    Src da = Access::batch_in(halves(a), L), db = Access::batch_in(halves(b), L);
+    Dst dout(B * 2 * L * n);
+    dev_binary(sub ? Bin::sub : Bin::add, n, L, q.data(), 2 * B, da.p, db.p, dout.p);
+    out = result_batch<ckks::CkksCt>(B, n, L, q, dout);
+    for (size_t i = 0; i < B; i++) {
+        out[i].scaling_factor = a[i].scaling_factor;
+        for (int h = 0; h < 2; h++) out[i][h].rep_form = a[i][h].rep_form;
+    }
+    return out;
+}
+
+} // namespace
+
+std::vector<ckks::CkksCt> mult(const std::vector<ckks::CkksCt> &a, const std::vector<ckks::CkksCt> &b, const RlweKsk &key) { return ckks_mult(a, b, key, false); }
+std::vector<ckks::CkksCt> mult_rescale(const std::vector<ckks::CkksCt> &a, const std::vector<ckks::CkksCt> &b, const RlweKsk &key) { return ckks_mult(a, b, key, true); }
+std::vector<bgv::BgvCt> mult(const std::vector<bgv::BgvCt> &a, const std::vector<bgv::BgvCt> &b, const RlweKsk &key) { return bgv_mult(a, b, key, false); }
+std::vector<bgv::BgvCt> mult_mod_switch(const std::vector<bgv::BgvCt> &a, const std::vector<bgv::BgvCt> &b, const RlweKsk &key) { return bgv_mult(a, b, key, true); }
+std::vector<ckks::CkksCt> rotate(const std::vector<ckks::CkksCt> &cts, const RlweKsk &rot_key, size_t step) { return ckks_key_switched(cts, rot_key, false, step); }
+std::vector<ckks::CkksCt> conjugate(const std::vector<ckks::CkksCt> &cts, const RlweKsk &conj_key) { return ckks_key_switched(cts, conj_key, true, 0); }
+std::vector<ckks::CkksCt> add(const std::vector<ckks::CkksCt> &a, const std::vector<ckks::CkksCt> &b) { return ckks_addsub(a, b, false); }
+std::vector<ckks::CkksCt> sub(const std::vector<ckks::CkksCt> &a, const std::vector<ckks::CkksCt> &b) { return ckks_addsub(a, b, true); }
+
+void rescale_inplace(std::vector<ckks::CkksCt> &cts) {
+    size_t n, L;
+    std::vector<u64> q;
+    if (cts.empty()) return;
+    for (auto &ct : cts) check_ct_wellformed(ct);   // rescaling.cpp:15-29
+    if (!uniform_shape(cts, n, L, q)) {
+        for (auto &ct : cts) ckks::rescale_inplace(ct);
+        return;
+    }
+    drop_batch(cts, false, 0, n, L, q);
+    for (auto &ct : cts) ct.scaling_factor /= q[L - 1];
+}
+
+void mod_switch_inplace(std::vector<bgv::BgvCt> &cts) {
+    size_t n, L;
+    std::vector<u64> q;
+    if (cts.empty()) return;
+    for (auto &ct : cts) check_ct_wellformed(ct);   // mod_switch.cpp:14-28
+    bool one_t = true;
+    for (auto &ct : cts) one_t = one_t && ct.plain_modulus == cts[0].plain_modulus;
+    if (!one_t || !uniform_shape(cts, n, L, q)) {
+        for (auto &ct : cts) bgv::mod_switch_inplace(ct);
+        return;
+    }
+    drop_batch(cts, true, cts[0].plain_modulus, n, L, q);
+}
+
+} // namespace amd
 
 } // namespace hehub

@@ -15,8 +15,8 @@
 // rns_base_transform.  A hehub build keeps its own files for those and links this layer for the rest
 // (INTEGRATION.md).
 //
-// Operands stay in HBM between calls (see RnsIntVec below); batches of ciphertexts use the device-resident batch entry
-// points of the C ABI directly.
+// Operands stay in HBM between calls (see RnsIntVec below).  Independent single calls overlap on the device (lanes), and
+// hehub_amd_ext.hpp (included at the end) adds batched forms of the scheme-level calls: std::vector<CkksCt> in, ONE engine call.
 #pragma once
 
 #include <array>
@@ -34,19 +34,6 @@ namespace hehub {
 using u64 = uint64_t;
 using u128 = unsigned __int128;
 
-namespace amd {
-/// The process-wide engine (device 0 unless HEHUB_AMD_DEVICE is set); created on first use, like the
-/// reference's lazily filled global caches (ntt.cpp:107-143).  Throws std::runtime_error when no GPU
-/// or no engine library is available -- there is no CPU fallback.
-hp_ctx *engine();
-/// Parity level of the process-wide engine (include/hehub_amd.h: hp_ctx_set_parity_level; also HP_PARITY_LEVEL=A in the environment).
-/// false = B (default): every word is hehub's raw lazy word.  true = A: ckks / bgv mult, relinearize, rotate, rescale, mod_switch return
-/// the canonical residue of every word (reduce_strict of hehub's word; decryptions are identical) through the FP64 transforms -- 20 % more
-/// hom-mult/s at N = 32768.  The NTT / mod-arith primitives and the operators are never affected.
-void set_parity_level_a(bool on);
-bool parity_level_a();
-} // namespace amd
-
 // Stand-alone mirror of hehub's RNS vector (rns.h:15-115): the public names a caller of hehub uses.  Only built when hehub's own
 // headers are not (the real binding compiles against those: -DHEHUB_AMD_BIND_REFERENCE).
 //
@@ -62,15 +49,6 @@ bool parity_level_a();
 namespace amd {
 struct DevBlock;   // a pooled device allocation (hehub.cpp)
 struct Access;     // the binding's view of a vector's two copies (hehub.cpp)
-/// bytes and calls that crossed PCIe through this layer since the process started, and engine calls made
-struct TransferStats {
-    unsigned long long h2d_bytes = 0, d2h_bytes = 0, h2d_copies = 0, d2h_copies = 0, engine_calls = 0, host_blocks_registered = 0;
-    // device copies thrown away because host words were handed out WRITABLE (operator[], components(), begin() / end() / last() on a
-    // non-const vector): each one costs a re-upload at the next engine call (and a key-cache miss for a key polynomial).  Code that
-    // only reads should go through view() / a const reference; this counter shows when it does not.
-    unsigned long long device_copies_invalidated = 0;
-};
-TransferStats transfer_stats();
 } // namespace amd
 
 class RnsIntVec {
@@ -290,3 +268,6 @@ using CkksCt = ckks::CkksCt;
 using BgvCt = bgv::BgvCt;
 
 } // namespace hehub
+
+// the engine handle, parity level, PCIe accounting, lanes and the BATCHED forms of the scheme-level calls (namespace hehub::amd)
+#include "hehub_amd_ext.hpp"

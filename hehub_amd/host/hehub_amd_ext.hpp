@@ -1,0 +1,76 @@
+// hehub_amd_ext.hpp -- what the MI355X layer adds to hehub's public interface, in namespace hehub::amd.  Everything here is an
+// ADDITION next to hehub's one-ciphertext-per-call functions (ckks.h:270-313, bgv.h:150-167), never a replacement:
+//
+//   * the engine handle, the parity level, PCIe accounting;
+//   * BATCHED forms of the scheme-level calls: std::vector<CkksCt> in, one engine call, std::vector<CkksCt> out.  Element i of a
+//     result is word for word what the single call of hehub's interface returns for element i (same checks, same exceptions --
+//     a batch whose members do not all have one shape simply runs as that loop of single calls).  hehub's callers loop over
+//     independent ciphertexts (src/circuits/linear_algebra.h:109-133, bench/benchmarks.cpp:24-35); one C3 ciphertext fills
+//     10 .. 100 of the 256 CUs, a batch of 256 fills the GPU: 29.6 k instead of 4.3 k hom-mult/s;
+//   * lanes: how many independent single calls may overlap on the device (own-mirror build; see hehub.cpp "lanes").
+//
+// Include it after hehub_amd/host/hehub.hpp (which does so itself) or, in a build against hehub's OWN headers over the binding
+// (-DHEHUB_AMD_BIND_REFERENCE), after "fhe/ckks/ckks.h", "fhe/bgv/bgv.h" and "fhe/primitives/keys.h".
+#pragma once
+
+#include <cstddef>
+#include <vector>
+
+struct hp_ctx;
+
+namespace hehub {
+namespace amd {
+
+/// The process-wide engine (device 0 unless HEHUB_AMD_DEVICE is set); created on first use, like the
+/// reference's lazily filled global caches (ntt.cpp:107-143).  Throws std::runtime_error when no GPU
+/// or no engine library is available -- there is no CPU fallback.
+hp_ctx *engine();
+/// Parity level of the process-wide engine (include/hehub_amd.h: hp_ctx_set_parity_level; also HP_PARITY_LEVEL=A in the environment).
+/// false = B (default): every word is hehub's raw lazy word.  true = A: ckks / bgv mult, relinearize, rotate, rescale, mod_switch return
+/// the canonical residue of every word (reduce_strict of hehub's word; decryptions are identical) through the FP64 transforms -- 35 % more
+/// hom-mult/s at N = 32768.  The NTT / mod-arith primitives and the operators are never affected.
+void set_parity_level_a(bool on);
+bool parity_level_a();
+
+/// bytes and calls that crossed PCIe through this layer since the process started, and engine calls made
+struct TransferStats {
+    unsigned long long h2d_bytes = 0, d2h_bytes = 0, h2d_copies = 0, d2h_copies = 0, engine_calls = 0, host_blocks_registered = 0;
+    // device copies thrown away because host words were handed out WRITABLE (operator[], components(), begin() / end() / last() on a
+    // non-const vector): each one costs a re-upload at the next engine call (and a key-cache miss for a key polynomial).  Code that
+    // only reads should go through view() / a const reference; this counter shows when it does not.
+    unsigned long long device_copies_invalidated = 0;
+    // device-side waits between lanes (one event each): how often a call depended on a call that ran on another lane
+    unsigned long long lane_waits = 0;
+};
+TransferStats transfer_stats();
+
+/// Lanes: independent single-ciphertext calls are spread over this many streams of the engine and overlap on the device; a call
+/// waits, on the device, for exactly the calls that produced its operands.  Default 4 (HEHUB_AMD_LANES), at most 8; 1 = everything on
+/// one stream.  The binding build (hehub's own host-memory objects) always has one.  set_lanes() drains the device first.
+int lanes();
+void set_lanes(int n);
+/// wait until everything the layer has enqueued so far has run (hehub's interface has no such call: its functions are synchronous;
+/// here a result is waited for when somebody looks at its words -- this is for timing loops)
+void synchronize();
+
+// ---- batched forms ---------------------------------------------------------------------------------------------------------
+// ckks.h:270  mult(ct1, ct2, relin_key), element by element
+std::vector<ckks::CkksCt> mult(const std::vector<ckks::CkksCt> &a, const std::vector<ckks::CkksCt> &b, const RlweKsk &relin_key);
+// ckks.h:270 + :313  mult followed by rescale_inplace(ct, 1): the engine's fused pipeline (one tensor product, one key switch, the
+// drop of the special prime and of q_last) -- the "hom-mult" of the headline metric
+std::vector<ckks::CkksCt> mult_rescale(const std::vector<ckks::CkksCt> &a, const std::vector<ckks::CkksCt> &b, const RlweKsk &relin_key);
+// ckks.h:313  rescale_inplace(ct, 1) on every element
+void rescale_inplace(std::vector<ckks::CkksCt> &cts);
+// ckks.h:284 / :282  rotate(ct, rot_key, step) / conjugate(ct, conj_key), one key for the whole batch
+std::vector<ckks::CkksCt> rotate(const std::vector<ckks::CkksCt> &cts, const RlweKsk &rot_key, size_t step);
+std::vector<ckks::CkksCt> conjugate(const std::vector<ckks::CkksCt> &cts, const RlweKsk &conj_key);
+// ckks.h:73-89  add / sub, element by element
+std::vector<ckks::CkksCt> add(const std::vector<ckks::CkksCt> &a, const std::vector<ckks::CkksCt> &b);
+std::vector<ckks::CkksCt> sub(const std::vector<ckks::CkksCt> &a, const std::vector<ckks::CkksCt> &b);
+// bgv.h:150-159  mult_low_level + relinearize, element by element; _mod_switch: followed by mod_switch_inplace(ct, 1) (bgv.h:167)
+std::vector<bgv::BgvCt> mult(const std::vector<bgv::BgvCt> &a, const std::vector<bgv::BgvCt> &b, const RlweKsk &relin_key);
+std::vector<bgv::BgvCt> mult_mod_switch(const std::vector<bgv::BgvCt> &a, const std::vector<bgv::BgvCt> &b, const RlweKsk &relin_key);
+void mod_switch_inplace(std::vector<bgv::BgvCt> &cts);
+
+} // namespace amd
+} // namespace hehub

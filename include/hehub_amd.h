@@ -74,6 +74,17 @@ void hp_ctx_destroy(hp_ctx *ctx);
  *     mod-down with the rescale / mod switch into one transform per output limb (same residues; HP_NO_DOUBLE_DROP=1 at
  *     hp_ctx_create keeps the two launches).  The NTT / mod-arith primitives (hp_ntt_*, hp_dev_ntt_*, hp_dev_poly_*, hp_batched_*) are
  *     never affected: they stay bit-exact with ntt.cpp:145-223 / mod_arith.cpp. */
+/* A second LANE on the parent's GPU (hehub's callers are loops of independent single-ciphertext operations,
+ * src/circuits/linear_algebra.h:109-133, bench/benchmarks.cpp:24-35: one ciphertext fills 10 .. 100 of the 256 CUs, so independent
+ * calls should overlap): a context with its own stream and scratch workspace whose calls run concurrently on the device with those
+ * of its parent and siblings.  The family shares ONE lock (host-side enqueueing is serialised exactly as on a single context) and ONE
+ * copy of the twiddle tables / per-chain constants / gather maps.  Knobs and parity level start as the parent's are at the fork.
+ * Destroy every member with hp_ctx_destroy (any order).  hp_ctx_wait_for is the ordering primitive between lanes: everything
+ * `ctx` enqueues from now on runs after everything `other` has enqueued so far -- a device-side event, no host synchronisation.
+ * Buffers are the caller's: a lane that reads what another lane wrote (or reuses memory another lane still reads) needs that
+ * ordering; hehub_amd/host keeps the book per device block. */
+int hp_ctx_fork(hp_ctx *parent, hp_ctx **out);
+int hp_ctx_wait_for(hp_ctx *ctx, hp_ctx *other);
 typedef enum { HP_PARITY_B = 0, HP_PARITY_A = 1 } hp_parity_level;
 int hp_ctx_set_parity_level(hp_ctx *ctx, int level);
 int hp_ctx_get_parity_level(hp_ctx *ctx);
@@ -120,6 +131,11 @@ int hp_memcpy_d2h_async(hp_ctx *ctx, void *h_dst, const void *d_src, size_t byte
  * 16-byte aligned memory from hp_host_alloc or registered with hp_host_register; words even.  Enqueue only (see above). */
 int hp_dev_store_host_rows(hp_ctx *ctx, size_t rows, size_t words, const uint64_t *d_src, uint64_t *const *h_rows);
 int hp_dev_load_host_rows(hp_ctx *ctx, size_t rows, size_t words, uint64_t *d_dst, const uint64_t *const *h_rows);
+/* The same between device rows that lie ANYWHERE (the ciphertexts of an application are separate objects, rlwe.h:27; the batch
+ * entry points below want u64[batch][2][L][N]) and one packed block u64[rows][words]: d_rows is a HOST array of `rows` device
+ * pointers, 16-byte aligned; words even.  One streaming kernel per 64 rows on the ctx stream. */
+int hp_dev_gather_rows(hp_ctx *ctx, size_t rows, size_t words, const uint64_t *const *d_rows, uint64_t *d_dst);
+int hp_dev_scatter_rows(hp_ctx *ctx, size_t rows, size_t words, const uint64_t *d_src, uint64_t *const *d_rows);
 /* force the simple one-stage-at-a-time transform kernels (debug / cross-check) */
 int hp_ctx_set_force_generic(hp_ctx *ctx, int on);
 /* timing of the last profiled launch group: see hp_prof_* below */
