@@ -26,6 +26,8 @@ SIGNATURES = {
     "hp_ctx_destroy": (None, [P]),
     "hp_last_error": (C.c_char_p, [P]),
     "hp_version": (C.c_char_p, []),
+    "hp_ctx_fork": (INT, [P, C.POINTER(P)]),
+    "hp_ctx_wait_for": (INT, [P, P]),
     "hp_ctx_set_stream": (INT, [P, P]),
     "hp_ctx_reset_stream": (INT, [P]),
     "hp_ctx_get_stream": (P, [P]),
@@ -45,6 +47,8 @@ SIGNATURES = {
     "hp_memcpy_d2h_async": (INT, [P, P, P, szt]),
     "hp_dev_store_host_rows": (INT, [P, szt, szt, P, P]),
     "hp_dev_load_host_rows": (INT, [P, szt, szt, P, P]),
+    "hp_dev_gather_rows": (INT, [P, szt, szt, P, P]),
+    "hp_dev_scatter_rows": (INT, [P, szt, szt, P, P]),
     "hp_ctx_set_force_generic": (INT, [P, INT]),
     "hp_ctx_set_parity_level": (INT, [P, INT]),
     "hp_ctx_get_parity_level": (INT, [P]),
