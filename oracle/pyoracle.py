@@ -33,7 +33,7 @@ def build(ref: bool = True) -> None:
         subprocess.run(["make", "-s", "-C", HERE, "ref"], check=True)
         if os.path.exists(os.path.join(HERE, "..", "hehub_amd", "lib", "libhehub_amd.so")):
             # hehub's own test-suite / benchmark program and our end-to-end program over the binding (GPU box only)
-            subprocess.run(["make", "-s", "-j8", "-C", HERE, "ref_tests", "ref_e2e", "ref_bench", "ref_chain"], check=True)
+            subprocess.run(["make", "-s", "-j8", "-C", HERE, "ref_tests", "ref_e2e", "ref_bench", "ref_chain", "ref_indep"], check=True)
 
 
 def have_ref() -> bool:

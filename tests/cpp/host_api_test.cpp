@@ -582,6 +582,154 @@ static void test_device_residency() {
     REQUIRE((const RnsIntVec &)z[0] == (const RnsIntVec &)chk0);
 }
 
+
+// ---- hehub_amd_ext.hpp: batched forms and lanes ----------------------------------------------------------------------------
+static bool same_words(const RlweCt &x, const RlweCt &y) {
+    std::vector<u64> fx, fy;
+    for (int h = 0; h < 2; h++) { flatten(x[h], fx); flatten(y[h], fy); }
+    return x[0].modulus_vec() == y[0].modulus_vec() && x[0].rep_form == y[0].rep_form && fx == fy;
+}
+struct BatchFixture {
+    size_t logn = 11, N = 1 << 11, L = 3, B = 5;
+    std::vector<u64> mext{1099510054913ull, 1099507695617ull, 1099506515969ull, 1125899904679937ull}, q;
+    std::vector<ckks::CkksCt> a, b;
+    RlweKsk key;
+    BatchFixture() : q(mext.begin(), mext.begin() + 3), key(3) {
+        for (size_t i = 0; i < B; i++) {
+            ckks::CkksCt x, y;
+            for (int h = 0; h < 2; h++) {
+                x[h] = RnsPolynomial(N, L, q); y[h] = RnsPolynomial(N, L, q);
+                for (size_t k = 0; k < L; k++) { for (auto &w : x[h][(int)k]) w = rnd() % q[k]; for (auto &w : y[h][(int)k]) w = rnd() % q[k]; }
+                x[h].rep_form = y[h].rep_form = PolyRepForm::value;
+            }
+            x.scaling_factor = std::pow(2.0, 40) * (double)(i + 1);
+            y.scaling_factor = std::pow(2.0, 40);
+            a.push_back(std::move(x)); b.push_back(std::move(y));
+        }
+        for (auto &smp : key) for (auto &p : smp) {
+            p = RnsPolynomial(N, L + 1, mext);
+            for (size_t k = 0; k <= L; k++) for (auto &w : p[(int)k]) w = rnd() % mext[k];
+            p.rep_form = PolyRepForm::value;
+        }
+    }
+};
+
+// every batched form returns, element by element, the words of the single call of hehub's interface (which the tests above pin
+// to the oracle), whatever the lane count; operands that a batched call gathered or produced are found packed by the next one
+static void test_batched_forms() {
+    BatchFixture f;
+    const size_t B = f.B;
+    std::vector<ckks::CkksCt> single_m, single_mr, single_rot, single_cj, single_add, single_sub;
+    for (size_t i = 0; i < B; i++) {
+        single_m.push_back(ckks::mult(f.a[i], f.b[i], f.key));
+        single_mr.push_back(single_m.back());
+        ckks::rescale_inplace(single_mr.back());
+        single_rot.push_back(ckks::rotate(f.a[i], f.key, 5));
+        single_cj.push_back(ckks::conjugate(f.b[i], f.key));
+    }
+    const auto before = amd::transfer_stats();
+    auto m = amd::mult(f.a, f.b, f.key);
+    auto mr = amd::mult_rescale(f.a, f.b, f.key);
+    auto rot = amd::rotate(f.a, f.key, 5);
+    auto cj = amd::conjugate(f.b, f.key);
+    REQUIRE(m.size() == B && mr.size() == B && rot.size() == B && cj.size() == B);
+    for (size_t i = 0; i < B; i++) {
+        REQUIRE(same_words(m[i], single_m[i]) && m[i].scaling_factor == single_m[i].scaling_factor);
+        REQUIRE(same_words(mr[i], single_mr[i]) && mr[i].scaling_factor == single_mr[i].scaling_factor);
+        REQUIRE(same_words(rot[i], single_rot[i]) && rot[i].scaling_factor == f.a[i].scaling_factor);
+        REQUIRE(same_words(cj[i], single_cj[i]));
+    }
+    // results of a batched call feed the next one: add / sub / rescale on the products (equal scaling factors pairwise)
+    for (size_t i = 0; i < B; i++) {
+        single_add.push_back(ckks::add(single_m[i], single_m[i]));
+        single_sub.push_back(ckks::sub(single_m[i], single_m[i]));
+        ckks::rescale_inplace(single_add.back());
+    }
+    auto sum = amd::add(m, m), dif = amd::sub(m, m);
+    amd::rescale_inplace(sum);
+    for (size_t i = 0; i < B; i++) {
+        REQUIRE(same_words(sum[i], single_add[i]) && sum[i].scaling_factor == single_add[i].scaling_factor);
+        REQUIRE(same_words(dif[i], single_sub[i]));
+        REQUIRE(sum[i][0].component_count() == f.L - 1);
+    }
+    // nothing crossed PCIe for all of that except the looks at the words (the operands were on the device already)
+    REQUIRE(amd::transfer_stats().h2d_bytes == before.h2d_bytes);
+
+    // bgv: mult_low_level + relinearize [+ mod_switch_inplace]
+    std::vector<bgv::BgvCt> ba, bb, s1, s2;
+    for (size_t i = 0; i < B; i++) {
+        bgv::BgvCt x(RlweCt{f.a[i][0], f.a[i][1]}), y(RlweCt{f.b[i][0], f.b[i][1]});
+        x.plain_modulus = y.plain_modulus = 65537;
+        ba.push_back(std::move(x)); bb.push_back(std::move(y));
+        s1.push_back(bgv::relinearize(bgv::mult_low_level(ba.back(), bb.back()), f.key));
+        s2.push_back(s1.back());
+        bgv::mod_switch_inplace(s2.back());
+    }
+    auto g1 = amd::mult(ba, bb, f.key), g2 = amd::mult_mod_switch(ba, bb, f.key);
+    auto g3 = g1;
+    amd::mod_switch_inplace(g3);
+    for (size_t i = 0; i < B; i++) {
+        REQUIRE(same_words(g1[i], s1[i]) && g1[i].plain_modulus == 65537);
+        REQUIRE(same_words(g2[i], s2[i]) && g2[i].plain_modulus == 65537);
+        REQUIRE(same_words(g3[i], s2[i]));
+    }
+
+    // a batch without one common shape is the loop of single calls; the checks of the single call are kept
+    auto ragged = f.a;
+    ragged[2][0].remove_components();
+    ragged[2][1].remove_components();
+    auto rr = amd::rotate(std::vector<ckks::CkksCt>{f.a[0], f.a[1]}, f.key, 1);
+    REQUIRE(same_words(rr[1], ckks::rotate(f.a[1], f.key, 1)));
+    REQUIRE_THROWS_AS(amd::rotate(ragged, f.key, 1), std::invalid_argument);          // member 2 has no key for its level
+    auto coeff = f.a;
+    coeff[3][1].rep_form = PolyRepForm::coeff;
+    REQUIRE_THROWS_AS(amd::mult(coeff, f.b, f.key), std::invalid_argument);           // "Operand a is in coefficient form."
+    REQUIRE_THROWS_AS(amd::rotate(coeff, f.key, 1), std::invalid_argument);
+    REQUIRE_THROWS_AS(amd::add(f.a, f.b), std::invalid_argument);                     // scaling factors mismatch (member 1 on)
+    REQUIRE_THROWS_AS(amd::mult(f.a, std::vector<ckks::CkksCt>(f.b.begin(), f.b.begin() + 2), f.key), std::invalid_argument);
+    bb[1].plain_modulus = 257;
+    REQUIRE_THROWS_AS(amd::mult(ba, bb, f.key), std::invalid_argument);               // "Plain moduli mismatch."
+    std::vector<ckks::CkksCt> one_limb;
+    for (size_t i = 0; i < 2; i++) {
+        ckks::CkksCt x = f.a[i];
+        x[0].remove_components(2); x[1].remove_components(2);
+        one_limb.push_back(std::move(x));
+    }
+    REQUIRE_THROWS_AS(amd::rescale_inplace(one_limb), std::invalid_argument);         // "Unable to drop the only one prime."
+    REQUIRE(amd::mult(std::vector<ckks::CkksCt>(), std::vector<ckks::CkksCt>(), f.key).empty());
+}
+
+// independent chains of single calls over 1 and over several lanes: same words, and the lanes are really used
+static void test_lanes() {
+    BatchFixture f;
+    const int before = amd::lanes();
+    std::vector<std::vector<ckks::CkksCt>> res;
+    for (int lanes : {1, 3, 8}) {
+        amd::set_lanes(lanes);
+        REQUIRE(amd::lanes() == lanes);
+        std::vector<ckks::CkksCt> x(f.a.begin(), f.a.end());
+        ckks::CkksCt acc;
+        for (int it = 0; it < 3; it++)
+            for (size_t c = 0; c < x.size(); c++) {
+                x[c] = ckks::rotate(ckks::mult(x[c], f.b[c], f.key), f.key, c + 1);
+                x[c][0] *= (u64)(it + 2);             // an in-place operator on one half (its own lane's block)
+            }
+        // a fan-in: one call reads what several lanes produced
+        acc = ckks::mult(x[0], x[1], f.key);
+        for (size_t c = 2; c < x.size(); c++) acc = ckks::mult(acc, x[c], f.key);
+        x.push_back(acc);
+        // and a batched call on what the lanes produced
+        auto rot = amd::rotate(x, f.key, 2);
+        x.insert(x.end(), rot.begin(), rot.end());
+        res.push_back(std::move(x));
+    }
+    amd::synchronize();
+    for (size_t v = 1; v < res.size(); v++)
+        for (size_t i = 0; i < res[0].size(); i++) REQUIRE(same_words(res[0][i], res[v][i]));
+    REQUIRE(amd::transfer_stats().lane_waits > 0);   // the fan-in needed them
+    amd::set_lanes(before);
+}
+
 int main() {
     test_batched_barrett();
     test_batched_mul_mod();
@@ -594,6 +742,8 @@ int main() {
     test_ragged_operands();
     test_device_residency();
     test_parity_level_a();
+    test_batched_forms();
+    test_lanes();
     std::printf("%s: %d checks, %d failures\n", g_fail ? "FAILED" : "All tests passed", g_checks, g_fail);
     return g_fail ? 1 : 0;
 }
