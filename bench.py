@@ -31,6 +31,9 @@ One process per GPU; ciphertext batches are sharded across ranks with no data-pa
   bgv                   (default ckks line) BASELINE config 5 per-GPU shape: N = 8192, L = 6, t = 65537, batch 512:
                         hom-mult/s, A_step fraction, the dominant kernel's roofline, all 512 outputs verified, CPU sample
   hbm_copy_ceiling_GBps (default ckks line) the measured device-to-device stream rate beside the 8 TB/s spec peak
+  object_api            (default ckks line) the same C3 hom-mult through hehub's OBJECT interface (hehub_amd/host/hehub.hpp): 256
+                        independent ckks::mult + rescale_inplace as single calls, as ONE batched call (hehub_amd_ext.hpp), and
+                        independent chains over 1 / 8 lanes; examples/independent_mults as a child process, digests compared
   cpu_baseline          the compiled reference (or the C restatement) on ONE core of this host; cpu_baseline_node: the
                         same as P independent processes (P = what affinity mask and CPU quota allow, stated)
   --roofline-only       drops everything after the timed region (for clean rocprofv3 summaries of the default command)
@@ -79,6 +82,7 @@ def parse(argv=None):
     ap.add_argument("--roofline-only", action="store_true",
                     help="only the timed region and its roofline: no transform / coefficient-wise rates, no verification, no "
                          "CPU legs -- a rocprofv3 summary of this command shows k_ntt_fwd in its digit-spread launches only")
+    ap.add_argument("--no-object-api", action="store_true", help="skip the object_api section (examples/independent_mults as a child process)")
     ap.add_argument("--no-rates", action="store_true", help="ckks workload: skip the extra sections (ntt, coeffwise, c2, bgv, ...)")
     ap.add_argument("--hks-alpha", type=int, default=2, help="ckks-hks: ciphertext moduli per key-switch digit")
     ap.add_argument("--hks-k", type=int, default=2, help="ckks-hks: number of (50-bit) special primes")
@@ -283,6 +287,12 @@ def extra_sections(run, res, wl, value, lib, cpu_budget):
     res["hbm_copy_ceiling_GBps"] = copy["hbm_copy_ceiling_GBps"]
     res["hbm_stream_ceiling_GBps"] = copy["hbm_stream_ceiling_GBps"]
     res["hbm_copy"] = copy
+    if run.rank == 0 and run.world == 1 and not run.args.no_object_api:
+        with sec("object_api"):
+            try:
+                res["object_api"] = S.object_api_section(run)
+            except Exception as e:   # (a missing host compiler must not void the headline; the section says so)
+                res["object_api"] = {"error": repr(e)[:300], "verified": None}
     if run.rank == 0 and run.world == 1 and cpu_budget > 0 and lib is not None:
         # the CPU path beside the two BASELINE configs that are not the headline (bounded samples, one core)
         # (... and beside the N = 32768 limb-transform rates, the other half of BASELINE's metric)
@@ -298,6 +308,7 @@ def extra_sections(run, res, wl, value, lib, cpu_budget):
                                                                         res["c2"], res["bgv"], res["level_a"]["ckks"],
                                                                         res["level_a"]["bgv"]] + [v for v in res["level_a"]["ntt"].values()
                                                                                                   if isinstance(v, dict)]
+    checks.append(res.get("object_api", {}))
     bad = any(s.get("verified") is False for s in checks) or not copy["engine_copy_verified"]
     return bad
 
@@ -349,6 +360,11 @@ def main() -> int:
             if world > 1:
                 raise
             rccl_info = {"initialised": False, "error": repr(e)[:300]}
+            if dist.is_initialized():   # the group exists but its first collective failed: later fences must not use it
+                try:
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
     # dist_ranks: size of the process group whatever its backend (1 = none); rccl_ranks: ranks of an initialised RCCL communicator
     dist_ranks = dist.get_world_size() if dist.is_initialized() else 1
     rccl_ranks = dist_ranks if (dist.is_initialized() and dist.get_backend() == "nccl") else 0
@@ -360,7 +376,8 @@ def main() -> int:
     chip = ChipSampler(torch, local)
     run.chip = chip
     extras = not args.roofline_only
-    level = (args.parity_level or ("A" if os.environ.get("HP_PARITY_LEVEL", "B")[:1] in "Aa1" else "B"))
+    env_level = os.environ.get("HP_PARITY_LEVEL", "")   # (parsed as hp_ctx_create does: an empty value is level B)
+    level = args.parity_level or ("A" if env_level and env_level[0] in "Aa1" else "B")
     run.eng.set_parity_level(level)
     wl = workloads.make(run, args.workload)
 

@@ -268,3 +268,58 @@ def hbm_copy_ceiling(run: Run):
             "stream_mix_GBps": mixes, "hbm_stream_ceiling_GBps": stream_best,
             "note": "hbm_copy_ceiling_GBps is the 1 read : 1 write rate only; kernels with more reads than writes stream faster -- "
                     "compare a streaming kernel with the mix of its own shape (stream_mix_GBps), the best of which is hbm_stream_ceiling_GBps"}
+
+
+def object_api_section(run: Run):
+    """Throughput through hehub's OBJECT interface (ckks.h:270-313 is one ciphertext per call): examples/independent_mults, a C++
+    program against hehub_amd/host/hehub.hpp, run as a child process AFTER the timed region on the same GPU (this process idles):
+    B = 256 independent C3 hom-mults as the loop of single calls (over the layer's default lanes), as ONE batched call
+    (hehub_amd_ext.hpp: amd::mult_rescale), and 8 independent chains of single calls on 1 lane / 8 lanes.  Every mode prints an
+    FNV digest of all result words; `digests_equal` says the batched call and the lanes returned the words of the single calls
+    (tests/test_object_api.py holds those to hehub on the CPU).  Not part of `value`."""
+    import os
+    import re
+    import subprocess
+    import time
+
+    from hehub_amd.build import build_example
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    P = run.P
+    shape = [P.C3_LOGN, len(P.C3_Q), 256]
+    t0 = time.perf_counter()
+    out = subprocess.run([build_example("independent_mults")] + [str(a) for a in shape + ["all", 3, 8, 8, 6]], capture_output=True,
+                         text=True, timeout=600, cwd=root)
+    ent = {"program": "examples/independent_mults " + " ".join(str(a) for a in shape) + " all 3 8 8 6", "wall_s": round(time.perf_counter() - t0, 1),
+           "N": 1 << shape[0], "L": shape[1], "B": shape[2], "unit": "hom-mult/s"}
+    if out.returncode != 0:
+        ent["error"] = (out.stdout[-300:] + out.stderr[-300:])
+        ent["verified"] = False
+        return ent
+    dg = {}
+    for line in out.stdout.splitlines():
+        m = re.match(r"([\w-]+) digest (\w+)", line)
+        if m:
+            dg[m.group(1)] = m.group(2)
+        m = re.match(r"serial ([\d.]+) ms per hom-mult \((\d+) hom-mult/s\); the calls themselves returned after ([\d.]+) ms", line)
+        if m:
+            ent["single_calls"] = {"per_s": float(m.group(2)), "ms_per_hom_mult": float(m.group(1)), "host_ms_per_hom_mult": float(m.group(3)),
+                                   "what": "for i: ckks::mult(a[i], b[i], key); ckks::rescale_inplace(.) -- hehub's interface as it is, default lanes"}
+        m = re.match(r"batch ([\d.]+) ms per hom-mult \((\d+) hom-mult/s\); first call .* ([\d.]+) ms per hom-mult", line)
+        if m:
+            ent["batched_call"] = {"per_s": float(m.group(2)), "ms_per_hom_mult": float(m.group(1)), "first_call_ms_per_hom_mult": float(m.group(3)),
+                                   "what": "amd::mult_rescale(std::vector<CkksCt>, std::vector<CkksCt>, key): one engine call"}
+        m = re.match(r"batch-chain rotate\+add\+rescale ([\d.]+) ms per ciphertext", line)
+        if m:
+            ent["batched_chain_ms_per_ct"] = float(m.group(1))
+        m = re.match(r"chains (\d+) x (\d+) mult\+rotate: ([\d.]+) ms per step on 1 lane, ([\d.]+) ms on (\d+) lanes", line)
+        if m:
+            ent["independent_chains"] = {"chains": int(m.group(1)), "steps": int(m.group(2)), "ms_per_step_1_lane": float(m.group(3)),
+                                         "ms_per_step_lanes": float(m.group(4)), "lanes": int(m.group(5)),
+                                         "speedup": float(m.group(3)) / float(m.group(4)),
+                                         "what": "x[c] = ckks::rotate(ckks::mult(x[c], b[c], key), key, 1), interleaved call by call"}
+    ent["digests"] = dg
+    ent["digests_equal"] = bool(dg) and dg.get("serial") == dg.get("batch") and dg.get("serial-chain") == dg.get("batch-chain") and \
+        dg.get("chains") == dg.get("chains-lanes")
+    ent["verified"] = ent["digests_equal"]
+    return ent

@@ -71,7 +71,8 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     """The hehub-compatible C++ host layer (hehub_amd/host) over the C ABI; plain g++, no HIP needed."""
     build_lib(force=False, verbose=verbose)
     src = os.path.join(HERE, "host", "hehub.cpp")
-    deps = [src, os.path.join(HERE, "host", "hehub.hpp"), os.path.join(os.path.dirname(HERE), "include", "hehub_amd.h")]
+    deps = [src, os.path.join(HERE, "host", "hehub.hpp"), os.path.join(HERE, "host", "hehub_amd_ext.hpp"),
+            os.path.join(os.path.dirname(HERE), "include", "hehub_amd.h")]
     if force or _stale(HOST_LIB, deps):
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", src, "-o", HOST_LIB, f"-L{LIBDIR}", "-lhehub_amd",
                "-Wl,-rpath,$ORIGIN"]
@@ -79,3 +80,16 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
     return HOST_LIB
+
+
+def build_example(name: str, force: bool = False) -> str:
+    """One of examples/*.cpp (programs written against the hehub-compatible host layer) -> examples/<name>"""
+    root = os.path.dirname(HERE)
+    host = build_host()
+    src = os.path.join(root, "examples", name + ".cpp")
+    out = os.path.join(root, "examples", name)
+    deps = [src, host, os.path.join(HERE, "host", "hehub.hpp"), os.path.join(HERE, "host", "hehub_amd_ext.hpp")]
+    if force or _stale(out, deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", src, "-o", out, f"-I{HERE}/host", f"-L{LIBDIR}", "-lhehub_amd_host",
+                        "-lhehub_amd", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return out
