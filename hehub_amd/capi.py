@@ -18,7 +18,7 @@ szt = C.c_size_t
 P = C.c_void_p
 INT = C.c_int
 
-HP_OK, HP_EINVAL, HP_EUNSUPPORTED, HP_EHIP, HP_ENOMEM, HP_ELOGIC = range(6)
+HP_OK, HP_EINVAL, HP_EUNSUPPORTED, HP_EHIP, HP_ENOMEM, HP_ELOGIC, HP_ERANGE = range(7)
 
 # name -> (restype, argtypes); mirrors include/hehub_amd.h one to one
 SIGNATURES = {

@@ -127,7 +127,8 @@ int hp_dev_intt(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size
 
 // The transforms as RESIDUES (parity level A as an explicit entry point, whatever the context's level): canonical words through the
 // FP64 kernels of hp_ntt_a.hip.  Forward: every output word == ntt.cpp:145-176's word modulo q, in [0, q).  Inverse: the words of
-// intt_negacyclic_inplace (ntt.h:88-92 = lazy inverse + reduce_strict).  Input words below 2^52; N = 2^11 .. 2^15; every q < 2^50.
+// intt_negacyclic_inplace (ntt.h:88-92 = lazy inverse + reduce_strict).  Input words are lazy words of their limb (below 2 q; checked on the
+// device, HP_ERANGE from the next synchronising call); N = 2^11 .. 2^15; every q < 2^50.
 static int dev_ntt_residues(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *d_x, int inverse) {
     HP_ENTER(ctx);
     HP_REQUIRE(ctx, moduli, d_x);
@@ -143,6 +144,7 @@ static int dev_ntt_residues(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *
         return fail(ctx, HP_EUNSUPPORTED, "residue transforms need a ring degree of 2^11 .. 2^15 and every modulus below 2^50 (and the tiled kernels enabled)");
     HpNttJob j = batch_job(plan, logn, L, batch, d_x, d_x, L, L, inverse, inverse);
     j.limbs_a = plan->d_limbs_a;
+    ctx->sh->a_used = true;   // (the range guard of the level-A kernels: hp_ctx.cpp range_check)
     return run_ntt(ctx, j);
 }
 int hp_dev_ntt_residues(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *d_x) {

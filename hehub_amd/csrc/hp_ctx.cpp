@@ -124,6 +124,10 @@ static int ensure_plan_a_impl(hp_ctx *ctx, const Plan *plan, bool *ok) {
     for (const hp::ModConsts &c : plan->consts)
         if (c.q >= ((u64)1 << 50) || c.q < 3) can = false;
     if (!can) { plan->a_state = -1; return HP_OK; }
+    if (!ctx->sh->range_flag) {
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->sh->range_flag, sizeof(u32)));
+        HIP_TRY(ctx, hipMemset(ctx->sh->range_flag, 0, sizeof(u32)));
+    }
     std::vector<HpLimbA> limbs(plan->consts.size());
     for (size_t k = 0; k < limbs.size(); k++) {
         const u64 q = plan->consts[k].q;
@@ -152,6 +156,8 @@ static int ensure_plan_a_impl(hp_ctx *ctx, const Plan *plan, bool *ok) {
         HpLimbA &l = limbs[k];
         memset(&l, 0, sizeof(l));
         l.q = (double)q; l.qinv = 1.0 / (double)q; l.qi = q; l.wide = q >= ((u64)1 << 44) ? 1u : 0u;
+        l.hi_bound = (u32)((2 * q - 1) >> 32);
+        l.range_flag = ctx->sh->range_flag;
         l.fwd_ref = it->second.fwd_ref; l.inv_ref = it->second.inv_ref; l.fwd_k = it->second.fwd_k; l.inv_k = it->second.inv_k;
     }
     HpLimbA *d = nullptr;
@@ -164,6 +170,18 @@ static int ensure_plan_a_impl(hp_ctx *ctx, const Plan *plan, bool *ok) {
 }
 int ensure_plan_a(hp_ctx *ctx, const Plan *plan, bool *ok) {
     return contained(ctx, [&] { return ensure_plan_a_impl(ctx, plan, ok); });
+}
+
+int range_check(hp_ctx *ctx) {
+    Shared *sh = ctx->sh;
+    if (!sh->a_used || !sh->range_flag) return HP_OK;
+    sh->a_used = false;
+    u32 flag = 0;
+    HIP_TRY(ctx, hipMemcpy(&flag, sh->range_flag, sizeof(u32), hipMemcpyDeviceToHost));
+    if (!flag) return HP_OK;
+    HIP_TRY(ctx, hipMemset(sh->range_flag, 0, sizeof(u32)));
+    return fail(ctx, HP_ERANGE, "parity level A: an input word was not a lazy word of its limb (>= 2 q): the results of the calls since the "
+                                "last synchronisation are not the residues of hehub's words (level B takes any u64)");
 }
 
 // A bounded cache of small device objects that is full gets emptied: kernels that may still read the entries are
@@ -443,6 +461,7 @@ void hp_ctx_destroy(hp_ctx *ctx) {
             for (auto &kv : sh->perms) (void)hipFree(kv.second);
             for (auto &kv : sh->crt) (void)hipFree(kv.second);
             for (auto &kv : sh->hks) (void)hipFree(kv.second);
+            if (sh->range_flag) (void)hipFree(sh->range_flag);
         }
         if (ctx->ws) (void)hipFree(ctx->ws);
         for (auto &ev : ctx->prof_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
@@ -497,7 +516,7 @@ unsigned long hp_ctx_workspace_generation(hp_ctx *ctx) { return ctx ? ctx->ws_ge
 int hp_sync(hp_ctx *ctx) {
     HP_ENTER(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return HP_OK;
+    return range_check(ctx);
 }
 
 int hp_dev_alloc(hp_ctx *ctx, size_t bytes, void **dptr) {
@@ -536,7 +555,7 @@ int hp_memcpy_d2h(hp_ctx *ctx, void *dst, const void *src, size_t bytes) {
     HP_ENTER(ctx);
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return HP_OK;
+    return range_check(ctx);   // (the words are there either way; the status says whether a level-A call that made them was in range)
 }
 // Host memory the CALLER owns, made DMA-able in place (hipHostRegister): transfers from / to it then run at the link rate and
 // asynchronously, without the runtime's internal staging of pageable memory.

@@ -61,6 +61,10 @@ struct Shared {
     std::map<std::pair<size_t, size_t>, u32 *> perms;                 // (logn, step mod N/2) -> gather map
     std::map<std::pair<std::vector<u64>, u64>, HpCrtConsts *> crt;    // (old moduli, new modulus) -> CRT-branch constants
     std::map<std::pair<std::vector<u64>, std::pair<size_t, size_t>>, HpHksConsts *> hks;   // (extended moduli, (k, alpha))
+    // level A range guard (hp_ntt_a.hip: RangeAcc): one sticky device word for the family, looked at by the synchronising entry
+    // points after a call has run at level A
+    u32 *range_flag = nullptr;
+    bool a_used = false;
 };
 } // namespace hpi
 
@@ -183,6 +187,8 @@ int get_tables(hp_ctx *ctx, u64 q, size_t logn, DevTables &out);
 int get_plan(hp_ctx *ctx, size_t logn, const uint64_t *moduli, size_t count, bool with_ntt, const Plan **out);
 // level-A records of a plan (built once); *ok = false when the chain / ring degree has no level-A kernels (the call then runs at B)
 int ensure_plan_a(hp_ctx *ctx, const Plan *plan, bool *ok);
+// after a host synchronisation: HP_ERANGE (and the flag cleared) when a level-A kernel of the family saw a word outside its range
+int range_check(hp_ctx *ctx);
 // first thing a scheme-level entry point does after get_plan: decides whether THIS call runs at level A
 struct LevelScope {
     hp_ctx *ctx;
@@ -195,6 +201,7 @@ struct LevelScope {
             bool ok = false;
             rc = ensure_plan_a(c, plan, &ok);
             c->cur_a = (rc == 0) && ok;
+            if (c->cur_a) c->sh->a_used = true;
         }
     }
     ~LevelScope() { ctx->cur_a = false; }

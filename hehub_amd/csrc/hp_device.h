@@ -42,8 +42,9 @@ struct HpLimbA {
     double qinv;    // RN(1 / q)
     u64 qi;         // q as an integer
     u32 wide;       // q >= 2^44: coefficients are brought back to |x| <= q/2 between the passes (see hp_ntt_a.hip)
-    u32 pad_;
+    u32 hi_bound;   // high half of 2 q - 1: a word of a caller's row whose high half is larger is not a lazy word of this limb
     const u64x2 *fwd_ref, *inv_ref, *fwd_k, *inv_k;
+    u32 *range_flag;   // the family's sticky "a level-A kernel was handed a word outside its range" flag (hp_ntt_a.hip: RangeAcc)
 };
 
 #define HP_DEV __device__ __forceinline__

@@ -58,15 +58,37 @@ HP_DEV void a_reduce_all(u64 (&x)[32], double qinv, double q) {
     for (int r = 0; r < 32; ++r) x[r] = U(a_reduce(D(x[r]), qinv, q));
 }
 
+// ---- range guard ---------------------------------------------------------------------------------------------------------------
+// The conversion of a word to a double (from_word) is exact below 2^52 and the growth bounds above assume lazy words (below 2 q of
+// the limb): hehub's own transforms take any u64 (ntt.cpp:155-175) and level B reproduces that, level A cannot.  Every word a
+// kernel of this file loads from a row a CALLER may have supplied (the plain forward and inverse transforms, the rows x and addend
+// of the drop epilogue) goes through one v_max_u32 on its high half; a thread that saw a high half above that of 2 q - 1 sets the
+// family's sticky flag, and the next synchronising call of the C ABI (hp_sync, hp_memcpy_d2h) returns HP_ERANGE (hp_ctx.cpp).
+struct RangeAcc {
+    u32 m = 0;
+    HP_DEV void see(u64 w) { m = max(m, hi32(w)); }
+    HP_DEV void report(cptr_limba lp) const {
+        if (m > lp->hi_bound) atomicOr(lp->range_flag, 1u);
+    }
+};
+
 // ---- load-side work of the forward kernels, done per 16-byte load right before the first butterfly that touches it ----------
 // F64: the row already holds doubles (the strict coefficient rows of the key switch, written by k_ntt_inv_a with job.dst_f64)
+// words (a caller's row): range guard, and the word is brought to |x| <= q/2 at once -- a lazy word of a 50-bit modulus (up to
+// 2^51) would otherwise leave the exact range within the first pass (B' = B (1 + q 2^-52) + q/2 from 2^51: 10.2 * 2^50)
 template <bool SWAP, bool F64> struct ConvPre {
     static constexpr bool on = SWAP || !F64;
+    double q = 0.0, qinv = 0.0;
+    mutable RangeAcc acc;
     HP_DEV void operator()(u64 (&x)[32], int r) const {
         if (SWAP) lazy_swap(x, r);
         if (!F64) {
-            x[r] = U(from_word(x[r]));
-            x[r + 1] = U(from_word(x[r + 1]));
+            acc.see(x[r]);
+            acc.see(x[r + 1]);
+            // (unconditionally: a uniform branch on `wide` here costs the small ring degrees 6 .. 16 spilled registers, three FP64
+            // instructions per word cost a narrow limb 3 % of this kernel -- which no scheme-level pipeline launches)
+            x[r] = U(a_reduce(from_word(x[r]), qinv, q));
+            x[r + 1] = U(a_reduce(from_word(x[r + 1]), qinv, q));
         }
     }
 };
@@ -218,6 +240,7 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
     u64 x[32];
     constexpr bool SW = G::PB == 0;   // N = 32768: registers left as loaded, sorted into columns by the lane-pair swap of the first stage
     constexpr bool TWO = FLAV == 6 || FLAV == 7;
+    RangeAcc guard;
     DropPre2A<LOGN, SW, FLAV == 7> pre2;
     if constexpr (TWO) pre2.prime(da->comb + (size_t)it.poly * G::N, tid);
     load_flight<LOGN, SW>(it.src, tid, x);
@@ -239,11 +262,18 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
         const DropPreA<SW, BGV> pre{q, D(da->dc.q_last), D(da->dc.half_q_last), D(da->dc.t[k]), D(da->dc.t_h[k])};
         fwd_pass_a<G::PB, STab>(x, STab(lp->fwd_ref + 1), 1u, 0u, q, pre);
     } else {
-        fwd_pass_a<G::PB, STab>(x, STab(lp->fwd_ref + 1), 1u, 0u, q, ConvPre<SW, SPREAD>());
+        ConvPre<SW, SPREAD> pre;
+        pre.q = q; pre.qinv = qinv;
+        fwd_pass_a<G::PB, STab>(x, STab(lp->fwd_ref + 1), 1u, 0u, q, pre);
+        // N = 32768 reports after the exchange that follows (a divergent branch + two scalar loads here, where it has no SGPR to
+        // spare, spilled 60 of them; carried to the end of the kernel the accumulator spilled 6 VGPRs); the smaller degrees report now
+        if constexpr (LOGN == 15) guard = pre.acc;
+        else if (!SPREAD) pre.acc.report(lp);
     }
     if (wide) a_reduce_all(x, qinv, q);
     TRACE_MARK();   // 2
     exchange<LOGN, LAY_A, LAY_B, true>(x, lds, ad);
+    if (!DROP && !SPREAD && LOGN == 15) guard.report(lp);
     TRACE_MARK();   // 3
     // pass B: global stages A+1..A+5, twiddles depend on the 1024-block
     fwd_pass_a<0>(x, LTab(lds_tw), 1u << G::A, tid >> 5, q);
@@ -314,6 +344,7 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
                                    : da->x);
         const StreamBuf d(da->out + ((size_t)p2 * da->out_stride + k) * G::N);
         const double inv = D(da->dc.inv[k]), invu = D(da->dc.inv_h[k]), ql = D(da->dc.qlt[k]), qlu = D(da->dc.qlt_h[k]);
+        RangeAcc acc;
         auto rows = [&](auto add_tag) {
             constexpr bool ADD = decltype(add_tag)::value;
             constexpr int EPI_DEPTH = HP_EPI_DEPTH;
@@ -334,6 +365,14 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
                     if (ADD) ar[s % EPI_DEPTH] = as.load(voff, (u32)(s + EPI_DEPTH) << 10);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (!TWO) {   // (the two-drop flavours only run inside the fused mult pipelines: their rows are the engine's own, lazy by construction)
+                    acc.see(xv.x);
+                    acc.see(xv.y);
+                    if (ADD) {
+                        acc.see(av.x);
+                        acc.see(av.y);
+                    }
+                }
                 double v0, v1;
                 if constexpr (TWO) {
                     // ((A x + a) - NTT(...)) B: |A x| <= q/2 (1 + 2^-1), a < 2^51, |NTT| < 1.12 * 2^50 (narrow limbs; q/2 for wide ones): below 2^52
@@ -359,6 +398,7 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
         else if constexpr (FLAV == 1 || FLAV == 3) rows(std::false_type{});
         else if (has_add) rows(std::true_type{});
         else rows(std::false_type{});
+        if (!TWO) acc.report(lp);
     }
     TRACE_MARK();   // 9: stores issued
     TRACE_FLUSH();
@@ -437,6 +477,12 @@ HP_DEV void ntt_inv_a_body(const HpNttJob &job, const HpInvMixArgs *mx) {
     for (int i = 0; i < NSTG; ++i) {
         const u32 e = threadIdx.x + (u32)i * TT;
         if (e < 31u * 32u) lds_tw[e] = stg[i];
+    }
+    if (!MIX) {   // (MIX rows are the engine's own)
+        RangeAcc acc;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) acc.see(x[r]);
+        acc.report(lp);
     }
     if constexpr (MIX) {
         const u64 *as = mx->add + ((size_t)(it.poly >> 1) * mx->add_ct_stride + (size_t)(it.poly & 1) * mx->add_poly_stride) * G::N +

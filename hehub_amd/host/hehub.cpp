@@ -166,7 +166,7 @@ void check(int rc) {
     std::string msg = hp_last_error(cur());   // the calling thread's own last failure (hp_ctx.cpp)
     (void)hp_sync(cur());   // operands may have been enqueued for upload from the caller's memory (limb_copy_h2d): let them finish
                             // before the exception hands that memory back
-    if (rc == HP_EINVAL) throw std::invalid_argument(msg);
+    if (rc == HP_EINVAL || rc == HP_ERANGE) throw std::invalid_argument(msg);   // (HP_ERANGE: a level-A call was handed a word >= 2 q)
     if (rc == HP_ELOGIC) throw std::logic_error(msg);
     throw std::runtime_error("hehub_amd: " + msg);
 }

@@ -54,7 +54,8 @@ typedef enum {
     HP_EUNSUPPORTED = 2, /* reference throws "under development" / not built */
     HP_EHIP = 3,         /* HIP runtime failure */
     HP_ENOMEM = 4,
-    HP_ELOGIC = 5
+    HP_ELOGIC = 5,
+    HP_ERANGE = 6        /* parity level A only: a kernel was handed a word that is not a lazy word of its limb (see hp_parity_level) */
 } hp_status;
 
 /* ---- engine ------------------------------------------------------------ */
@@ -69,8 +70,11 @@ void hp_ctx_destroy(hp_ctx *ctx);
  *     intt_negacyclic_inplace (ntt.h:88-92) extended to the whole pipeline.  hp_dev_ext_prod_montgomery* returns lazy words
  *     (< 2q, rgsw.cpp:151) with hehub's residues.  Their transforms then run on error-free FP64
  *     products (hp_ntt_a.hip: 8 instead of 16 instructions per butterfly).  Needs every modulus of the chain below 2^50, a ring
- *     degree of 2^11 .. 2^15 and ciphertext words below 2^51 (any lazy word hehub produces is below 2q); a call whose chain does
- *     not qualify runs at level B.  At this level the fused mult entry points (hp_dev_*_mult_relin_*) also merge relinearize's
+ *     degree of 2^11 .. 2^15; a call whose chain does not qualify runs at level B.  Input words must be LAZY words of their limb
+ *     (below 2 q: everything hehub or this engine produces is; hehub's own transforms take any u64, ntt.cpp:155-175, and level B
+ *     reproduces that).  The precondition is CHECKED: every word a level-A kernel loads from a caller's row passes a range guard
+ *     (one instruction), a word above 2 q sets a sticky flag, and the next synchronising call on the family (hp_sync,
+ *     hp_memcpy_d2h) returns HP_ERANGE -- the results since the previous synchronisation are then void.  At this level the fused mult entry points (hp_dev_*_mult_relin_*) also merge relinearize's
  *     mod-down with the rescale / mod switch into one transform per output limb (same residues; HP_NO_DOUBLE_DROP=1 at
  *     hp_ctx_create keeps the two launches).  The NTT / mod-arith primitives (hp_ntt_*, hp_dev_ntt_*, hp_dev_poly_*, hp_batched_*) are
  *     never affected: they stay bit-exact with ntt.cpp:145-223 / mod_arith.cpp. */
@@ -173,8 +177,8 @@ int hp_dev_intt(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size
  * FP64 butterflies, 8 instead of 16 instructions each): in place, every output word is the canonical residue in [0, q).
  *   hp_dev_ntt_residues:  word == (ntt.cpp:145-176's lazy word) mod q, i.e. reduce_strict of it where that one is below 2q
  *   hp_dev_intt_residues: the words of intt_negacyclic_inplace (ntt.h:88-92 = lazy inverse + reduce_strict), bit for bit
- * Input words must be below 2^52 (any lazy word hehub produces is below 2q); N = 2^11 .. 2^15 and every modulus below 2^50, else
- * HP_EUNSUPPORTED.  hp_dev_ntt / hp_dev_intt above stay bit-exact with the reference's lazy words. */
+ * Input words must be lazy words of their limb (below 2 q; checked: HP_ERANGE from the next hp_sync / hp_memcpy_d2h, see
+ * hp_parity_level); N = 2^11 .. 2^15 and every modulus below 2^50, else HP_EUNSUPPORTED.  hp_dev_ntt / hp_dev_intt above stay bit-exact with the reference's lazy words. */
 int hp_dev_ntt_residues(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *d_x);
 int hp_dev_intt_residues(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *d_x);
 /* rns.cpp:58-87 / :89-118 / :120-140 / :142-171 on u64[batch][L][N].  d_self may alias d_out. */

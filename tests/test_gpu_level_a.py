@@ -375,3 +375,80 @@ def test_debug_switches_keep_a_call_at_level_b(orc):
         assert np.array_equal(eng.to_host(eng.ckks_mult(mext, d1, d2, dk)), canon(mext, raw))
     finally:
         eng.close()
+
+
+def test_all_max_lazy_words_on_wide_moduli(enga, orc):
+    """four 50-bit moduli (the C2 shape), EVERY input word the largest lazy word 2q - 1 (and a second batch member
+    alternating 2q - 1 / 0, the input that grows fastest through the butterflies): without the reduction on load the first forward
+    pass leaves the exact FP64 range (hp_ntt_a.hip: B' = B (1 + q 2^-52) + q/2 from 2^51).  Residues of ntt.cpp:155-175, :178-223."""
+    eng = enga
+    for logn in (11, 14, 15):
+        moduli = P.P50[:4]
+        n, L = 1 << logn, 4
+        top = (U(2) * np.array(moduli, dtype=U) - U(1))[:, None]
+        a = np.empty((3, L, n), dtype=U)
+        a[0] = top
+        a[1] = np.where(np.arange(n)[None, :] % 2 == 0, top, U(0))
+        a[2] = SplitMix(880 + logn).poly((L, n), moduli) + np.array(moduli, dtype=U)[:, None] * (np.arange(n)[None, :] % 2).astype(U)   # lazy: some words in [q, 2q)
+        fwd = np.stack([orc.poly_ntt(moduli, a[i]) for i in range(3)])
+        y = eng.to_host(eng.ntt_residues_(moduli, eng.to_device(a)))
+        assert np.array_equal(y, canon(moduli, fwd)), logn
+        inv = np.stack([orc.poly_intt(moduli, a[i]) for i in range(3)])
+        z = eng.to_host(eng.intt_residues_(moduli, eng.to_device(a)))
+        assert np.array_equal(z, canon(moduli, inv)), logn
+        eng.sync()   # in range: the guard stays quiet
+
+
+def test_range_guard_flags_words_that_are_not_lazy(enga):
+    """level A converts words with an exact-below-2^52 bit trick and its growth bounds assume lazy words
+    (< 2q); hehub's transforms take any u64 (ntt.cpp:155-175) and level B reproduces that.  A word outside the range must not
+    pass silently: the kernels set a sticky flag and the next synchronising call returns HP_ERANGE -- once; then the flag is clear."""
+    from hehub_amd import capi
+    from hehub_amd.engine import HpError
+
+    eng = enga
+    logn, mext = 12, [P.P50[1]] + P.P40[:3] + [P.P50[0]]
+    n, L = 1 << logn, len(mext) - 1
+    q = mext[:L]
+    rng = SplitMix(4242)
+    good = rng.poly((2, 2, L, n), q)
+    dkey = eng.to_device(rng.poly((L, 2, L + 1, n), mext))
+
+    def expect_flag(run):
+        eng.sync()                      # clean before
+        run()
+        with pytest.raises(HpError) as e:
+            eng.sync()
+        assert e.value.code == capi.HP_ERANGE and "lazy word" in e.value.msg
+        eng.sync()                      # reported once, then clear
+
+    for bad_word in (1 << 52, (1 << 52) + 12345, (1 << 63) + 7, 2 * q[1] + (1 << 33)):
+        for entry in ("ntt_residues", "intt_residues", "rescale", "rescale_kept_row", "relin_addend"):
+            x = good.copy()
+            limb = 1                    # a 40-bit limb: 2q + 2^33 is far below 2^52 and still not a lazy word
+            if entry == "rescale":
+                x[1, 0, L - 1, 77] = U(bad_word)          # the limb that is dropped: read by the level-A inverse transform
+            else:
+                x[1, 1, limb, n - 3] = U(bad_word)
+            if entry == "ntt_residues":
+                expect_flag(lambda: eng.ntt_residues_(q, eng.to_device(x[:, 1])))
+            elif entry == "intt_residues":
+                expect_flag(lambda: eng.intt_residues_(q, eng.to_device(x[:, 1])))
+            elif entry == "relin_addend":   # quad[0] / quad[1] are the addend rows of the drop that ends relinearize (ckks/arith.cpp:70-71)
+                quad = np.concatenate([x, good[:, :1]], axis=1)
+                expect_flag(lambda: eng.ckks_relinearize(mext, eng.to_device(quad), dkey))
+            else:
+                expect_flag(lambda: eng.ckks_rescale(q, eng.to_device(x)))   # x rows of the drop epilogue / its inverse launch
+    # words in range: nothing is flagged, whatever ran before
+    eng.ckks_rescale(q, eng.to_device(good))
+    eng.ntt_residues_(q, eng.to_device(good[:, 0]))
+    eng.sync()
+    # level B takes any word: no flag can come from there
+    eng.set_parity_level("B")
+    try:
+        x = good.copy()
+        x[0, 0, 0, 0] = U((1 << 63) + 9)
+        eng.ckks_rescale(q, eng.to_device(x))
+        eng.sync()
+    finally:
+        eng.set_parity_level("A")
