@@ -36,6 +36,10 @@ One process per GPU; ciphertext batches are sharded across ranks with no data-pa
                         independent chains over 1 / 8 lanes; examples/independent_mults as a child process, digests compared
   cpu_baseline          the compiled reference (or the C restatement) on ONE core of this host; cpu_baseline_node: the
                         same as P independent processes (P = what affinity mask and CPU quota allow, stated)
+  step                  (pipelines) a pass after the timed region with HIP events around EVERY launch: per kernel family launches,
+                        ms, its share of A_step and the HBM fraction that makes; `step_traffic`: the measured HBM bytes of one
+                        step (sum of 2 x FETCH_SIZE + WRITE_SIZE over every kernel, committed rocprofv3 passes of this command)
+                        beside A_step / A_min -- a pipeline_roofline above 1 is cross-stage fusion, not a measurement error
   --roofline-only       drops everything after the timed region (for clean rocprofv3 summaries of the default command)
 
 The workloads, inputs, fences and sections live in benchkit/ (no checker there).  The oracle / compiled reference is used
@@ -430,7 +434,12 @@ def main() -> int:
                                  "the same inputs), bit for bit"}
         failed = not res["verified"]
     if launches:
-        res["roofline"] = roofline_entry(wl.family, wl.alg_bytes_per_step, args.steps, launches, kern_ms, elapsed, wl.logn, wl.spread)
+        res["roofline"] = roofline_entry(wl.family, wl.alg_bytes_per_step, args.steps, launches, kern_ms, elapsed, wl.logn, wl.spread,
+                                         level=level, sclk_mhz=chip.sections["timed_region"].get("sclk_MHz"))
+    if isinstance(wl, workloads.Scheme) and wl.name in ("ckks", "bgv", "rotate") and extras:
+        from benchkit.timing import step_kernels
+
+        res["step"] = step_kernels(run, wl, level)   # every launch of one step + the measured HBM bytes of a step (after the timed region)
     if wl.a_limbs is not None:
         res["pipeline_roofline"] = wl.pipeline_roofline(value / world, HBM_PEAK_GBS)
     if args.workload == "ckks" and extras and not args.no_rates and not args.logn and not args.batch and level == "B":

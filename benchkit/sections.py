@@ -5,7 +5,7 @@ checker handed in by bench.py (None: no output checks)."""
 from __future__ import annotations
 
 from .inputs import Batch, compare_classes, rand_words
-from .timing import HBM_PEAK_GBS, Run, rate_entry, roofline_entry, timed_launches
+from .timing import HBM_PEAK_GBS, Run, rate_entry, roofline_entry, step_kernels, timed_launches
 from .workloads import Scheme, Transform
 
 
@@ -67,7 +67,7 @@ def c2_section(run: Run, lib):
         e["unit"] = "limb-NTT/s"
         e["ms_per_pass"] = 1e3 * dt / steps
         if launches:
-            e["roofline"] = roofline_entry(fam, 16.0 * n * wl.B * wl.L, steps, launches, kern_ms, dt, wl.logn, False)
+            e["roofline"] = roofline_entry(fam, 16.0 * n * wl.B * wl.L, steps, launches, kern_ms, dt, wl.logn, False, sclk_mhz=run.sclk())
         ent[name] = e
     if lib is not None:
         ent["verified"], polys = _check_transforms(run, lib, moduli, wl.xb)
@@ -134,7 +134,8 @@ def bgv_section(run: Run, lib):
            "per_s": per_gpu * run.world, "unit": "hom-mult/s", "steps": steps, "ms_per_step": 1e3 * dt / steps,
            "A_step_bytes_per_op": wl.a_limbs * 8 * wl.n, "pipeline_roofline": wl.pipeline_roofline(per_gpu, HBM_PEAK_GBS)}
     if launches:
-        ent["roofline"] = roofline_entry(wl.family, wl.alg_bytes_per_step, steps, launches, kern_ms, dt, wl.logn, True)
+        ent["roofline"] = roofline_entry(wl.family, wl.alg_bytes_per_step, steps, launches, kern_ms, dt, wl.logn, True, sclk_mhz=run.sclk())
+    ent["step"] = step_kernels(run, wl, "B")
     if lib is not None:
         ok, cnt, classes = wl.verify(lib)
         ent["verified"] = bool(ok)
@@ -159,22 +160,10 @@ def level_a_section(run: Run, lib, wl):
             ent = {"workload": w.cfg["workload"], "per_s": per_gpu * run.world, "unit": "hom-mult/s", "steps": steps,
                    "ms_per_step": 1e3 * dt / steps, "pipeline_roofline": w.pipeline_roofline(per_gpu, HBM_PEAK_GBS)}
             if launches:
-                r = roofline_entry(w.family, w.alg_bytes_per_step, steps, launches, kern_ms, dt, w.logn, True)
+                r = roofline_entry(w.family, w.alg_bytes_per_step, steps, launches, kern_ms, dt, w.logn, True, level="A", sclk_mhz=run.sclk())
                 r["kernel"] = "k_ntt_fwd_a (register/LDS-tiled forward NTT, FP64 residue butterflies), digit-spread launch"
-                r["traffic"], _src, _vb = None, r.pop("traffic_source", None), r.pop("valu_busy", None)
-                try:   # the level-A kernel's own PMC entry (tools/traffic_from_pmc.py), never the integer kernel's
-                    import json as _json
-
-                    from .timing import TRAFFIC_FILE
-                    tr = _json.load(open(TRAFFIC_FILE)).get(f"k_ntt_fwd_a_logn{w.logn}_spread")
-                    if tr:
-                        r["traffic"] = tr["bytes_per_limb"] * r["algorithmic_bytes_per_launch"] / (16.0 * (1 << w.logn))
-                        r["traffic_source"] = f"rocprofv3 PMC per-limb measurement x limbs per launch (profiles/traffic.json: {tr.get('source')})"
-                        if "valu_busy" in tr:
-                            r["valu_busy"] = tr["valu_busy"]
-                except (OSError, ValueError, KeyError):
-                    pass
                 ent["roofline"] = r
+            ent["step"] = step_kernels(run, w, "A")
             if lib is not None:
                 ok, cnt, classes = w.verify(lib, strict=True)
                 ent.update({"verified": bool(ok), "verified_outputs": cnt, "checker_evaluations": classes,

@@ -272,6 +272,15 @@ class Scheme(Workload):
         ok, cnt = compare_classes(self.run.torch, res, exp, self.b1.period, idx)
         return ok, cnt, len(idx)
 
+    def family_limbs(self):
+        """A_step split by profiling family (limbs of S = 8N bytes per op): tensor 7L; inverse transforms 2L (the key
+        switch's coefficient rows) + 2 x 2 per drop; digit transforms 2L^2; inner product (L + 1)(3L + 2); the two fused drops
+        12L + 10(L - 1).  A rotation has the gather instead of the tensor product and one drop.  Sums to a_limbs."""
+        L = self.L
+        if self.name == "rotate":
+            return {"elem": 4 * L, "intt": 2 * L + 4, "ntt": 2 * L * L, "ks_inner": (L + 1) * (3 * L + 2), "ntt_drop": 12 * L - 2 * L}
+        return {"tensor": 7 * L, "intt": 2 * L + 8, "ntt": 2 * L * L, "ks_inner": (L + 1) * (3 * L + 2), "ntt_drop": 12 * L + 10 * (L - 1)}
+
     def pipeline_roofline(self, per_gpu_ops_per_s, peak_gbs):
         """A_step / A_prim / A_min fractions of a per-GPU op rate"""
         n, L, B = self.n, self.L, self.B

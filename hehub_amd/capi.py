@@ -136,6 +136,7 @@ SIGNATURES = {
     "hp_dev_wire_store": (INT, [P, P, P, P, P, szt]),
     "hp_prof_begin": (INT, [P, C.c_char_p]),
     "hp_prof_end": (INT, [P, C.POINTER(szt), C.POINTER(C.c_double)]),
+    "hp_prof_end_families": (INT, [P, szt, P, P, P, P]),
 }
 
 _lib = None

@@ -40,6 +40,7 @@ struct Plan {
 
 struct ProfEvent {
     hipEvent_t a, b;
+    const char *family;   // a string literal of the launch site
 };
 
 // caches of small device objects are bounded: when one is full it is emptied (after a device synchronise), not grown

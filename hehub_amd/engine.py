@@ -119,6 +119,16 @@ class Engine:
         self._chk(self.lib.hp_prof_end(self.h, C.byref(n), C.byref(ms)))
         return int(n.value), float(ms.value)
 
+    def prof_end_families(self):
+        """after prof_begin("*"): {family: (launches, total ms)} of every bracketed launch, in order of first appearance"""
+        cap = 32
+        names = (C.c_char_p * cap)()
+        launches = (capi.szt * cap)()
+        ms = (C.c_double * cap)()
+        count = capi.szt(0)
+        self._chk(self.lib.hp_prof_end_families(self.h, cap, names, launches, ms, C.byref(count)))
+        return {names[i].decode(): (int(launches[i]), float(ms[i])) for i in range(int(count.value))}
+
     # -- drop-in host calls (numpy in, numpy out) ----------------------------
     def host_ntt(self, logn: int, q: int, x: np.ndarray) -> np.ndarray:
         x = np.ascontiguousarray(x.copy())

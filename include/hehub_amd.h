@@ -459,6 +459,9 @@ int hp_dev_wire_store(hp_ctx *ctx, const hp_wire_desc *d, const uint64_t *moduli
  * hp_prof_end synchronises and returns launches and total milliseconds. */
 int hp_prof_begin(hp_ctx *ctx, const char *kernel_family);
 int hp_prof_end(hp_ctx *ctx, size_t *launches, double *total_ms);
+/* With the family "*" every launch of every family is bracketed; this returns the totals per family (at most `cap` of them, in
+ * order of first appearance): names[i] is a static string ("tensor", "intt", "ntt", "ks_inner", "ntt_drop", "elem", "copy", ...). */
+int hp_prof_end_families(hp_ctx *ctx, size_t cap, const char **names, size_t *launches, double *total_ms, size_t *count);
 
 #ifdef __cplusplus
 }

@@ -47,14 +47,22 @@ def test_roofline_arithmetic():
 
     n, limbs, steps = 1 << 15, 25600, 20
     alg = 16.0 * n * limbs                      # algorithmic bytes per step (one launch per step)
-    r = roofline_entry("ntt", alg, steps, launches=steps, kern_ms=steps * 3.75, elapsed=steps * 8.6e-3, logn=15, spread=True)
-    assert r["bound"] == "hbm" and r["peak"] == HBM_PEAK_GBS == 8000.0 and r["unit"] == "GB/s" and r["launches"] == steps
+    r = roofline_entry("ntt", alg, steps, launches=steps, kern_ms=steps * 3.75, elapsed=steps * 8.6e-3, logn=15, spread=True, sclk_mhz=2200.0)
+    # the digit-spread launch: VALUBusy 0.83 at a quarter of the HBM peak in the committed counters -> the line says "valu"; achieved /
+    # peak / frac stay the HBM roofline (priced_against), `alu` prices the same launch against the issue peak of 1024 SIMDs
+    assert r["bound"] == "valu" and r["priced_against"] == "hbm" and r["traffic_frac_of_hbm_peak"] < 0.5
+    assert r["peak"] == HBM_PEAK_GBS == 8000.0 and r["unit"] == "GB/s" and r["launches"] == steps
+    alu = r["alu"]
+    assert alu["waves"] == limbs * 16 and alu["sclk_MHz"] == 2200.0 and 4000 < alu["valu_insts_per_wave"] < 5000
+    assert abs(alu["frac_of_issue_peak"] - alu["valu_insts_per_wave"] * alu["waves"] * alu["cycles_per_inst_mix"] / (1024 * 2.2e9 * 3.75e-3)) < 1e-9
+    assert 0.5 < alu["frac_of_issue_peak"] < 1.0
     assert abs(r["achieved"] - alg / 3.75e-3 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
     assert abs(r["share_of_step_time"] - 3.75 / 8.6) < 1e-9 and r["algorithmic_bytes_per_launch"] == alg
     # the committed PMC measurement of the digit-spread launch: less HBM traffic than algorithmic bytes (sources from L2, packed rows)
     assert r["traffic"] is not None and 0.3 * alg < r["traffic"] < alg and 0.5 < r["valu_busy"] < 1.0
     plain = roofline_entry("ntt", alg, steps, steps, steps * 3.9, steps * 3.9e-3, 15, spread=False)
     assert plain["traffic"] > r["traffic"] and abs(plain["traffic"] / alg - 1.0) < 0.05        # in-place launch: ~1.0 x algorithmic
+    assert roofline_entry("elem", 24.0 * n * 2040, 5, 5, 5 * 0.28, 5 * 0.28e-3, 15, False)["bound"] == "hbm"   # no counters say otherwise
     assert roofline_entry("elem", 24.0 * n * 2040, 5, 5, 5 * 0.28, 5 * 0.28e-3, 15, False)["traffic"] is None
     e = rate_entry(units_per_launch=5120, bytes_per_unit=16.0 * n, steps=10, world=2, dt=10e-3, launches=10, kern_ms=9.0)
     assert abs(e["per_s"] - 5120 * 2 * 10 / 10e-3) < 1e-6 and abs(e["avg_launch_ms"] - 0.9) < 1e-12

@@ -14,6 +14,7 @@ SPECS = [("ntt15", r"k_ntt_fwdILi15", "k_ntt_fwd_logn15", 256 * 11), ("intt15", 
          ("ckks", r"k_ntt_fwdILi15", "k_ntt_fwd_logn15_spread", 64 * 100), ("bgv", r"k_ntt_fwdILi13", "k_ntt_fwd_logn13_spread", 128 * 36),
          # parity level A (hp_ntt_a.hip): the same launches on the FP64 residue kernels
          ("ckks_a", r"k_ntt_fwd_aILi15", "k_ntt_fwd_a_logn15_spread", 64 * 100), ("bgv_a", r"k_ntt_fwd_aILi13", "k_ntt_fwd_a_logn13_spread", 128 * 36)]
+SPECS = [s for s in SPECS if not os.environ.get("TRAFFIC_ONLY") or s[0] in os.environ["TRAFFIC_ONLY"].split(",")]
 out_path = os.path.join(ROOT, "profiles", "traffic.json")
 tr = json.load(open(out_path)) if os.path.exists(out_path) else {}
 for name, kre, entry, limbs in SPECS:
@@ -38,6 +39,8 @@ for name, kre, entry, limbs in SPECS:
         e["valu_busy"] = round(4 * valu / 32 / gui, 3)
     if waves and insts:
         e["valu_insts_per_wave"] = round(insts / waves)
+    if valu and insts:
+        e["valu_cycles_per_inst"] = round(4 * valu / insts, 3)   # SIMD cycles one VALU instruction of this kernel's mix occupies (4 = full rate)
     tr[entry] = e
     print(entry, e)
 json.dump(tr, open(out_path, "w"), indent=1)
