@@ -209,5 +209,13 @@ int main(int argc, char **argv) {
         std::printf("chains %zu x %zu mult+rotate: %.3f ms per step\n", C, chain_len, ms[0]);
 #endif
     }
+#ifdef INDEP_AMD_EXT
+    {
+        const auto st = amd::transfer_stats();
+        if (st.deferred_calls)
+            std::printf("deferred: %llu recorded calls ran as %llu batched engine calls (%llu mult + rescale_inplace triples as the one-call pipeline)\n",
+                        st.deferred_calls, st.deferred_groups, st.deferred_fused);
+    }
+#endif
     return 0;
 }

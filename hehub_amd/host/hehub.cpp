@@ -110,8 +110,10 @@ int lanes() {
     (void)engine();
     return lane_set().count;
 }
+void flush_all();
 void synchronize() {
     (void)engine();
+    flush_all();
     LaneSet &S = lane_set();
     for (int l = 0; l < MAX_LANES; l++)
         if (S.v[l].ctx && hp_sync(S.v[l].ctx) != HP_OK) throw std::runtime_error(std::string("hehub_amd: ") + hp_last_error(S.v[l].ctx));
@@ -132,6 +134,7 @@ void set_lanes(int n) {
 // true = A, the scheme-level calls return canonical residues (reduce_strict of hehub's words) through the FP64 transforms
 void set_parity_level_a(bool on) {
     (void)engine();
+    flush_all();   // (recorded calls run at the level that was set when they were recorded)
     LaneSet &S = lane_set();
     for (int l = 0; l < MAX_LANES; l++)
         if (S.v[l].ctx && hp_ctx_set_parity_level(S.v[l].ctx, on ? HP_PARITY_A : HP_PARITY_B) != HP_OK)
@@ -150,10 +153,16 @@ namespace amd {
 // A device allocation out of a per-size free list (hehub pools its host blocks the same way and never gives them back to
 // the OS, allocator.h:19-49).  A block carries the tickets of the last call that wrote it and of the last call that read it, per
 // lane; the record stays with the block through the pool, so whoever gets it next is ordered behind its previous users.
+struct PendingOp;
 struct DevBlock {
     u64 *p = nullptr;
     size_t words = 0;
     unsigned long long rd[MAX_LANES] = {}, wr[MAX_LANES] = {};
+    // deferred mode (see "deferred execution" below): the result of a call that has been recorded but not run is a PLACEHOLDER
+    // (p == NULL, op = the recorded call); when the call runs, the placeholder becomes a view of the block its batch filled
+    std::shared_ptr<DevBlock> parent;
+    PendingOp *op = nullptr;
+    bool failed = false;
 };
 
 namespace {
@@ -215,17 +224,19 @@ void order_after(int l) {
 using BlockRef = std::shared_ptr<DevBlock>;
 
 // the current call reads / writes the block: wait for whoever it depends on, leave the call's ticket
-void track_read(DevBlock &b) {
+void track_read(DevBlock &b0) {
     LaneSet &S = lane_set();
     if (S.count == 1) return;
+    DevBlock &b = b0.parent ? *b0.parent : b0;
     Lane &me = S.v[S.cur];
     for (int l = 0; l < MAX_LANES; l++)
         if (l != S.cur && b.wr[l] > me.seen[l]) order_after(l);
     b.rd[S.cur] = me.ticket;
 }
-void track_write(DevBlock &b) {
+void track_write(DevBlock &b0) {
     LaneSet &S = lane_set();
     if (S.count == 1) return;
+    DevBlock &b = b0.parent ? *b0.parent : b0;
     Lane &me = S.v[S.cur];
     for (int l = 0; l < MAX_LANES; l++)
         if (l != S.cur && std::max(b.wr[l], b.rd[l]) > me.seen[l]) order_after(l);
@@ -233,6 +244,7 @@ void track_write(DevBlock &b) {
 }
 // after a host synchronisation of the current lane that followed track_write: every earlier user of the block has finished
 void settled(DevBlock &b) {
+    if (b.parent) return;
     for (int l = 0; l < MAX_LANES; l++) b.rd[l] = b.wr[l] = 0;
 }
 
@@ -302,8 +314,9 @@ struct OpScope {
         for (const BlockRef *r : operands) {
             if (lane >= 0) break;
             if (!r || !*r) continue;
+            const DevBlock &b = (*r)->parent ? *(*r)->parent : **r;
             for (int l = 0; l < S.count; l++)
-                if ((*r)->wr[l] && (*r)->wr[l] == S.v[l].ticket) { lane = l; break; }
+                if (b.wr[l] && b.wr[l] == S.v[l].ticket) { lane = l; break; }
         }
         if (lane < 0) lane = S.rr = (S.rr + 1) % S.count;
         S.cur = lane;
@@ -503,6 +516,66 @@ struct Dst {
     explicit Dst(size_t words) : blk(alloc_block(words)), p(blk->p) { track_write(*blk); }
 };
 
+// ---- deferred execution (own-mirror build, opt-in: amd::set_deferred / HEHUB_AMD_DEFER=1) --------------------------------------------
+// hehub's interface is one ciphertext per call and its callers loop over INDEPENDENT ciphertexts (src/circuits/linear_algebra.h:
+// 109-133, bench/benchmarks.cpp:24-35); at batch 1 a C3 call is a chain of ~12 dependent launches of 40 us that fill 10 .. 100 of
+// 256 CUs, and the GPU runs at most 2 - 3 such chains side by side (lanes: x 2.3).  In deferred mode the scheme-level calls
+// (mult_low_level, relinearize, rotate / conjugate, rescale_inplace / mod_switch_inplace, add / sub of ciphertexts) are RECORDED, not
+// run: every argument check of the single call has been made (same exceptions, same place), the result objects exist and carry
+// their shape, scaling factor and a placeholder for their device words.  The queue runs when somebody needs words -- a look at a
+// result (operator[], view(), ==), any call that is not deferrable, amd::synchronize(), 1024 recorded calls -- and then groups
+// the recorded calls: calls with the same signature (operation, ring degree, moduli, key, step, ...) whose operands are ready run as
+// ONE batched engine call (operands gathered by one kernel unless they already lie packed, results views of one block).  A loop of
+// 256 independent ckks::mult + rescale_inplace so runs as three batch-256 launches groups, 8 interleaved chains as batch-8 ones.
+// Results are word for word those of the eager calls.  What differs: a failure INSIDE the engine (a HIP error, a modulus the
+// transforms reject) surfaces when the queue runs, not at the call that recorded it.
+enum class OpKind { MultLow, Relin, KeySwitch, Drop, AddSub };
+struct PendingOp {
+    OpKind kind = OpKind::MultLow;
+    size_t logn = 0, L = 0, L0 = 0, step = 0;
+    std::vector<u64> mod;   // q_0 .. q_{L-1} (MultLow, Drop, AddSub) or the extended chain (Relin, KeySwitch)
+    BlockRef key;           // the assembled key block (Relin, KeySwitch)
+    bool conj = false, bgv = false, sub = false;
+    u64 t = 0;
+    std::vector<std::pair<BlockRef, size_t>> in;   // operand polynomials: block + word offset; `in_limbs` limbs are read of each
+    size_t in_limbs = 0, out_words = 0;
+    BlockRef out;           // placeholder of out_words words
+    bool done = false;
+    bool same_signature(const PendingOp &o) const {
+        return kind == o.kind && logn == o.logn && L == o.L && L0 == o.L0 && step == o.step && conj == o.conj && bgv == o.bgv &&
+               sub == o.sub && t == o.t && key == o.key && in_limbs == o.in_limbs && in.size() == o.in.size() && mod == o.mod;
+    }
+    bool ready() const {
+        for (auto &r : in)
+            if (r.first->op) return false;
+        return true;
+    }
+};
+struct OpQueue {
+    std::vector<std::unique_ptr<PendingOp>> ops;
+    bool on = false, flushing = false;
+    static constexpr size_t MAX_PENDING = 1024;
+};
+namespace {
+OpQueue &op_queue() {
+    static OpQueue &q = *[] {
+        OpQueue *x = new OpQueue;
+#ifndef HEHUB_AMD_BIND_REFERENCE
+        if (const char *e = std::getenv("HEHUB_AMD_DEFER")) x->on = std::atoi(e) != 0;
+#endif
+        return x;
+    }();
+    return q;
+}
+} // namespace
+void flush_all();
+// device address of a block's words; a placeholder is resolved by running the queue
+u64 *words_of(const BlockRef &b) {
+    if (b->op) flush_all();
+    if (!b->p) throw std::runtime_error("hehub_amd: this object is the result of a deferred call that failed when the queue ran");
+    return b->p;
+}
+
 #ifndef HEHUB_AMD_BIND_REFERENCE
 // ---- own mirror: the vector carries its device copy -----------------------------------------------------------
 namespace {
@@ -517,25 +590,41 @@ struct Access {
     // the device copy of the first `limbs` limbs, uploading the host words if they are newer
     static Src in(const RnsIntVec &v, size_t limbs) {
         const size_t n = v.dimension();
+        if (v.dev_ok_ && v.blk_->op) flush_all();   // a placeholder: the recorded calls run now
         if (!v.dev_ok_) {
+            if (v.blk_) flush_all();   // (a recorded call may still want the words this upload replaces)
             if (!v.blk_ || v.off_ + v.count_ * n > v.blk_->words) {   // (a view keeps its place: sibling views are disjoint)
                 v.blk_ = alloc_block(v.count_ * n);
                 v.off_ = 0;
             }
             const bool whole = v.off_ == 0 && v.count_ * n == v.blk_->words;
             track_write(*v.blk_);
-            h2d_limbs(v.blk_->p + v.off_, v.limbs_, v.count_, n);   // (synchronous: the upload leaves no debt on its lane)
+            h2d_limbs(words_of(v.blk_) + v.off_, v.limbs_, v.count_, n);   // (synchronous: the upload leaves no debt on its lane)
             if (whole) settled(*v.blk_);
             v.dev_ok_ = true;
         }
         (void)limbs;
         track_read(*v.blk_);
-        return Src{v.blk_->p + v.off_, v.blk_};
+        return Src{words_of(v.blk_) + v.off_, v.blk_};
+    }
+    // deferred mode: where the vector's device words are or WILL be (a placeholder is not resolved); host words are uploaded now
+    static std::pair<BlockRef, size_t> ref(const RnsIntVec &v) {
+        if (!v.dev_ok_) (void)in(v, v.count_);
+        return {v.blk_, v.off_};
+    }
+    // a result polynomial whose words are the view [off, ..) of a block (or placeholder)
+    static void bind_block(RnsIntVec &v, const BlockRef &blk, size_t off) {
+        v.blk_ = blk;
+        v.off_ = off;
+        v.dev_ok_ = true;
+        v.host_ok_ = false;
+        v.stamp_ = next_stamp();
     }
     // the block that holds the vector's current device words, if any: what OpScope looks at to keep a dependent chain on one lane
     static const BlockRef *home(const RnsIntVec &v) { return v.dev_ok_ ? &v.blk_ : nullptr; }
     // the vector's own device words, to be overwritten in place by an engine call that has read them (operator+= ...)
     static u64 *inout(RnsIntVec &v) {
+        flush_all();   // (a recorded call may read the words this call overwrites)
         Src s = in(v, v.count_);
         track_write(*v.blk_);
         v.host_ok_ = false;
@@ -589,11 +678,14 @@ struct Access {
             // the download runs on the lane that wrote the words last (no event needed there), behind the block's other writers
             LaneSet &S = lane_set();
             int lane = 0;
+            if (v.blk_->op) flush_all();
+            const DevBlock &root = v.blk_->parent ? *v.blk_->parent : *v.blk_;
+            lane = 0;
             for (int l = 1; l < MAX_LANES; l++)
-                if (v.blk_->wr[l] > v.blk_->wr[lane]) lane = l;
+                if (root.wr[l] > root.wr[lane]) lane = l;
             OpScope op({}, S.depth ? S.cur : lane);
             track_read(*v.blk_);
-            d2h_limbs(v.limbs_, v.blk_->p + v.off_, v.count_, n);   // (synchronous)
+            d2h_limbs(v.limbs_, words_of(v.blk_) + v.off_, v.count_, n);   // (synchronous)
         }
         v.host_ok_ = true;
     }
@@ -609,11 +701,12 @@ struct Access {
         dst.stamp_ = next_stamp();
         if (o.dev_ok_ && o.count_) {   // device-to-device: the host copy (if any) is not duplicated, it can be fetched again
             const size_t w = o.count_ * o.dimension();
+            if (o.blk_->op) flush_all();   // (a copy of a placeholder: the recorded calls run now)
             OpScope op({&o.blk_});
             dst.blk_ = alloc_block(w);
             track_read(*o.blk_);
             track_write(*dst.blk_);
-            check(hp_dev_copy(cur(), w, o.blk_->p + o.off_, dst.blk_->p));
+            check(hp_dev_copy(cur(), w, words_of(o.blk_) + o.off_, dst.blk_->p));
             dst.dev_ok_ = true;
             dst.host_ok_ = false;
         } else {
@@ -630,11 +723,11 @@ struct Access {
         bool packed = true;
         for (size_t r = 0; r < polys.size() && packed; r++) {
             const RnsIntVec &v = *polys[r];
-            packed = v.dev_ok_ && v.blk_ == f.blk_ && v.off_ == f.off_ + r * w && v.count_ == limbs;
+            packed = v.dev_ok_ && !v.blk_->op && v.blk_->p && f.blk_->p && v.blk_->p + v.off_ == f.blk_->p + f.off_ + r * w && v.count_ == limbs;
         }
-        if (packed) {
-            track_read(*f.blk_);
-            return Src{f.blk_->p + f.off_, f.blk_};
+        if (packed) {   // (polynomials that are views of one block, directly or through the placeholders a deferred batch resolved)
+            for (const RnsIntVec *v : polys) track_read(*v->blk_);
+            return Src{f.blk_->p + f.off_, f.blk_->parent ? f.blk_->parent : f.blk_};
         }
         std::vector<const u64 *> rows(polys.size());
         std::vector<BlockRef> holds(polys.size());
@@ -824,6 +917,195 @@ Src gather(std::initializer_list<const RnsIntVec *> polys, size_t limbs) {
     }
 #endif
     return Src{tmp->p, tmp};
+}
+
+
+// ---- deferred execution: running the queue -----------------------------------------------------------------------------------
+bool deferred() { return op_queue().on; }
+
+namespace {
+
+// operand polynomials [first, first + count) of every call of a group as u64[B][count][in_limbs][N]: their own words when they
+// already lie like that, otherwise one gather kernel
+Src group_rows(const std::vector<PendingOp *> &g, size_t first, size_t count, size_t n) {
+    const size_t w = g[0]->in_limbs * n;
+    const u64 *base = words_of(g[0]->in[first].first) + g[0]->in[first].second;
+    bool packed = true;
+    std::vector<const u64 *> rows;
+    rows.reserve(g.size() * count);
+    for (size_t b = 0; b < g.size(); b++)
+        for (size_t c = 0; c < count; c++) {
+            const auto &r = g[b]->in[first + c];
+            const u64 *p = words_of(r.first) + r.second;
+            track_read(*r.first);
+            packed = packed && p == base + (b * count + c) * w;
+            rows.push_back(p);
+        }
+    if (packed) return Src{base, nullptr};   // (the calls of the group hold their operand blocks until the group has been enqueued)
+    BlockRef tmp = alloc_block(rows.size() * w);
+    track_write(*tmp);
+    check(hp_dev_gather_rows(cur(), rows.size(), w, rows.data(), tmp->p));
+    return Src{tmp->p, tmp};
+}
+
+void run_group(const std::vector<PendingOp *> &g) {
+    const PendingOp &o = *g[0];
+    const size_t B = g.size(), n = (size_t)1 << o.logn, L = o.L;
+    BlockRef big = alloc_block(B * o.out_words);
+    track_write(*big);
+    switch (o.kind) {
+    case OpKind::MultLow: {
+        Src d1 = group_rows(g, 0, 2, n), d2 = group_rows(g, 2, 2, n);
+        check(hp_dev_mult_low_level(cur(), o.logn, L, o.mod.data(), B, d1.p, d2.p, big->p));
+        break;
+    }
+    case OpKind::Relin: {
+        Src dq = group_rows(g, 0, 3, n);
+        track_read(*o.key);
+        if (o.bgv) check(hp_dev_bgv_relinearize(cur(), o.logn, L, o.mod.data(), 1 /* bgv.h:32 */, B, dq.p, o.key->p, big->p));
+        else check(hp_dev_ckks_relinearize_at(cur(), o.logn, L, o.L0, o.mod.data(), B, dq.p, o.key->p, big->p));
+        break;
+    }
+    case OpKind::KeySwitch: {
+        Src dc = group_rows(g, 0, 2, n);
+        track_read(*o.key);
+        if (o.conj) check(hp_dev_ckks_conjugate_at(cur(), o.logn, L, o.L0, o.mod.data(), B, dc.p, o.key->p, big->p));
+        else check(hp_dev_ckks_rotate_at(cur(), o.logn, L, o.L0, o.mod.data(), B, o.step, dc.p, o.key->p, big->p));
+        break;
+    }
+    case OpKind::Drop: {
+        Src dc = group_rows(g, 0, 2, n);
+        if (o.bgv) check(hp_dev_bgv_mod_switch(cur(), o.logn, L, o.mod.data(), o.t, B, dc.p, big->p));
+        else check(hp_dev_ckks_rescale(cur(), o.logn, L, o.mod.data(), B, dc.p, big->p));
+        break;
+    }
+    case OpKind::AddSub: {
+        Src da = group_rows(g, 0, 2, n), db = group_rows(g, 2, 2, n);
+        if (o.sub) check(hp_dev_poly_sub(cur(), n, L, o.mod.data(), 2 * B, da.p, db.p, big->p));
+        else check(hp_dev_poly_add(cur(), n, L, o.mod.data(), 2 * B, da.p, db.p, big->p));
+        break;
+    }
+    }
+    for (size_t b = 0; b < B; b++) {   // the placeholders become views of the block the batch filled
+        DevBlock &ph = *g[b]->out;
+        ph.p = big->p + b * o.out_words;
+        ph.parent = big;
+        ph.op = nullptr;
+        g[b]->done = true;
+    }
+    g_stats.deferred_groups++;
+    g_stats.deferred_calls += B;
+}
+
+// The fused pipeline: a group of mult_low_level calls every one of which feeds exactly one recorded relinearize whose result feeds
+// exactly one recorded rescale_inplace / mod_switch_inplace, with NOBODY else holding the intermediate results (the tensor product
+// of an inline ckks::mult dies inside it, the relinearised ciphertext was rebound by the in-place drop): that is ckks::mult +
+// rescale_inplace in a loop, and it runs as the engine's one-call pipeline (hp_dev_ckks_mult_relin_rescale: no quadratic or
+// intermediate ciphertexts in HBM, at level A the two drops as one transform) -- same words as the three separate calls.
+// Returns the calls of the group that were NOT part of such a triple (they run as an ordinary group).
+std::vector<PendingOp *> run_fused_mults(const std::vector<std::unique_ptr<PendingOp>> &ops, const std::vector<PendingOp *> &g_all) {
+    if (g_all[0]->kind != OpKind::MultLow) return g_all;
+    std::vector<PendingOp *> g, rest;
+    const size_t n = (size_t)1 << g_all[0]->logn, L = g_all[0]->L, w = L * n;
+    std::vector<PendingOp *> relin, drop;
+    auto consumer_of = [&](const BlockRef &ph, OpKind kind, size_t polys) -> PendingOp * {
+        if ((size_t)ph.use_count() != 1 + polys) return nullptr;   // the producer's handle + the consumer's operand entries, nothing else
+        for (auto &o : ops) {
+            if (o->done || o->kind != kind || o->in.size() != polys) continue;
+            bool all = true;
+            for (size_t h = 0; h < polys && all; h++) all = o->in[h].first == ph && o->in[h].second == h * w;
+            if (all) return o.get();
+        }
+        return nullptr;
+    };
+    for (PendingOp *m : g_all) {
+        PendingOp *r = consumer_of(m->out, OpKind::Relin, 3);
+        PendingOp *d = (r && r->L == L && (!r->bgv || r->L0 == L)) ? consumer_of(r->out, OpKind::Drop, 2) : nullptr;
+        const bool ok = d && d->L == L && d->bgv == r->bgv && (relin.empty() || (r->same_signature(*relin[0]) && d->same_signature(*drop[0])));
+        if (!ok) {
+            rest.push_back(m);
+            continue;
+        }
+        g.push_back(m);
+        relin.push_back(r);
+        drop.push_back(d);
+    }
+    if (g.empty()) return rest;
+    const PendingOp &r0 = *relin[0], &d0 = *drop[0];
+    const size_t B = g.size();
+    BlockRef big = alloc_block(B * d0.out_words);
+    track_write(*big);
+    Src d1 = group_rows(g, 0, 2, n), d2 = group_rows(g, 2, 2, n);
+    track_read(*r0.key);
+    if (r0.bgv) check(hp_dev_bgv_mult_relin_modswitch(cur(), r0.logn, L, r0.mod.data(), d0.t, B, d1.p, d2.p, r0.key->p, big->p));
+    else check(hp_dev_ckks_mult_relin_rescale_at(cur(), r0.logn, L, r0.L0, r0.mod.data(), B, d1.p, d2.p, r0.key->p, big->p));
+    for (size_t b = 0; b < B; b++) {
+        DevBlock &ph = *drop[b]->out;
+        ph.p = big->p + b * d0.out_words;
+        ph.parent = big;
+        ph.op = nullptr;
+        for (PendingOp *o : {g[b], relin[b]}) {   // never materialised, and nobody can ask: see above
+            o->out->op = nullptr;
+            o->out->failed = true;
+            o->done = true;
+        }
+        drop[b]->done = true;
+    }
+    g_stats.deferred_groups++;
+    g_stats.deferred_calls += 3 * B;
+    g_stats.deferred_fused += B;
+    return rest;
+}
+
+} // namespace
+
+// Run everything that has been recorded: repeatedly take the oldest call that has not run (its operands are ready: whatever
+// produced them was recorded earlier) and every later call with the same signature whose operands are ready too, as one batch.
+void flush_all() {
+    OpQueue &Q = op_queue();
+    if (Q.flushing || Q.ops.empty()) return;
+    Q.flushing = true;
+    std::vector<std::unique_ptr<PendingOp>> ops;
+    ops.swap(Q.ops);
+    try {
+        OpScope scope({}, 0);   // (batches run on lane 0)
+        size_t first = 0;
+        while (first < ops.size()) {
+            if (ops[first]->done) { first++; continue; }
+            std::vector<PendingOp *> g{ops[first].get()};
+            for (size_t j = first + 1; j < ops.size(); j++)
+                if (!ops[j]->done && ops[j]->same_signature(*g[0]) && ops[j]->ready()) g.push_back(ops[j].get());
+            g = run_fused_mults(ops, g);
+            if (!g.empty()) run_group(g);
+        }
+    } catch (...) {
+        for (auto &o : ops)
+            if (!o->done) { o->out->op = nullptr; o->out->failed = true; }   // their results throw when somebody asks for words
+        Q.flushing = false;
+        throw;
+    }
+    Q.flushing = false;
+}
+
+// record a call: returns the placeholder of its result words
+BlockRef record(std::unique_ptr<PendingOp> op) {
+    OpQueue &Q = op_queue();
+    BlockRef ph(new DevBlock, [](DevBlock *b) { delete b; });
+    ph->words = op->out_words;
+    ph->op = op.get();
+    op->out = ph;
+    Q.ops.push_back(std::move(op));
+    if (Q.ops.size() >= OpQueue::MAX_PENDING) flush_all();
+    return ph;
+}
+
+void set_deferred(bool on) {
+#ifdef HEHUB_AMD_BIND_REFERENCE
+    (void)on;
+#else
+    if (!on) flush_all();
+    op_queue().on = on;
+#endif
 }
 
 } // namespace amd
@@ -1050,6 +1332,7 @@ public:
         cache.emplace_back(std::move(sig), own_);
     }
     const u64 *p() const { return own_->p; }
+    const amd::BlockRef &block() const { return own_; }
 
 private:
     static void assemble(u64 *dst, const RgswCt &rgsw, size_t L, size_t n) {
@@ -1067,6 +1350,21 @@ private:
     }
     amd::BlockRef own_;
 };
+
+#ifndef HEHUB_AMD_BIND_REFERENCE
+// deferred mode: a recorded call over the given operand polynomials (host words are uploaded now, placeholders stay placeholders)
+std::unique_ptr<amd::PendingOp> new_op(amd::OpKind kind, size_t logn, size_t L, const std::vector<u64> &mod,
+                                       std::initializer_list<const RnsIntVec *> operands, size_t in_limbs, size_t out_words) {
+    std::unique_ptr<amd::PendingOp> op(new amd::PendingOp);
+    op->kind = kind; op->logn = logn; op->L = L; op->L0 = L; op->mod = mod; op->in_limbs = in_limbs; op->out_words = out_words;
+    for (const RnsIntVec *v : operands) op->in.push_back(Access::ref(*v));
+    return op;
+}
+// the polynomials of a recorded call's result: views [h * limbs * N, ..) of its placeholder
+template <class Polys> void bind_placeholder(Polys &polys, size_t count, const amd::BlockRef &ph, size_t limbs, size_t n) {
+    for (size_t h = 0; h < count; h++) Access::bind_block(polys[h], ph, h * limbs * n);
+}
+#endif
 
 // the two polynomials of a result ciphertext as views of the block an engine call filled: [2][L][N]
 RlweCt make_ct(size_t n, size_t L, const std::vector<u64> &moduli, const Dst &d) {
@@ -1087,6 +1385,18 @@ RlweCt relinearize_common(const std::array<RnsPolynomial, 3> &quad, const RlweKs
     const size_t L0 = check_ext_prod(quad[2], key, mext);
     const size_t n = quad[2].dimension(), L = quad[2].component_count();
     if (bgv && L0 != L) throw std::invalid_argument("Inconsistent RGSW ciphertext.");   // no higher-level keys for the BGV quirk path
+#ifndef HEHUB_AMD_BIND_REFERENCE
+    if (amd::deferred()) {
+        OpScope scope({}, 0);
+        DevKey dk(key, L0, n);
+        auto rec = new_op(amd::OpKind::Relin, quad[2].log_dimension(), L, mext, {&quad[0], &quad[1], &quad[2]}, L, 2 * L * n);
+        rec->L0 = L0; rec->bgv = bgv; rec->key = dk.block();
+        std::vector<u64> q(mext.begin(), mext.begin() + L);
+        RlweCt ct{result_poly(n, L, q, PolyRepForm::value), result_poly(n, L, q, PolyRepForm::value)};
+        bind_placeholder(ct, 2, amd::record(std::move(rec)), L, n);
+        return ct;
+    }
+#endif
     OpScope op({Access::home(quad[0]), Access::home(quad[1]), Access::home(quad[2])});
     DevKey dk(key, L0, n);
     Src dq = amd::gather({&quad[0], &quad[1], &quad[2]}, L);
@@ -1109,6 +1419,16 @@ template <class Quad, class Ct> Quad mult_low_level_common(const Ct &ct1, const 
     std::vector<u64> m1(ct1[0].modulus_vec()), m2(ct2[0].modulus_vec());
     m1.resize(L); m2.resize(L);
     if (m1 != m2) throw std::invalid_argument("Operands' moduli mismatch.");
+#ifndef HEHUB_AMD_BIND_REFERENCE
+    if (amd::deferred()) {
+        OpScope scope({}, 0);
+        auto rec = new_op(amd::OpKind::MultLow, ct1[0].log_dimension(), L, m1, {&ct1[0], &ct1[1], &ct2[0], &ct2[1]}, L, 3 * L * n);
+        Quad quad;
+        for (int h = 0; h < 3; h++) quad[h] = result_poly(n, L, m1, PolyRepForm::value);
+        bind_placeholder(quad, 3, amd::record(std::move(rec)), L, n);
+        return quad;
+    }
+#endif
     // (a ciphertext with more limbs than L does not lie as [2][L][N]: gather() then copies the first L limbs of each half)
     OpScope op({Access::home(ct1[0]), Access::home(ct1[1]), Access::home(ct2[0]), Access::home(ct2[1])});
     Src d1 = amd::gather({&ct1[0], &ct1[1]}, L);
@@ -1135,6 +1455,19 @@ template <class Quad, class Ct> Quad mult_low_level_common(const Ct &ct1, const 
 void drop_last_prime(RlweCt &ct, bool bgv, u64 t) {
     check_ct_wellformed(ct);
     const size_t n = ct[0].dimension(), L = ct[0].component_count(), logn = ct[0].log_dimension();
+#ifndef HEHUB_AMD_BIND_REFERENCE
+    if (amd::deferred()) {
+        OpScope scope({}, 0);
+        auto rec = new_op(amd::OpKind::Drop, logn, L, ct[0].modulus_vec(), {&ct[0], &ct[1]}, L, 2 * (L - 1) * n);
+        rec->bgv = bgv; rec->t = t;
+        const amd::BlockRef ph = amd::record(std::move(rec));
+        for (int h = 0; h < 2; h++) {
+            ct[h].remove_components();
+            Access::bind_block(ct[h], ph, (size_t)h * (L - 1) * n);
+        }
+        return;
+    }
+#endif
     OpScope op({Access::home(ct[0]), Access::home(ct[1])});
     Src din = amd::gather({&ct[0], &ct[1]}, L);
     Dst dout(2 * (L - 1) * n);
@@ -1353,6 +1686,16 @@ static RlweCt addsub(const RlweCt &a, const RlweCt &b, bool sub) {
     const size_t n = a[0].dimension();
     const bool same = L[0] == L[1] && L[0] > 0 && a[1].dimension() == n && a[0].modulus_vec() == a[1].modulus_vec() &&
                       b[0].component_count() == L[0] && b[1].component_count() == L[0];
+    if (same && amd::deferred()) {
+        OpScope scope({}, 0);
+        size_t lg = 0;
+        while (((size_t)1 << lg) < n) lg++;
+        auto rec = new_op(amd::OpKind::AddSub, lg, L[0], a[0].modulus_vec(), {&a[0], &a[1], &b[0], &b[1]}, L[0], 2 * L[0] * n);
+        rec->sub = sub;
+        RlweCt r{result_poly(n, L[0], a[0].modulus_vec(), a[0].rep_form), result_poly(n, L[0], a[1].modulus_vec(), a[1].rep_form)};
+        bind_placeholder(r, 2, amd::record(std::move(rec)), L[0], n);
+        return r;
+    }
     OpScope op({Access::home(a[0]), Access::home(a[1]), Access::home(b[0]), Access::home(b[1])});
     if (!same) return sub ? RlweCt{a[0] - b[0], a[1] - b[1]} : RlweCt{a[0] + b[0], a[1] + b[1]};
     Src sa = amd::gather({&a[0], &a[1]}, L[0]), sb = amd::gather({&b[0], &b[1]}, L[0]);
@@ -1522,6 +1865,19 @@ static CkksCt key_switched(const CkksCt &ct, const RlweKsk &key, bool conj, size
     const size_t L0 = check_ext_prod(ct[1], key, mext);
     const size_t n = ct[1].dimension(), L = ct[1].component_count(), logn = ct[1].log_dimension();
     if (ct[0].dimension() != n || ct[0].component_count() != L) throw std::invalid_argument("Ill-formed ciphertext.");
+#ifndef HEHUB_AMD_BIND_REFERENCE
+    if (amd::deferred()) {
+        OpScope scope({}, 0);
+        DevKey dk(key, L0, n);
+        auto rec = new_op(amd::OpKind::KeySwitch, logn, L, mext, {&ct[0], &ct[1]}, L, 2 * L * n);
+        rec->L0 = L0; rec->conj = conj; rec->step = conj ? 0 : step; rec->key = dk.block();
+        std::vector<u64> q(mext.begin(), mext.begin() + L);
+        CkksCt r(RlweCt{result_poly(n, L, q, PolyRepForm::value), result_poly(n, L, q, PolyRepForm::value)});
+        bind_placeholder(r, 2, amd::record(std::move(rec)), L, n);
+        r.scaling_factor = ct.scaling_factor;
+        return r;
+    }
+#endif
     OpScope op({Access::home(ct[0]), Access::home(ct[1])});
     DevKey dk(key, L0, n);
     Src dct = amd::gather({&ct[0], &ct[1]}, L);

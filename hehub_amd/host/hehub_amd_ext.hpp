@@ -41,6 +41,9 @@ struct TransferStats {
     unsigned long long device_copies_invalidated = 0;
     // device-side waits between lanes (one event each): how often a call depended on a call that ran on another lane
     unsigned long long lane_waits = 0;
+    // deferred mode: recorded calls that have run, and the batched engine calls they ran as
+    // (deferred_fused: ckks::mult + rescale_inplace / bgv mult + mod_switch_inplace triples that ran as the engine's one-call pipeline)
+    unsigned long long deferred_calls = 0, deferred_groups = 0, deferred_fused = 0;
 };
 TransferStats transfer_stats();
 
@@ -49,7 +52,16 @@ TransferStats transfer_stats();
 /// one stream.  The binding build (hehub's own host-memory objects) always has one.  set_lanes() drains the device first.
 int lanes();
 void set_lanes(int n);
-/// wait until everything the layer has enqueued so far has run (hehub's interface has no such call: its functions are synchronous;
+/// Deferred mode (own-mirror build; default off, HEHUB_AMD_DEFER=1 in the environment turns it on): the scheme-level calls of hehub's
+/// interface -- mult_low_level, relinearize, mult, rotate, conjugate, rescale_inplace, mod_switch_inplace, add / sub of ciphertexts --
+/// are RECORDED with all their argument checks made and their result objects returned; they run when somebody needs words (a look at
+/// a result, a call that cannot be recorded, synchronize(), 1024 recorded calls), grouped: recorded calls with one signature whose
+/// operands are ready run as ONE batched engine call.  An unchanged loop over independent ciphertexts thereby gets the batch rate
+/// (hehub.cpp "deferred execution").  Results are word for word those of the eager calls; a failure inside the engine surfaces when
+/// the queue runs instead of at the call.  set_deferred(false) runs what is pending.
+void set_deferred(bool on);
+bool deferred();
+/// wait until everything the layer has enqueued (or recorded) so far has run (hehub's interface has no such call: its functions are synchronous;
 /// here a result is waited for when somebody looks at its words -- this is for timing loops)
 void synchronize();
 

@@ -730,20 +730,105 @@ static void test_lanes() {
     amd::set_lanes(before);
 }
 
+// deferred mode: the same calls recorded and run as batches -- the words, the argument checks and the object state of the eager calls
+static void test_deferred() {
+    BatchFixture f;
+    const size_t B = f.B;
+    const bool was = amd::deferred();
+    // eager reference: a loop of independent mults + rescale, interleaved chains, an accumulate chain
+    amd::set_deferred(false);
+    std::vector<ckks::CkksCt> e_out, e_chain(f.a.begin(), f.a.end());
+    for (size_t i = 0; i < B; i++) {
+        e_out.push_back(ckks::mult(f.a[i], f.b[i], f.key));
+        ckks::rescale_inplace(e_out.back());
+    }
+    for (int it = 0; it < 2; it++)
+        for (size_t c = 0; c < B; c++) e_chain[c] = ckks::rotate(ckks::mult(e_chain[c], f.b[c], f.key), f.key, 1);
+    ckks::CkksCt e_sum = ckks::mult(f.a[0], f.b[0], f.key);
+    for (size_t i = 1; i < B; i++) {
+        auto p = ckks::mult(f.a[i], f.b[i], f.key);
+        p.scaling_factor = e_sum.scaling_factor;
+        e_sum = ckks::add(e_sum, p);
+    }
+    ckks::CkksCt e_cj = ckks::sub(ckks::conjugate(f.a[1], f.key), f.a[1]);
+    amd::synchronize();
+
+    amd::set_deferred(true);
+    REQUIRE(amd::deferred());
+    const auto st0 = amd::transfer_stats();
+    std::vector<ckks::CkksCt> d_out, d_chain(f.a.begin(), f.a.end());
+    for (size_t i = 0; i < B; i++) {
+        d_out.push_back(ckks::mult(f.a[i], f.b[i], f.key));
+        ckks::rescale_inplace(d_out.back());
+        // object state is there at once, words are not asked for
+        REQUIRE(d_out.back()[0].component_count() == f.L - 1 && d_out.back()[1].modulus_vec().size() == f.L - 1);
+        REQUIRE(d_out.back().scaling_factor == e_out[i].scaling_factor);
+    }
+    REQUIRE(amd::transfer_stats().deferred_calls == st0.deferred_calls);   // nothing has run yet
+    for (int it = 0; it < 2; it++)
+        for (size_t c = 0; c < B; c++) d_chain[c] = ckks::rotate(ckks::mult(d_chain[c], f.b[c], f.key), f.key, 1);
+    ckks::CkksCt d_sum = ckks::mult(f.a[0], f.b[0], f.key);
+    for (size_t i = 1; i < B; i++) {
+        auto p = ckks::mult(f.a[i], f.b[i], f.key);
+        p.scaling_factor = d_sum.scaling_factor;
+        d_sum = ckks::add(d_sum, p);
+    }
+    ckks::CkksCt d_cj = ckks::sub(ckks::conjugate(f.a[1], f.key), f.a[1]);
+    // the argument checks of the single calls are made when the call is recorded
+    auto coeff = f.a[0];
+    coeff[1].rep_form = PolyRepForm::coeff;
+    REQUIRE_THROWS_AS(ckks::mult(coeff, f.b[0], f.key), std::invalid_argument);
+    REQUIRE_THROWS_AS(ckks::rotate(coeff, f.key, 1), std::invalid_argument);
+    REQUIRE_THROWS_AS(ckks::relinearize(ckks::mult_low_level(f.a[0], f.b[0]), RlweKsk()), std::invalid_argument);
+    auto other_scale = f.a[1];
+    other_scale.scaling_factor = 3.0;
+    REQUIRE_THROWS_AS(ckks::add(f.a[1], other_scale), std::invalid_argument);
+    // a look at one word runs the queue; the recorded calls ran as a few batched engine calls
+    REQUIRE(same_words(d_out[B - 1], e_out[B - 1]));
+    const auto st1 = amd::transfer_stats();
+    REQUIRE(st1.deferred_calls - st0.deferred_calls >= 3 * B + 2 * 3 * B);
+    REQUIRE(st1.deferred_groups - st0.deferred_groups < (st1.deferred_calls - st0.deferred_calls) / 2);
+    REQUIRE(st1.deferred_fused - st0.deferred_fused >= B);   // the mult + rescale_inplace loop ran as the engine's one-call pipeline
+    for (size_t i = 0; i < B; i++) {
+        REQUIRE(same_words(d_out[i], e_out[i]));
+        REQUIRE(same_words(d_chain[i], e_chain[i]));
+    }
+    REQUIRE(same_words(d_sum, e_sum) && same_words(d_cj, e_cj));
+    // an eager in-place operator on an operand of a recorded call: the recorded call saw the words as they were
+    ckks::CkksCt x = f.a[2];
+    auto prod = ckks::mult(x, f.b[2], f.key);
+    x[0] *= (u64)3;
+    REQUIRE(same_words(prod, ckks::mult(f.a[2], f.b[2], f.key)));
+    // bgv: mult_low_level + relinearize + mod_switch_inplace
+    bgv::BgvCt ba(RlweCt{f.a[0][0], f.a[0][1]}), bb(RlweCt{f.b[0][0], f.b[0][1]});
+    ba.plain_modulus = bb.plain_modulus = 65537;
+    auto db = bgv::relinearize(bgv::mult_low_level(ba, bb), f.key);
+    bgv::mod_switch_inplace(db);
+    amd::set_deferred(false);   // runs what is pending
+    auto eb = bgv::relinearize(bgv::mult_low_level(ba, bb), f.key);
+    bgv::mod_switch_inplace(eb);
+    REQUIRE(same_words(db, eb) && db.plain_modulus == 65537);
+    amd::set_deferred(was);
+}
+
 int main() {
-    test_batched_barrett();
-    test_batched_mul_mod();
-    test_montgomery();
-    test_ntt();
-    test_rns_polynomial();
-    test_ckks_rescaling();
-    test_scheme_level_vs_oracle();
-    test_plain_ops_and_decrypt_core();
-    test_ragged_operands();
-    test_device_residency();
-    test_parity_level_a();
-    test_batched_forms();
-    test_lanes();
+    struct { const char *name; void (*fn)(); } tests[] = {
+        {"batched_barrett", test_batched_barrett}, {"batched_mul_mod", test_batched_mul_mod}, {"montgomery", test_montgomery},
+        {"ntt", test_ntt}, {"rns_polynomial", test_rns_polynomial}, {"ckks_rescaling", test_ckks_rescaling},
+        {"scheme_level_vs_oracle", test_scheme_level_vs_oracle}, {"plain_ops_and_decrypt_core", test_plain_ops_and_decrypt_core},
+        {"ragged_operands", test_ragged_operands}, {"device_residency", test_device_residency}, {"parity_level_a", test_parity_level_a},
+        {"batched_forms", test_batched_forms}, {"lanes", test_lanes}, {"deferred", test_deferred}};
+    for (auto &t : tests) {
+        try {
+            t.fn();
+        } catch (const std::exception &e) {
+            g_fail++;
+            std::printf("FAIL test %s: unexpected exception: %s\n", t.name, e.what());
+        } catch (...) {
+            g_fail++;
+            std::printf("FAIL test %s: unexpected exception\n", t.name);
+        }
+    }
     std::printf("%s: %d checks, %d failures\n", g_fail ? "FAILED" : "All tests passed", g_checks, g_fail);
     return g_fail ? 1 : 0;
 }

@@ -71,6 +71,28 @@ def test_every_mode_prints_hehubs_words(shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(12, 4, 6), (13, 6, 9)])
+def test_deferred_mode_prints_the_same_words(shape):
+    """HEHUB_AMD_DEFER=1: the scheme-level calls are recorded and run as batches (hehub.cpp "deferred execution") -- every mode of the
+    program must print what the eager run prints"""
+    args = list(shape) + ["all", 2, 8, 3, 2]
+    eager = run(build_example(), args)
+    lazy = run(build_example(), args, {"HEHUB_AMD_DEFER": "1"})
+    for k in ("serial", "batch", "serial-chain", "batch-chain", "chains", "chains-lanes"):
+        assert lazy[k] == eager[k], (k, lazy, eager)
+
+
+@pytest.mark.gpu
+def test_c3_unchanged_loop_in_deferred_mode():
+    """the loop of single calls (hehub's interface as it is) in deferred mode: the recorded mult + rescale_inplace pairs run as the
+    engine's fused batch pipeline -- the batch rate without a source change (24 - 28 k hom-mult/s at B = 256; loose bound here)"""
+    eager = run(build_example(), [15, 10, 64, "serial", 3])
+    lazy = run(build_example(), [15, 10, 64, "serial", 3], {"HEHUB_AMD_DEFER": "1"})
+    assert lazy["serial"] == eager["serial"] and lazy["serial-chain"] == eager["serial-chain"]
+    assert lazy["serial_per_s"] > 12000 and lazy["serial_per_s"] > 2 * eager["serial_per_s"], (lazy, eager)
+
+
+@pytest.mark.gpu
 def test_c3_batched_form_reaches_the_engine_rate():
     """C3 (N = 32768, L = 10) through hehub's types: the batched form must deliver the engine's batch rate (29 k hom-mult/s on an
     MI355X at B = 256, 24 k at the B = 64 used here; the bounds are loose: shared boxes), the loop of single calls is latency-bound

@@ -1,8 +1,18 @@
 #!/bin/bash
 # build here (hipcc cross-compiles), then run a command on the GPU box: tools/gpu.sh <timeout s> '<command>'
-# (a stale in-tree .so would travel to the box and be measured instead of the sources next to it)
+# (a stale in-tree .so or test binary would travel to the box and be measured instead of the sources next to it: the engine, the host
+# layer, the example programs and the C++ test binary are all brought up to date first)
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd $R && python -m hehub_amd.build > /dev/null
+python - <<PY
+import sys
+sys.path.insert(0, "$R"); sys.path.insert(0, "$R/tests")
+from hehub_amd.build import build_example
+for name in ("independent_mults", "resident_chain"):
+    build_example(name)
+import test_host_api
+test_host_api.build_binary()
+PY
 T=$1; shift
 exec /usr/local/graft/bin/gpurun --timeout $T -- "$@"
