@@ -349,6 +349,8 @@ def main() -> int:
               f"visible (no CPU fallback)", file=sys.stderr)
         return 2
     torch.cuda.set_device(local)
+    cpus_all = os.sched_getaffinity(0)
+    placement = bhost.bind_to_gpu_numa(local)   # this rank's process on the socket of its GPU (two sockets x four GPUs on an MI355X node)
     rccl_info = {"initialised": False}
     if share_gpu:
         hd.init("gloo")
@@ -451,8 +453,10 @@ def main() -> int:
     res["chip"] = dict(chip.sections, source="amdgpu hwmon sysfs (sclk freq1_input, socket power1_input), sampled every 4 ms by a thread of this process"
                        if chip.dir else "no amdgpu hwmon files visible: not sampled")
     res["cpu_model"] = cpu_model()
+    res["placement"] = placement
     chip.close()
     if rank == 0:
+        os.sched_setaffinity(0, cpus_all)   # the CPU baselines below use whatever cores the host gives, as before
         if world == 1 and extras and not args.no_cpu_baseline:
             cwl = wl.cpu_name
             try:

@@ -310,5 +310,33 @@ def object_api_section(run: Run):
     ent["digests"] = dg
     ent["digests_equal"] = bool(dg) and dg.get("serial") == dg.get("batch") and dg.get("serial-chain") == dg.get("batch-chain") and \
         dg.get("chains") == dg.get("chains-lanes")
-    ent["verified"] = ent["digests_equal"]
+    # the same program, unchanged, in deferred mode (HEHUB_AMD_DEFER=1: calls are recorded and run as batches, hehub.cpp)
+    t0 = time.perf_counter()
+    out2 = subprocess.run([build_example("independent_mults")] + [str(a) for a in shape + ["all", 3, 1, 8, 6]], capture_output=True,
+                          text=True, timeout=600, cwd=root, env=dict(os.environ, HEHUB_AMD_DEFER="1"))
+    de = {"wall_s": round(time.perf_counter() - t0, 1), "what": "HEHUB_AMD_DEFER=1: the scheme-level calls are recorded and run grouped as batched "
+          "engine calls when somebody needs words; mult + rescale_inplace triples as the fused one-call pipeline"}
+    dg2 = {}
+    if out2.returncode == 0:
+        for line in out2.stdout.splitlines():
+            m = re.match(r"([\w-]+) digest (\w+)", line)
+            if m:
+                dg2[m.group(1)] = m.group(2)
+            m = re.match(r"serial ([\d.]+) ms per hom-mult \((\d+) hom-mult/s\)", line)
+            if m:
+                de["single_calls"] = {"per_s": float(m.group(2)), "ms_per_hom_mult": float(m.group(1))}
+            m = re.match(r"chains (\d+) x (\d+) mult\+rotate: ([\d.]+) ms per step on 1 lane", line)
+            if m:
+                de["independent_chains_ms_per_step"] = float(m.group(3))
+                if "independent_chains" in ent:
+                    de["independent_chains_speedup_vs_eager_1_lane"] = ent["independent_chains"]["ms_per_step_1_lane"] / float(m.group(3))
+            m = re.match(r"deferred: (\d+) recorded calls ran as (\d+) batched engine calls \((\d+) ", line)
+            if m:
+                de.update({"recorded_calls": int(m.group(1)), "batched_engine_calls": int(m.group(2)), "fused_triples": int(m.group(3))})
+        de["digests_equal_eager"] = all(dg2.get(k) == dg.get(k) for k in ("serial", "serial-chain", "batch", "batch-chain", "chains"))
+    else:
+        de["error"] = (out2.stdout[-300:] + out2.stderr[-300:])
+        de["digests_equal_eager"] = False
+    ent["deferred"] = de
+    ent["verified"] = ent["digests_equal"] and de["digests_equal_eager"]
     return ent

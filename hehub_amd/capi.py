@@ -98,6 +98,8 @@ SIGNATURES = {
     "hp_node_ctx": (P, [P, szt]),
     "hp_node_set_parity_level": (INT, [P, INT]),
     "hp_node_last_error": (C.c_char_p, [P]),
+    "hp_node_placement": (INT, [P, szt, P, P]),
+    "hp_device_numa": (INT, [INT, P, P, szt]),
     "hp_node_peer_matrix": (INT, [P, P]),
     "hp_node_slice": (INT, [P, szt, szt, C.POINTER(szt), C.POINTER(szt)]),
     "hp_node_sync": (INT, [P]),

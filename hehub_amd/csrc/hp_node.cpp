@@ -19,11 +19,15 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
 #include <thread>
+
+#include <pthread.h>
+#include <sched.h>
 
 using namespace hpi;
 
@@ -58,7 +62,57 @@ struct Staging {
     size_t bytes[3] = {0, 0, 0};
 };
 
+// ---- NUMA placement -------------------------------------------------------------------------------------------------------------
+// An 8-GPU MI355X node has two sockets with four GPUs each; a rank's host thread (launches, staging copies of host-resident batches,
+// page-locked buffers it allocates) belongs on the socket its GPU hangs off: PCI address of the HIP device -> sysfs numa_node ->
+// the node's cpulist.  -1 / empty where the platform does not say (one-socket boxes, containers without sysfs).
+int device_numa(int device, std::string *cpulist) {
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, sizeof(bdf), device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char *c = bdf; *c; ++c) *c = (char)tolower(*c);
+    char path[256];
+    std::snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+    int node = -1;
+    if (FILE *f = std::fopen(path, "r")) {
+        if (std::fscanf(f, "%d", &node) != 1) node = -1;
+        std::fclose(f);
+    }
+    if (node >= 0 && cpulist) {
+        std::snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+        if (FILE *f = std::fopen(path, "r")) {
+            char buf[1024] = {0};
+            if (std::fgets(buf, sizeof(buf), f)) {
+                cpulist->assign(buf);
+                while (!cpulist->empty() && (cpulist->back() == '\n' || cpulist->back() == ' ')) cpulist->pop_back();
+            }
+            std::fclose(f);
+        }
+    }
+    return node;
+}
+// "0-3,8,10-11" -> cpu set, intersected with what the process may use; the number of CPUs in the result
+int parse_cpulist(const std::string &list, cpu_set_t *out) {
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return 0;
+    CPU_ZERO(out);
+    const char *p = list.c_str();
+    int count = 0;
+    while (*p) {
+        char *end = nullptr;
+        long a = std::strtol(p, &end, 10), b = a;
+        if (end == p) break;
+        if (*end == '-') { p = end + 1; b = std::strtol(p, &end, 10); }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (c >= 0 && CPU_ISSET((int)c, &allowed)) { CPU_SET((int)c, out); count++; }
+        p = (*end == ',') ? end + 1 : end;
+        if (*end != ',' ) break;
+    }
+    return count;
+}
+
 struct Worker {
+    int numa_node = -1, cpus_bound = 0;   // where the thread was put (hp_node_placement)
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
@@ -88,7 +142,17 @@ struct hp_node {
 
 namespace {
 
-void worker_loop(Worker *w) {
+void worker_loop(Worker *w, int device) {
+    // the rank's thread runs on the socket of its GPU (HP_NODE_NO_AFFINITY: leave it where the scheduler puts it)
+    if (!getenv("HP_NODE_NO_AFFINITY")) {
+        std::string cpus;
+        w->numa_node = device_numa(device, &cpus);
+        cpu_set_t set;
+        if (w->numa_node >= 0 && !cpus.empty()) {
+            const int n = parse_cpulist(cpus, &set);
+            if (n > 0 && pthread_setaffinity_np(pthread_self(), sizeof(set), &set) == 0) w->cpus_bound = n;
+        }
+    }
     for (;;) {
         std::function<int()> task;
         {
@@ -222,7 +286,7 @@ int hp_node_create(const int *devices, size_t count, hp_node **out) {
     for (size_t r = 0; r < count; r++) {
         node->workers.emplace_back(new Worker());
         Worker *w = node->workers.back().get();
-        w->th = std::thread(worker_loop, w);
+        w->th = std::thread(worker_loop, w, devices[r]);
     }
     *out = node;
     return HP_OK;
@@ -246,6 +310,21 @@ void hp_node_destroy(hp_node *node) {
 }
 
 size_t hp_node_size(const hp_node *node) { return node ? node->ctx.size() : 0; }
+int hp_node_placement(const hp_node *node, size_t rank, int *numa_node, int *cpus_bound) {
+    if (!node || rank >= node->workers.size()) return HP_EINVAL;
+    if (numa_node) *numa_node = node->workers[rank]->numa_node;
+    if (cpus_bound) *cpus_bound = node->workers[rank]->cpus_bound;
+    return HP_OK;
+}
+int hp_device_numa(int device, int *numa_node, char *cpulist, size_t cap) {
+    std::string cpus;
+    const int node = device_numa(device, &cpus);
+    if (numa_node) *numa_node = node;
+    if (cpulist && cap) {
+        std::snprintf(cpulist, cap, "%s", cpus.c_str());
+    }
+    return HP_OK;
+}
 hp_ctx *hp_node_ctx(hp_node *node, size_t rank) { return (node && rank < node->ctx.size()) ? node->ctx[rank] : nullptr; }
 const char *hp_node_last_error(hp_node *node) { return node ? node->err.c_str() : "null node"; }
 // parity level of every rank's context (hp_ctx_set_parity_level): the batch-sharded entry points then return canonical residues;

@@ -336,6 +336,13 @@ const char *hp_node_last_error(hp_node *node);   /* "rank r: <message of that ra
  * page-locked host memory where it cannot (sender: one device-to-host copy of its block; receiver: host-to-device after the
  * rendezvous).  HP_NODE_NO_PEER in the environment at hp_node_create forces 0 for every pair a != b (tests / debugging). */
 int hp_node_peer_matrix(const hp_node *node, int *matrix);
+/* NUMA placement: every rank's worker thread is bound to the CPUs of the socket its GPU hangs off (PCI address of the HIP device ->
+ * sysfs numa_node -> that node's cpulist, intersected with the process's affinity mask; HP_NODE_NO_AFFINITY in the environment at
+ * hp_node_create leaves the threads alone).  hp_node_placement reports what was done for a rank (numa_node -1 / cpus_bound 0: the
+ * platform does not say, nothing was bound); hp_device_numa is the lookup itself, for a process that places its own ranks
+ * (bench.py binds each rank's process the same way). */
+int hp_node_placement(const hp_node *node, size_t rank, int *numa_node, int *cpus_bound);
+int hp_device_numa(int device, int *numa_node, char *cpulist, size_t cap);
 int hp_node_slice(const hp_node *node, size_t total, size_t rank, size_t *lo, size_t *hi);
 int hp_node_sync(hp_node *node);
 /* copy a read-only host object (a key-switching key) to every rank: d_copies[rank] receives the device pointers */

@@ -68,3 +68,26 @@ def test_roofline_arithmetic():
     assert abs(e["per_s"] - 5120 * 2 * 10 / 10e-3) < 1e-6 and abs(e["avg_launch_ms"] - 0.9) < 1e-12
     assert abs(e["frac_of_hbm_peak"] - 5120 * 16.0 * n / 0.9e-3 / 1e9 / 8000.0) < 1e-12
     assert "achieved_GBps" not in rate_entry(1, 1.0, 1, 1, 1.0, 0, 0.0)
+
+
+def test_rank_placement_on_the_gpus_numa_node():
+    """benchkit/host.py: a bench rank binds itself to the CPUs of its GPU's NUMA node (sysfs lookup injected here); a platform that
+    does not say (-1 / empty) or HP_BENCH_NO_AFFINITY leaves the affinity mask alone"""
+    import os
+
+    from benchkit.host import bind_to_gpu_numa, parse_cpulist
+
+    assert parse_cpulist("0-3,8,10-11") == {0, 1, 2, 3, 8, 10, 11} and parse_cpulist("") == set()
+    before = os.sched_getaffinity(0)
+    try:
+        first = min(before)
+        r = bind_to_gpu_numa(0, lookup=lambda d: (1, f"{first}"))
+        assert r["numa_node"] == 1 and r["cpus_bound"] == 1 and os.sched_getaffinity(0) == {first}
+        os.sched_setaffinity(0, before)
+        assert bind_to_gpu_numa(0, lookup=lambda d: (-1, ""))["cpus_bound"] == 0 and os.sched_getaffinity(0) == before
+        assert bind_to_gpu_numa(0, lookup=lambda d: (0, "100000-100001"))["cpus_bound"] == 0   # CPUs this process may not use: nothing bound
+        os.environ["HP_BENCH_NO_AFFINITY"] = "1"
+        assert "skipped" in bind_to_gpu_numa(0, lookup=lambda d: (0, f"{first}")) and os.sched_getaffinity(0) == before
+    finally:
+        os.environ.pop("HP_BENCH_NO_AFFINITY", None)
+        os.sched_setaffinity(0, before)
