@@ -75,8 +75,9 @@ done
 
 # 5 ---- the C node layer ------------------------------------------------------------------------------------------------------------
 if [ -x examples/node_batch ]; then
-  if [ $TEST_RANKS -gt 1 ]; then examples/node_batch $(python -c "print(' '.join(['0'] * $TEST_RANKS))") > $OUT/node_batch.txt 2>&1
-  else examples/node_batch $(seq -s ' ' 0 $((G - 1))) > $OUT/node_batch.txt 2>&1; fi
+  # node_batch <ranks> <gpus> [logN] [batch]: rank r runs on device r % gpus
+  if [ $TEST_RANKS -gt 1 ]; then examples/node_batch $TEST_RANKS 1 13 16 > $OUT/node_batch.txt 2>&1
+  else examples/node_batch $G $G 15 $((32 * G)) > $OUT/node_batch.txt 2>&1; fi
   tail -5 $OUT/node_batch.txt
 fi
 
