@@ -126,6 +126,9 @@ static int hks_front(hp_ctx *ctx, const Plan *plan, const HpHksConsts *hc, size_
         j.limbs = plan->d_limbs; j.src = lifted; j.dst = lifted; j.logn = (u32)logn; j.L = (u32)L; j.P = (u32)P;
         j.hks_nd = (u32)nd; j.hks_E = (u32)E; j.hks_alpha = (u32)alpha; j.mode = HP_NTT_HKS;
         j.W = (u32)(L * (nd - 1) * P + k * nd * P);
+        // parity level A: the lifted rows are canonical residues (ModUp's exact conversion), the inner product takes any
+        // representative, and hybrid results have no word-level contract with hehub (other keys): the FP64 transform where allowed
+        if (ctx->cur_a) j.limbs_a = plan->d_limbs_a;
         if ((rc = run_ntt(ctx, j))) return rc;
     }
     {
@@ -138,6 +141,7 @@ static int hks_front(hp_ctx *ctx, const Plan *plan, const HpHksConsts *hc, size_
     {
         HpNttJob j = batch_job(plan, logn, k, 2 * P, ks + L * n, yp, E, k, 1, 1);
         j.limbs = plan->d_limbs + L;
+        if (ctx->cur_a) j.limbs_a = plan->d_limbs_a + L;   // (strict either way: the same words)
         if ((rc = run_ntt(ctx, j))) return rc;
     }
     if (k <= HP_HKS_MAX_ALPHA) {
@@ -204,6 +208,8 @@ extern "C" int hp_dev_hks_switch(hp_ctx *ctx, size_t logn, size_t L, size_t k, s
     if ((rc = get_plan(ctx, logn, moduli_ext, L + k, true, &plan))) return rc;
     const HpHksConsts *hc;
     if ((rc = get_hks_consts(ctx, moduli_ext, L, k, alpha, &hc))) return rc;
+    LevelScope lvl(ctx, plan);   // level A: the transforms of the lifted digits and the coefficient rows on the FP64 kernels
+    if (lvl.rc) return lvl.rc;
     const size_t n = (size_t)1 << logn, nd = (L + alpha - 1) / alpha;
     if ((rc = ws_reserve(ctx, hks_ws_words(n, L, k, nd, batch) * 8))) return rc;
     Carver cv(ctx->ws);
@@ -223,6 +229,8 @@ static int dev_hks_automorphism(hp_ctx *ctx, size_t logn, size_t L, size_t k, si
     if ((rc = get_plan(ctx, logn, mext, L + k, true, &plan))) return rc;
     const HpHksConsts *hc;
     if ((rc = get_hks_consts(ctx, mext, L, k, alpha, &hc))) return rc;
+    LevelScope lvl(ctx, plan);
+    if (lvl.rc) return lvl.rc;
     const size_t n = (size_t)1 << logn, nd = (L + alpha - 1) / alpha;
     if ((rc = ws_reserve(ctx, (padded(batch * 2 * L * n) / 8 + hks_ws_words(n, L, k, nd, batch)) * 8))) return rc;
     Carver cv(ctx->ws);
@@ -263,6 +271,8 @@ extern "C" int hp_dev_ckks_mult_relin_rescale_hks(hp_ctx *ctx, size_t logn, size
     if ((rc = get_plan(ctx, logn, moduli_ext, L + k, true, &plan))) return rc;
     const HpHksConsts *hc;
     if ((rc = get_hks_consts(ctx, moduli_ext, L, k, alpha, &hc))) return rc;
+    LevelScope lvl(ctx, plan);
+    if (lvl.rc) return lvl.rc;
     const size_t n = (size_t)1 << logn, nd = (L + alpha - 1) / alpha;
     const size_t words = padded(batch * 3 * L * n) / 8 + padded(batch * 2 * L * n) / 8 + hks_ws_words(n, L, k, nd, batch) +
                          drop_ws_words(n, L, 2 * batch) + 2 * (padded(2 * batch * n) / 8);
@@ -298,6 +308,7 @@ extern "C" int hp_dev_ckks_mult_relin_rescale_hks(hp_ctx *ctx, size_t logn, size
         {
             HpNttJob lj = batch_job(plan, logn, 1, P2, r_last, c_last, 1, 1, 1, 1);
             lj.limbs = plan->d_limbs + (L - 1);
+            if (ctx->cur_a) lj.limbs_a = plan->d_limbs_a + (L - 1);
             if ((rc = run_ntt(ctx, lj))) return rc;
         }
         const bool in_loads = !ctx->hks_combine_kernel;   // HP_HKS_COMBINE_KERNEL: the combination as its own kernel

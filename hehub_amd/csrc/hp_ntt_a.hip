@@ -634,7 +634,8 @@ template <int LOGN> hipError_t launch_inv_mix_a(const HpNttJob &job, const HpInv
 
 template <int LOGN> hipError_t launch_a(const HpNttJob &job, hipStream_t stream) {
     if (!job.inverse) {
-        if (job.mode != HP_NTT_BATCH && job.mode != HP_NTT_SPREAD) return hipErrorNotSupported;
+        // (HP_NTT_HKS: the lifted digits of the hybrid key switch, in place -- canonical residues in, canonical residues out: the plain kernel)
+        if (job.mode != HP_NTT_BATCH && job.mode != HP_NTT_SPREAD && job.mode != HP_NTT_HKS) return hipErrorNotSupported;
         if (job.mode == HP_NTT_SPREAD) k_ntt_fwd_a<LOGN, true><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
         else k_ntt_fwd_a<LOGN, false><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
         return hipGetLastError();

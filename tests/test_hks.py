@@ -248,3 +248,43 @@ def test_merged_and_two_step_hybrid_mult_agree_on_random_shapes(eng, orc, monkey
             assert np.array_equal(a % qa, b % qa), (case, logn, L, k, alpha, B)
     finally:
         two.close()
+
+
+@pytest.mark.parametrize("logn,L,k,alpha", [(11, 4, 2, 2), (12, 5, 1, 3), (13, 6, 3, 3), (15, 3, 2, 2), (11, 2, 9, 1)])
+def test_hybrid_key_switch_at_parity_level_a(eng, orc, logn, L, k, alpha):
+    """Round 5: with hp_ctx_set_parity_level(HP_PARITY_A) the hybrid key switch runs its
+    transforms -- the coefficient rows, the lifted digits (HP_NTT_HKS), the P-part inverse -- on the FP64 residue kernels.  Hybrid
+    results have no word-level contract with hehub (other keys, rgsw.cpp:98-153 is the single-prime scheme); the contract is the
+    exact integer model: same residues, every word a lazy word (< 2q), at both levels."""
+    mext = P.P40[:L] + (P.P50 + P.P40[L:])[:k]
+    n, q = 1 << logn, mext[:L]
+    rng = SplitMix(1700 + logn + L)
+    nd = (L + alpha - 1) // alpha
+    B = 2
+    pt = np.stack([rng.poly((L, n), q) for _ in range(B)])
+    ct1 = rng.poly((B, 2, L, n), q); ct2 = rng.poly((B, 2, L, n), q)
+    key = rng.poly((nd, 2, L + k, n), mext)
+    dk = eng.to_device(key)
+    qa = np.array(q, dtype=U)[None, :, None]
+    res = {}
+    for level in ("B", "A"):
+        eng.set_parity_level(level)
+        try:
+            sw = eng.to_host(eng.hks_switch(mext, k, alpha, eng.to_device(pt), dk))
+            rot = eng.to_host(eng.ckks_rotate_hks(mext, k, alpha, eng.to_device(ct1), dk, 3))
+            mul = eng.to_host(eng.ckks_mult_hks(mext, k, alpha, eng.to_device(ct1), eng.to_device(ct2), dk)) if L >= 2 else None
+            eng.sync()   # (level A: the range guard stays quiet on canonical rows)
+        finally:
+            eng.set_parity_level("B")
+        res[level] = (sw, rot, mul)
+    for i in range(B):
+        model = model_switch(orc, logn, mext, L, k, alpha, pt[i], key)
+        for level in ("B", "A"):
+            got = res[level][0][i]
+            assert (got < 2 * qa).all(), level
+            assert np.array_equal(got % qa, model % qa), (level, i)
+    for a, b, mods in ((res["B"][1], res["A"][1], q), (res["B"][2], res["A"][2], q[:-1])):
+        if a is None:
+            continue
+        m = np.array(mods, dtype=U)[None, None, :, None]
+        assert (b < 2 * m).all() and np.array_equal(a % m, b % m)
