@@ -89,6 +89,7 @@ SIGNATURES = {
     "hp_dev_mult_low_level_range": (INT, [P, szt, szt, P, szt, szt, szt, P, P, P]),
     "hp_dev_ks_coef_range": (INT, [P, szt, szt, P, szt, szt, szt, P, szt, P]),
     "hp_dev_ks_inner_range": (INT, [P, szt, szt, P, szt, szt, szt, P, P, szt, P, P]),
+    "hp_dev_ks_inner_range_strict": (INT, [P, szt, szt, P, szt, szt, szt, P, P, szt, P, P]),
     "hp_dev_drop_coeffs": (INT, [P, szt, szt, P, u64, szt, P, P]),
     "hp_dev_drop_apply_range": (INT, [P, szt, szt, P, u64, szt, szt, szt, P, P, P, szt, szt, C.c_uint, P]),
     "hp_dev_drop_apply_range_strict": (INT, [P, szt, szt, P, u64, szt, szt, szt, P, P, P, szt, szt, C.c_uint, P]),

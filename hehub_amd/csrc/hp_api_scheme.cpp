@@ -63,7 +63,8 @@ static u32 spread_pack_mask(const hp_ctx *ctx, const Plan *plan, size_t logn, si
 // strict_coef: coef was produced by ks_coef in this call (rows are strict residues); false for caller-supplied rows, which are
 // then not trusted to be below their moduli and the digit rows stay plain u64
 int ks_digits_inner(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P, size_t k0, size_t k1, const u64 *coef,
-                    const u64 *pt, size_t pt_pstride, const u64 *key, size_t key_L0, u64 *out, u64 *digits, bool strict_coef) {
+                    const u64 *pt, size_t pt_pstride, const u64 *key, size_t key_L0, u64 *out, u64 *digits, bool strict_coef,
+                    bool coef_words = false) {
     const size_t n = (size_t)1 << logn;
     int rc;
     // (ii) D[j][k] = NTT_{q_k}(c[j]), k != j                       rgsw.cpp:108-119
@@ -79,9 +80,11 @@ int ks_digits_inner(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t
     sj.pack_mask = strict_coef ? spread_pack_mask(ctx, plan, logn, L, P, k0, k1) : 0u;
     // level A: digit rows as residues in [q/2, 3q/2] (the inner product below is the same integer kernel: its u128 sums then differ
     // from rgsw.cpp:126-149's by multiples of q_k, its Montgomery outputs are congruent to the reference's and below 2 q_k).
-    // Caller-supplied coefficient rows (limb-range stages) are not known to be below 2^50: level B.
+    // Caller-supplied coefficient rows (limb-range stages) are not known to be below 2^50: level B -- unless the caller vouches
+    // (hp_dev_ks_inner_range_strict: the rows were written by hp_dev_ks_coef_range, strict residues).
     if (ctx->cur_a && strict_coef) {
         sj.limbs_a = plan->d_limbs_a;
+        sj.src_words = coef_words ? 1u : 0u;   // rows of this call's own ks_coef are doubles; rows a caller hands in are words
         // ... and, where q_k + 2 <= 2^40, as 5 bytes per word (HP_PACK40, hp_device.h): same preconditions as the 48-bit rows
         if (!ctx->no_pack40)
             for (size_t k = k0; k < k1; k++)
@@ -651,11 +654,13 @@ int hp_dev_ks_coef_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *mod
     if (j0 == j1) return HP_OK;
     const Plan *plan;
     if ((rc = get_plan(ctx, logn, moduli_ext, L + 1, true, &plan))) return rc;
+    LevelScope lvl(ctx, plan);   // (strict residues at either level: the same words)
+    if (lvl.rc) return lvl.rc;
     return ks_coef(ctx, plan, logn, L, batch, j0, j1, pt, pt_pstride, coef);
 }
 
-int hp_dev_ks_inner_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch, size_t k0, size_t k1,
-                          const uint64_t *coef, const uint64_t *pt, size_t pt_pstride, const uint64_t *key, uint64_t *out) {
+static int ks_inner_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch, size_t k0, size_t k1,
+                          const uint64_t *coef, bool coef_strict, const uint64_t *pt, size_t pt_pstride, const uint64_t *key, uint64_t *out) {
     HP_ENTER(ctx);
     HP_REQUIRE(ctx, moduli_ext, coef, pt, key, out);
     HP_ALIGNED(ctx, coef, pt, key, out);
@@ -668,7 +673,18 @@ int hp_dev_ks_inner_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *mo
     if ((rc = ws_reserve(ctx, padded(batch * L * (L + 1) * n)))) return rc;
     Carver cv(ctx->ws);
     u64 *digits = cv.take(batch * L * (L + 1) * n);
-    return ks_digits_inner(ctx, plan, logn, L, batch, k0, k1, coef, pt, pt_pstride, key, L, out, digits, false);
+    if (!coef_strict) return ks_digits_inner(ctx, plan, logn, L, batch, k0, k1, coef, pt, pt_pstride, key, L, out, digits, false);
+    LevelScope lvl(ctx, plan);   // strict rows: packed digit rows, and the FP64 digit spread (from words) when the context is at level A
+    if (lvl.rc) return lvl.rc;
+    return ks_digits_inner(ctx, plan, logn, L, batch, k0, k1, coef, pt, pt_pstride, key, L, out, digits, true, true);
+}
+int hp_dev_ks_inner_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch, size_t k0, size_t k1,
+                          const uint64_t *coef, const uint64_t *pt, size_t pt_pstride, const uint64_t *key, uint64_t *out) {
+    return ks_inner_range(ctx, logn, L, moduli_ext, batch, k0, k1, coef, false, pt, pt_pstride, key, out);
+}
+int hp_dev_ks_inner_range_strict(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch, size_t k0, size_t k1,
+                                 const uint64_t *coef, const uint64_t *pt, size_t pt_pstride, const uint64_t *key, uint64_t *out) {
+    return ks_inner_range(ctx, logn, L, moduli_ext, batch, k0, k1, coef, true, pt, pt_pstride, key, out);
 }
 
 int hp_dev_drop_coeffs(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, uint64_t plain_modulus, size_t P2,
@@ -682,6 +698,8 @@ int hp_dev_drop_coeffs(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *modul
     const Plan *plan;
     int rc = get_plan(ctx, logn, moduli, L, true, &plan);
     if (rc) return rc;
+    LevelScope lvl(ctx, plan);   // (strict residues at either level: the same words)
+    if (lvl.rc) return lvl.rc;
     return drop_coeffs(ctx, plan, logn, L, P2, plain_modulus != 0, plain_modulus, x, clast);
 }
 
@@ -704,6 +722,9 @@ static int drop_apply_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *
     u64 *rem = cv.take(P2 * (k1 - k0) * n);
     HpDropConsts dc;
     make_drop_consts(plan, L, plain_modulus != 0, plain_modulus, dc);
+    // the _strict form follows the context's parity level (canonical residues at level A); the plain form stays at level B
+    LevelScope lvl(ctx, clast_strict ? plan : nullptr);
+    if (lvl.rc) return lvl.rc;
     return drop_apply(ctx, plan, logn, L, P2, k0, k1, dc, x, clast, clast_strict, addend, add_poly_stride, add_ct_stride, add_mask, out, rem);
 }
 

@@ -49,6 +49,8 @@ struct HpNttJob {
     // which return CANONICAL residues (equal to reduce_strict of the level-B words); post_scalar / post_scalar_h then hold the
     // bit patterns of the doubles (s, RN(s / q))
     const HpLimbA *limbs_a;
+    u32 src_words;  // level A, HP_NTT_SPREAD: the source rows are WORDS (strict coefficient rows a caller supplied: the limb-range stage
+                    // hp_dev_ks_inner_range_strict), not the doubles k_ntt_inv_a writes with dst_f64 for the launch of its own call
     u32 dst_f64;    // level A, inverse: the output rows are the doubles themselves, not words -- only for rows that feed a level-A
                     // HP_NTT_SPREAD launch (k_ntt_fwd_a<., true> reads doubles), never for rows a caller sees
 };

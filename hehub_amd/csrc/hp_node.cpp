@@ -327,8 +327,8 @@ int hp_device_numa(int device, int *numa_node, char *cpulist, size_t cap) {
 }
 hp_ctx *hp_node_ctx(hp_node *node, size_t rank) { return (node && rank < node->ctx.size()) ? node->ctx[rank] : nullptr; }
 const char *hp_node_last_error(hp_node *node) { return node ? node->err.c_str() : "null node"; }
-// parity level of every rank's context (hp_ctx_set_parity_level): the batch-sharded entry points then return canonical residues;
-// the limb-sharded mode exchanges caller-visible coefficient rows between ranks and stays at level B whatever the setting
+// parity level of every rank's context (hp_ctx_set_parity_level): the batch-sharded entry points then return canonical residues, and
+// so does the limb-sharded mode (its stages work on rows the engine wrote itself: the _strict limb-range stages follow the level)
 int hp_node_set_parity_level(hp_node *node, int level) {
     if (!node) return HP_EINVAL;
     std::lock_guard<std::mutex> lk(node->mu);
@@ -627,7 +627,7 @@ int sharded_run(hp_node_sharded *p, const uint64_t *h_ct1, const uint64_t *h_ct2
             for (size_t d = 0; d < W && !rc; d++)
                 if (d != r) step(recv_block(p, r, 0, s, d, R.coef));
         // stage 2: digits + inner product for the owned output moduli; the owner of p prepares the coefficients of its limb
-        if (!rc && all_ok()) step(hp_dev_ks_inner_range(c, logn, L, mext, B, k0, k1, R.coef, d2, 3 * L, d_key[r], R.ks));
+        if (!rc && all_ok()) step(hp_dev_ks_inner_range_strict(c, logn, L, mext, B, k0, k1, R.coef, d2, 3 * L, d_key[r], R.ks));
         if (!rc && all_ok() && r == own_p) {
             step(hp_dev_drop_coeffs(c, logn, L + 1, mext, inner_t, 2 * B, R.ks, R.c_p));
             if (!rc) step(send_block(p, r, 1, s, R.c_p, [&](size_t d) { return p->rk[d].c_p; }, everyone));

@@ -76,15 +76,19 @@ struct RangeAcc {
 // F64: the row already holds doubles (the strict coefficient rows of the key switch, written by k_ntt_inv_a with job.dst_f64)
 // words (a caller's row): range guard, and the word is brought to |x| <= q/2 at once -- a lazy word of a 50-bit modulus (up to
 // 2^51) would otherwise leave the exact range within the first pass (B' = B (1 + q 2^-52) + q/2 from 2^51: 10.2 * 2^50)
-template <bool SWAP, bool F64> struct ConvPre {
+// GUARD off: strict coefficient rows of ANOTHER modulus of the chain (the digit spread from words): any residue below 2^50 is in
+// range, the caller vouches for "strict" (hp_dev_ks_inner_range_strict) and the bound of the TARGET limb would be the wrong one
+template <bool SWAP, bool F64, bool GUARD = true> struct ConvPre {
     static constexpr bool on = SWAP || !F64;
     double q = 0.0, qinv = 0.0;
     mutable RangeAcc acc;
     HP_DEV void operator()(u64 (&x)[32], int r) const {
         if (SWAP) lazy_swap(x, r);
         if (!F64) {
-            acc.see(x[r]);
-            acc.see(x[r + 1]);
+            if (GUARD) {
+                acc.see(x[r]);
+                acc.see(x[r + 1]);
+            }
             // (unconditionally: a uniform branch on `wide` here costs the small ring degrees 6 .. 16 spilled registers, three FP64
             // instructions per word cost a narrow limb 3 % of this kernel -- which no scheme-level pipeline launches)
             x[r] = U(a_reduce(from_word(x[r]), qinv, q));
@@ -217,7 +221,7 @@ template <int BLO, class Tab> HP_DEV void inv_pass_a(u64 (&x)[32], const Tab tbl
 // FLAV (fused drop): 1 CKKS, no addend; 2 CKKS, addend on both polynomials (relinearize's +=, ckks/arith.cpp:70-71); 3 / 4 the
 // same with the BGV factors (mod_switch.cpp:70,76); 5 CKKS, addend on polynomial 0 only (rotations, ckks/arith.cpp:75-93);
 // 6 / 7 two drops at once (DropPre2A), CKKS / BGV, addend of the first drop on both polynomials
-template <int LOGN, bool DROP, int FLAV, bool SPREAD = false>
+template <int LOGN, bool DROP, int FLAV, bool SPREAD = false, bool WORDS = false>
 HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
     using G = Geo<LOGN>;
     using AD = Addr<LOGN, LOGN == 15>;
@@ -262,7 +266,7 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
         const DropPreA<SW, BGV> pre{q, D(da->dc.q_last), D(da->dc.half_q_last), D(da->dc.t[k]), D(da->dc.t_h[k])};
         fwd_pass_a<G::PB, STab>(x, STab(lp->fwd_ref + 1), 1u, 0u, q, pre);
     } else {
-        ConvPre<SW, SPREAD> pre;
+        ConvPre<SW, SPREAD && !WORDS, !SPREAD> pre;
         pre.q = q; pre.qinv = qinv;
         fwd_pass_a<G::PB, STab>(x, STab(lp->fwd_ref + 1), 1u, 0u, q, pre);
         // N = 32768 reports after the exchange that follows (a divergent branch + two scalar loads here, where it has no SGPR to
@@ -407,6 +411,11 @@ HP_DEV void ntt_fwd_a_body(const HpNttJob &job, const HpDropArgs *da) {
 template <int LOGN, bool SPREAD>
 __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd_a(HpNttJob job) {
     ntt_fwd_a_body<LOGN, false, 0, SPREAD>(job, nullptr);
+}
+// the digit spread from WORDS (limb-range stage of the limb-sharded mode: coefficient rows that came from other ranks)
+template <int LOGN>
+__global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd_a_words(HpNttJob job) {
+    ntt_fwd_a_body<LOGN, false, 0, true, true>(job, nullptr);
 }
 template <int LOGN, int FLAV>
 __global__ void __launch_bounds__(Geo<LOGN>::T, Geo<LOGN>::MINW) k_ntt_fwd_drop_a(HpNttJob job, HpDropArgs da) {
@@ -636,7 +645,8 @@ template <int LOGN> hipError_t launch_a(const HpNttJob &job, hipStream_t stream)
     if (!job.inverse) {
         // (HP_NTT_HKS: the lifted digits of the hybrid key switch, in place -- canonical residues in, canonical residues out: the plain kernel)
         if (job.mode != HP_NTT_BATCH && job.mode != HP_NTT_SPREAD && job.mode != HP_NTT_HKS) return hipErrorNotSupported;
-        if (job.mode == HP_NTT_SPREAD) k_ntt_fwd_a<LOGN, true><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
+        if (job.mode == HP_NTT_SPREAD && job.src_words) k_ntt_fwd_a_words<LOGN><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
+        else if (job.mode == HP_NTT_SPREAD) k_ntt_fwd_a<LOGN, true><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
         else k_ntt_fwd_a<LOGN, false><<<job.W, Geo<LOGN>::T, 0, stream>>>(job);
         return hipGetLastError();
     }

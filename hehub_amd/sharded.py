@@ -207,7 +207,7 @@ class ShardedMult:
         e._chk(lib.hp_dev_ks_coef_range(h, logn, L, m_ext, B, a0, a1, d2, 3 * L, P(coef)))
         yield ("all_gather", coef, clip(self.ranges, L))
 
-        e._chk(lib.hp_dev_ks_inner_range(h, logn, L, m_ext, B, k0, k1, P(coef), d2, 3 * L, P(key), P(ks)))
+        e._chk(lib.hp_dev_ks_inner_range_strict(h, logn, L, m_ext, B, k0, k1, P(coef), d2, 3 * L, P(key), P(ks)))
         own_p = owner_of(L, self.ranges)
         if rank == own_p:
             e._chk(lib.hp_dev_drop_coeffs(h, logn, L + 1, m_ext, inner_t, 2 * B, P(ks), P(c_p)))

@@ -294,6 +294,12 @@ int hp_dev_ks_coef_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *mod
 int hp_dev_ks_inner_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch, size_t k0,
                           size_t k1, const uint64_t *d_coef, const uint64_t *d_pt, size_t pt_pstride,
                           const uint64_t *d_key, uint64_t *d_out);
+/* The same when the caller vouches that every row of coef holds strict residues (the rows were written by hp_dev_ks_coef_range, here or
+ * on another rank): the digit rows of the workspace may then be packed (HP_PACK48), and at parity level A the digit transforms run on
+ * the FP64 kernels (same residues; the output words are then lazy words with hehub's residues, as hp_dev_ext_prod_montgomery's). */
+int hp_dev_ks_inner_range_strict(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch, size_t k0,
+                                 size_t k1, const uint64_t *d_coef, const uint64_t *d_pt, size_t pt_pstride,
+                                 const uint64_t *d_key, uint64_t *d_out);
 /* rescaling.cpp:47-50 / mod_switch.cpp:47-50 (plain_modulus 0 = CKKS): clast[p2] = strict(INTT_{q_last}(x[p2][L-1]))
  * for P2 polynomials of L limbs; run by the owner of the limb that is being dropped.  clast u64[P2][N] */
 int hp_dev_drop_coeffs(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, uint64_t plain_modulus, size_t P2,
@@ -308,7 +314,9 @@ int hp_dev_drop_apply_range(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *
                             uint64_t *d_out);
 /* The same when the caller vouches that every word of clast is below q_last (the rows were written by hp_dev_drop_coeffs):
  * where q_last <= 2 q_k the remainder of rescaling.cpp:54-58 is then one conditional subtraction instead of a Barrett quotient --
- * the canonical residue either way, so the words are identical.  hp_dev_drop_apply_range makes no such assumption. */
+ * the canonical residue either way, so the words are identical.  hp_dev_drop_apply_range makes no such assumption.
+ * The _strict stages (this one, hp_dev_ks_inner_range_strict) and hp_dev_ks_coef_range / hp_dev_drop_coeffs follow the context's parity
+ * level: at HP_PARITY_A the limb-sharded pipeline returns canonical residues like the single-GPU entry points. */
 int hp_dev_drop_apply_range_strict(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, uint64_t plain_modulus,
                                    size_t P2, size_t k0, size_t k1, const uint64_t *d_x, const uint64_t *d_clast,
                                    const uint64_t *d_addend, size_t add_poly_stride, size_t add_ct_stride, unsigned add_mask,
@@ -328,7 +336,7 @@ void hp_node_destroy(hp_node *node);
 size_t hp_node_size(const hp_node *node);
 hp_ctx *hp_node_ctx(hp_node *node, size_t rank);      /* the rank's engine context, for the hp_dev_* entry points */
 /* hp_ctx_set_parity_level on every rank's context: the batch-sharded entry points below then return canonical residues (level A);
- * the limb-sharded mode passes coefficient rows between ranks and runs at level B whatever the setting */
+ * the limb-sharded mode follows it too since round 5 (its stages run on rows the engine wrote itself: hp_dev_*_range_strict) */
 int hp_node_set_parity_level(hp_node *node, int level);
 const char *hp_node_last_error(hp_node *node);   /* "rank r: <message of that rank's failing call>"; the first rank with a failure of its own */
 /* matrix[a * size + b] = 1 when rank a can write rank b's device memory directly (same device, or hipDeviceEnablePeerAccess

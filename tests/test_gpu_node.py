@@ -61,10 +61,11 @@ def test_batch_sharded_host_batches(orc, world):
         node.close()
 
 
-@pytest.mark.parametrize("world", [1, 3])
+@pytest.mark.parametrize("world", [1, 3, 8])
 def test_batch_sharded_at_parity_level_a(orc, world):
-    """hp_node_set_parity_level(A): the batch slices come back as canonical residues = reduce_strict of the oracle's words; the
-    limb-sharded mode stays at level B (raw words) whatever the node's setting"""
+    """hp_node_set_parity_level(A): the batch slices come back as canonical residues = reduce_strict of the oracle's words, and so
+    does the limb-sharded mode (round 5: its _strict limb-range stages follow the level -- the digit spread from coefficient WORDS
+    that came from other ranks runs on the FP64 kernels; rgsw.cpp:98-153, rescaling.cpp:46-75)"""
     from hehub_amd.node import ShardedPlan
 
     node = make_node(world)
@@ -82,13 +83,15 @@ def test_batch_sharded_at_parity_level_a(orc, world):
         out = node.bgv_mult(mext, P.C5_T, ct1, ct2, dk)
         for i in range(B):
             assert np.array_equal(out[i], strict(orc.bgv_mult(mext, P.C5_T, ct1[i], ct2[i], key))), (world, i)
-        plan = ShardedPlan(node, logn, mext, 2)
-        try:
-            res = plan.mult(ct1[:2], ct2[:2], dk)
-            for i in range(2):
-                assert np.array_equal(res[i], orc.ckks_mult(mext, ct1[i], ct2[i], key))
-        finally:
-            plan.close()
+        for t in (0, P.C5_T):
+            plan = ShardedPlan(node, logn, mext, 2, plain_modulus=t)
+            try:
+                res = plan.mult(ct1[:2], ct2[:2], dk)
+                for i in range(2):
+                    exp = orc.bgv_mult(mext, t, ct1[i], ct2[i], key) if t else orc.ckks_mult(mext, ct1[i], ct2[i], key)
+                    assert np.array_equal(res[i], strict(exp)), (world, t, i)
+            finally:
+                plan.close()
         node.free_replicas(dk)
         node.set_parity_level("B")
         out = node.ckks_mult(mext, ct1, ct2, node.replicate(key))

@@ -91,9 +91,12 @@ def _case(orc, logn, mext, B, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("level", ["B", "A"])
 @pytest.mark.parametrize("logn,nmod", [(11, 4), (12, 3), (5, 4), (13, 6)])
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
-def test_virtual_ranks_compose_to_the_oracle(orc, logn, nmod, world):
+def test_virtual_ranks_compose_to_the_oracle(orc, logn, nmod, world, level):
+    """level A (round 5): the limb-range stages follow the context's parity level -- every output word is reduce_strict of the
+    oracle's word (a ring degree without tiled kernels runs at level B and returns the raw words)"""
     from hehub_amd.engine import Engine
     from hehub_amd.sharded import ShardedMult
 
@@ -101,6 +104,9 @@ def test_virtual_ranks_compose_to_the_oracle(orc, logn, nmod, world):
     B = 2
     ct1, ct2, key = _case(orc, logn, mext, B, 100 + logn)
     eng = Engine(0)
+    eng.set_parity_level(level)
+    qs = np.array(mext[:nmod - 2], dtype=np.uint64)[:, None]
+    fin = (lambda a: np.where(a >= qs, a - qs, a)) if (level == "A" and 11 <= logn <= 15) else (lambda a: a)
     d1, d2, dk = eng.to_device(ct1), eng.to_device(ct2), eng.to_device(key)
     for t in (0, 65537):
         sm = ShardedMult(eng, mext, world, plain_modulus=t)
@@ -116,7 +122,7 @@ def test_virtual_ranks_compose_to_the_oracle(orc, logn, nmod, world):
         got = eng.to_host(bufs["out"])
         exp = np.stack([orc.ckks_mult(mext, ct1[i], ct2[i], key) if t == 0 else orc.bgv_mult(mext, t, ct1[i], ct2[i], key)
                         for i in range(B)])
-        assert np.array_equal(got, exp), (logn, nmod, world, t)
+        assert np.array_equal(got, fin(exp)), (logn, nmod, world, t, level)
     eng.close()
 
 
