@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libhehub_amd.so")
 SOURCES = ["hp_ctx.cpp", "hp_prof.cpp", "hp_api_poly.cpp", "hp_api_scheme.cpp", "hp_api_hks.cpp", "hp_node.cpp", "hp_tables.cpp", "hp_wire.cpp",
-           "hp_elem.hip", "hp_hks.hip", "hp_ntt_generic.hip", "hp_ntt_fast.hip", "hp_ntt_a.hip"]
+           "hp_elem.hip", "hp_hks.hip", "hp_ntt_generic.hip", "hp_ntt_split.hip", "hp_ntt_fast.hip", "hp_ntt_a.hip"]
 # the FP64 residue kernels rely on separately rounded products (error-free transformations): no contraction of a * b + c
 EXTRA_FLAGS = {"hp_ntt_a.hip": ["-ffp-contract=off"]}
 ARCH = "gfx950"

@@ -185,7 +185,8 @@ int drop_apply(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, 
     if (addend) addend += k0 * n;
     int rc;
     // tiled sizes: Barrett + centring fused into the remainder NTT's loads, (x - rem)*inv [+ addend] into its stores
-    if (fused_drop_ok(ctx, logn)) {
+    // (not for a launch of a few limbs at level B: three short launches around the SPLIT transform beat one 45 us workgroup per limb)
+    if (fused_drop_ok(ctx, logn) && !(split_ok(ctx, logn, kc * P2) && !ctx->cur_a)) {
         HpNttJob fj = batch_job(plan, logn, kc, P2, clast, nullptr, 1, 0, 0, 0);
         fj.limbs = limbs;
         fj.src_kstride = 0;

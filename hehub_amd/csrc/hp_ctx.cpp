@@ -302,6 +302,7 @@ int run_ntt(hp_ctx *ctx, const HpNttJob &job) {
     {
         ProfScope ps(ctx, job.inverse ? "intt" : "ntt");
         if (job.limbs_a) e = hp_launch_ntt_a(job, ctx->stream);
+        else if (split_ok(ctx, job.logn, job.W) && !job.pack_mask && !job.pack40_mask) e = hp_launch_ntt_split(job, ctx->stream);   // few limbs: latency
         else if (tiled_ok(ctx, job.logn)) e = hp_launch_ntt_fast(job, ctx->stream);
         else e = hp_launch_ntt_generic(job, ctx->stream);
     }
@@ -381,6 +382,7 @@ int hp_ctx_create(int device, hp_ctx **out) {
     c->hks_combine_kernel = getenv("HP_HKS_COMBINE_KERNEL") != nullptr;
     if (const char *e = getenv("HP_DROP_GROUP")) c->drop_group = (int)clampi(atol(e), 0, HP_MAX_LIMBS);
     if (const char *e = getenv("HP_SPREAD_GROUP")) c->spread_group = (int)clampi(atol(e), 0, HP_MAX_LIMBS);   // measured (tools/ab/ab_groups.sh): 4..8 beat 2 by 2-3 % on the launch since the rows are packed; 11 (all moduli) loses it again
+    if (const char *e = getenv("HP_SPLIT_MAX_ITEMS")) c->split_max_items = (size_t)clampi(atol(e), 0, 4096);
     if (const char *e = getenv("HP_MULT_STREAMS")) c->mult_streams = atoi(e) >= 2 ? 2 : 1;
     if (const char *e = getenv("HP_MULT_CHUNK")) c->mult_chunk = (size_t)clampi(atol(e), 0, 1l << 30);
     if (const char *e = getenv("HP_PARITY_LEVEL")) c->parity_level = (e[0] == 'A' || e[0] == 'a' || e[0] == '1') ? 1 : 0;
@@ -403,7 +405,7 @@ int hp_ctx_fork(hp_ctx *parent, hp_ctx **out) {
     c->drop_group = parent->drop_group; c->spread_group = parent->spread_group; c->hks_two_step = parent->hks_two_step;
     c->hks_combine_kernel = parent->hks_combine_kernel; c->no_fused_drop = parent->no_fused_drop; c->no_pack48 = parent->no_pack48;
     c->no_pack40 = parent->no_pack40; c->no_double_drop = parent->no_double_drop; c->pack48_min_logn = parent->pack48_min_logn;
-    c->mult_streams = parent->mult_streams; c->mult_chunk = parent->mult_chunk;
+    c->mult_streams = parent->mult_streams; c->mult_chunk = parent->mult_chunk; c->split_max_items = parent->split_max_items;
     *out = c;
     return HP_OK;
 }

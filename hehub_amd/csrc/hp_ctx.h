@@ -113,6 +113,8 @@ struct hp_ctx {
     bool no_pack40 = false;       // HP_NO_PACK40: level A keeps 48-bit digit rows for the moduli below 2^40
     bool no_double_drop = false;  // HP_NO_DOUBLE_DROP: level A keeps relinearize's mod-down and the rescale / mod switch of a mult as two launches
     int pack48_min_logn = 11;     // HP_PACK48_MIN_LOGN: smallest ring degree whose digit rows are packed
+    size_t split_max_items = 128; // HP_SPLIT_MAX_ITEMS: a level-B transform launch of at most this many limbs (N >= 4096) runs split over
+                                  // N / 2048 workgroups per limb (hp_ntt_split.hip: a quarter of the latency, a third of the throughput); 0 = never
     int mult_streams = 1;         // HP_MULT_STREAMS=2: software-pipeline two sub-batches in dev_mult
     size_t mult_chunk = 0;        // HP_MULT_CHUNK: sub-batch size of dev_mult (0 = whole batch, or half with 2 streams)
 };
@@ -239,6 +241,10 @@ struct ProfScope {
 inline bool logn_ok(size_t logn) { return logn >= 1 && logn <= 16; }   // (ntt.cpp:26-29 takes any degree with 2N | q - 1; the reference's bit reversal is 16 bits wide, permutation.h:41-55)
 inline bool tiled_ok(const hp_ctx *ctx, size_t logn) { return !ctx->force_generic && logn >= 11 && logn <= 15; }
 inline bool fused_drop_ok(const hp_ctx *ctx, size_t logn) { return tiled_ok(ctx, logn) && !ctx->no_fused_drop; }
+// a launch of `items` limb transforms small enough for the split (latency) path
+inline bool split_ok(const hp_ctx *ctx, size_t logn, size_t items) {
+    return !ctx->force_generic && logn >= 12 && logn <= 16 && items > 0 && items <= ctx->split_max_items;
+}
 #define HP_LOGN_MSG "ring degrees 2^1 .. 2^16 are supported"
 int run_ntt(hp_ctx *ctx, const HpNttJob &job);
 HpNttJob batch_job(const Plan *plan, size_t logn, size_t L, size_t P, const u64 *src, u64 *dst, size_t src_ps, size_t dst_ps,

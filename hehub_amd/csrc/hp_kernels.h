@@ -58,6 +58,9 @@ struct HpNttJob {
 hipError_t hp_launch_ntt_generic(const HpNttJob &job, hipStream_t stream);
 // fast path: logn in [11,15]; returns hipErrorNotSupported otherwise
 hipError_t hp_launch_ntt_fast(const HpNttJob &job, hipStream_t stream);
+// a limb split over N / 2048 workgroups and two launches (hp_ntt_split.hip): the latency path for launches with few limbs; logn in
+// [12, 16], plain u64 rows, level B; returns hipErrorNotSupported otherwise
+hipError_t hp_launch_ntt_split(const HpNttJob &job, hipStream_t stream);
 // the same tiling with FP64 residue butterflies (job.limbs_a; HP_NTT_BATCH and HP_NTT_SPREAD; the inverse is always strict)
 hipError_t hp_launch_ntt_a(const HpNttJob &job, hipStream_t stream);
 

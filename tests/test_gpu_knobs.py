@@ -17,6 +17,8 @@ KNOBS = [
     {"HP_NO_FUSED_DROP": "1"},
     {"HP_MULT_STREAMS": "2"}, {"HP_MULT_STREAMS": "2", "HP_MULT_CHUNK": "3"}, {"HP_MULT_CHUNK": "1"}, {"HP_MULT_CHUNK": "-1"},
     {"HP_MULT_STREAMS": "7", "HP_MULT_CHUNK": "100000000000"},
+    {"HP_SPLIT_MAX_ITEMS": "0"}, {"HP_SPLIT_MAX_ITEMS": "4096"}, {"HP_SPLIT_MAX_ITEMS": "-3"}, {"HP_SPLIT_MAX_ITEMS": "20"},
+    {"HP_SPLIT_MAX_ITEMS": "4096", "HP_NO_FUSED_DROP": "1"},
 ]
 
 
@@ -40,7 +42,7 @@ def test_knob_settings_give_the_same_words(cases, monkeypatch, env):
     from hehub_amd.engine import Engine
 
     for k in ("HP_SPREAD_GROUP", "HP_DROP_GROUP", "HP_NO_PACK48", "HP_PACK48_MIN_LOGN", "HP_NO_FUSED_DROP", "HP_MULT_STREAMS",
-              "HP_MULT_CHUNK"):
+              "HP_MULT_CHUNK", "HP_SPLIT_MAX_ITEMS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -82,3 +84,43 @@ def test_knob_settings_at_parity_level_a(cases, monkeypatch, env):
             assert np.array_equal(eng.to_host(eng.ckks_rotate(mext, d1, dk, 3)), fin(exp["rot"])), env
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("logn", [12, 13, 14, 15, 16])
+def test_split_limb_transforms_are_the_reference_words(orc, monkeypatch, logn):
+    """hp_ntt_split.hip (round 5): a launch of few limbs cuts every limb into N / 2048 tiles and runs the
+    reference's stages in two launches of small workgroups -- the same butterflies in another order (ntt.cpp:155-176, :178-223), so
+    the raw words must be hehub's: forward, inverse, strict inverse, against the oracle and against the tiled kernels
+    (HP_SPLIT_MAX_ITEMS=0) where those exist."""
+    from hehub_amd.engine import Engine
+
+    moduli = _moduli_for(logn)
+    n, L, B = 1 << logn, len(moduli), 3
+    rng = SplitMix(9100 + logn)
+    x = rng.poly((B, L, n), moduli)
+    x[0, :, :5] = (np.array(moduli, dtype=np.uint64) - np.uint64(1))[:, None]
+    fwd = np.stack([orc.poly_ntt(moduli, x[i]) for i in range(B)])
+    inv = np.stack([orc.poly_intt(moduli, fwd[i]) for i in range(B)])
+    got = {}
+    for setting in ("4096", "0"):
+        monkeypatch.setenv("HP_SPLIT_MAX_ITEMS", setting)
+        eng = Engine(0)
+        try:
+            y = eng.ntt_(moduli, eng.to_device(x))
+            f = eng.to_host(y).copy()
+            z = eng.to_host(eng.intt_(moduli, y)).copy()
+            s = eng.to_host(eng.intt_(moduli, eng.to_device(fwd), strict=True)).copy()
+            got[setting] = (f, z, s)
+        finally:
+            eng.close()
+        assert np.array_equal(f, fwd) and np.array_equal(z, inv), (logn, setting)
+        assert np.array_equal(s, np.stack([orc.poly_reduce_strict(moduli, inv[i]) for i in range(B)])), (logn, setting)
+    for a, b in zip(got["4096"], got["0"]):
+        assert np.array_equal(a, b)
+
+
+def _moduli_for(logn):
+    if logn <= 15:
+        return [P.P50[1]] + P.P40[:3]
+    from test_gpu_parity import _ntt_primes
+    return _ntt_primes(2, 16, 40) + _ntt_primes(1, 16, 49)
