@@ -34,3 +34,14 @@ tools/prof_pmc.sh ${TAG}_ckks_a --workload ckks --steps 2 --warmup 1 --batch 64 
 tools/prof_pmc.sh ${TAG}_bgv_a --workload bgv --steps 2 --warmup 1 --batch 128 --parity-level A
 # device residency behind hehub's object API: the same program as hehub on the CPU, over the binding, and over the own mirror
 tools/prof_resident.sh > gpurun_out/${TAG}_resident_chain.txt 2>&1
+# round 5: the HBM bytes of a whole step (both pipelines, both levels), hehub's object API at batch 1 and in all its modes, by-N at both
+# levels, the hybrid key switch at both levels, the GPU test tier on the same tree
+tools/prof_step_traffic.sh ${TAG}
+tools/prof_object_api.sh ${TAG} > gpurun_out/${TAG}_objapi.txt 2>&1
+for s in "15 10 256 all 3 8 8 6" "13 6 512 all 3 8 8 6"; do for d in 0 1; do echo "== HEHUB_AMD_DEFER=$d independent_mults $s"; HEHUB_AMD_DEFER=$d examples/independent_mults $s; done; done > gpurun_out/${TAG}_independent_mults.txt 2>&1
+tools/by_n_levels.sh > gpurun_out/${TAG}_by_n_levels.txt 2>&1
+for lv in B A; do python bench.py --workload ckks-hks --parity-level $lv --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('ckks-hks level $lv', round(d['value']), 'hom-mult/s', round(d['ms_per_step'], 3), 'ms per step')"; done > gpurun_out/${TAG}_hks_levels.txt 2>&1
+python tools/bench_latency.py > gpurun_out/${TAG}_latency.txt 2>&1
+python -m pytest tests -m gpu -q > gpurun_out/${TAG}_pytest_gpu.txt 2>&1
