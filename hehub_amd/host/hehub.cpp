@@ -163,6 +163,7 @@ struct DevBlock {
     std::shared_ptr<DevBlock> parent;
     PendingOp *op = nullptr;
     bool failed = false;
+    unsigned pending_reads = 0;   // recorded calls that will read this block: an eager write into it has to run them first
 };
 
 namespace {
@@ -592,7 +593,7 @@ struct Access {
         const size_t n = v.dimension();
         if (v.dev_ok_ && v.blk_->op) flush_all();   // a placeholder: the recorded calls run now
         if (!v.dev_ok_) {
-            if (v.blk_) flush_all();   // (a recorded call may still want the words this upload replaces)
+            if (v.blk_ && (v.blk_->pending_reads || (v.blk_->parent && v.blk_->parent->pending_reads))) flush_all();   // (a recorded call still wants the words this upload replaces)
             if (!v.blk_ || v.off_ + v.count_ * n > v.blk_->words) {   // (a view keeps its place: sibling views are disjoint)
                 v.blk_ = alloc_block(v.count_ * n);
                 v.off_ = 0;
@@ -624,7 +625,8 @@ struct Access {
     static const BlockRef *home(const RnsIntVec &v) { return v.dev_ok_ ? &v.blk_ : nullptr; }
     // the vector's own device words, to be overwritten in place by an engine call that has read them (operator+= ...)
     static u64 *inout(RnsIntVec &v) {
-        flush_all();   // (a recorded call may read the words this call overwrites)
+        // (a recorded call may read the words this call overwrites: it runs first; a vector no recorded call knows is simply written)
+        if (v.blk_ && (v.blk_->op || v.blk_->pending_reads || (v.blk_->parent && v.blk_->parent->pending_reads))) flush_all();
         Src s = in(v, v.count_);
         track_write(*v.blk_);
         v.host_ok_ = false;
@@ -1059,6 +1061,15 @@ std::vector<PendingOp *> run_fused_mults(const std::vector<std::unique_ptr<Pendi
 
 } // namespace
 
+// nothing is recorded any more: no block is waiting to be read by a recorded call
+static void release_reads(const std::vector<std::unique_ptr<PendingOp>> &ops) {
+    for (auto &o : ops)
+        for (auto &r : o->in) {
+            r.first->pending_reads = 0;
+            if (r.first->parent) r.first->parent->pending_reads = 0;
+        }
+}
+
 // Run everything that has been recorded: repeatedly take the oldest call that has not run (its operands are ready: whatever
 // produced them was recorded earlier) and every later call with the same signature whose operands are ready too, as one batch.
 void flush_all() {
@@ -1081,9 +1092,11 @@ void flush_all() {
     } catch (...) {
         for (auto &o : ops)
             if (!o->done) { o->out->op = nullptr; o->out->failed = true; }   // their results throw when somebody asks for words
+        release_reads(ops);
         Q.flushing = false;
         throw;
     }
+    release_reads(ops);
     Q.flushing = false;
 }
 
@@ -1094,6 +1107,11 @@ BlockRef record(std::unique_ptr<PendingOp> op) {
     ph->words = op->out_words;
     ph->op = op.get();
     op->out = ph;
+    for (auto &r : op->in) {   // (views of a batch block share its words: the count lives on the block that owns them)
+        DevBlock &owner = r.first->parent ? *r.first->parent : *r.first;
+        owner.pending_reads++;
+        r.first->pending_reads += (&owner != r.first.get());
+    }
     Q.ops.push_back(std::move(op));
     if (Q.ops.size() >= OpQueue::MAX_PENDING) flush_all();
     return ph;

@@ -799,6 +799,18 @@ static void test_deferred() {
     auto prod = ckks::mult(x, f.b[2], f.key);
     x[0] *= (u64)3;
     REQUIRE(same_words(prod, ckks::mult(f.a[2], f.b[2], f.key)));
+    // ... while an eager call on a vector no recorded call knows about leaves the queue alone
+    {
+        auto pend = ckks::mult(f.a[3], f.b[3], f.key);
+        const auto q0 = amd::transfer_stats();
+        RnsPolynomial other(f.N, f.L, f.q);
+        for (size_t k = 0; k < f.L; k++) for (auto &w : other[(int)k]) w = rnd() % f.q[k];
+        ntt_negacyclic_inplace_lazy(other);
+        other *= (u64)5;
+        REQUIRE(amd::transfer_stats().deferred_calls == q0.deferred_calls);   // nothing ran
+        REQUIRE(same_words(pend, ckks::mult(f.a[3], f.b[3], f.key)));
+        REQUIRE(amd::transfer_stats().deferred_calls > q0.deferred_calls);
+    }
     // bgv: mult_low_level + relinearize + mod_switch_inplace
     bgv::BgvCt ba(RlweCt{f.a[0][0], f.a[0][1]}), bb(RlweCt{f.b[0][0], f.b[0][1]});
     ba.plain_modulus = bb.plain_modulus = 65537;
