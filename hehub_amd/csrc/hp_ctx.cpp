@@ -406,6 +406,13 @@ int hp_ctx_fork(hp_ctx *parent, hp_ctx **out) {
     c->hks_combine_kernel = parent->hks_combine_kernel; c->no_fused_drop = parent->no_fused_drop; c->no_pack48 = parent->no_pack48;
     c->no_pack40 = parent->no_pack40; c->no_double_drop = parent->no_double_drop; c->pack48_min_logn = parent->pack48_min_logn;
     c->mult_streams = parent->mult_streams; c->mult_chunk = parent->mult_chunk; c->split_max_items = parent->split_max_items;
+    // the lane will see the calls its parent sees: give it the parent's scratch size now instead of growing to it call by call
+    // (a growth drains the device); a failure here is not one of the fork -- the first call reserves what it needs
+    if (parent->ws_bytes) {
+        (void)hipSetDevice(parent->device);
+        if (hipMalloc(&c->ws, parent->ws_bytes) == hipSuccess) c->ws_bytes = parent->ws_bytes;
+        else { c->ws = nullptr; (void)hipGetLastError(); }
+    }
     *out = c;
     return HP_OK;
 }

@@ -131,7 +131,7 @@ int hp_memcpy_h2d_async(hp_ctx *ctx, void *d_dst, const void *h_src, size_t byte
 int hp_memcpy_d2h_async(hp_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 /* A polynomial whose limbs are SEPARATE registered host blocks (rns.h:15-156: one SmartArray per limb) <-> its contiguous device rows
  * u64[rows][words], by ONE kernel that reads / writes the host blocks over PCIe: 47-49 GB/s either way on an MI355X against
- * 11-17 GB/s for one DMA command per 256 KiB block (tools/ubench/ubench_pcie.hip, profiles/r04_ubench_pcie.txt).  Every h_rows[r] must be
+ * 11-17 GB/s for one DMA command per 256 KiB block (tools/ubench/ubench_pcie.hip, profiles/archive/r04_ubench_pcie.txt).  Every h_rows[r] must be
  * 16-byte aligned memory from hp_host_alloc or registered with hp_host_register; words even.  Enqueue only (see above). */
 int hp_dev_store_host_rows(hp_ctx *ctx, size_t rows, size_t words, const uint64_t *d_src, uint64_t *const *h_rows);
 int hp_dev_load_host_rows(hp_ctx *ctx, size_t rows, size_t words, uint64_t *d_dst, const uint64_t *const *h_rows);
