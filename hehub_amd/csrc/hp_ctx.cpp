@@ -574,6 +574,13 @@ int hp_host_register(hp_ctx *ctx, void *hptr, size_t bytes) {
     hipError_t e = hipHostRegister(hptr, bytes, hipHostRegisterPortable);
     if (e != hipSuccess) {
         (void)hipGetLastError();
+        // a range that lies inside pages an earlier registration already covers (two heap blocks on one page, a block that was
+        // registered as part of a larger one) is as DMA-able as it gets: that is a success, anything else is not
+        void *d0 = nullptr, *d1 = nullptr;
+        if (e == hipErrorHostMemoryAlreadyRegistered && bytes > 0 && hipHostGetDevicePointer(&d0, hptr, 0) == hipSuccess &&
+            hipHostGetDevicePointer(&d1, (char *)hptr + bytes - 1, 0) == hipSuccess)
+            return HP_OK;
+        (void)hipGetLastError();
         return fail(ctx, HP_EHIP, std::string("hipHostRegister: ") + hipGetErrorString(e));
     }
     return HP_OK;

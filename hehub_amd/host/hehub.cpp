@@ -31,6 +31,8 @@
 
 #include "../../include/hehub_amd.h"
 
+#include <malloc.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -371,6 +373,12 @@ bool pinned_block(const u64 *p, size_t words) {
     PinSet &P = pins();
     if (!P.on || words * sizeof(u64) < (128u << 10)) return false;
     std::lock_guard<std::mutex> lk(P.mu);
+    // glibc gives a block of >= M_MMAP_THRESHOLD bytes its own mapping, but RAISES that threshold (up to 32 MiB) whenever such a block
+    // is freed, after which later 256 KiB limbs come out of the main heap and share pages with their neighbours.  Setting the
+    // threshold explicitly switches the adaptation off: every limb block of 128 KiB and more keeps its own pages for the life of the
+    // process.  (A block that nevertheless overlaps registered pages is accepted by hp_host_register when it is fully covered.)
+    static const bool fixed_threshold = mallopt(M_MMAP_THRESHOLD, 128 << 10) != 0;
+    (void)fixed_threshold;
     auto it = P.seen.find(p);
     if (it != P.seen.end()) return it->second;
     const bool ok = hp_host_register(cur(), const_cast<u64 *>(p), words * sizeof(u64)) == HP_OK;
@@ -393,6 +401,9 @@ void limb_copy_d2h(u64 *dst, const u64 *src, size_t words) {
 }
 // Limbs that cannot be registered (smaller than 128 KiB: they share pages with other heap objects) cross PCIe through a page-locked
 // arena instead, a whole polynomial per DMA: packed by memcpy on the way up, unpacked after the wait on the way down.
+// (Arena, the PCIe counters and the lane book are NOT synchronised: like hehub itself -- process-global unsynchronised caches and
+// pools, SURVEY.md section 5 -- the layer serves one thread at a time; only the registration set and the block pool take a lock,
+// because destructors of objects handed to other threads may run there.)
 namespace {
 struct Arena {
     u64 *buf = nullptr;

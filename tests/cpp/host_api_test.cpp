@@ -811,6 +811,33 @@ static void test_deferred() {
         REQUIRE(same_words(pend, ckks::mult(f.a[3], f.b[3], f.key)));
         REQUIRE(amd::transfer_stats().deferred_calls > q0.deferred_calls);
     }
+    // a failure INSIDE the engine (a modulus the transforms reject: 2N does not divide q - 1) surfaces when the queue runs, not at
+    // the recording call; the results of the calls that could not run throw when somebody asks for their words, nothing crashes,
+    // and the layer goes on working
+    {
+        const std::vector<u64> badq{1099511627689ull, 1099511627563ull};   // 40-bit primes, not = 1 mod 2N
+        ckks::CkksCt bad;
+        for (int h = 0; h < 2; h++) {
+            bad[h] = RnsPolynomial(f.N, 2, badq);
+            for (size_t k = 0; k < 2; k++) for (auto &w : bad[h][(int)k]) w = rnd() % badq[k];
+            bad[h].rep_form = PolyRepForm::value;
+        }
+        auto good = ckks::mult(f.a[4], f.b[4], f.key);         // recorded
+        ckks::CkksCt victim = bad;
+        ckks::rescale_inplace(victim);                          // recorded: its inverse transform will be refused
+        bool threw = false;
+        try { (void)victim[0].view(0)[0]; } catch (const std::exception &) { threw = true; }
+        REQUIRE(threw);
+        threw = false;
+        try { (void)victim[1].view(0)[0]; } catch (const std::runtime_error &) { threw = true; }   // "result of a deferred call that failed"
+        REQUIRE(threw);
+        auto again = ckks::mult(f.a[4], f.b[4], f.key);
+        amd::set_deferred(false);
+        REQUIRE(same_words(again, ckks::mult(f.a[4], f.b[4], f.key)));
+        REQUIRE_THROWS_AS(ckks::rescale_inplace(bad), std::invalid_argument);   // eager: the same refusal, at the call
+        amd::set_deferred(true);
+        (void)good;
+    }
     // bgv: mult_low_level + relinearize + mod_switch_inplace
     bgv::BgvCt ba(RlweCt{f.a[0][0], f.a[0][1]}), bb(RlweCt{f.b[0][0], f.b[0][1]});
     ba.plain_modulus = bb.plain_modulus = 65537;
