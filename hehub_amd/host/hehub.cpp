@@ -541,7 +541,7 @@ struct Dst {
 // 256 independent ckks::mult + rescale_inplace so runs as three batch-256 launches groups, 8 interleaved chains as batch-8 ones.
 // Results are word for word those of the eager calls.  What differs: a failure INSIDE the engine (a HIP error, a modulus the
 // transforms reject) surfaces when the queue runs, not at the call that recorded it.
-enum class OpKind { MultLow, Relin, KeySwitch, Drop, AddSub };
+enum class OpKind { MultLow, Relin, KeySwitch, Drop, AddSub, Copy };
 struct PendingOp {
     OpKind kind = OpKind::MultLow;
     size_t logn = 0, L = 0, L0 = 0, step = 0;
@@ -581,6 +581,7 @@ OpQueue &op_queue() {
 }
 } // namespace
 void flush_all();
+BlockRef record(std::unique_ptr<PendingOp> op);
 // device address of a block's words; a placeholder is resolved by running the queue
 u64 *words_of(const BlockRef &b) {
     if (b->op) flush_all();
@@ -714,6 +715,15 @@ struct Access {
         dst.stamp_ = next_stamp();
         if (o.dev_ok_ && o.count_) {   // device-to-device: the host copy (if any) is not duplicated, it can be fetched again
             const size_t w = o.count_ * o.dimension();
+            if (o.blk_->op && deferred() && (w & 1) == 0) {   // a copy of a result that is still a placeholder is recorded like the call that makes it
+                std::unique_ptr<PendingOp> rec(new PendingOp);
+                rec->kind = OpKind::Copy; rec->logn = o.logn_; rec->L = o.count_; rec->in_limbs = o.count_; rec->out_words = w;
+                rec->in.push_back({o.blk_, o.off_});
+                dst.blk_ = record(std::move(rec));
+                dst.dev_ok_ = true;
+                dst.host_ok_ = false;
+                return;
+            }
             if (o.blk_->op) flush_all();   // (a copy of a placeholder: the recorded calls run now)
             OpScope op({&o.blk_});
             dst.blk_ = alloc_block(w);
@@ -990,6 +1000,15 @@ void run_group(const std::vector<PendingOp *> &g) {
         Src dc = group_rows(g, 0, 2, n);
         if (o.bgv) check(hp_dev_bgv_mod_switch(cur(), o.logn, L, o.mod.data(), o.t, B, dc.p, big->p));
         else check(hp_dev_ckks_rescale(cur(), o.logn, L, o.mod.data(), B, dc.p, big->p));
+        break;
+    }
+    case OpKind::Copy: {   // a deep copy of a result that has not been computed yet (`ct_sum = ct_prod`): the gather IS the copy
+        std::vector<const u64 *> rows;
+        for (PendingOp *c : g) {
+            rows.push_back(words_of(c->in[0].first) + c->in[0].second);
+            track_read(*c->in[0].first);
+        }
+        check(hp_dev_gather_rows(cur(), rows.size(), o.in_limbs * n, rows.data(), big->p));
         break;
     }
     case OpKind::AddSub: {

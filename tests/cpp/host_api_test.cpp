@@ -774,6 +774,10 @@ static void test_deferred() {
         d_sum = ckks::add(d_sum, p);
     }
     ckks::CkksCt d_cj = ckks::sub(ckks::conjugate(f.a[1], f.key), f.a[1]);
+    // a copy of a result that has not been computed yet is recorded too (examples/ckks_example.cpp: `ct_sum = ct_prod`)
+    ckks::CkksCt d_copy = d_sum, d_copy2;
+    d_copy2 = d_out[0];
+    REQUIRE(amd::transfer_stats().deferred_calls == st0.deferred_calls);   // still nothing has run
     // the argument checks of the single calls are made when the call is recorded
     auto coeff = f.a[0];
     coeff[1].rep_form = PolyRepForm::coeff;
@@ -794,6 +798,7 @@ static void test_deferred() {
         REQUIRE(same_words(d_chain[i], e_chain[i]));
     }
     REQUIRE(same_words(d_sum, e_sum) && same_words(d_cj, e_cj));
+    REQUIRE(same_words(d_copy, e_sum) && same_words(d_copy2, e_out[0]) && d_copy2.scaling_factor == e_out[0].scaling_factor);
     // an eager in-place operator on an operand of a recorded call: the recorded call saw the words as they were
     ckks::CkksCt x = f.a[2];
     auto prod = ckks::mult(x, f.b[2], f.key);
