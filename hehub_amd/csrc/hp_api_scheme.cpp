@@ -217,6 +217,18 @@ int drop_apply(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P2, 
         }
         return chk(ctx, hp_launch_ntt_fast_drop(fj, da, ctx->stream), "fused drop NTT");
     }
+    if (split_ok(ctx, logn, kc * P2) && !ctx->cur_a && !ctx->no_fused_drop) {
+        // a few limbs: the fused drop around the SPLIT transform (two launches of small workgroups; `rem` holds the rows between them)
+        HpNttJob sj = batch_job(plan, logn, kc, P2, clast, rem, 1, kc, 0, 0);
+        sj.limbs = limbs;
+        sj.src_kstride = 0;
+        HpDropArgs da;
+        memset(&da, 0, sizeof(da));
+        da.dc = dc; da.x = x; da.L = (u32)L; da.addend = addend; da.add_poly_stride = (u32)add_poly_stride;
+        da.add_ct_stride = (u32)add_ct_stride; da.add_mask = add_mask; da.out = out; da.out_stride = (u32)(L - 1);
+        ProfScope ps(ctx, "ntt_drop");
+        return chk(ctx, hp_launch_ntt_split_drop(sj, da, ctx->stream), "fused drop NTT (split)");
+    }
     {
         ProfScope ps(ctx, "drop_rem");
         if ((rc = chk(ctx, hp_launch_drop_rem(limbs, dc, (u32)kc, (u32)n, (u32)P2, clast, rem, ctx->stream), "drop_rem"))) return rc;

@@ -337,6 +337,10 @@ hipError_t hp_launch_tensor(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32
 // out[p][half][k][i] = montgomery_128( sum_j D[p][j][k][i] * key[j][half][k][i] ), 128-bit accumulators
 // in registers, both halves from one pass over the digits.  Per (p, k, i): reads L digit words and 2L key
 // words (the key is shared by the whole batch and stays in L2 / Infinity Cache), writes 2 words.
+// One ciphertext (or an odd one out) per call: a LATENCY kernel -- hehub's one-call-per-ciphertext interface (ckks.h:270-313) puts a
+// single key switch on the critical path of every call.  A workgroup covers 512 coefficients (two per lane, one pass), and the
+// three 16-byte loads of FOUR digits are issued before their multiplications: the dependent rounds to memory drop from 4 x L to L / 4.
+#define KS1_CHUNK 512u
 __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner(const HpLimb *__restrict__ limbs, u32 L, u32 k_first, u32 P,
                                                           u32 key_Le, u32 n, u32 chunks, const u64 *__restrict__ digits,
                                                           const u64 *__restrict__ pt,
@@ -347,48 +351,56 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner(const HpLimb *__restr
     // modulus-major numbering keeps one key column (2L limbs) hot per XCD slice
     const u32 k = k_first + row / P, p = row % P;
     const u64 q = limbs[k].q, mqinv = limbs[k].mqinv;
-    const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
-    for (u32 i = chunk * ELEM_CHUNK + threadIdx.x * 2; i < end; i += ELEM_THREADS * 2) {
-        const bool two = (i + 1 < end);
-        u64 a0l[2] = {0, 0}, a0h[2] = {0, 0}, a1l[2] = {0, 0}, a1h[2] = {0, 0};
-        for (u32 j = 0; j < L; j++) {
+    const u32 i = chunk * KS1_CHUNK + threadIdx.x * 2;
+    if (i >= n) return;
+    const bool two = (i + 1 < n);
+    // a key made for more moduli than the ciphertext has (extension): its special-prime column is the last one
+    const u32 kcol = (k == L) ? key_Le - 1 : k;
+    u64 a0l[2] = {0, 0}, a0h[2] = {0, 0}, a1l[2] = {0, 0}, a1h[2] = {0, 0};
+    constexpr u32 G = 4;
+    for (u32 j0 = 0; j0 < L; j0 += G) {
+        u64 dv[G][2], k0[G][2], k1[G][2];
+#pragma unroll
+        for (u32 t = 0; t < G; t++) {
+            const u32 j = j0 + t < L ? j0 + t : L - 1;   // (a slot past the last digit reloads it and is skipped below)
             const u64 *d = (j == k) ? pt + ((size_t)p * pt_pstride + j) * n : digits + (((size_t)p * L + j) * Le + k) * n;
-            // a key made for more moduli than the ciphertext has (extension): its special-prime column is the last one
-            const u32 kcol = (k == L) ? key_Le - 1 : k;
             const u64 *g0 = key + (((size_t)j * 2 + 0) * key_Le + kcol) * n;
             const u64 *g1 = key + (((size_t)j * 2 + 1) * key_Le + kcol) * n;
-            u64 dv[2], k0[2], k1[2];
             if (two) {
                 // digits are read exactly once: non-temporal, so they do not evict the key column from L2
                 typedef u64 __attribute__((ext_vector_type(2))) vv;
                 const vv dvv = __builtin_nontemporal_load(reinterpret_cast<const vv *>(d + i));
-                dv[0] = dvv.x; dv[1] = dvv.y;
-                U2 t;
-                t = *reinterpret_cast<const U2 *>(g0 + i); k0[0] = t.x; k0[1] = t.y;
-                t = *reinterpret_cast<const U2 *>(g1 + i); k1[0] = t.x; k1[1] = t.y;
+                dv[t][0] = dvv.x; dv[t][1] = dvv.y;
+                U2 w;
+                w = *reinterpret_cast<const U2 *>(g0 + i); k0[t][0] = w.x; k0[t][1] = w.y;
+                w = *reinterpret_cast<const U2 *>(g1 + i); k1[t][0] = w.x; k1[t][1] = w.y;
             } else {
-                dv[0] = d[i]; k0[0] = g0[i]; k1[0] = g1[i]; dv[1] = k0[1] = k1[1] = 0;
+                dv[t][0] = d[i]; k0[t][0] = g0[i]; k1[t][0] = g1[i]; dv[t][1] = k0[t][1] = k1[t][1] = 0;
             }
+        }
 #pragma unroll
-            for (int e = 0; e < 2; e++) {
+        for (u32 t = 0; t < G; t++) {
+            if (j0 + t >= L) break;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {   // the sums in the reference's order j = 0 .. L-1 (rgsw.cpp:126-149; u128 addition is associative anyway)
                 u64 lo, hi;
-                hp_mul128(dv[e], k0[e], lo, hi);
+                hp_mul128(dv[t][e], k0[t][e], lo, hi);
                 a0l[e] += lo; a0h[e] += hi + (a0l[e] < lo ? 1ull : 0ull);
-                hp_mul128(dv[e], k1[e], lo, hi);
+                hp_mul128(dv[t][e], k1[t][e], lo, hi);
                 a1l[e] += lo; a1h[e] += hi + (a1l[e] < lo ? 1ull : 0ull);
             }
         }
-        u64 *o0 = out + (((size_t)p * 2 + 0) * Le + k) * n;
-        u64 *o1 = out + (((size_t)p * 2 + 1) * Le + k) * n;
-        u64 r00 = hp_montgomery128_lazy(a0l[0], a0h[0], q, mqinv), r10 = hp_montgomery128_lazy(a1l[0], a1h[0], q, mqinv);
-        if (two) {
-            U2 v0{r00, hp_montgomery128_lazy(a0l[1], a0h[1], q, mqinv)};
-            U2 v1{r10, hp_montgomery128_lazy(a1l[1], a1h[1], q, mqinv)};
-            *reinterpret_cast<U2 *>(o0 + i) = v0;
-            *reinterpret_cast<U2 *>(o1 + i) = v1;
-        } else {
-            o0[i] = r00; o1[i] = r10;
-        }
+    }
+    u64 *o0 = out + (((size_t)p * 2 + 0) * Le + k) * n;
+    u64 *o1 = out + (((size_t)p * 2 + 1) * Le + k) * n;
+    u64 r00 = hp_montgomery128_lazy(a0l[0], a0h[0], q, mqinv), r10 = hp_montgomery128_lazy(a1l[0], a1h[0], q, mqinv);
+    if (two) {
+        U2 v0{r00, hp_montgomery128_lazy(a0l[1], a0h[1], q, mqinv)};
+        U2 v1{r10, hp_montgomery128_lazy(a1l[1], a1h[1], q, mqinv)};
+        *reinterpret_cast<U2 *>(o0 + i) = v0;
+        *reinterpret_cast<U2 *>(o1 + i) = v1;
+    } else {
+        o0[i] = r00; o1[i] = r10;
     }
 }
 
@@ -563,7 +575,8 @@ hipError_t hp_launch_ks_inner(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u
         if (pack40_mask) k_ks_inner_blk<2, true><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, key_Le, n, chunks, digits, pt, pt_pstride, key, out, pack_mask, pack40_mask);
         else k_ks_inner_blk<2><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, key_Le, n, chunks, digits, pt, pt_pstride, key, out, pack_mask, 0u);
     } else {
-        elem_grid(n, P * kc, chunks, grid);
+        chunks = (n + KS1_CHUNK - 1) / KS1_CHUNK;
+        grid = dim3(chunks * P * kc, 1, 1);
         k_ks_inner<<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, key_Le, n, chunks, digits, pt, pt_pstride, key, out);
     }
     return hipGetLastError();

@@ -152,6 +152,8 @@ struct HpDropArgs {
 };
 // job: HP_NTT_BATCH over L-1 limbs and P2 polynomials with src = clast [P2][n] (src_pstride 1, src_kstride 0)
 hipError_t hp_launch_ntt_fast_drop(const HpNttJob &job, const HpDropArgs &da, hipStream_t stream);
+// the same for a launch of few limbs, split over N / 2048 workgroups per limb (hp_ntt_split.hip); job.dst = scratch rows [P2][kc][n]
+hipError_t hp_launch_ntt_split_drop(const HpNttJob &job, const HpDropArgs &da, hipStream_t stream);
 // level A: dc.q_last / half_q_last and the pairs (inv, inv_h), (t, t_h), (qlt, qlt_h) hold bit patterns of doubles (v, RN(v / q_k));
 // r, small_rem, raw_input, fin, comb are not used; output rows are canonical residues
 hipError_t hp_launch_ntt_a_drop(const HpNttJob &job, const HpDropArgs &da, hipStream_t stream);

@@ -91,8 +91,12 @@ template <bool INVERSE, bool COLS> HP_DEV Bfly bfly_of(u32 logn, const TileMap<C
     return f;
 }
 
-template <bool INVERSE, bool COLS, bool FIRST>
-__global__ void __launch_bounds__(SPLIT_THREADS) k_ntt_split(HpNttJob job) {
+// DROP (forward only): the drop-last-prime step around the transform, as the tiled k_ntt_fwd_drop has it -- the first launch reads
+// the strict last-limb coefficients and applies Barrett + centring [+ * t] while loading (rescaling.cpp:54-69, mod_switch.cpp:52-69:
+// k_drop_rem's arithmetic), the second finishes with out = ((x - NTT(rem)) * inv) [* (q_last mod t)] [+ addend] while storing
+// (rescaling.cpp:72-74, mod_switch.cpp:72-76, ckks/arith.cpp:70-71: k_drop_fin's arithmetic); the rows between the launches are scratch
+template <bool INVERSE, bool COLS, bool FIRST, bool DROP>
+HP_DEV void ntt_split_body(const HpNttJob &job, const HpDropArgs *da) {
     __shared__ __attribute__((aligned(16))) u64 buf[SPLIT_TILE];
     constexpr int PER = SPLIT_TILE / SPLIT_THREADS, BPT = PER / 2;   // coefficients and butterflies per thread and stage
     const u32 logn = job.logn, n = 1u << logn, tiles = n / SPLIT_TILE;
@@ -109,6 +113,18 @@ __global__ void __launch_bounds__(SPLIT_THREADS) k_ntt_split(HpNttJob job) {
     u64 x[PER];
 #pragma unroll
     for (int e = 0; e < PER; ++e) x[e] = in[tm.global(threadIdx.x + e * SPLIT_THREADS)];
+    if (DROP && FIRST) {
+        const u32 k = it.limb;
+        const u64 bump = m.q - da->dc.r[k];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const u64 c = x[e];
+            u64 v = hp_strict(hp_barrett_lazy(c, m.q, m.barrett_c), m.q);
+            if (c >= da->dc.half_q_last) v += bump;
+            if (da->dc.bgv) v = hp_harvey_lazy(v, da->dc.t[k], da->dc.t_h[k], m.q);
+            x[e] = v;
+        }
+    }
     Bfly cur[BPT];
     u64x2 tw[BPT];
 #pragma unroll
@@ -149,6 +165,17 @@ __global__ void __launch_bounds__(SPLIT_THREADS) k_ntt_split(HpNttJob job) {
         const u32 i = threadIdx.x + e * SPLIT_THREADS, g = tm.global(i);
         u64 v = buf[i];
         if (!INVERSE && !COLS) v = hp_shift_fold(v, m.q, m.k, m.fix);                         // ntt.cpp:171-175 after the last stage
+        if (DROP && !FIRST) {
+            const u32 k = it.limb, p2 = it.poly;
+            const u64 *xs = da->x + ((size_t)p2 * da->L + k) * n;
+            v = hp_sub_lazy(xs[g], v, m.two_q);
+            v = hp_harvey_lazy(v, da->dc.inv[k], da->dc.inv_h[k], m.q);
+            if (da->dc.bgv) v = hp_harvey_lazy(v, da->dc.qlt[k], da->dc.qlt_h[k], m.q);
+            if (da->addend && ((da->add_mask >> (p2 & 1)) & 1u))
+                v = hp_add_lazy(v, da->addend[((size_t)(p2 >> 1) * da->add_ct_stride + (size_t)(p2 & 1) * da->add_poly_stride + k) * n + g], m.two_q);
+            da->out[((size_t)p2 * da->out_stride + k) * n + g] = v;
+            continue;
+        }
         if (INVERSE && COLS) {
             v = hp_harvey_lazy(hp_shift_fold(v, m.q, m.k, m.fix), sc[e].x, sc[e].y, m.q);     // ntt.cpp:214-222
             if (job.use_post_scalar) v = hp_harvey_lazy(v, job.post_scalar, job.post_scalar_h, m.q);
@@ -158,7 +185,30 @@ __global__ void __launch_bounds__(SPLIT_THREADS) k_ntt_split(HpNttJob job) {
     }
 }
 
+template <bool INVERSE, bool COLS, bool FIRST>
+__global__ void __launch_bounds__(SPLIT_THREADS) k_ntt_split(HpNttJob job) {
+    ntt_split_body<INVERSE, COLS, FIRST, false>(job, nullptr);
+}
+template <bool COLS, bool FIRST>
+__global__ void __launch_bounds__(SPLIT_THREADS) k_ntt_split_drop(HpNttJob job, HpDropArgs da) {
+    ntt_split_body<false, COLS, FIRST, true>(job, &da);
+}
+
 } // namespace
+
+// the fused drop of a few limbs: job = HP_NTT_BATCH over the remaining limbs with src = clast [P2][n] (src_pstride 1, src_kstride 0)
+// and dst = scratch rows [P2][kc][n]; plain drops only (no raw input, no final multiplication, no combination: those are the hybrid
+// key switch's, which keeps the tiled kernel)
+hipError_t hp_launch_ntt_split_drop(const HpNttJob &job, const HpDropArgs &da, hipStream_t stream) {
+    if (job.W == 0) return hipSuccess;
+    if (job.logn < 12 || job.logn > 16 || job.limbs_a || job.inverse || job.mode != HP_NTT_BATCH || job.pair_moduli || !job.dst ||
+        da.raw_input || da.fin_on || da.comb)
+        return hipErrorNotSupported;
+    const dim3 grid(job.W * ((1u << job.logn) / SPLIT_TILE));
+    k_ntt_split_drop<true, true><<<grid, SPLIT_THREADS, 0, stream>>>(job, da);
+    k_ntt_split_drop<false, false><<<grid, SPLIT_THREADS, 0, stream>>>(job, da);
+    return hipGetLastError();
+}
 
 // logn in [12, 16] (at least two tiles per limb and eight block stages); plain u64 rows only (no packed digit rows, no level A)
 hipError_t hp_launch_ntt_split(const HpNttJob &job, hipStream_t stream) {
