@@ -532,7 +532,8 @@ struct Dst {
 // hehub's interface is one ciphertext per call and its callers loop over INDEPENDENT ciphertexts (src/circuits/linear_algebra.h:
 // 109-133, bench/benchmarks.cpp:24-35); at batch 1 a C3 call is a chain of ~12 dependent launches of 40 us that fill 10 .. 100 of
 // 256 CUs, and the GPU runs at most 2 - 3 such chains side by side (lanes: x 2.3).  In deferred mode the scheme-level calls
-// (mult_low_level, relinearize, rotate / conjugate, rescale_inplace / mod_switch_inplace, add / sub of ciphertexts) are RECORDED, not
+// (mult_low_level, relinearize, rotate / conjugate, rescale_inplace / mod_switch_inplace, add / sub of ciphertexts, polynomial
+// products, copies of pending results) are RECORDED, not
 // run: every argument check of the single call has been made (same exceptions, same place), the result objects exist and carry
 // their shape, scaling factor and a placeholder for their device words.  The queue runs when somebody needs words -- a look at a
 // result (operator[], view(), ==), any call that is not deferrable, amd::synchronize(), 1024 recorded calls -- and then groups
@@ -541,7 +542,7 @@ struct Dst {
 // 256 independent ckks::mult + rescale_inplace so runs as three batch-256 launches groups, 8 interleaved chains as batch-8 ones.
 // Results are word for word those of the eager calls.  What differs: a failure INSIDE the engine (a HIP error, a modulus the
 // transforms reject) surfaces when the queue runs, not at the call that recorded it.
-enum class OpKind { MultLow, Relin, KeySwitch, Drop, AddSub, Copy };
+enum class OpKind { MultLow, Relin, KeySwitch, Drop, AddSub, Copy, PolyMul };
 struct PendingOp {
     OpKind kind = OpKind::MultLow;
     size_t logn = 0, L = 0, L0 = 0, step = 0;
@@ -1009,6 +1010,11 @@ void run_group(const std::vector<PendingOp *> &g) {
             track_read(*c->in[0].first);
         }
         check(hp_dev_gather_rows(cur(), rows.size(), o.in_limbs * n, rows.data(), big->p));
+        break;
+    }
+    case OpKind::PolyMul: {   // operator* of two polynomials (rns.cpp:120-140): the plaintext products of mult_plain
+        Src da = group_rows(g, 0, 1, n), db = group_rows(g, 1, 1, n);
+        check(hp_dev_poly_mul(cur(), n, L, o.mod.data(), B, da.p, db.p, big->p));
         break;
     }
     case OpKind::AddSub: {
@@ -1568,6 +1574,16 @@ RnsIntVec operator*(const RnsIntVec &a, const RnsIntVec &b) {
     Access::shape(result, a.dimension(), components, moduli);
     const size_t n = a.dimension();
     if (components == 0 || n == 0) return result;
+#ifndef HEHUB_AMD_BIND_REFERENCE
+    if (amd::deferred() && n >= 2) {
+        OpScope scope({}, 0);
+        size_t lg = 0;
+        while (((size_t)1 << lg) < n) lg++;
+        auto rec = new_op(amd::OpKind::PolyMul, lg, components, moduli, {&a, &b}, components, components * n);
+        Access::bind_block(result, amd::record(std::move(rec)), 0);
+        return result;
+    }
+#endif
     OpScope op({Access::home(a), Access::home(b)});
     Src sa = Access::in(a, components), sb = Access::in(b, components);
     Dst d(components * n);

@@ -53,7 +53,8 @@ TransferStats transfer_stats();
 int lanes();
 void set_lanes(int n);
 /// Deferred mode (own-mirror build; default off, HEHUB_AMD_DEFER=1 in the environment turns it on): the scheme-level calls of hehub's
-/// interface -- mult_low_level, relinearize, mult, rotate, conjugate, rescale_inplace, mod_switch_inplace, add / sub of ciphertexts --
+/// interface -- mult_low_level, relinearize, mult, rotate, conjugate, rescale_inplace, mod_switch_inplace, add / sub of ciphertexts,
+/// polynomial products (mult_plain) and copies of results that are still pending --
 /// are RECORDED with all their argument checks made and their result objects returned; they run when somebody needs words (a look at
 /// a result, a call that cannot be recorded, synchronize(), 1024 recorded calls), grouped: recorded calls with one signature whose
 /// operands are ready run as ONE batched engine call.  An unchanged loop over independent ciphertexts thereby gets the batch rate

@@ -774,6 +774,19 @@ static void test_deferred() {
         d_sum = ckks::add(d_sum, p);
     }
     ckks::CkksCt d_cj = ckks::sub(ckks::conjugate(f.a[1], f.key), f.a[1]);
+    // plaintext products (ckks::mult_plain = two operator* calls, ckks/arith.cpp:47-53) are recorded too: the diagonal loop of
+    // src/circuits/linear_algebra.h:109-133 (rotate, mult_plain, add) never runs the queue by itself
+    ckks::CkksPt d_pt;
+    {
+        RnsPolynomial ptp(f.N, f.L, f.q);
+        for (size_t k = 0; k < f.L; k++) for (auto &w : ptp[(int)k]) w = rnd() % f.q[k];
+        ptp.rep_form = PolyRepForm::coeff;
+        d_pt = ckks::CkksPt(std::move(ptp));
+        d_pt.scaling_factor = std::pow(2.0, 40);
+    }
+    std::vector<ckks::CkksCt> d_lin;
+    for (size_t i = 0; i < B; i++) d_lin.push_back(ckks::mult_plain(ckks::rotate(f.a[i], f.key, i + 1), d_pt));
+    REQUIRE(amd::transfer_stats().deferred_calls == st0.deferred_calls);   // still nothing has run
     // a copy of a result that has not been computed yet is recorded too (examples/ckks_example.cpp: `ct_sum = ct_prod`)
     ckks::CkksCt d_copy = d_sum, d_copy2;
     d_copy2 = d_out[0];
@@ -799,6 +812,12 @@ static void test_deferred() {
     }
     REQUIRE(same_words(d_sum, e_sum) && same_words(d_cj, e_cj));
     REQUIRE(same_words(d_copy, e_sum) && same_words(d_copy2, e_out[0]) && d_copy2.scaling_factor == e_out[0].scaling_factor);
+    amd::set_deferred(false);
+    for (size_t i = 0; i < B; i++) {
+        auto e = ckks::mult_plain(ckks::rotate(f.a[i], f.key, i + 1), d_pt);
+        REQUIRE(same_words(d_lin[i], e) && d_lin[i].scaling_factor == e.scaling_factor);
+    }
+    amd::set_deferred(true);
     // an eager in-place operator on an operand of a recorded call: the recorded call saw the words as they were
     ckks::CkksCt x = f.a[2];
     auto prod = ckks::mult(x, f.b[2], f.key);
