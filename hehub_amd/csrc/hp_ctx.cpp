@@ -408,9 +408,11 @@ int hp_ctx_fork(hp_ctx *parent, hp_ctx **out) {
     c->mult_streams = parent->mult_streams; c->mult_chunk = parent->mult_chunk; c->split_max_items = parent->split_max_items;
     // the lane will see the calls its parent sees: give it the parent's scratch size now instead of growing to it call by call
     // (a growth drains the device); a failure here is not one of the fork -- the first call reserves what it needs
-    if (parent->ws_bytes) {
+    // (capped: a parent that has run a batch of 256 holds 10 GiB of scratch, a lane is made for single calls)
+    const size_t lane_ws = parent->ws_bytes < ((size_t)256 << 20) ? parent->ws_bytes : ((size_t)256 << 20);
+    if (lane_ws) {
         (void)hipSetDevice(parent->device);
-        if (hipMalloc(&c->ws, parent->ws_bytes) == hipSuccess) c->ws_bytes = parent->ws_bytes;
+        if (hipMalloc(&c->ws, lane_ws) == hipSuccess) c->ws_bytes = lane_ws;
         else { c->ws = nullptr; (void)hipGetLastError(); }
     }
     *out = c;

@@ -949,6 +949,16 @@ bool deferred() { return op_queue().on; }
 
 namespace {
 
+// a call has run: it lets go of its operands at once (a dependent chain recycles its blocks through the pool while the queue
+// runs, like the eager calls do, instead of holding every intermediate result until the end)
+void release_operands(PendingOp &o) {
+    for (auto &r : o.in) {
+        if (r.first->pending_reads) r.first->pending_reads--;
+        if (r.first->parent && r.first->parent->pending_reads) r.first->parent->pending_reads--;
+    }
+    o.in.clear();
+}
+
 // operand polynomials [first, first + count) of every call of a group as u64[B][count][in_limbs][N]: their own words when they
 // already lie like that, otherwise one gather kernel
 Src group_rows(const std::vector<PendingOp *> &g, size_t first, size_t count, size_t n) {
@@ -1030,6 +1040,7 @@ void run_group(const std::vector<PendingOp *> &g) {
         ph.parent = big;
         ph.op = nullptr;
         g[b]->done = true;
+        release_operands(*g[b]);
     }
     g_stats.deferred_groups++;
     g_stats.deferred_calls += B;
@@ -1086,8 +1097,10 @@ std::vector<PendingOp *> run_fused_mults(const std::vector<std::unique_ptr<Pendi
             o->out->op = nullptr;
             o->out->failed = true;
             o->done = true;
+            release_operands(*o);
         }
         drop[b]->done = true;
+        release_operands(*drop[b]);
     }
     g_stats.deferred_groups++;
     g_stats.deferred_calls += 3 * B;
@@ -1115,13 +1128,16 @@ void flush_all() {
     std::vector<std::unique_ptr<PendingOp>> ops;
     ops.swap(Q.ops);
     try {
-        OpScope scope({}, 0);   // (batches run on lane 0)
         size_t first = 0;
         while (first < ops.size()) {
             if (ops[first]->done) { first++; continue; }
             std::vector<PendingOp *> g{ops[first].get()};
             for (size_t j = first + 1; j < ops.size(); j++)
                 if (!ops[j]->done && ops[j]->same_signature(*g[0]) && ops[j]->ready()) g.push_back(ops[j].get());
+            // everything the queue runs goes to lane 0: a batch fills the GPU by itself and only one lane grows a batch-sized workspace.
+            // (Groups of one or two calls spread over the lanes like eager calls were measured: a dependent chain of rotations 0.163
+            // against 0.126 ms per call -- the hops cost more than independent small groups could win.)
+            OpScope scope({}, 0);
             g = run_fused_mults(ops, g);
             if (!g.empty()) run_group(g);
         }
@@ -1143,10 +1159,9 @@ BlockRef record(std::unique_ptr<PendingOp> op) {
     ph->words = op->out_words;
     ph->op = op.get();
     op->out = ph;
-    for (auto &r : op->in) {   // (views of a batch block share its words: the count lives on the block that owns them)
-        DevBlock &owner = r.first->parent ? *r.first->parent : *r.first;
-        owner.pending_reads++;
-        r.first->pending_reads += (&owner != r.first.get());
+    for (auto &r : op->in) {   // (views of a batch block share its words: counted on the view and on the block that owns them)
+        r.first->pending_reads++;
+        if (r.first->parent) r.first->parent->pending_reads++;
     }
     Q.ops.push_back(std::move(op));
     if (Q.ops.size() >= OpQueue::MAX_PENDING) flush_all();
