@@ -50,6 +50,30 @@ class Engine:
         if use_torch_stream:
             self.use_stream(torch.cuda.current_stream(device))
 
+    def fork(self) -> "Engine":
+        """A second lane on the same GPU (hp_ctx_fork): its own stream and scratch workspace, the family's tables and lock; calls on it
+        overlap on the device with calls on this one.  Order them with wait_for where one reads what the other wrote."""
+        e = object.__new__(Engine)
+        e.torch, e.lib, e.device = self.torch, self.lib, self.device
+        h = capi.P()
+        self._chk(self.lib.hp_ctx_fork(self.h, C.byref(h)))
+        e.h = h
+        return e
+
+    def wait_for(self, other: "Engine"):
+        """everything enqueued on this context from now on runs after everything `other` has enqueued so far (device-side event)"""
+        self._chk(self.lib.hp_ctx_wait_for(self.h, other.h))
+
+    def gather_rows(self, rows, words: int, out):
+        """rows: device tensors (each `words` int64 words, anywhere) -> out[len(rows)][words] by one kernel per 64 rows"""
+        ptrs = (capi.P * len(rows))(*[r.data_ptr() for r in rows])
+        self._chk(self.lib.hp_dev_gather_rows(self.h, len(rows), words, ptrs, self._ptr(out)))
+        return out
+
+    def scatter_rows(self, packed, words: int, rows):
+        ptrs = (capi.P * len(rows))(*[r.data_ptr() for r in rows])
+        self._chk(self.lib.hp_dev_scatter_rows(self.h, len(rows), words, self._ptr(packed), ptrs))
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.hp_ctx_destroy(self.h)
