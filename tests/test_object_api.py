@@ -83,6 +83,20 @@ def test_deferred_mode_prints_the_same_words(shape):
 
 
 @pytest.mark.gpu
+def test_modes_agree_at_parity_level_a():
+    """HP_PARITY_LEVEL=A (canonical residues): single calls, the batched form (fused pipeline: two drops as one transform), lanes and
+    deferred mode (recorded triples run as the fused pipeline) all return the same words -- residues have one representative"""
+    args = [13, 6, 9, "all", 2, 8, 3, 2]
+    eager = run(build_example(), args, {"HP_PARITY_LEVEL": "A"})
+    lazy = run(build_example(), args, {"HP_PARITY_LEVEL": "A", "HEHUB_AMD_DEFER": "1"})
+    level_b = run(build_example(), args)
+    assert eager["serial"] == eager["batch"] and eager["serial-chain"] == eager["batch-chain"] and eager["chains"] == eager["chains-lanes"]
+    for k in ("serial", "batch", "serial-chain", "batch-chain", "chains"):
+        assert lazy[k] == eager[k], (k, lazy, eager)
+    assert eager["serial"] != level_b["serial"]          # (some lazy word of hehub's is >= q: level A is not level B)
+
+
+@pytest.mark.gpu
 def test_c3_unchanged_loop_in_deferred_mode():
     """the loop of single calls (hehub's interface as it is) in deferred mode: the recorded mult + rescale_inplace pairs run as the
     engine's fused batch pipeline -- the batch rate without a source change (24 - 28 k hom-mult/s at B = 256; loose bound here)"""
