@@ -153,9 +153,10 @@ def roofline_entry(family, alg_bytes_per_step, steps, launches, kern_ms, elapsed
                 out["bound"] = "valu"
             if "valu_insts_per_wave" in tr:
                 # the committed instruction count of this kernel shape against THIS run's launch duration and shader clock:
-                # 16 waves per limb transform, 1024 SIMDs (256 CUs x 4), one VALU instruction of the kernel's mix occupies its SIMD for
-                # cycles_per_inst_mix cycles (4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU; 4 = a full-rate instruction)
-                waves = limbs_per_launch * 16
+                # N / 2048 waves per limb transform (32 coefficients per thread, hp_ntt_tile.h Geo: 16 waves at N = 32768), 1024 SIMDs
+                # (256 CUs x 4), one VALU instruction of the kernel's mix occupies its SIMD for cycles_per_inst_mix cycles
+                # (4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU; 4 = a full-rate instruction)
+                waves = limbs_per_launch * max(1, (1 << logn) // 2048)
                 cpi = tr.get("valu_cycles_per_inst", 4.0)
                 alu = {"valu_insts_per_wave": tr["valu_insts_per_wave"], "waves": waves, "cycles_per_inst_mix": cpi, "sclk_MHz": sclk_mhz,
                        "simds": 1024}

@@ -77,6 +77,9 @@ def test_default_line_carries_both_halves_of_the_metric():
     assert c2["moduli"] == [1125899904679937, 1125899903827969, 1125899903500289, 1125899903107073]
     for d in ("forward", "inverse"):
         assert c2[d]["per_s"] > 0 and 0.05 < c2[d]["roofline"]["frac"] < 1 and c2[d]["cpu_baseline"]["value"] > 0
+        alu = c2[d]["roofline"].get("alu")
+        if alu:   # N / 2048 = 8 waves per limb at N = 16384; nothing issues faster than the issue peak
+            assert alu["waves"] == 4096 * 8 and ("frac_of_issue_peak" not in alu or 0 < alu["frac_of_issue_peak"] < 1.1)
     bgv = r["bgv"]
     assert bgv["N"] == 8192 and bgv["L"] == 6 and bgv["plain_modulus"] == 65537 and bgv["batch_per_gpu"] == 512
     assert bgv["verified"] is True and bgv["verified_outputs"] == 512 and bgv["A_step_bytes_per_op"] == 396 * 65536

@@ -60,6 +60,9 @@ def test_roofline_arithmetic():
     assert abs(r["share_of_step_time"] - 3.75 / 8.6) < 1e-9 and r["algorithmic_bytes_per_launch"] == alg
     # the committed PMC measurement of the digit-spread launch: less HBM traffic than algorithmic bytes (sources from L2, packed rows)
     assert r["traffic"] is not None and 0.3 * alg < r["traffic"] < alg and 0.5 < r["valu_busy"] < 1.0
+    # a smaller ring has fewer waves per limb (32 coefficients per thread: N / 2048 waves): C2's launch of 4096 limbs at N = 16384
+    c2 = roofline_entry("ntt", 16.0 * (1 << 14) * 4096, 20, launches=20, kern_ms=20 * 0.344, elapsed=20 * 0.35e-3, logn=14, spread=False, sclk_mhz=2250.0)
+    assert c2["alu"]["waves"] == 4096 * 8 and 0.5 < c2["alu"]["frac_of_issue_peak"] < 1.0
     plain = roofline_entry("ntt", alg, steps, steps, steps * 3.9, steps * 3.9e-3, 15, spread=False)
     assert plain["traffic"] > r["traffic"] and abs(plain["traffic"] / alg - 1.0) < 0.05        # in-place launch: ~1.0 x algorithmic
     assert roofline_entry("elem", 24.0 * n * 2040, 5, 5, 5 * 0.28, 5 * 0.28e-3, 15, False)["bound"] == "hbm"   # no counters say otherwise
