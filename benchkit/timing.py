@@ -54,6 +54,14 @@ def timed_launches(run: Run, fn, family, steps, warm=1):
     return dt, launches, kern_ms
 
 
+def family_of_kernel(name):
+    """profiling family (hp_prof.cpp) of a kernel name as rocprofv3 prints it (profiles/traffic.json `by_kernel`)"""
+    for pat, fam in (("k_ntt_fwd_drop", "ntt_drop"), ("k_ntt_fwd", "ntt"), ("k_ntt_inv", "intt"), ("k_ks_inner", "ks_inner"), ("k_tensor", "tensor")):
+        if pat in name:
+            return fam
+    return None
+
+
 def step_kernels(run: Run, wl, level, steps=3):
     """Every launch of one step, per profiling family (a separate short pass AFTER the timed regions: hp_prof_begin("*") brackets
     every launch with HIP events): launches per step, average milliseconds, the family's share of A_step and the
@@ -89,6 +97,13 @@ def step_kernels(run: Run, wl, level, steps=3):
     except (OSError, ValueError):
         tr = None
     if tr and tr.get("batch") and wl.n == tr.get("N") and wl.L == tr.get("L"):
+        # each family of the table against its own MEASURED bytes as well (the A_step share counts the key once per ciphertext and
+        # every digit row at 8 bytes: the inner product's share is 2 x what crosses HBM, its A_step fraction is above 1 for that reason)
+        for fam, ent in table.items():
+            b = sum(v for k, v in tr.get("by_kernel", {}).items() if family_of_kernel(k) == fam) * wl.B / tr["batch"]
+            if b:
+                ent.update({"measured_bytes_per_step": b, "measured_GBps": b / (ent["ms_per_step"] * 1e-3) / 1e9,
+                            "measured_frac_of_hbm_peak": b / (ent["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS})
         per_op = tr["bytes_per_step"] / tr["batch"]
         a_step = wl.a_limbs * S
         a_min = (6 * wl.L - 2) * S + 2 * wl.L * (wl.L + 1) * S / wl.B

@@ -110,6 +110,10 @@ def test_default_line_carries_both_halves_of_the_metric():
     tr = step["step_traffic"]
     assert 0.2 < tr["measured_over_A_step"] < 1.0 and tr["measured_over_A_min"] > 1.0 and 0.1 < tr["frac_of_hbm_peak"] < 1.0
     assert r["level_a"]["ckks"]["step"]["step_traffic"]["measured_bytes_per_op"] < tr["measured_bytes_per_op"]
+    # every family against its own measured bytes: nothing moves more than the HBM peak, the families' measured bytes add up to the step's
+    meas = [k["measured_bytes_per_step"] for k in step["kernels"].values() if "measured_bytes_per_step" in k]
+    assert len(meas) >= 5 and abs(sum(meas) - 256 * tr["measured_bytes_per_op"]) < 0.02 * sum(meas)
+    assert all(0 < k["measured_frac_of_hbm_peak"] < 1.0 for k in step["kernels"].values() if "measured_frac_of_hbm_peak" in k)
     api = r["object_api"]
     assert api["verified"] is True and api["digests_equal"] is True and api["deferred"]["digests_equal_eager"] is True
     assert api["batched_call"]["per_s"] > 15000 and api["batched_call"]["per_s"] > 2 * api["single_calls"]["per_s"]
