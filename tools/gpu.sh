@@ -9,7 +9,7 @@ python - <<PY
 import sys
 sys.path.insert(0, "$R"); sys.path.insert(0, "$R/tests")
 from hehub_amd.build import build_example
-for name in ("independent_mults", "resident_chain"):
+for name in ("independent_mults", "resident_chain", "random_program"):
     build_example(name)
 import test_host_api
 test_host_api.build_binary()
