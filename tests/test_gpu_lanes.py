@@ -77,3 +77,69 @@ def test_fork_shares_tables_and_keeps_own_workspace():
     finally:
         child.close()
         root.close()
+
+
+def strict(moduli, a):
+    """reduce_strict per limb (mod_arith.h:58-72): a [..., L, n] of lazy words below 2q"""
+    q = np.array(moduli, dtype=np.uint64)[:, None]
+    return np.where(a >= q, a - q, a)
+
+
+def test_family_members_driven_by_their_own_threads(orc):
+    """four members of one family, each called from its own host thread AT THE SAME TIME, each touching moduli / ring degrees the
+    family has not seen yet (tables, plans, FP64 tables of level A, permutations are built under the family's one mutex while the
+    other threads are inside their own calls): every result is the oracle's"""
+    import threading
+
+    from hehub_amd.engine import Engine
+
+    root = Engine(0, use_torch_stream=False)
+    members = [root, root.fork(), root.fork(), root.fork()]
+    members[3].set_parity_level("A")
+    rng = SplitMix(777)
+    work = []
+    for t, logn in enumerate((12, 13, 11, 12)):
+        mext = [P.P50[1]] + P.P40[t:t + 3] + [P.P50[0]]           # a different set of primes per thread
+        n, L = 1 << logn, len(mext) - 1
+        work.append((logn, mext, rng.poly((L, 2, L + 1, n), mext), rng.poly((3, 2, L, n), mext[:L]), rng.poly((3, 2, L, n), mext[:L])))
+    got, errors = [None] * 4, []
+    start = threading.Barrier(4)
+
+    def body(t):
+        try:
+            e, (logn, mext, key, a, b) = members[t], work[t]
+            L = len(mext) - 1
+            start.wait()
+            dk, da, db = e.to_device(key), e.to_device(a), e.to_device(b)
+            for _ in range(4):
+                out = e.ckks_mult(mext, da, db, dk)
+                rot = e.ckks_rotate(mext, da, dk, 1)
+                x = e.ntt_(mext[:L], e.intt_(mext[:L], da.clone().reshape(6, L, 1 << logn)))
+            e.sync()
+            got[t] = (e.to_host(out), e.to_host(rot), e.to_host(x))
+        except Exception as exc:  # noqa: BLE001
+            errors.append((t, repr(exc)))
+
+    threads = [threading.Thread(target=body, args=(t,)) for t in range(4)]
+    try:
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(600)
+        assert not errors, errors
+        for t, (logn, mext, key, a, b) in enumerate(work):
+            L, n = len(mext) - 1, 1 << logn
+            out, rot, x = got[t]
+            for i in range(3):
+                want = orc.ckks_mult(mext, a[i], b[i], key)
+                want_rot = orc.ckks_rotate(mext, a[i], key, 1)
+                if t == 3:      # level A: the canonical residue of hehub's word
+                    want, want_rot = strict(mext[:L - 1], want), strict(mext[:L], want_rot)
+                assert np.array_equal(out[i], want), (t, i)
+                assert np.array_equal(rot[i], want_rot), (t, i)
+            rt = np.stack([orc.poly_ntt(mext[:L], orc.poly_intt(mext[:L], p)) for p in a.reshape(6, L, n)])
+            assert np.array_equal(x, rt), t
+    finally:
+        for e in members[1:]:
+            e.close()
+        root.close()
