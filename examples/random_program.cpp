@@ -12,6 +12,7 @@
 #ifdef CHAIN_REFERENCE_HEADERS
 #include "fhe/bgv/bgv.h"
 #include "fhe/ckks/ckks.h"
+#include "fhe/common/ntt.h"
 #include "fhe/primitives/keys.h"
 #else
 #include "hehub.hpp"
@@ -79,7 +80,7 @@ template <class Ct, class Quad, bool BGV> struct Program {
     Quad quad;
     bool quad_full = false;
     u64 h = 0xcbf29ce484222325ull;
-    unsigned long long count[16] = {0};
+    unsigned long long count[18] = {0};
 
     std::vector<u64> moduli_at(size_t lv) const { return std::vector<u64>(q.begin(), q.begin() + lv); }
     void settle(Ct &ct) {
@@ -108,7 +109,7 @@ template <class Ct, class Quad, bool BGV> struct Program {
     void run(size_t ops) {
         const size_t P = pool.size();
         for (size_t it = 0; it < ops; it++) {
-            const size_t op = pick(16), x = pick(P), z = pick(P);
+            const size_t op = pick(18), x = pick(P), z = pick(P);
             count[op]++;
             switch (op) {
             case 0: case 1: {   // add / sub of two ciphertexts of one level; the result may replace an operand
@@ -196,12 +197,29 @@ template <class Ct, class Quad, bool BGV> struct Program {
                 const size_t which = pick(3);
                 if (which == 0) pool[x][0] += pool[y][0];
                 else if (which == 1) pool[x][1] -= pool[y][1];
-                else pool[x][pick(2)] *= (u64)(pick() % 1000003 + 2);
+                else {
+                    const size_t half = pick(2);
+                    const u64 scalar = pick() % 1000003 + 2;
+                    pool[x][half] *= scalar;
+                }
                 break;
             }
             case 14: {   // a fresh ciphertext (keeps the top level populated)
                 pool[x] = fresh();
                 level[x] = L;
+                break;
+            }
+            case 15: {   // the caller writes a word of a polynomial in place (operator[] on a non-const limb), then goes on computing with it
+                const size_t half = pick(2), k = pick(level[x]), i = pick(n);
+                const u64 w = pick() % q[0] % 1000;
+                auto &limb = pool[x][half][(int)k];
+                limb[i] = w;
+                break;
+            }
+            case 16: {   // transforms in place on one polynomial (ntt.h:41-51, :72-92): to coefficients and back -- other lazy words, same residues
+                auto &poly = pool[x][pick(2)];
+                intt_negacyclic_inplace_lazy(poly);
+                ntt_negacyclic_inplace_lazy(poly);
                 break;
             }
             default: {   // a chain on one slot: mult, rotate (or a second mult), all at the key's level
@@ -242,7 +260,7 @@ template <class Ct, class Quad, bool BGV> static int run_program(size_t logn, si
     p.run(ops);
     std::printf("program digest %016llx\n", (unsigned long long)p.h);
     std::printf("calls:");
-    for (int i = 0; i < 16; i++) std::printf(" %llu", p.count[i]);
+    for (int i = 0; i < 18; i++) std::printf(" %llu", p.count[i]);
     std::printf("\n");
 #ifndef CHAIN_REFERENCE_HEADERS
     const auto st = amd::transfer_stats();

@@ -20,7 +20,7 @@ def digest(binary, case, env=None):
 
 
 if __name__ == "__main__":
-    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref_randprog"], check=True)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref_randprog", "ref_randprog_amd"], check=True)
     table = {" ".join(str(a) for a in c): digest(REF, c)[0] for c in CASES}
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "random_program.json"), "w") as f:
         json.dump({"_comment": "hehub's own digests of examples/random_program.cpp (tests/golden/make_random_program.py); key = logN L pool ops seed bgv",

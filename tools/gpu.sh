@@ -14,5 +14,7 @@ for name in ("independent_mults", "resident_chain", "random_program"):
 import test_host_api
 test_host_api.build_binary()
 PY
+# programs compiled against hehub's own headers (oracle/_ref/: prebuilt here, where the reference tree is) follow their sources too
+[ -d /root/reference/src ] && make -s -C $R/oracle ref_indep ref_chain ref_randprog ref_randprog_amd
 T=$1; shift
 exec /usr/local/graft/bin/gpurun --timeout $T -- "$@"
