@@ -64,7 +64,7 @@ static u32 spread_pack_mask(const hp_ctx *ctx, const Plan *plan, size_t logn, si
 // then not trusted to be below their moduli and the digit rows stay plain u64
 int ks_digits_inner(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P, size_t k0, size_t k1, const u64 *coef,
                     const u64 *pt, size_t pt_pstride, const u64 *key, size_t key_L0, u64 *out, u64 *digits, bool strict_coef,
-                    bool coef_words = false) {
+                    bool coef_words = false, const u64 *const *keys = nullptr) {
     const size_t n = (size_t)1 << logn;
     int rc;
     // (ii) D[j][k] = NTT_{q_k}(c[j]), k != j                       rgsw.cpp:108-119
@@ -77,7 +77,8 @@ int ks_digits_inner(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t
     sj.pair_moduli = (k0 == 0 && k1 == L + 1 && L >= 2) ? (u32)ctx->spread_group : 0u;
     if (sj.pair_moduli > L) sj.pair_moduli = (u32)L;
     // digit rows of the output moduli whose words are provably below 2^48 cross HBM as 6 bytes per word (HP_PACK48)
-    sj.pack_mask = strict_coef ? spread_pack_mask(ctx, plan, logn, L, P, k0, k1) : 0u;
+    // (keys: every ciphertext with its own key -- that inner product reads plain rows)
+    sj.pack_mask = strict_coef && !keys ? spread_pack_mask(ctx, plan, logn, L, P, k0, k1) : 0u;
     // level A: digit rows as residues in [q/2, 3q/2] (the inner product below is the same integer kernel: its u128 sums then differ
     // from rgsw.cpp:126-149's by multiples of q_k, its Montgomery outputs are congruent to the reference's and below 2 q_k).
     // Caller-supplied coefficient rows (limb-range stages) are not known to be below 2^50: level B -- unless the caller vouches
@@ -92,6 +93,19 @@ int ks_digits_inner(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t
     }
     if ((rc = run_ntt(ctx, sj))) return rc;
     // (iii) u128 inner product + Montgomery                         rgsw.cpp:121-153
+    if (keys) {
+        ProfScope ps(ctx, "ks_inner");
+        for (size_t p0 = 0; p0 < P && !rc; p0 += HP_KEY_TABLE_MAX) {
+            const size_t cnt = P - p0 < HP_KEY_TABLE_MAX ? P - p0 : HP_KEY_TABLE_MAX;
+            HpKeyTable kt;
+            memset(&kt, 0, sizeof(kt));
+            for (size_t b = 0; b < cnt; b++) kt.p[b] = keys[p0 + b];
+            rc = chk(ctx, hp_launch_ks_inner_many(plan->d_limbs, (u32)L, (u32)k0, (u32)(k1 - k0), (u32)(key_L0 + 1), (u32)n, (u32)cnt,
+                                                  digits + p0 * L * (L + 1) * n, pt + p0 * pt_pstride * n, (u32)pt_pstride, kt,
+                                                  out + p0 * 2 * (L + 1) * n, ctx->stream), "ks_inner (a key per ciphertext)");
+        }
+        return rc;
+    }
     {
         ProfScope ps(ctx, "ks_inner");
         rc = chk(ctx, hp_launch_ks_inner(plan->d_limbs, (u32)L, (u32)k0, (u32)(k1 - k0), (u32)(key_L0 + 1), (u32)n, (u32)P, digits, pt,
@@ -101,13 +115,13 @@ int ks_digits_inner(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t
 }
 
 int ext_prod(hp_ctx *ctx, const Plan *plan, size_t logn, size_t L, size_t P, const u64 *pt, size_t pt_pstride,
-             const u64 *key, size_t key_L0, u64 *out, Carver &cv) {
+             const u64 *key, size_t key_L0, u64 *out, Carver &cv, const u64 *const *keys = nullptr) {
     const size_t n = (size_t)1 << logn;
     u64 *coef = cv.take(P * L * n);
     u64 *digits = cv.take(P * L * (L + 1) * n);
     int rc;
     if ((rc = ks_coef(ctx, plan, logn, L, P, 0, L, pt, pt_pstride, coef, true))) return rc;
-    return ks_digits_inner(ctx, plan, logn, L, P, 0, L + 1, coef, pt, pt_pstride, key, key_L0, out, digits, true);
+    return ks_digits_inner(ctx, plan, logn, L, P, 0, L + 1, coef, pt, pt_pstride, key, key_L0, out, digits, true, false, keys);
 }
 
 } // namespace
@@ -492,13 +506,30 @@ int hp_dev_bgv_relinearize(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *m
 
 // ckks/arith.cpp:75-93: rotate (cycle by `step`) or conjugate (involution) a batch and switch back to the
 // original key: moved = gather(ct); ext = ext_prod(moved[1], key); drop p; out[0] += moved[0]
+// many != nullptr: ciphertext b is moved by its own step (steps[b]; conj_of[b] != 0: involution) and switched with its own key keys[b]
+struct ManyKeys {
+    const size_t *steps;
+    const unsigned char *conj_of;
+    const uint64_t *const *keys;
+};
 static int dev_ckks_automorphism(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, size_t batch,
-                                 bool conj, size_t step, const uint64_t *ct, const uint64_t *key, uint64_t *out) {
+                                 bool conj, size_t step, const uint64_t *ct, const uint64_t *key, uint64_t *out,
+                                 const ManyKeys *many = nullptr) {
     HP_ENTER(ctx);
-    HP_REQUIRE(ctx, moduli_ext, ct, key, out);
-    HP_ALIGNED(ctx, ct, key, out);
+    HP_REQUIRE(ctx, moduli_ext, ct, out);
+    HP_ALIGNED(ctx, ct, out);
     int rc = check_ext_args(ctx, logn, L, batch);
     if (rc || (rc = key_level_ok(ctx, L, key_L0))) return rc;
+    if (many) {
+        HP_REQUIRE(ctx, many->steps, many->keys);
+        for (size_t b = 0; b < batch; b++) {
+            if (!many->keys[b] || ((uintptr_t)many->keys[b] & 15u)) return fail(ctx, HP_EINVAL, "rotate_many: NULL or misaligned key");
+            if (!(many->conj_of && many->conj_of[b]) && many->steps[b] >= ((size_t)1 << 17)) return fail(ctx, HP_EINVAL, "rotation step out of range");
+        }
+    } else {
+        HP_REQUIRE(ctx, key);
+        HP_ALIGNED(ctx, key);
+    }
     if (!conj && step >= ((size_t)1 << 17)) return fail(ctx, HP_EINVAL, "rotation step out of range");
     const Plan *plan;
     if ((rc = get_plan(ctx, logn, moduli_ext, L + 1, true, &plan))) return rc;
@@ -513,16 +544,32 @@ static int dev_ckks_automorphism(hp_ctx *ctx, size_t logn, size_t L, size_t key_
     u64 *ext = cv.take(batch * 2 * (L + 1) * n);
     {
         ProfScope ps(ctx, "elem");
-        if (conj) {
-            rc = chk(ctx, hp_launch_reverse((u32)n, (u32)(batch * 2 * L), ct, moved, ctx->stream), "involution");
-        } else {
-            const u32 *perm;
-            if ((rc = get_cycle_perm(ctx, logn, step, &perm))) return rc;
-            rc = chk(ctx, hp_launch_gather(perm, (u32)n, (u32)(batch * 2 * L), ct, moved, ctx->stream), "cycle");
+        // one launch per run of ciphertexts that move alike (all of them, for the one-key calls)
+        for (size_t b0 = 0, b1; b0 < batch && !rc; b0 = b1) {
+            bool cj = conj;
+            size_t st = step;
+            b1 = batch;
+            if (many) {
+                cj = many->conj_of && many->conj_of[b0];
+                st = cj ? 0 : many->steps[b0];
+                for (b1 = b0 + 1; b1 < batch; b1++) {
+                    const bool cj1 = many->conj_of && many->conj_of[b1];
+                    if (cj1 != cj || (!cj && many->steps[b1] != st)) break;
+                }
+            }
+            const u64 *src = ct + b0 * 2 * L * n;
+            u64 *dst = moved + b0 * 2 * L * n;
+            if (cj) {
+                rc = chk(ctx, hp_launch_reverse((u32)n, (u32)((b1 - b0) * 2 * L), src, dst, ctx->stream), "involution");
+            } else {
+                const u32 *perm;
+                if ((rc = get_cycle_perm(ctx, logn, st, &perm))) return rc;
+                rc = chk(ctx, hp_launch_gather(perm, (u32)n, (u32)((b1 - b0) * 2 * L), src, dst, ctx->stream), "cycle");
+            }
         }
     }
     if (rc) return rc;
-    if ((rc = ext_prod(ctx, plan, logn, L, batch, moved + L * n, 2 * L, key, key_L0, ext, cv))) return rc;
+    if ((rc = ext_prod(ctx, plan, logn, L, batch, moved + L * n, 2 * L, key, key_L0, ext, cv, many ? many->keys : nullptr))) return rc;
     return drop_last(ctx, plan, logn, L + 1, 2 * batch, false, 0, ext, moved, L, 2 * L, 1, out, cv);
 }
 
@@ -606,6 +653,12 @@ int hp_dev_ckks_rotate(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *modul
 int hp_dev_ckks_rotate_at(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, size_t batch,
                           size_t step, const uint64_t *ct, const uint64_t *rot_key, uint64_t *out) {
     return dev_ckks_automorphism(ctx, logn, L, key_L0, moduli_ext, batch, false, step, ct, rot_key, out);
+}
+int hp_dev_ckks_rotate_many(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, size_t batch,
+                            const size_t *steps, const unsigned char *conj, const uint64_t *ct, const uint64_t *const *d_keys,
+                            uint64_t *out) {
+    const ManyKeys many{steps, conj, d_keys};
+    return dev_ckks_automorphism(ctx, logn, L, key_L0, moduli_ext, batch, false, 0, ct, nullptr, out, &many);
 }
 int hp_dev_ckks_conjugate(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch,
                           const uint64_t *ct, const uint64_t *conj_key, uint64_t *out) {

@@ -44,7 +44,7 @@ struct ProfEvent {
 };
 
 // caches of small device objects are bounded: when one is full it is emptied (after a device synchronise), not grown
-constexpr size_t MAX_PERMS = 64, MAX_CRT = 128, MAX_HKS = 16;
+constexpr size_t MAX_PERMS = 1024, MAX_CRT = 128, MAX_HKS = 16;
 
 } // namespace hpi
 

@@ -340,16 +340,21 @@ hipError_t hp_launch_tensor(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32
 // One ciphertext (or an odd one out) per call: a LATENCY kernel -- hehub's one-call-per-ciphertext interface (ckks.h:270-313) puts a
 // single key switch on the critical path of every call.  A workgroup covers 512 coefficients (two per lane, one pass), and the
 // three 16-byte loads of FOUR digits are issued before their multiplications: the dependent rounds to memory drop from 4 x L to L / 4.
+// MANY: every ciphertext of the launch has its OWN key (hp_dev_ckks_rotate_many: the rotations of one vector by different steps in
+// the diagonal loop of src/circuits/linear_algebra.h:123-130); the key addresses travel as kernel arguments.  Nothing is shared
+// between ciphertexts then, so this one-ciphertext-per-thread kernel is also the right one for a batch: 3L rows per (p, k).
 #define KS1_CHUNK 512u
+template <bool MANY>
 __global__ void __launch_bounds__(ELEM_THREADS) k_ks_inner(const HpLimb *__restrict__ limbs, u32 L, u32 k_first, u32 P,
                                                           u32 key_Le, u32 n, u32 chunks, const u64 *__restrict__ digits,
                                                           const u64 *__restrict__ pt,
-                                                          u32 pt_pstride, const u64 *__restrict__ key,
+                                                          u32 pt_pstride, const u64 *__restrict__ key_one, HpKeyTable keys,
                                                           u64 *__restrict__ out) {
     const u32 Le = L + 1;
     const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;   // row = k*P' ... decoded below
     // modulus-major numbering keeps one key column (2L limbs) hot per XCD slice
     const u32 k = k_first + row / P, p = row % P;
+    const u64 *__restrict__ key = MANY ? keys.p[p] : key_one;
     const u64 q = limbs[k].q, mqinv = limbs[k].mqinv;
     const u32 i = chunk * KS1_CHUNK + threadIdx.x * 2;
     if (i >= n) return;
@@ -577,8 +582,19 @@ hipError_t hp_launch_ks_inner(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u
     } else {
         chunks = (n + KS1_CHUNK - 1) / KS1_CHUNK;
         grid = dim3(chunks * P * kc, 1, 1);
-        k_ks_inner<<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, key_Le, n, chunks, digits, pt, pt_pstride, key, out);
+        k_ks_inner<false><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, key_Le, n, chunks, digits, pt, pt_pstride, key, HpKeyTable{}, out);
     }
+    return hipGetLastError();
+}
+
+// every ciphertext with its own key: plain digit rows, P <= HP_KEY_TABLE_MAX per launch
+hipError_t hp_launch_ks_inner_many(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32 key_Le, u32 n, u32 P, const u64 *digits,
+                                   const u64 *pt, u32 pt_pstride, const HpKeyTable &keys, u64 *out, hipStream_t stream) {
+    if (kc == 0 || P == 0) return hipSuccess;
+    if (P > HP_KEY_TABLE_MAX) return hipErrorInvalidValue;
+    const u32 chunks = (n + KS1_CHUNK - 1) / KS1_CHUNK;
+    k_ks_inner<true><<<dim3(chunks * P * kc, 1, 1), ELEM_THREADS, 0, stream>>>(limbs, L, k_first, P, key_Le, n, chunks, digits, pt, pt_pstride,
+                                                                               nullptr, keys, out);
     return hipGetLastError();
 }
 

@@ -115,6 +115,13 @@ hipError_t hp_launch_tensor(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32
 hipError_t hp_launch_ks_inner(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32 key_Le, u32 n, u32 P, const u64 *digits,
                               const u64 *pt, u32 pt_pstride, const u64 *key, u64 *out, u32 pack_mask, u32 pack40_mask,
                               hipStream_t stream);
+// the same inner product when every ciphertext has its own key (hp_dev_ckks_rotate_many): key addresses as kernel arguments
+#define HP_KEY_TABLE_MAX 32
+struct HpKeyTable {
+    const u64 *p[HP_KEY_TABLE_MAX];
+};
+hipError_t hp_launch_ks_inner_many(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32 key_Le, u32 n, u32 P, const u64 *digits,
+                                   const u64 *pt, u32 pt_pstride, const HpKeyTable &keys, u64 *out, hipStream_t stream);
 
 // drop-last-prime helpers (rescaling.cpp:46-75 / mod_switch.cpp:45-77)
 struct HpDropConsts {

@@ -351,6 +351,18 @@ class Engine:
                                                  self._ptr(ct), self._ptr(key), self._ptr(out)))
         return out
 
+    def ckks_rotate_many(self, moduli_ext, key_L0: int, ct, keys, steps, conj=None):
+        """ciphertext b rotated by steps[b] (conjugated where conj[b]) and switched with ITS OWN key keys[b] (device tensors)."""
+        B, _, L, n = ct.shape
+        assert len(keys) == B and len(steps) == B
+        out = self.empty((B, 2, L, n))
+        kp = (capi.P * B)(*[k.data_ptr() for k in keys])
+        st = (C.c_size_t * B)(*[int(s) for s in steps])
+        cj = (C.c_ubyte * B)(*[1 if c else 0 for c in conj]) if conj is not None else None
+        self._chk(self.lib.hp_dev_ckks_rotate_many(self.h, n.bit_length() - 1, L, key_L0, _u64arr(moduli_ext), B, st, cj,
+                                                   self._ptr(ct), kp, self._ptr(out)))
+        return out
+
     def ext_prod_at(self, moduli_ext, key_L0: int, pt, key):
         B, L, n = pt.shape
         out = self.empty((B, 2, L + 1, n))

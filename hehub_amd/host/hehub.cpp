@@ -554,9 +554,12 @@ struct PendingOp {
     size_t in_limbs = 0, out_words = 0;
     BlockRef out;           // placeholder of out_words words
     bool done = false;
+    // (rotations / conjugations group ACROSS keys and steps: the engine takes a key and a step per ciphertext, hp_dev_ckks_rotate_many --
+    // the rotations of one vector under the keys of a rotation key set, src/circuits/linear_algebra.h:123-130, are one launch sequence)
     bool same_signature(const PendingOp &o) const {
-        return kind == o.kind && logn == o.logn && L == o.L && L0 == o.L0 && step == o.step && conj == o.conj && bgv == o.bgv &&
-               sub == o.sub && t == o.t && key == o.key && in_limbs == o.in_limbs && in.size() == o.in.size() && mod == o.mod;
+        const bool ks = kind == OpKind::KeySwitch;
+        return kind == o.kind && logn == o.logn && L == o.L && L0 == o.L0 && (ks || (step == o.step && conj == o.conj && key == o.key)) &&
+               bgv == o.bgv && sub == o.sub && t == o.t && in_limbs == o.in_limbs && in.size() == o.in.size() && mod == o.mod;
     }
     bool ready() const {
         for (auto &r : in)
@@ -1002,9 +1005,27 @@ void run_group(const std::vector<PendingOp *> &g) {
     }
     case OpKind::KeySwitch: {
         Src dc = group_rows(g, 0, 2, n);
-        track_read(*o.key);
-        if (o.conj) check(hp_dev_ckks_conjugate_at(cur(), o.logn, L, o.L0, o.mod.data(), B, dc.p, o.key->p, big->p));
-        else check(hp_dev_ckks_rotate_at(cur(), o.logn, L, o.L0, o.mod.data(), B, o.step, dc.p, o.key->p, big->p));
+        bool one_key = true;
+        for (PendingOp *c : g) {
+            track_read(*c->key);
+            one_key = one_key && c->key == o.key && c->step == o.step && c->conj == o.conj;
+        }
+        if (!one_key) {   // every ciphertext with its own key and step
+            std::vector<const u64 *> keys;
+            std::vector<size_t> steps;
+            std::vector<unsigned char> conj;
+            for (PendingOp *c : g) {
+                keys.push_back(c->key->p);
+                steps.push_back(c->step);
+                conj.push_back(c->conj ? 1 : 0);
+            }
+            check(hp_dev_ckks_rotate_many(cur(), o.logn, L, o.L0, o.mod.data(), B, steps.data(), conj.data(), dc.p, keys.data(), big->p));
+            g_stats.deferred_many_key_groups++;
+        } else if (o.conj) {
+            check(hp_dev_ckks_conjugate_at(cur(), o.logn, L, o.L0, o.mod.data(), B, dc.p, o.key->p, big->p));
+        } else {
+            check(hp_dev_ckks_rotate_at(cur(), o.logn, L, o.L0, o.mod.data(), B, o.step, dc.p, o.key->p, big->p));
+        }
         break;
     }
     case OpKind::Drop: {
@@ -1174,6 +1195,18 @@ void set_deferred(bool on) {
 #else
     if (!on) flush_all();
     op_queue().on = on;
+#endif
+}
+
+// upload a vector's host words now; both copies stay current (an operand that is read call after call -- an encoded diagonal of
+// src/circuits/linear_algebra.h:111-116 -- then never crosses PCIe again, and copies of it are made on the device)
+void prefetch(const RnsIntVec &v) {
+#ifdef HEHUB_AMD_BIND_REFERENCE
+    (void)v;   // (hehub's own objects: the device side is a cache keyed by their words, filled by the first call that reads them)
+#else
+    if (v.component_count() == 0) return;
+    OpScope op({});
+    (void)Access::in(v, v.component_count());
 #endif
 }
 
@@ -1347,7 +1380,7 @@ size_t check_ext_prod(const RlwePt &pt, const RgswCt &rgsw, std::vector<u64> &ex
 
 // Device copy of a key-switching key: u64[L][2][L+1][N], one block, assembled from the key's 2L polynomials.  A key is
 // 2L(L+1) limbs (55 MiB at N=32768, L=10) and the same object call after call, so assembling it every time dominates.
-//   own mirror:        the last HEHUB_AMD_KEY_CACHE (default 4) keys stay resident, recognised EXACTLY: every polynomial
+//   own mirror:        the last HEHUB_AMD_KEY_CACHE (default 64) keys stay resident, recognised EXACTLY: every polynomial
 //                      carries a stamp that changes whenever its words can have changed (RnsIntVec, hehub.hpp)
 //   binding hehub's:   with HEHUB_AMD_KEY_CACHE=<entries> keys stay resident, recognised by the address of their first
 //                      limb, their shape and four sampled words of every limb (a key that is modified in place between
@@ -1357,7 +1390,8 @@ class DevKey {
 public:
     DevKey(const RgswCt &rgsw, size_t L, size_t n) {
 #ifndef HEHUB_AMD_BIND_REFERENCE
-        static const size_t cap = std::getenv("HEHUB_AMD_KEY_CACHE") ? (size_t)std::atoi(std::getenv("HEHUB_AMD_KEY_CACHE")) : 4;
+        // (64: a rotation key set stays resident -- 3.4 GiB of 288 at the C3 shape)
+        static const size_t cap = std::getenv("HEHUB_AMD_KEY_CACHE") ? (size_t)std::atoi(std::getenv("HEHUB_AMD_KEY_CACHE")) : 64;
 #else
         static const size_t cap = std::getenv("HEHUB_AMD_KEY_CACHE") ? (size_t)std::atoi(std::getenv("HEHUB_AMD_KEY_CACHE")) : 0;
 #endif
@@ -2226,6 +2260,52 @@ std::vector<ckks::CkksCt> ckks_key_switched(const std::vector<ckks::CkksCt> &cts
     return out;
 }
 
+// ckks::rotate(cts[i], *keys[i], steps[i]) for every i as ONE engine call (hp_dev_ckks_rotate_many); a batch that is not of one shape,
+// or whose keys were not all made for the same number of moduli, runs as the loop of single calls
+std::vector<ckks::CkksCt> ckks_rotate_many(const std::vector<ckks::CkksCt> &cts, const std::vector<const RlweKsk *> &keys,
+                                           const std::vector<size_t> &steps) {
+    same_size(cts.size(), keys.size());
+    same_size(cts.size(), steps.size());
+    size_t n, L;
+    std::vector<u64> q;
+    std::vector<ckks::CkksCt> out;
+    if (cts.empty()) return out;
+    for (const RlweKsk *k : keys)
+        if (!k) throw std::invalid_argument("Empty RGSW ciphertext.");
+    bool uniform = uniform_shape(cts, n, L, q);
+    for (size_t i = 1; uniform && i < keys.size(); i++) uniform = keys[i]->size() == keys[0]->size();
+    if (!uniform) {
+        for (size_t i = 0; i < cts.size(); i++) out.push_back(ckks::rotate(cts[i], *keys[i], steps[i]));
+        return out;
+    }
+    for (auto &ct : cts)
+        for (int h = 0; h < 2; h++)
+            if (ct[h].rep_form != PolyRepForm::value) throw std::invalid_argument("poly_ntt is expected to be in NTT value form");
+    std::vector<u64> mext, mext_i;
+    const size_t L0 = check_ext_prod(cts[0][1], *keys[0], mext);
+    for (size_t i = 1; i < cts.size(); i++)
+        if (check_ext_prod(cts[i][1], *keys[i], mext_i) != L0 || mext_i != mext) throw std::invalid_argument("Inconsistent RGSW ciphertext.");
+    const size_t logn = cts[0][1].log_dimension(), B = cts.size();
+    OpScope op({}, 0);
+    std::vector<DevKey> dks;
+    dks.reserve(B);
+    std::vector<const u64 *> kp;
+    for (size_t i = 0; i < B; i++) {   // (a key that appears several times is assembled once: the key cache, or the earlier element)
+        size_t same = i;
+        for (size_t j = 0; j < i && same == i; j++)
+            if (keys[j] == keys[i]) same = j;
+        if (same < i) { kp.push_back(kp[same]); continue; }
+        dks.emplace_back(*keys[i], L0, n);
+        kp.push_back(dks.back().p());
+    }
+    Src din = Access::batch_in(halves(cts), L);
+    Dst dout(B * 2 * L * n);
+    check(hp_dev_ckks_rotate_many(cur(), logn, L, L0, mext.data(), B, steps.data(), nullptr, din.p, kp.data(), dout.p));
+    out = result_batch<ckks::CkksCt>(B, n, L, q, dout);
+    for (size_t i = 0; i < B; i++) out[i].scaling_factor = cts[i].scaling_factor;
+    return out;
+}
+
 std::vector<ckks::CkksCt> ckks_addsub(const std::vector<ckks::CkksCt> &a, const std::vector<ckks::CkksCt> &b, bool sub) {
     same_size(a.size(), b.size());
     size_t n, L, nb, Lb;
@@ -2265,6 +2345,9 @@ std::vector<bgv::BgvCt> mult(const std::vector<bgv::BgvCt> &a, const std::vector
 std::vector<bgv::BgvCt> mult_mod_switch(const std::vector<bgv::BgvCt> &a, const std::vector<bgv::BgvCt> &b, const RlweKsk &key) { return bgv_mult(a, b, key, true); }
 std::vector<ckks::CkksCt> rotate(const std::vector<ckks::CkksCt> &cts, const RlweKsk &rot_key, size_t step) { return ckks_key_switched(cts, rot_key, false, step); }
 std::vector<ckks::CkksCt> conjugate(const std::vector<ckks::CkksCt> &cts, const RlweKsk &conj_key) { return ckks_key_switched(cts, conj_key, true, 0); }
+std::vector<ckks::CkksCt> rotate(const std::vector<ckks::CkksCt> &cts, const std::vector<const RlweKsk *> &rot_keys, const std::vector<size_t> &steps) {
+    return ckks_rotate_many(cts, rot_keys, steps);
+}
 std::vector<ckks::CkksCt> add(const std::vector<ckks::CkksCt> &a, const std::vector<ckks::CkksCt> &b) { return ckks_addsub(a, b, false); }
 std::vector<ckks::CkksCt> sub(const std::vector<ckks::CkksCt> &a, const std::vector<ckks::CkksCt> &b) { return ckks_addsub(a, b, true); }
 

@@ -44,6 +44,8 @@ struct TransferStats {
     // deferred mode: recorded calls that have run, and the batched engine calls they ran as
     // (deferred_fused: ckks::mult + rescale_inplace / bgv mult + mod_switch_inplace triples that ran as the engine's one-call pipeline)
     unsigned long long deferred_calls = 0, deferred_groups = 0, deferred_fused = 0;
+    // ... and the groups of rotations / conjugations that ran with a key per ciphertext (hp_dev_ckks_rotate_many)
+    unsigned long long deferred_many_key_groups = 0;
 };
 TransferStats transfer_stats();
 
@@ -57,11 +59,17 @@ void set_lanes(int n);
 /// polynomial products (mult_plain) and copies of results that are still pending --
 /// are RECORDED with all their argument checks made and their result objects returned; they run when somebody needs words (a look at
 /// a result, a call that cannot be recorded, synchronize(), 1024 recorded calls), grouped: recorded calls with one signature whose
-/// operands are ready run as ONE batched engine call.  An unchanged loop over independent ciphertexts thereby gets the batch rate
+/// operands are ready run as ONE batched engine call (rotations and conjugations group across keys and steps: the engine takes a key
+/// per ciphertext).  An unchanged loop over independent ciphertexts thereby gets the batch rate
 /// (hehub.cpp "deferred execution").  Results are word for word those of the eager calls; a failure inside the engine surfaces when
 /// the queue runs instead of at the call.  set_deferred(false) runs what is pending.
 void set_deferred(bool on);
 bool deferred();
+/// Upload a vector's host words now (own-mirror build; both copies stay current).  hehub's objects are created on the host; the layer
+/// uploads one when a call first reads it and keeps the device copy WITH THE OBJECT -- but a copy of a host-only object is a host copy.
+/// An operand that is copied and then transformed call after call (the encoded diagonal inside ckks::mult_plain, ckks/arith.cpp:47-53)
+/// crosses PCIe every time unless it is resident first.
+void prefetch(const RnsIntVec &v);
 /// wait until everything the layer has enqueued (or recorded) so far has run (hehub's interface has no such call: its functions are synchronous;
 /// here a result is waited for when somebody looks at its words -- this is for timing loops)
 void synchronize();
@@ -77,6 +85,10 @@ void rescale_inplace(std::vector<ckks::CkksCt> &cts);
 // ckks.h:284 / :282  rotate(ct, rot_key, step) / conjugate(ct, conj_key), one key for the whole batch
 std::vector<ckks::CkksCt> rotate(const std::vector<ckks::CkksCt> &cts, const RlweKsk &rot_key, size_t step);
 std::vector<ckks::CkksCt> conjugate(const std::vector<ckks::CkksCt> &cts, const RlweKsk &conj_key);
+// ckks.h:284  rotate(cts[i], *rot_keys[i], steps[i]): EVERY ciphertext under its own key and step, one engine call -- the rotations of
+// one vector under the keys of a rotation key set (src/circuits/linear_algebra.h:123-130: pass the same ciphertext 2 (width - 1) times)
+std::vector<ckks::CkksCt> rotate(const std::vector<ckks::CkksCt> &cts, const std::vector<const RlweKsk *> &rot_keys,
+                                 const std::vector<size_t> &steps);
 // ckks.h:73-89  add / sub, element by element
 std::vector<ckks::CkksCt> add(const std::vector<ckks::CkksCt> &a, const std::vector<ckks::CkksCt> &b);
 std::vector<ckks::CkksCt> sub(const std::vector<ckks::CkksCt> &a, const std::vector<ckks::CkksCt> &b);

@@ -408,6 +408,16 @@ int hp_dev_ckks_rotate_at(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, con
                           size_t step, const uint64_t *d_ct, const uint64_t *d_rot_key, uint64_t *d_out);
 int hp_dev_ckks_conjugate_at(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext,
                              size_t batch, const uint64_t *d_ct, const uint64_t *d_conj_key, uint64_t *d_out);
+/* (3) ckks.h:284 rotate / ckks.h:282 conjugate of `batch` ciphertexts, EACH WITH ITS OWN KEY AND STEP: hehub's circuits rotate one
+ *     vector by many steps, every step under its own key (src/circuits/linear_algebra.h:123-130: rotate(ct_vec, rot_key_set[s]) for
+ *     2 (width - 1) values of s) -- independent calls, but no two share a key, so the one-key batch form above does not apply.
+ *     d_ct u64[batch][2][L][N]; steps[b] and d_keys[b] (a HOST array of device addresses, key b laid out as for
+ *     hp_dev_ckks_rotate_at with key_L0) belong to ciphertext b; conj (may be NULL) marks the ciphertexts that are conjugated
+ *     instead (their step is ignored).  -> d_out u64[batch][2][L][N], word for word what `batch` calls of
+ *     hp_dev_ckks_rotate_at / hp_dev_ckks_conjugate_at with batch 1 write (ckks/arith.cpp:75-93). */
+int hp_dev_ckks_rotate_many(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, size_t batch,
+                            const size_t *steps, const unsigned char *conj, const uint64_t *d_ct,
+                            const uint64_t *const *d_keys, uint64_t *d_out);
 int hp_dev_ckks_mult_relin_rescale_at(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext,
                                       size_t batch, const uint64_t *d_ct1, const uint64_t *d_ct2,
                                       const uint64_t *d_key, uint64_t *d_out);

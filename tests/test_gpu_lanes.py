@@ -91,6 +91,8 @@ def test_family_members_driven_by_their_own_threads(orc):
     other threads are inside their own calls): every result is the oracle's"""
     import threading
 
+    import torch
+
     from hehub_amd.engine import Engine
 
     root = Engine(0, use_torch_stream=False)
@@ -114,7 +116,9 @@ def test_family_members_driven_by_their_own_threads(orc):
             for _ in range(4):
                 out = e.ckks_mult(mext, da, db, dk)
                 rot = e.ckks_rotate(mext, da, dk, 1)
-                x = e.ntt_(mext[:L], e.intt_(mext[:L], da.clone().reshape(6, L, 1 << logn)))
+                src = da.clone().reshape(6, L, 1 << logn)
+                torch.cuda.current_stream().synchronize()   # the copy ran on torch's stream, these engines own theirs (use_torch_stream=False)
+                x = e.ntt_(mext[:L], e.intt_(mext[:L], src))
             e.sync()
             got[t] = (e.to_host(out), e.to_host(rot), e.to_host(x))
         except Exception as exc:  # noqa: BLE001
