@@ -111,7 +111,6 @@ static CkksCt diag_loop(const std::vector<CkksPt> &diags, const CkksCt &ct_vec, 
 static CkksCt diag_loop_batched(const std::vector<CkksPt> &diags, const CkksCt &ct_vec, const std::vector<RotKey> &rot_key_set,
                                 size_t slot_count) {
     const size_t w = diags.size();
-    std::vector<CkksCt> src(2 * (w - 1), ct_vec);
     std::vector<const RlweKsk *> keys;
     std::vector<size_t> steps;
     for (size_t s = 1; s < w; s++)
@@ -119,7 +118,7 @@ static CkksCt diag_loop_batched(const std::vector<CkksPt> &diags, const CkksCt &
             keys.push_back(&rot_key_set[step]);
             steps.push_back(rot_key_set[step].step);
         }
-    std::vector<CkksCt> rot = amd::rotate(src, keys, steps);
+    std::vector<CkksCt> rot = amd::rotate(ct_vec, keys, steps);
     CkksCt acc = ckks::mult_plain(ct_vec, diags[0]);
     for (size_t i = 1; i < w; i++) acc = ckks::add(acc, ckks::mult_plain(ckks::add(rot[2 * (i - 1)], rot[2 * (i - 1) + 1]), diags[i]));
     ckks::rescale_inplace(acc);

@@ -511,17 +511,24 @@ struct ManyKeys {
     const size_t *steps;
     const unsigned char *conj_of;
     const uint64_t *const *keys;
+    const uint64_t *const *polys;   // not NULL: polynomial h of ciphertext b is polys[2 b + h] (u64[L][N]) instead of ct[b][h]
 };
 static int dev_ckks_automorphism(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, size_t batch,
                                  bool conj, size_t step, const uint64_t *ct, const uint64_t *key, uint64_t *out,
                                  const ManyKeys *many = nullptr) {
     HP_ENTER(ctx);
-    HP_REQUIRE(ctx, moduli_ext, ct, out);
-    HP_ALIGNED(ctx, ct, out);
+    HP_REQUIRE(ctx, moduli_ext, out);
+    HP_ALIGNED(ctx, out);
+    if (!(many && many->polys)) {
+        HP_REQUIRE(ctx, ct);
+        HP_ALIGNED(ctx, ct);
+    }
     int rc = check_ext_args(ctx, logn, L, batch);
     if (rc || (rc = key_level_ok(ctx, L, key_L0))) return rc;
     if (many) {
         HP_REQUIRE(ctx, many->steps, many->keys);
+        for (size_t b = 0; many->polys && b < 2 * batch; b++)
+            if (!many->polys[b] || ((uintptr_t)many->polys[b] & 15u)) return fail(ctx, HP_EINVAL, "rotate_many: NULL or misaligned polynomial");
         for (size_t b = 0; b < batch; b++) {
             if (!many->keys[b] || ((uintptr_t)many->keys[b] & 15u)) return fail(ctx, HP_EINVAL, "rotate_many: NULL or misaligned key");
             if (!(many->conj_of && many->conj_of[b]) && many->steps[b] >= ((size_t)1 << 17)) return fail(ctx, HP_EINVAL, "rotation step out of range");
@@ -544,28 +551,25 @@ static int dev_ckks_automorphism(hp_ctx *ctx, size_t logn, size_t L, size_t key_
     u64 *ext = cv.take(batch * 2 * (L + 1) * n);
     {
         ProfScope ps(ctx, "elem");
-        // one launch per run of ciphertexts that move alike (all of them, for the one-key calls)
-        for (size_t b0 = 0, b1; b0 < batch && !rc; b0 = b1) {
-            bool cj = conj;
-            size_t st = step;
-            b1 = batch;
-            if (many) {
-                cj = many->conj_of && many->conj_of[b0];
-                st = cj ? 0 : many->steps[b0];
-                for (b1 = b0 + 1; b1 < batch; b1++) {
-                    const bool cj1 = many->conj_of && many->conj_of[b1];
-                    if (cj1 != cj || (!cj && many->steps[b1] != st)) break;
+        if (many) {
+            // every ciphertext with its own map (and its polynomials possibly anywhere): sources and maps as kernel arguments
+            for (size_t b0 = 0; b0 < batch && !rc; b0 += HP_GATHER_TABLE_MAX) {
+                const size_t cnt = batch - b0 < HP_GATHER_TABLE_MAX ? batch - b0 : HP_GATHER_TABLE_MAX;
+                HpGatherTable gt;
+                memset(&gt, 0, sizeof(gt));
+                if ((rc = reserve_cycle_perms(ctx, cnt))) break;   // (a miss in a full map cache empties it: not between these)
+                for (size_t b = b0; b < b0 + cnt && !rc; b++) {
+                    for (size_t h = 0; h < 2; h++) gt.src[b - b0][h] = many->polys ? many->polys[2 * b + h] : ct + (b * 2 + h) * L * n;
+                    if (!(many->conj_of && many->conj_of[b])) rc = get_cycle_perm(ctx, logn, many->steps[b], &gt.perm[b - b0]);
                 }
+                if (!rc) rc = chk(ctx, hp_launch_gather_many(gt, (u32)cnt, (u32)n, (u32)L, moved + b0 * 2 * L * n, ctx->stream), "cycle / involution");
             }
-            const u64 *src = ct + b0 * 2 * L * n;
-            u64 *dst = moved + b0 * 2 * L * n;
-            if (cj) {
-                rc = chk(ctx, hp_launch_reverse((u32)n, (u32)((b1 - b0) * 2 * L), src, dst, ctx->stream), "involution");
-            } else {
-                const u32 *perm;
-                if ((rc = get_cycle_perm(ctx, logn, st, &perm))) return rc;
-                rc = chk(ctx, hp_launch_gather(perm, (u32)n, (u32)((b1 - b0) * 2 * L), src, dst, ctx->stream), "cycle");
-            }
+        } else if (conj) {
+            rc = chk(ctx, hp_launch_reverse((u32)n, (u32)(batch * 2 * L), ct, moved, ctx->stream), "involution");
+        } else {
+            const u32 *perm;
+            if ((rc = get_cycle_perm(ctx, logn, step, &perm))) return rc;
+            rc = chk(ctx, hp_launch_gather(perm, (u32)n, (u32)(batch * 2 * L), ct, moved, ctx->stream), "cycle");
         }
     }
     if (rc) return rc;
@@ -657,8 +661,16 @@ int hp_dev_ckks_rotate_at(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, con
 int hp_dev_ckks_rotate_many(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, size_t batch,
                             const size_t *steps, const unsigned char *conj, const uint64_t *ct, const uint64_t *const *d_keys,
                             uint64_t *out) {
-    const ManyKeys many{steps, conj, d_keys};
+    const ManyKeys many{steps, conj, d_keys, nullptr};
     return dev_ckks_automorphism(ctx, logn, L, key_L0, moduli_ext, batch, false, 0, ct, nullptr, out, &many);
+}
+int hp_dev_ckks_rotate_many_rows(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, size_t batch,
+                                 const size_t *steps, const unsigned char *conj, const uint64_t *const *d_polys,
+                                 const uint64_t *const *d_keys, uint64_t *out) {
+    if (!ctx) return HP_EINVAL;
+    if (!d_polys) { HP_ENTER(ctx); return fail(ctx, HP_EINVAL, "rotate_many: NULL polynomial table"); }
+    const ManyKeys many{steps, conj, d_keys, d_polys};
+    return dev_ckks_automorphism(ctx, logn, L, key_L0, moduli_ext, batch, false, 0, nullptr, nullptr, out, &many);
 }
 int hp_dev_ckks_conjugate(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, size_t batch,
                           const uint64_t *ct, const uint64_t *conj_key, uint64_t *out) {

@@ -229,6 +229,11 @@ static int get_cycle_perm_impl(hp_ctx *ctx, size_t logn, size_t step, const u32 
 int get_cycle_perm(hp_ctx *ctx, size_t logn, size_t step, const u32 **out) {
     return contained(ctx, [&] { return get_cycle_perm_impl(ctx, logn, step, out); });
 }
+// room for `count` more maps without the cache being emptied in between: a launch that takes several maps as kernel arguments
+// collects their addresses first (hp_dev_ckks_rotate_many)
+int reserve_cycle_perms(hp_ctx *ctx, size_t count) {
+    return contained(ctx, [&] { return make_room(ctx, ctx->perms, count >= MAX_PERMS ? 1 : MAX_PERMS - count); });
+}
 
 // constants of the CRT branch of the many -> one base transform (rns_transform.cpp:86-104), cached per (moduli, t)
 int get_crt_consts(hp_ctx *ctx, const uint64_t *moduli, size_t L, u64 t, const HpCrtConsts **out) {

@@ -211,6 +211,7 @@ struct LevelScope {
 };
 // gather map of cycle(poly, step) (permutation.cpp:39-53): out[to] = in[perm[to]]
 int get_cycle_perm(hp_ctx *ctx, size_t logn, size_t step, const u32 **out);
+int reserve_cycle_perms(hp_ctx *ctx, size_t count);   // the next `count` get_cycle_perm calls do not empty the cache
 int get_crt_consts(hp_ctx *ctx, const uint64_t *moduli, size_t L, u64 t, const HpCrtConsts **out);
 
 // ---- workspace --------------------------------------------------------------------------------------------

@@ -230,6 +230,44 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_reverse(u32 n, u32 chunks, con
     for (u32 i = chunk * ELEM_CHUNK + threadIdx.x; i < end; i += ELEM_THREADS) out[base + i] = in[base + (n - 1 - i)];
 }
 
+// cycle / involution of several ciphertexts in one launch, each with its own map and its two polynomials anywhere in device memory
+// (hp_dev_ckks_rotate_many: the sources and maps travel as kernel arguments): out u64[count][2][L][N]
+__global__ void __launch_bounds__(ELEM_THREADS) k_gather_many(HpGatherTable tab, u32 n, u32 chunks, u32 L, u64 *__restrict__ out) {
+    const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    const u32 b = row / (2 * L), r = row % (2 * L), h = r / L, k = r % L;
+    const u64 *__restrict__ in = tab.src[b][h] + (size_t)k * n;
+    const u32 *__restrict__ perm = tab.perm[b];
+    u64 *__restrict__ o = out + (size_t)row * n;
+    const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
+    if (!perm) {   // involution: permutation.cpp:57-75
+        for (u32 i = chunk * ELEM_CHUNK + threadIdx.x; i < end; i += ELEM_THREADS) __builtin_nontemporal_store(in[n - 1 - i], o + i);
+        return;
+    }
+    if ((chunk + 1) * ELEM_CHUNK <= n) {
+        constexpr int IT = ELEM_CHUNK / ELEM_THREADS;
+        const u32 i0 = chunk * ELEM_CHUNK + threadIdx.x;
+        u32 idx[IT];
+        u64 v[IT];
+#pragma unroll
+        for (int t = 0; t < IT; ++t) idx[t] = perm[i0 + t * ELEM_THREADS];
+#pragma unroll
+        for (int t = 0; t < IT; ++t) v[t] = in[idx[t]];
+#pragma unroll
+        for (int t = 0; t < IT; ++t) __builtin_nontemporal_store(v[t], o + i0 + t * ELEM_THREADS);
+        return;
+    }
+    for (u32 i = chunk * ELEM_CHUNK + threadIdx.x; i < end; i += ELEM_THREADS) __builtin_nontemporal_store(in[perm[i]], o + i);
+}
+
+hipError_t hp_launch_gather_many(const HpGatherTable &tab, u32 count, u32 n, u32 L, u64 *out, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    if (count > HP_GATHER_TABLE_MAX) return hipErrorInvalidValue;
+    u32 chunks; dim3 grid;
+    elem_grid(n, count * 2 * L, chunks, grid);
+    k_gather_many<<<grid, ELEM_THREADS, 0, stream>>>(tab, n, chunks, L, out);
+    return hipGetLastError();
+}
+
 hipError_t hp_launch_reverse(u32 n, u32 rows, const u64 *in, u64 *out, hipStream_t stream) {
     u32 chunks; dim3 grid;
     elem_grid(n, rows, chunks, grid);

@@ -85,6 +85,14 @@ struct HpHostRows {
 hipError_t hp_launch_host_rows(bool to_host, const HpHostRows &rows, u32 count, size_t words, u64 *dev, hipStream_t stream);
 hipError_t hp_launch_gather(const u32 *perm, u32 n, u32 rows, const u64 *in, u64 *out, hipStream_t stream);
 hipError_t hp_launch_reverse(u32 n, u32 rows, const u64 *in, u64 *out, hipStream_t stream);
+// several ciphertexts moved in one launch: ciphertext b = polynomials src[b][0], src[b][1] (u64[L][N] each, anywhere), map perm[b]
+// (NULL: involution) -> out u64[count][2][L][N]
+#define HP_GATHER_TABLE_MAX 32
+struct HpGatherTable {
+    const u64 *src[HP_GATHER_TABLE_MAX][2];
+    const u32 *perm[HP_GATHER_TABLE_MAX];
+};
+hipError_t hp_launch_gather_many(const HpGatherTable &tab, u32 count, u32 n, u32 L, u64 *out, hipStream_t stream);
 
 // single-vector kernels behind the drop-in mod_arith entry points
 enum HpVecOp : int {

@@ -363,6 +363,20 @@ class Engine:
                                                    self._ptr(ct), kp, self._ptr(out)))
         return out
 
+    def ckks_rotate_many_rows(self, moduli_ext, key_L0: int, polys, keys, steps, conj=None):
+        """the same with the polynomials of ciphertext b anywhere on the device: polys[b] = (poly0, poly1), tensors [L][n]"""
+        B = len(polys)
+        L, n = polys[0][0].shape
+        assert len(keys) == B and len(steps) == B
+        out = self.empty((B, 2, L, n))
+        pp = (capi.P * (2 * B))(*[p.data_ptr() for pair in polys for p in pair])
+        kp = (capi.P * B)(*[k.data_ptr() for k in keys])
+        st = (C.c_size_t * B)(*[int(s) for s in steps])
+        cj = (C.c_ubyte * B)(*[1 if c else 0 for c in conj]) if conj is not None else None
+        self._chk(self.lib.hp_dev_ckks_rotate_many_rows(self.h, n.bit_length() - 1, L, key_L0, _u64arr(moduli_ext), B, st, cj, pp, kp,
+                                                        self._ptr(out)))
+        return out
+
     def ext_prod_at(self, moduli_ext, key_L0: int, pt, key):
         B, L, n = pt.shape
         out = self.empty((B, 2, L + 1, n))

@@ -542,7 +542,7 @@ struct Dst {
 // 256 independent ckks::mult + rescale_inplace so runs as three batch-256 launches groups, 8 interleaved chains as batch-8 ones.
 // Results are word for word those of the eager calls.  What differs: a failure INSIDE the engine (a HIP error, a modulus the
 // transforms reject) surfaces when the queue runs, not at the call that recorded it.
-enum class OpKind { MultLow, Relin, KeySwitch, Drop, AddSub, Copy, PolyMul };
+enum class OpKind { MultLow, Relin, KeySwitch, Drop, AddSub, Copy, PolyMul, Transform };
 struct PendingOp {
     OpKind kind = OpKind::MultLow;
     size_t logn = 0, L = 0, L0 = 0, step = 0;
@@ -1004,28 +1004,31 @@ void run_group(const std::vector<PendingOp *> &g) {
         break;
     }
     case OpKind::KeySwitch: {
-        Src dc = group_rows(g, 0, 2, n);
         bool one_key = true;
         for (PendingOp *c : g) {
             track_read(*c->key);
             one_key = one_key && c->key == o.key && c->step == o.step && c->conj == o.conj;
         }
-        if (!one_key) {   // every ciphertext with its own key and step
-            std::vector<const u64 *> keys;
+        if (!one_key) {   // every ciphertext with its own key and step; the operands are read where they are (often ONE vector)
+            std::vector<const u64 *> keys, polys;
             std::vector<size_t> steps;
             std::vector<unsigned char> conj;
             for (PendingOp *c : g) {
                 keys.push_back(c->key->p);
                 steps.push_back(c->step);
                 conj.push_back(c->conj ? 1 : 0);
+                for (size_t h = 0; h < 2; h++) {
+                    polys.push_back(words_of(c->in[h].first) + c->in[h].second);
+                    track_read(*c->in[h].first);
+                }
             }
-            check(hp_dev_ckks_rotate_many(cur(), o.logn, L, o.L0, o.mod.data(), B, steps.data(), conj.data(), dc.p, keys.data(), big->p));
+            check(hp_dev_ckks_rotate_many_rows(cur(), o.logn, L, o.L0, o.mod.data(), B, steps.data(), conj.data(), polys.data(), keys.data(), big->p));
             g_stats.deferred_many_key_groups++;
-        } else if (o.conj) {
-            check(hp_dev_ckks_conjugate_at(cur(), o.logn, L, o.L0, o.mod.data(), B, dc.p, o.key->p, big->p));
-        } else {
-            check(hp_dev_ckks_rotate_at(cur(), o.logn, L, o.L0, o.mod.data(), B, o.step, dc.p, o.key->p, big->p));
+            break;
         }
+        Src dc = group_rows(g, 0, 2, n);
+        if (o.conj) check(hp_dev_ckks_conjugate_at(cur(), o.logn, L, o.L0, o.mod.data(), B, dc.p, o.key->p, big->p));
+        else check(hp_dev_ckks_rotate_at(cur(), o.logn, L, o.L0, o.mod.data(), B, o.step, dc.p, o.key->p, big->p));
         break;
     }
     case OpKind::Drop: {
@@ -1041,6 +1044,17 @@ void run_group(const std::vector<PendingOp *> &g) {
             track_read(*c->in[0].first);
         }
         check(hp_dev_gather_rows(cur(), rows.size(), o.in_limbs * n, rows.data(), big->p));
+        break;
+    }
+    case OpKind::Transform: {   // NTT / INTT of a polynomial in place (ntt.h:41-92): the plaintext transforms inside add / sub / mult_plain (ckks/arith.cpp:25,41,49)
+        std::vector<const u64 *> rows;   // (the operands' blocks may have other holders: the batch is transformed in its own block)
+        for (PendingOp *c : g) {
+            rows.push_back(words_of(c->in[0].first) + c->in[0].second);
+            track_read(*c->in[0].first);
+        }
+        check(hp_dev_gather_rows(cur(), rows.size(), o.in_limbs * n, rows.data(), big->p));
+        if (o.conj) check(hp_dev_intt(cur(), o.logn, L, o.mod.data(), B, big->p, o.sub ? 1 : 0));
+        else check(hp_dev_ntt(cur(), o.logn, L, o.mod.data(), B, big->p));
         break;
     }
     case OpKind::PolyMul: {   // operator* of two polynomials (rns.cpp:120-140): the plaintext products of mult_plain
@@ -1747,8 +1761,12 @@ void intt_negacyclic_inplace_lazy(const size_t logn, const u64 q, u64 v[]) {
 #ifndef HEHUB_AMD_BIND_REFERENCE   // ntt.h:41-92 (inline per-limb loops) stay the reference's
 static void poly_transform(RnsPolynomial &p, bool inverse, bool strict) {
     const size_t n = p.dimension(), L = p.component_count();
-    (void)n;
-    if (L) {
+    if (L && n >= 2 && amd::deferred()) {   // recorded: the transforms of a loop's plaintexts run as one batch (conj = inverse, sub = strict)
+        OpScope scope({}, 0);
+        auto rec = new_op(amd::OpKind::Transform, p.log_dimension(), L, p.modulus_vec(), {&p}, L, L * n);
+        rec->conj = inverse; rec->sub = strict;
+        Access::bind_block(p, amd::record(std::move(rec)), 0);
+    } else if (L) {
         OpScope op({Access::home(p)});
         u64 *d = Access::inout(p);
         if (inverse) check(hp_dev_intt(amd::cur(), p.log_dimension(), L, p.modulus_vec().data(), 1, d, strict ? 1 : 0));
@@ -2262,30 +2280,39 @@ std::vector<ckks::CkksCt> ckks_key_switched(const std::vector<ckks::CkksCt> &cts
 
 // ckks::rotate(cts[i], *keys[i], steps[i]) for every i as ONE engine call (hp_dev_ckks_rotate_many); a batch that is not of one shape,
 // or whose keys were not all made for the same number of moduli, runs as the loop of single calls
-std::vector<ckks::CkksCt> ckks_rotate_many(const std::vector<ckks::CkksCt> &cts, const std::vector<const RlweKsk *> &keys,
+std::vector<ckks::CkksCt> ckks_rotate_many(const std::vector<const ckks::CkksCt *> &cts, const std::vector<const RlweKsk *> &keys,
                                            const std::vector<size_t> &steps) {
     same_size(cts.size(), keys.size());
     same_size(cts.size(), steps.size());
-    size_t n, L;
-    std::vector<u64> q;
     std::vector<ckks::CkksCt> out;
     if (cts.empty()) return out;
     for (const RlweKsk *k : keys)
         if (!k) throw std::invalid_argument("Empty RGSW ciphertext.");
-    bool uniform = uniform_shape(cts, n, L, q);
-    for (size_t i = 1; uniform && i < keys.size(); i++) uniform = keys[i]->size() == keys[0]->size();
+    const size_t n = (*cts[0])[0].dimension(), L = (*cts[0])[0].component_count(), B = cts.size();
+    std::vector<u64> q((*cts[0])[0].modulus_vec());
+    q.resize(L);
+    bool uniform = L > 0 && n >= 2;
+    for (size_t i = 0; uniform && i < B; i++) {
+        for (int h = 0; h < 2 && uniform; h++) {
+            const RnsPolynomial &p = (*cts[i])[h];
+            std::vector<u64> m(p.modulus_vec());
+            m.resize(L);
+            uniform = p.dimension() == n && p.component_count() == L && m == q;
+        }
+        uniform = uniform && keys[i]->size() == keys[0]->size();
+    }
     if (!uniform) {
-        for (size_t i = 0; i < cts.size(); i++) out.push_back(ckks::rotate(cts[i], *keys[i], steps[i]));
+        for (size_t i = 0; i < B; i++) out.push_back(ckks::rotate(*cts[i], *keys[i], steps[i]));
         return out;
     }
-    for (auto &ct : cts)
+    for (const ckks::CkksCt *ct : cts)
         for (int h = 0; h < 2; h++)
-            if (ct[h].rep_form != PolyRepForm::value) throw std::invalid_argument("poly_ntt is expected to be in NTT value form");
+            if ((*ct)[h].rep_form != PolyRepForm::value) throw std::invalid_argument("poly_ntt is expected to be in NTT value form");
     std::vector<u64> mext, mext_i;
-    const size_t L0 = check_ext_prod(cts[0][1], *keys[0], mext);
-    for (size_t i = 1; i < cts.size(); i++)
-        if (check_ext_prod(cts[i][1], *keys[i], mext_i) != L0 || mext_i != mext) throw std::invalid_argument("Inconsistent RGSW ciphertext.");
-    const size_t logn = cts[0][1].log_dimension(), B = cts.size();
+    const size_t L0 = check_ext_prod((*cts[0])[1], *keys[0], mext);
+    for (size_t i = 1; i < B; i++)
+        if (check_ext_prod((*cts[i])[1], *keys[i], mext_i) != L0 || mext_i != mext) throw std::invalid_argument("Inconsistent RGSW ciphertext.");
+    const size_t logn = (*cts[0])[1].log_dimension();
     OpScope op({}, 0);
     std::vector<DevKey> dks;
     dks.reserve(B);
@@ -2298,11 +2325,17 @@ std::vector<ckks::CkksCt> ckks_rotate_many(const std::vector<ckks::CkksCt> &cts,
         dks.emplace_back(*keys[i], L0, n);
         kp.push_back(dks.back().p());
     }
-    Src din = Access::batch_in(halves(cts), L);
+    std::vector<const u64 *> polys;   // the operands are read where they are: the same object may appear many times
+    std::vector<Src> holds;
+    for (const ckks::CkksCt *ct : cts)
+        for (int h = 0; h < 2; h++) {
+            holds.push_back(Access::in((*ct)[h], L));
+            polys.push_back(holds.back().p);
+        }
     Dst dout(B * 2 * L * n);
-    check(hp_dev_ckks_rotate_many(cur(), logn, L, L0, mext.data(), B, steps.data(), nullptr, din.p, kp.data(), dout.p));
+    check(hp_dev_ckks_rotate_many_rows(cur(), logn, L, L0, mext.data(), B, steps.data(), nullptr, polys.data(), kp.data(), dout.p));
     out = result_batch<ckks::CkksCt>(B, n, L, q, dout);
-    for (size_t i = 0; i < B; i++) out[i].scaling_factor = cts[i].scaling_factor;
+    for (size_t i = 0; i < B; i++) out[i].scaling_factor = cts[i]->scaling_factor;
     return out;
 }
 
@@ -2346,7 +2379,12 @@ std::vector<bgv::BgvCt> mult_mod_switch(const std::vector<bgv::BgvCt> &a, const 
 std::vector<ckks::CkksCt> rotate(const std::vector<ckks::CkksCt> &cts, const RlweKsk &rot_key, size_t step) { return ckks_key_switched(cts, rot_key, false, step); }
 std::vector<ckks::CkksCt> conjugate(const std::vector<ckks::CkksCt> &cts, const RlweKsk &conj_key) { return ckks_key_switched(cts, conj_key, true, 0); }
 std::vector<ckks::CkksCt> rotate(const std::vector<ckks::CkksCt> &cts, const std::vector<const RlweKsk *> &rot_keys, const std::vector<size_t> &steps) {
-    return ckks_rotate_many(cts, rot_keys, steps);
+    std::vector<const ckks::CkksCt *> p;
+    for (auto &ct : cts) p.push_back(&ct);
+    return ckks_rotate_many(p, rot_keys, steps);
+}
+std::vector<ckks::CkksCt> rotate(const ckks::CkksCt &ct, const std::vector<const RlweKsk *> &rot_keys, const std::vector<size_t> &steps) {
+    return ckks_rotate_many(std::vector<const ckks::CkksCt *>(rot_keys.size(), &ct), rot_keys, steps);
 }
 std::vector<ckks::CkksCt> add(const std::vector<ckks::CkksCt> &a, const std::vector<ckks::CkksCt> &b) { return ckks_addsub(a, b, false); }
 std::vector<ckks::CkksCt> sub(const std::vector<ckks::CkksCt> &a, const std::vector<ckks::CkksCt> &b) { return ckks_addsub(a, b, true); }

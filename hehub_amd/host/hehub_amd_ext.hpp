@@ -86,9 +86,11 @@ void rescale_inplace(std::vector<ckks::CkksCt> &cts);
 std::vector<ckks::CkksCt> rotate(const std::vector<ckks::CkksCt> &cts, const RlweKsk &rot_key, size_t step);
 std::vector<ckks::CkksCt> conjugate(const std::vector<ckks::CkksCt> &cts, const RlweKsk &conj_key);
 // ckks.h:284  rotate(cts[i], *rot_keys[i], steps[i]): EVERY ciphertext under its own key and step, one engine call -- the rotations of
-// one vector under the keys of a rotation key set (src/circuits/linear_algebra.h:123-130: pass the same ciphertext 2 (width - 1) times)
+// one vector under the keys of a rotation key set (src/circuits/linear_algebra.h:123-130)
 std::vector<ckks::CkksCt> rotate(const std::vector<ckks::CkksCt> &cts, const std::vector<const RlweKsk *> &rot_keys,
                                  const std::vector<size_t> &steps);
+// ... and ONE ciphertext under many keys: element i = rotate(ct, *rot_keys[i], steps[i])
+std::vector<ckks::CkksCt> rotate(const ckks::CkksCt &ct, const std::vector<const RlweKsk *> &rot_keys, const std::vector<size_t> &steps);
 // ckks.h:73-89  add / sub, element by element
 std::vector<ckks::CkksCt> add(const std::vector<ckks::CkksCt> &a, const std::vector<ckks::CkksCt> &b);
 std::vector<ckks::CkksCt> sub(const std::vector<ckks::CkksCt> &a, const std::vector<ckks::CkksCt> &b);

@@ -418,6 +418,12 @@ int hp_dev_ckks_conjugate_at(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, 
 int hp_dev_ckks_rotate_many(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, size_t batch,
                             const size_t *steps, const unsigned char *conj, const uint64_t *d_ct,
                             const uint64_t *const *d_keys, uint64_t *d_out);
+/*     The same with the ciphertexts' polynomials anywhere in device memory: d_polys[2 b + h] (a HOST array of device addresses) is
+ *     polynomial h of ciphertext b, u64[L][N] -- an application's ciphertexts are separate objects, and the rotations of ONE vector
+ *     (linear_algebra.h:123-130) all read the same two polynomials: no packed copy of the batch is made. */
+int hp_dev_ckks_rotate_many_rows(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, size_t batch,
+                                 const size_t *steps, const unsigned char *conj, const uint64_t *const *d_polys,
+                                 const uint64_t *const *d_keys, uint64_t *d_out);
 int hp_dev_ckks_mult_relin_rescale_at(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext,
                                       size_t batch, const uint64_t *d_ct1, const uint64_t *d_ct2,
                                       const uint64_t *d_key, uint64_t *d_out);

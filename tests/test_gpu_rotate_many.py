@@ -62,6 +62,29 @@ def test_rotate_many_against_single_calls(eng, orc, logn, L0, L, B):
         assert np.array_equal(got2[b], canon(mext, want) if eng.level == "A" and logn >= 11 else want)
 
 
+@pytest.mark.parametrize("logn,L,B", [(12, 3, 6), (13, 2, 40)])
+def test_rotate_many_rows_one_vector_many_keys(eng, orc, logn, L, B):
+    """the polynomials by address: ONE vector (two separate device tensors) rotated under B keys, plus a second vector in between"""
+    n = 1 << logn
+    q, p = ([P.P50[1]] + P.P40)[:L], P.P50[0]
+    mext = q + [p]
+    rng = SplitMix(4300 + logn)
+    nkeys = min(B, 5)
+    keys = [rng.poly((L, 2, L + 1, n), mext) for _ in range(nkeys)]
+    dkeys = [eng.to_device(k) for k in keys]
+    vec, other = rng.poly((2, L, n), q), rng.poly((2, L, n), q)
+    dv = (eng.to_device(vec[0]), eng.to_device(vec[1]))
+    do = eng.to_device(other)
+    polys = [dv if b % 4 != 3 else (do[0], do[1]) for b in range(B)]
+    steps = [b + 1 for b in range(B)]
+    conj = [b % 9 == 8 for b in range(B)]
+    got = eng.to_host(eng.ckks_rotate_many_rows(mext, L, polys, [dkeys[b % nkeys] for b in range(B)], steps, conj))
+    for b in range(B):
+        src = vec if b % 4 != 3 else other
+        want = orc.ckks_conjugate(mext, src, keys[b % nkeys]) if conj[b] else orc.ckks_rotate(mext, src, keys[b % nkeys], steps[b])
+        assert np.array_equal(got[b], canon(mext, want) if eng.level == "A" else want), b
+
+
 def test_rotate_many_rejects_bad_arguments(eng):
     from hehub_amd.engine import InvalidArgument
 
@@ -80,4 +103,10 @@ def test_rotate_many_rejects_bad_arguments(eng):
     st = (C.c_size_t * 2)(1, 1)
     out = eng.empty((2, 2, L, n))
     rc = eng.lib.hp_dev_ckks_rotate_many(eng.h, logn, L, L, (capi.u64 * 3)(*mext), 2, st, None, C.c_void_p(ct.data_ptr()), kp, C.c_void_p(out.data_ptr()))
+    assert rc == capi.HP_EINVAL
+    kp = (capi.P * 2)(key.data_ptr(), key.data_ptr())
+    pp = (capi.P * 4)(ct[0, 0].data_ptr(), ct[0, 1].data_ptr(), ct[1, 0].data_ptr(), None)
+    rc = eng.lib.hp_dev_ckks_rotate_many_rows(eng.h, logn, L, L, (capi.u64 * 3)(*mext), 2, st, None, pp, kp, C.c_void_p(out.data_ptr()))
+    assert rc == capi.HP_EINVAL
+    rc = eng.lib.hp_dev_ckks_rotate_many_rows(eng.h, logn, L, L, (capi.u64 * 3)(*mext), 2, st, None, None, kp, C.c_void_p(out.data_ptr()))
     assert rc == capi.HP_EINVAL
