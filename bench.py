@@ -34,6 +34,9 @@ One process per GPU; ciphertext batches are sharded across ranks with no data-pa
   object_api            (default ckks line) the same C3 hom-mult through hehub's OBJECT interface (hehub_amd/host/hehub.hpp): 256
                         independent ckks::mult + rescale_inplace as single calls, as ONE batched call (hehub_amd_ext.hpp), and
                         independent chains over 1 / 8 lanes; examples/independent_mults as a child process, digests compared
+                        object_api.matvec: the diagonal loop of hehub's matrix_vector_mul_short (linear_algebra.h:104-136) at the C3
+                        shape, width 16 (30 rotations of one vector under 30 keys): eager / deferred / batched form, hehub's digest,
+                        hehub itself on this host's CPU beside it (examples/diag_matvec, oracle/_ref/ref_matvec_cpu)
   cpu_baseline          the compiled reference (or the C restatement) on ONE core of this host; cpu_baseline_node: the
                         same as P independent processes (P = what affinity mask and CPU quota allow, stated)
   step                  (pipelines) a pass after the timed region with HIP events around EVERY launch: per kernel family launches,

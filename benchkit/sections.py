@@ -339,4 +339,52 @@ def object_api_section(run: Run):
         de["digests_equal_eager"] = False
     ent["deferred"] = de
     ent["verified"] = ent["digests_equal"] and de["digests_equal_eager"]
+    try:
+        ent["matvec"] = matvec_entry(root)
+        ent["verified"] = ent["verified"] and ent["matvec"]["verified"]
+    except Exception as e:   # noqa: BLE001
+        ent["matvec"] = {"error": repr(e)[:300], "verified": None}
+    return ent
+
+
+def matvec_entry(root: str):
+    """hehub's circuit-level caller of the key switch, the diagonal loop of matrix_vector_mul_short (src/circuits/linear_algebra.h:104-136),
+    at the C3 shape, width 16 (30 rotations of one vector under 30 keys + 16 plaintext products): examples/diag_matvec as a child process --
+    eager single calls over the lanes, deferred mode (the rotations run as ONE hp_dev_ckks_rotate_many_rows sequence with a key per
+    ciphertext), the batched form amd::rotate(ct, keys, steps); every digest must be hehub's own (tests/golden/matvec.json, generated from
+    hehub on the CPU).  `cpu_reference_ms`: the prebuilt oracle/_ref/ref_matvec_cpu (hehub itself) on this host, when it travelled."""
+    import json
+    import os
+    import re
+    import subprocess
+    import time
+
+    from hehub_amd.build import build_example
+
+    case = [15, 10, 16, "short"]
+    with open(os.path.join(root, "tests", "golden", "matvec.json")) as f:
+        want = json.load(f)["digests"][" ".join(str(a) for a in case)]
+    t0 = time.perf_counter()
+    out = subprocess.run([build_example("diag_matvec")] + [str(a) for a in case + [5]], capture_output=True, text=True, timeout=600, cwd=root)
+    ent = {"program": "examples/diag_matvec 15 10 16 short 5", "wall_s": round(time.perf_counter() - t0, 1), "N": 32768, "L": 10, "width": 16,
+           "rotations": 30, "keys": 30, "unit": "ms per product vector", "hehub_digest": want}
+    if out.returncode != 0:
+        ent["error"] = (out.stdout[-300:] + out.stderr[-300:])
+        ent["verified"] = False
+        return ent
+    dg = {m.group(1): m.group(2) for m in re.finditer(r"([\w-]+) digest (\w+)", out.stdout)}
+    ms = {m.group(1): float(m.group(2)) for m in re.finditer(r"([\w-]+) ([\d.]+) ms per product vector", out.stdout)}
+    ent["ms"] = ms
+    ent["digests"] = dg
+    ent["verified"] = len(dg) == 3 and all(v == want for v in dg.values())
+    ref = os.path.join(root, "oracle", "_ref", "ref_matvec_cpu")
+    if os.path.exists(ref):
+        r = subprocess.run([ref] + [str(a) for a in case + [1]], capture_output=True, text=True, timeout=600, cwd=root)
+        m = re.search(r"loop ([\d.]+) ms per product vector", r.stdout)
+        d = re.search(r"loop digest (\w+)", r.stdout)
+        if r.returncode == 0 and m and d:
+            ent["cpu_reference_ms"] = float(m.group(1))
+            ent["cpu_reference_digest_equal"] = d.group(1) == want
+            if "deferred" in ms:
+                ent["speedup_vs_cpu_reference"] = float(m.group(1)) / ms["deferred"]
     return ent

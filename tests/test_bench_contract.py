@@ -119,6 +119,9 @@ def test_default_line_carries_both_halves_of_the_metric():
     assert api["batched_call"]["per_s"] > 15000 and api["batched_call"]["per_s"] > 2 * api["single_calls"]["per_s"]
     assert api["deferred"]["single_calls"]["per_s"] > 2 * api["single_calls"]["per_s"] and api["deferred"]["fused_triples"] >= 256
     assert api["independent_chains"]["speedup"] > 1.2 and "numa_node" in r["placement"]
+    mv = api["matvec"]      # the diagonal loop of matrix_vector_mul_short: every mode prints hehub's digest, recorded rotations beat single calls
+    assert mv["verified"] is True and set(mv["digests"]) == {"eager", "deferred", "batched-form"} and mv["ms"]["deferred"] < mv["ms"]["eager"]
+    assert mv.get("cpu_reference_digest_equal", True) is True
     la = r["level_a"]
     assert r["parity_level"] == "B"
     for k, outs in (("ckks", 256), ("bgv", 512)):

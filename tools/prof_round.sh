@@ -39,6 +39,7 @@ tools/prof_resident.sh > gpurun_out/${TAG}_resident_chain.txt 2>&1
 tools/prof_step_traffic.sh ${TAG}
 tools/prof_object_api.sh ${TAG} > gpurun_out/${TAG}_objapi.txt 2>&1
 for s in "15 10 256 all 3 8 8 6" "13 6 512 all 3 8 8 6"; do for d in 0 1; do echo "== HEHUB_AMD_DEFER=$d independent_mults $s"; HEHUB_AMD_DEFER=$d examples/independent_mults $s; done; done > gpurun_out/${TAG}_independent_mults.txt 2>&1
+tools/prof_matvec.sh ${TAG} > /dev/null 2>&1      # hehub's circuit-level caller: the diagonal loop of matrix_vector_mul_short, every mode + CPU
 tools/by_n_levels.sh > gpurun_out/${TAG}_by_n_levels.txt 2>&1
 for lv in B A; do python bench.py --workload ckks-hks --parity-level $lv --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
