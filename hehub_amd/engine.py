@@ -52,7 +52,10 @@ class Engine:
 
     def fork(self) -> "Engine":
         """A second lane on the same GPU (hp_ctx_fork): its own stream and scratch workspace, the family's tables and lock; calls on it
-        overlap on the device with calls on this one.  Order them with wait_for where one reads what the other wrote."""
+        overlap on the device with calls on this one.  Order them with wait_for where one reads what the other wrote.
+        A lane's stream is not torch's: torch's caching allocator recycles a freed tensor's block at once, so keep every tensor a lane's
+        calls touch referenced until that lane has been synchronised (sync / wait_for), and wait for copies torch makes on its own stream
+        before a lane reads them."""
         e = object.__new__(Engine)
         e.torch, e.lib, e.device = self.torch, self.lib, self.device
         h = capi.P()

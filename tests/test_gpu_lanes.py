@@ -113,12 +113,17 @@ def test_family_members_driven_by_their_own_threads(orc):
             L = len(mext) - 1
             start.wait()
             dk, da, db = e.to_device(key), e.to_device(a), e.to_device(b)
+            # These engines own their streams (use_torch_stream=False) while the tensors come from torch's caching allocator, which hands
+            # a freed block to the next allocation at once -- of ANY thread: every tensor an engine call touches stays referenced until
+            # that engine has been synchronised, and the copy torch makes on its own stream is waited for before the engine reads it.
+            keep = []
             for _ in range(4):
                 out = e.ckks_mult(mext, da, db, dk)
                 rot = e.ckks_rotate(mext, da, dk, 1)
                 src = da.clone().reshape(6, L, 1 << logn)
-                torch.cuda.current_stream().synchronize()   # the copy ran on torch's stream, these engines own theirs (use_torch_stream=False)
+                torch.cuda.current_stream().synchronize()
                 x = e.ntt_(mext[:L], e.intt_(mext[:L], src))
+                keep.append((out, rot, src, x))
             e.sync()
             got[t] = (e.to_host(out), e.to_host(rot), e.to_host(x))
         except Exception as exc:  # noqa: BLE001
