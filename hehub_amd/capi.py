@@ -124,6 +124,8 @@ SIGNATURES = {
     "hp_dev_ckks_rotate_at": (INT, [P, szt, szt, szt, P, szt, szt, P, P, P]),
     "hp_dev_ckks_rotate_many": (INT, [P, szt, szt, szt, P, szt, P, P, P, P, P]),
     "hp_dev_ckks_rotate_many_rows": (INT, [P, szt, szt, szt, P, szt, P, P, P, P, P]),
+    "hp_dev_ckks_mult_relin_rescale_rows": (INT, [P, szt, szt, szt, P, szt, P, P, P]),
+    "hp_dev_bgv_mult_relin_modswitch_rows": (INT, [P, szt, szt, P, u64, szt, P, P, P]),
     "hp_dev_ckks_conjugate_at": (INT, [P, szt, szt, szt, P, szt, P, P, P]),
     "hp_dev_ckks_mult_relin_rescale_at": (INT, [P, szt, szt, szt, P, szt, P, P, P, P]),
     "hp_dev_rns_base_many_to_many": (INT, [P, szt, szt, P, szt, P, szt, P, P]),

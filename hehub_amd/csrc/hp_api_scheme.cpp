@@ -579,11 +579,19 @@ static int dev_ckks_automorphism(hp_ctx *ctx, size_t logn, size_t L, size_t key_
 
 // mult_low_level + relinearize + drop q_last, processed in sub-batches so the working set
 // (dominated by the L(L+1) digit limbs per ciphertext) stays small
+// polys != nullptr: the operands by address, polys[4 b + {0, 1, 2, 3}] = ct1[b][0], ct1[b][1], ct2[b][0], ct2[b][1] (u64[L][N] each)
 static int dev_mult(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, bool bgv, u64 t, u64 inner_t, size_t batch,
-                    const uint64_t *ct1, const uint64_t *ct2, const uint64_t *key, uint64_t *out) {
+                    const uint64_t *ct1, const uint64_t *ct2, const uint64_t *key, uint64_t *out, const uint64_t *const *polys = nullptr) {
     HP_ENTER(ctx);
-    HP_REQUIRE(ctx, moduli_ext, ct1, ct2, key, out);
-    HP_ALIGNED(ctx, ct1, ct2, key, out);
+    HP_REQUIRE(ctx, moduli_ext, key, out);
+    HP_ALIGNED(ctx, key, out);
+    if (polys) {
+        for (size_t b = 0; b < 4 * batch; b++)
+            if (!polys[b] || ((uintptr_t)polys[b] & 15u)) return fail(ctx, HP_EINVAL, "mult: NULL or misaligned operand polynomial");
+    } else {
+        HP_REQUIRE(ctx, ct1, ct2);
+        HP_ALIGNED(ctx, ct1, ct2);
+    }
     int rc = check_ext_args(ctx, logn, L, batch);
     if (rc || (rc = key_level_ok(ctx, L, key_L0))) return rc;
     if (L < 2) return fail(ctx, HP_EINVAL, "Unable to drop the only one prime.");
@@ -623,7 +631,18 @@ static int dev_mult(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uin
         Carver cv((char *)ctx->ws + si * chunk_words * 8);
         u64 *quad = cv.take(P * 3 * L * n);
         u64 *lin = cv.take(P * 2 * L * n);
-        {
+        if (polys) {
+            ProfScope ps(ctx, "tensor");
+            for (size_t c0 = 0; c0 < P && !rc; c0 += HP_TENSOR_ROWS_MAX) {
+                const size_t cnt = P - c0 < HP_TENSOR_ROWS_MAX ? P - c0 : HP_TENSOR_ROWS_MAX;
+                HpTensorRows tr;
+                memset(&tr, 0, sizeof(tr));
+                for (size_t b = 0; b < cnt; b++)
+                    for (size_t h = 0; h < 4; h++) tr.p[b][h] = polys[4 * (b0 + c0 + b) + h];
+                rc = chk(ctx, hp_launch_tensor_rows(plan->d_limbs, (u32)L, 0, (u32)L, (u32)n, (u32)cnt, tr, quad + c0 * 3 * L * n, ctx->stream),
+                         "tensor (operands by address)");
+            }
+        } else {
             ProfScope ps(ctx, "tensor");
             rc = chk(ctx, hp_launch_tensor(plan->d_limbs, (u32)L, 0, (u32)L, (u32)n, (u32)P, ct1 + b0 * 2 * L * n,
                                            ct2 + b0 * 2 * L * n, quad, ctx->stream), "tensor");
@@ -688,6 +707,19 @@ int hp_dev_ckks_mult_relin_rescale_at(hp_ctx *ctx, size_t logn, size_t L, size_t
                                       size_t batch, const uint64_t *ct1, const uint64_t *ct2, const uint64_t *key,
                                       uint64_t *out) {
     return dev_mult(ctx, logn, L, key_L0, moduli_ext, false, 0, 1, batch, ct1, ct2, key, out);
+}
+// the fused pipelines with the operand polynomials by address (a HOST array of 4 device addresses per pair)
+int hp_dev_ckks_mult_relin_rescale_rows(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, size_t batch,
+                                        const uint64_t *const *d_polys, const uint64_t *key, uint64_t *out) {
+    if (!ctx) return HP_EINVAL;
+    if (!d_polys) { HP_ENTER(ctx); return fail(ctx, HP_EINVAL, "mult: NULL operand table"); }
+    return dev_mult(ctx, logn, L, key_L0, moduli_ext, false, 0, 1, batch, nullptr, nullptr, key, out, d_polys);
+}
+int hp_dev_bgv_mult_relin_modswitch_rows(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, uint64_t t, size_t batch,
+                                         const uint64_t *const *d_polys, const uint64_t *key, uint64_t *out) {
+    if (!ctx) return HP_EINVAL;
+    if (!d_polys) { HP_ENTER(ctx); return fail(ctx, HP_EINVAL, "mult: NULL operand table"); }
+    return dev_mult(ctx, logn, L, L, moduli_ext, true, t, 1, batch, nullptr, nullptr, key, out, d_polys);
 }
 int hp_dev_bgv_mult_relin_modswitch(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext, uint64_t t,
                                     size_t batch, const uint64_t *ct1, const uint64_t *ct2, const uint64_t *key,

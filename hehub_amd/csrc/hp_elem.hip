@@ -327,15 +327,20 @@ hipError_t hp_launch_vec(int op, const HpVecConsts &c, size_t n, const u64 *a, c
 
 // ---- fused tensor product: ckks/arith.cpp:55-62 / bgv/arith.cpp:59-69 -------------------
 // d0 = a0*b0, d1 = (a0*b1) + (a1*b0), d2 = a1*b1.  Reads 4 limbs, writes 3: 56n bytes per limb index.
+// ROWS: the four operand polynomials of ciphertext pair p by address (an application's ciphertexts are separate objects: the fused
+// pipelines read them where they lie, hp_dev_*_mult_*_rows); the addresses travel as kernel arguments
+template <bool ROWS>
 __global__ void __launch_bounds__(ELEM_THREADS) k_tensor(const HpLimb *__restrict__ limbs, u32 L, u32 k_first, u32 kc,
                                                         u32 n, u32 chunks, const u64 *__restrict__ ct1,
-                                                        const u64 *__restrict__ ct2, u64 *__restrict__ quad) {
+                                                        const u64 *__restrict__ ct2, HpTensorRows rows, u64 *__restrict__ quad) {
     const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;   // row = p*kc + (k - k_first)
     const u32 p = row / kc, k = k_first + row % kc;
     const HpLimb m = limbs[k];
     const size_t poly = (size_t)L * n;
-    const u64 *a0 = ct1 + (size_t)p * 2 * poly + (size_t)k * n, *a1 = a0 + poly;
-    const u64 *b0 = ct2 + (size_t)p * 2 * poly + (size_t)k * n, *b1 = b0 + poly;
+    const u64 *a0 = ROWS ? rows.p[p][0] + (size_t)k * n : ct1 + (size_t)p * 2 * poly + (size_t)k * n;
+    const u64 *a1 = ROWS ? rows.p[p][1] + (size_t)k * n : a0 + poly;
+    const u64 *b0 = ROWS ? rows.p[p][2] + (size_t)k * n : ct2 + (size_t)p * 2 * poly + (size_t)k * n;
+    const u64 *b1 = ROWS ? rows.p[p][3] + (size_t)k * n : b0 + poly;
     u64 *d0 = quad + (size_t)p * 3 * poly + (size_t)k * n, *d1 = d0 + poly, *d2 = d1 + poly;
     const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
     // (issuing the loads of several steps together, which gains 5-9 % in k_poly_binary, measured +-0 here: 0.830 vs 0.827 ms)
@@ -367,7 +372,17 @@ hipError_t hp_launch_tensor(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32
     if (kc == 0) return hipSuccess;
     u32 chunks; dim3 grid;
     elem_grid(n, P * kc, chunks, grid);
-    k_tensor<<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, kc, n, chunks, ct1, ct2, quad);
+    k_tensor<false><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, kc, n, chunks, ct1, ct2, HpTensorRows{}, quad);
+    return hipGetLastError();
+}
+
+hipError_t hp_launch_tensor_rows(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32 n, u32 P, const HpTensorRows &rows, u64 *quad,
+                                 hipStream_t stream) {
+    if (kc == 0 || P == 0) return hipSuccess;
+    if (P > HP_TENSOR_ROWS_MAX) return hipErrorInvalidValue;
+    u32 chunks; dim3 grid;
+    elem_grid(n, P * kc, chunks, grid);
+    k_tensor<true><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, kc, n, chunks, nullptr, nullptr, rows, quad);
     return hipGetLastError();
 }
 

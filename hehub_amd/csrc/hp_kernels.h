@@ -114,6 +114,13 @@ hipError_t hp_launch_vec(int op, const HpVecConsts &c, size_t n, const u64 *a, c
 // only limbs [k_first, k_first + kc) are computed (kc = L: all)
 hipError_t hp_launch_tensor(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32 n, u32 P, const u64 *ct1,
                             const u64 *ct2, u64 *quad, hipStream_t stream);
+// the same with the operands by address: polynomials ct1[0], ct1[1], ct2[0], ct2[1] (u64[L][N] each) of pair p at rows.p[p][0..3]
+#define HP_TENSOR_ROWS_MAX 64
+struct HpTensorRows {
+    const u64 *p[HP_TENSOR_ROWS_MAX][4];
+};
+hipError_t hp_launch_tensor_rows(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32 n, u32 P, const HpTensorRows &rows, u64 *quad,
+                                 hipStream_t stream);
 // rgsw.cpp:121-153: digits [P][L][L+1][n] (diagonal taken from pt [P][L][n]), key [L][2][L+1][n]
 //   -> out [P][2][L+1][n]
 // only output moduli [k_first, k_first + kc) of the L+1 are computed (kc = L+1: all)

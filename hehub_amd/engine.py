@@ -354,6 +354,25 @@ class Engine:
                                                  self._ptr(ct), self._ptr(key), self._ptr(out)))
         return out
 
+    def ckks_mult_rows(self, moduli_ext, key_L0: int, pairs, key):
+        """ckks::mult + rescale with the operands by address: pairs[b] = (a0, a1, b0, b1), device tensors [L][n] anywhere"""
+        B = len(pairs)
+        L, n = pairs[0][0].shape
+        out = self.empty((B, 2, L - 1, n))
+        pp = (capi.P * (4 * B))(*[p.data_ptr() for quad in pairs for p in quad])
+        self._chk(self.lib.hp_dev_ckks_mult_relin_rescale_rows(self.h, n.bit_length() - 1, L, key_L0, _u64arr(moduli_ext), B, pp,
+                                                               self._ptr(key), self._ptr(out)))
+        return out
+
+    def bgv_mult_rows(self, moduli_ext, t: int, pairs, key):
+        B = len(pairs)
+        L, n = pairs[0][0].shape
+        out = self.empty((B, 2, L - 1, n))
+        pp = (capi.P * (4 * B))(*[p.data_ptr() for quad in pairs for p in quad])
+        self._chk(self.lib.hp_dev_bgv_mult_relin_modswitch_rows(self.h, n.bit_length() - 1, L, _u64arr(moduli_ext), t, B, pp,
+                                                                self._ptr(key), self._ptr(out)))
+        return out
+
     def ckks_rotate_many(self, moduli_ext, key_L0: int, ct, keys, steps, conj=None):
         """ciphertext b rotated by steps[b] (conjugated where conj[b]) and switched with ITS OWN key keys[b] (device tensors)."""
         B, _, L, n = ct.shape

@@ -1119,10 +1119,17 @@ std::vector<PendingOp *> run_fused_mults(const std::vector<std::unique_ptr<Pendi
     const size_t B = g.size();
     BlockRef big = alloc_block(B * d0.out_words);
     track_write(*big);
-    Src d1 = group_rows(g, 0, 2, n), d2 = group_rows(g, 2, 2, n);
+    // the operands are read where they lie (the tensor product takes their addresses): no gather of the 4 L limbs per pair
+    std::vector<const u64 *> polys;
+    polys.reserve(4 * B);
+    for (PendingOp *m : g)
+        for (size_t h = 0; h < 4; h++) {
+            polys.push_back(words_of(m->in[h].first) + m->in[h].second);
+            track_read(*m->in[h].first);
+        }
     track_read(*r0.key);
-    if (r0.bgv) check(hp_dev_bgv_mult_relin_modswitch(cur(), r0.logn, L, r0.mod.data(), d0.t, B, d1.p, d2.p, r0.key->p, big->p));
-    else check(hp_dev_ckks_mult_relin_rescale_at(cur(), r0.logn, L, r0.L0, r0.mod.data(), B, d1.p, d2.p, r0.key->p, big->p));
+    if (r0.bgv) check(hp_dev_bgv_mult_relin_modswitch_rows(cur(), r0.logn, L, r0.mod.data(), d0.t, B, polys.data(), r0.key->p, big->p));
+    else check(hp_dev_ckks_mult_relin_rescale_rows(cur(), r0.logn, L, r0.L0, r0.mod.data(), B, polys.data(), r0.key->p, big->p));
     for (size_t b = 0; b < B; b++) {
         DevBlock &ph = *drop[b]->out;
         ph.p = big->p + b * d0.out_words;

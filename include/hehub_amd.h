@@ -424,6 +424,16 @@ int hp_dev_ckks_rotate_many(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, c
 int hp_dev_ckks_rotate_many_rows(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext, size_t batch,
                                  const size_t *steps, const unsigned char *conj, const uint64_t *const *d_polys,
                                  const uint64_t *const *d_keys, uint64_t *d_out);
+/* (4) The fused multiplication pipelines with the OPERANDS BY ADDRESS: d_polys[4 b + {0, 1, 2, 3}] (a HOST array of device addresses)
+ *     = polynomials ct1[b][0], ct1[b][1], ct2[b][0], ct2[b][1], u64[L][N] each, anywhere in device memory.  An application's
+ *     ciphertexts are separate objects (hehub's are: ckks.h:73-93); the packed forms above would cost a gather of 4 L limbs per pair
+ *     (12 % of a C3 step), here the tensor product -- the only kernel that reads the operands -- takes the addresses as arguments.
+ *     Same words as hp_dev_ckks_mult_relin_rescale_at / hp_dev_bgv_mult_relin_modswitch. */
+int hp_dev_ckks_mult_relin_rescale_rows(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext,
+                                        size_t batch, const uint64_t *const *d_polys, const uint64_t *d_key, uint64_t *d_out);
+int hp_dev_bgv_mult_relin_modswitch_rows(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli_ext,
+                                         uint64_t plain_modulus, size_t batch, const uint64_t *const *d_polys,
+                                         const uint64_t *d_key, uint64_t *d_out);
 int hp_dev_ckks_mult_relin_rescale_at(hp_ctx *ctx, size_t logn, size_t L, size_t key_L0, const uint64_t *moduli_ext,
                                       size_t batch, const uint64_t *d_ct1, const uint64_t *d_ct2,
                                       const uint64_t *d_key, uint64_t *d_out);

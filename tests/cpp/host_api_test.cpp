@@ -829,11 +829,25 @@ static void test_deferred() {
         const auto q0 = amd::transfer_stats();
         RnsPolynomial other(f.N, f.L, f.q);
         for (size_t k = 0; k < f.L; k++) for (auto &w : other[(int)k]) w = rnd() % f.q[k];
-        ntt_negacyclic_inplace_lazy(other);
         other *= (u64)5;
         REQUIRE(amd::transfer_stats().deferred_calls == q0.deferred_calls);   // nothing ran
         REQUIRE(same_words(pend, ckks::mult(f.a[3], f.b[3], f.key)));
         REQUIRE(amd::transfer_stats().deferred_calls > q0.deferred_calls);
+        // the in-place transforms of polynomials are recorded too (the plaintext NTTs inside mult_plain run as one batch): several of
+        // them, and an eager operator on a recorded result -- the words of the eager calls
+        std::vector<RnsPolynomial> rec(3, other), eag(3, other);
+        const auto q1 = amd::transfer_stats();
+        for (auto &p : rec) ntt_negacyclic_inplace_lazy(p);
+        REQUIRE(amd::transfer_stats().deferred_calls == q1.deferred_calls);   // recorded, not run
+        rec[1] *= (u64)7;                                                     // (an eager write to a pending result runs the queue first)
+        intt_negacyclic_inplace(rec[2]);
+        amd::set_deferred(false);
+        for (auto &p : eag) ntt_negacyclic_inplace_lazy(p);
+        eag[1] *= (u64)7;
+        intt_negacyclic_inplace(eag[2]);
+        amd::set_deferred(true);
+        for (size_t i = 0; i < 3; i++) REQUIRE((rec[i] == eag[i] && rec[i].rep_form == eag[i].rep_form));
+        REQUIRE(amd::transfer_stats().deferred_calls >= q1.deferred_calls + 4);
     }
     // a failure INSIDE the engine (a modulus the transforms reject: 2N does not divide q - 1) surfaces when the queue runs, not at
     // the recording call; the results of the calls that could not run throw when somebody asks for their words, nothing crashes,

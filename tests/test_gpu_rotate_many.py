@@ -110,3 +110,28 @@ def test_rotate_many_rejects_bad_arguments(eng):
     assert rc == capi.HP_EINVAL
     rc = eng.lib.hp_dev_ckks_rotate_many_rows(eng.h, logn, L, L, (capi.u64 * 3)(*mext), 2, st, None, None, kp, C.c_void_p(out.data_ptr()))
     assert rc == capi.HP_EINVAL
+
+
+@pytest.mark.parametrize("logn,L,B", [(11, 3, 3), (12, 4, 70), (13, 2, 5)])
+def test_fused_mult_with_operands_by_address(eng, orc, logn, L, B):
+    """hp_dev_ckks_mult_relin_rescale_rows / hp_dev_bgv_mult_relin_modswitch_rows: the operand polynomials anywhere on the device (more
+    pairs than one table of 64 holds; some polynomials shared between pairs) -- the oracle's ckks::mult + rescale_inplace, word for word"""
+    n = 1 << logn
+    q, p = ([P.P50[1]] + P.P40)[:L], P.P50[0]
+    mext = q + [p]
+    rng = SplitMix(4400 + logn)
+    key = rng.poly((L, 2, L + 1, n), mext)
+    dk = eng.to_device(key)
+    nd = min(B, 6)
+    cts = [rng.poly((2, L, n), q) for _ in range(nd + 1)]
+    dev = [(eng.to_device(c[0]), eng.to_device(c[1])) for c in cts]
+    pairs = [(dev[b % nd][0], dev[b % nd][1], dev[(b * 3 + 1) % (nd + 1)][0], dev[(b * 3 + 1) % (nd + 1)][1]) for b in range(B)]
+    got = eng.to_host(eng.ckks_mult_rows(mext, L, pairs, dk))
+    t = 65537
+    gotb = eng.to_host(eng.bgv_mult_rows(mext, t, pairs, dk))
+    for b in sorted(set(list(range(min(B, 8))) + [B - 1])):
+        a, c = cts[b % nd], cts[(b * 3 + 1) % (nd + 1)]
+        want, wantb = orc.ckks_mult(mext, a, c, key), orc.bgv_mult(mext, t, a, c, key)
+        lvl_a = eng.level == "A"
+        assert np.array_equal(got[b], canon(mext, want) if lvl_a else want), b
+        assert np.array_equal(gotb[b], canon(mext, wantb) if lvl_a else wantb), b
