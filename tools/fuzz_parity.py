@@ -116,13 +116,33 @@ while time.time() - t0 < budget:
         d1, d2, dk = eng.to_device(ct1), eng.to_device(ct2), eng.to_device(key)
         if op == "mult":
             check("ckks_mult", eng.to_host(eng.ckks_mult(mext, d1, d2, dk)), np.stack([orc.ckks_mult(mext, ct1[i], ct2[i], key) for i in range(B)]), **kw)
+            pairs = [(d1[i, 0], d1[i, 1], d2[B - 1 - i, 0], d2[B - 1 - i, 1]) for i in range(B)]    # the fused pipeline, operands by address
+            check("ckks_mult_rows", eng.to_host(eng.ckks_mult_rows(mext, L, pairs, dk)),
+                  np.stack([orc.ckks_mult(mext, ct1[i], ct2[B - 1 - i], key) for i in range(B)]), **kw)
         elif op == "bgv":
             t = int(rs.choice([2, 257, 65537, 786433]))
             check("bgv_mult", eng.to_host(eng.bgv_mult(mext, t, d1, d2, dk)), np.stack([orc.bgv_mult(mext, t, ct1[i], ct2[i], key) for i in range(B)]), t=t, **kw)
+            pairs = [(d1[i, 0], d1[i, 1], d2[B - 1 - i, 0], d2[B - 1 - i, 1]) for i in range(B)]
+            check("bgv_mult_rows", eng.to_host(eng.bgv_mult_rows(mext, t, pairs, dk)),
+                  np.stack([orc.bgv_mult(mext, t, ct1[i], ct2[B - 1 - i], key) for i in range(B)]), t=t, **kw)
         elif op == "rot":
             step = int(rs.randint(0, max(1, n // 2)))
             check("rotate", eng.to_host(eng.ckks_rotate(mext, d1, dk, step)), np.stack([orc.ckks_rotate(mext, ct1[i], key, step) for i in range(B)]), step=step, **kw)
             check("conj", eng.to_host(eng.ckks_conjugate(mext, d2, dk)), np.stack([orc.ckks_conjugate(mext, ct2[i], key) for i in range(B)]), **kw)
+            # a key, a step and the operand addresses PER ciphertext (hp_dev_ckks_rotate_many / _rows): against the single calls
+            keys2 = [key, rng.poly((L, 2, L + 1, n), mext)]
+            dks = [dk, eng.to_device(keys2[1])]
+            which = [int(rs.randint(2)) for _ in range(B)]
+            steps = [int(rs.randint(0, max(1, n // 2))) for _ in range(B)]
+            cj = [bool(rs.randint(4) == 0) for _ in range(B)]
+            exp = np.stack([orc.ckks_conjugate(mext, ct1[i], keys2[which[i]]) if cj[i] else orc.ckks_rotate(mext, ct1[i], keys2[which[i]], steps[i])
+                            for i in range(B)])
+            check("rot_many", eng.to_host(eng.ckks_rotate_many(mext, L, d1, [dks[w] for w in which], steps, cj)), exp, steps=steps, **kw)
+            src = [int(rs.randint(B)) for _ in range(B)]           # ciphertexts picked (with repetition) by address
+            polys = [(d1[i, 0], d1[i, 1]) for i in src]
+            exp = np.stack([orc.ckks_conjugate(mext, ct1[src[i]], keys2[which[i]]) if cj[i] else orc.ckks_rotate(mext, ct1[src[i]], keys2[which[i]], steps[i])
+                            for i in range(B)])
+            check("rot_rows", eng.to_host(eng.ckks_rotate_many_rows(mext, L, polys, [dks[w] for w in which], steps, cj)), exp, steps=steps, **kw)
         elif op == "drop":
             t = int(rs.choice([2, 257, 65537]))
             check("rescale", eng.to_host(eng.ckks_rescale(q, d1)), np.stack([orc.ckks_rescale(q, ct1[i]) for i in range(B)]), **kw)
