@@ -15,7 +15,9 @@
 //
 // Every butterfly is the reference's, with the reference's twiddle (hp_ntt_generic.hip's indexing): the words are identical to the
 // tiled kernels' and to hehub's.  The intermediate limb crosses L2 once (the launches are small: it never reaches HBM).  Throughput is
-// a third of the tiled kernels', latency a quarter: hp_ctx.cpp picks this path when a launch has at most HP_SPLIT_MAX_ITEMS limbs.
+// a third of the tiled kernels', latency a fifth: hp_ctx.cpp picks this path when a launch has at most HP_SPLIT_MAX_ITEMS limbs.
+// Inside a launch the stages run in ROUNDS of up to three in registers (see below): 100 limbs of N = 32768 forward 18 + 16 us
+// (24 + 22 with one stage per LDS exchange), 10 limbs inverse 5 + 7.5 us (8.5 + 11): batch-1 C3 hom-mult 0.162 -> 0.124 ms.
 #include "hp_kernels.h"
 #include "hp_ntt_job.h"
 
@@ -48,71 +50,109 @@ template <bool COLS> struct TileMap {
     HP_DEV u32 global(u32 i) const { return COLS ? ((i >> lc) << 8) + base + (i & (ccount - 1)) : base + i; }
 };
 
-// LDS-only barrier: the twiddle loads of the NEXT stage stay in flight across it (__syncthreads would wait for them)
+// LDS-only barrier: the twiddle loads of the NEXT round stay in flight across it (__syncthreads would wait for them)
 HP_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-struct Bfly {
-    u32 l, h, tw;   // LDS slots of the pair, index of its twiddle in the limb's reference-order table
-};
+// A launch runs its stages in ROUNDS of up to three: a round covers K consecutive bits [p, p + K) of the 11-bit slot index, a thread
+// holds the 2^K slots that differ in those bits (8 / 2^K such groups) and runs the K stages on them in registers -- the hand-scheduled
+// dual butterfly of the tiled kernels, 16 instructions each, no index arithmetic per butterfly -- and only then goes through LDS
+// (one exchange per round instead of one per stage; the first version of this file, a stage per exchange, spent 40 VALU instructions
+// per butterfly and a third of its LDS cycles on bank conflicts: profiles/r05n_split_pmc_summary.txt).
+// Slot of register e (r = low K bits: the round's bits, g = the rest: which group) of thread tid:
+template <int K> HP_DEV u32 slot_of(u32 tid, u32 p, int e) {
+    const u32 r = (u32)e & ((1u << K) - 1u), u = tid | (((u32)e >> K) << 8);
+    return (u & ((1u << p) - 1u)) | (r << p) | ((u >> p) << (p + K));
+}
+HP_DEV u32 swz(u32 slot) { return slot ^ ((slot >> 4) & 15u); }   // LDS position of a slot (strided rounds would hit few banks)
 
-// butterfly number b (0 .. 1023) of step `step` of the kernel's run of stages
-template <bool INVERSE, bool COLS> HP_DEV Bfly bfly_of(u32 logn, const TileMap<COLS> &tm, u32 step, u32 b) {
-    Bfly f;
-    if (!INVERSE && COLS) {
-        // stages s = 1 .. logn - 8: row gap 2^lg, twiddle (1 << (s - 1)) + (row block)                  ntt.cpp:155-169
-        const u32 s = step + 1, lg = (logn - 8) - s;
-        const u32 col = b & (tm.ccount - 1), pr = b >> tm.lc;
-        const u32 blk = pr >> lg, j = pr & ((1u << lg) - 1);
-        const u32 r0 = (blk << (lg + 1)) | j;
-        f.l = (r0 << tm.lc) + col; f.h = f.l + (tm.ccount << lg);
-        f.tw = (1u << (s - 1)) + blk;
-    } else if (!INVERSE) {
-        // stages s = logn - 7 .. logn: gaps 128 .. 1 inside the tile; the block number is global
-        const u32 s = logn - 7 + step, lg = logn - s, gap = 1u << lg;
-        const u32 blk = b >> lg, j = b & (gap - 1);
-        f.l = (blk << (lg + 1)) | j; f.h = f.l + gap;
-        f.tw = (1u << (s - 1)) + ((tm.base + f.l) >> (lg + 1));
-    } else if (!COLS) {
-        // gaps 1 .. 128 (s = 0 .. 7): twiddle level s, entry bitrev_s(i mod 2^s)                           ntt.cpp:178-213
-        const u32 sft = step, gap = 1u << sft;
-        const u32 blk = b >> sft, c = b & (gap - 1);
-        f.l = (blk << (sft + 1)) | c; f.h = f.l + gap;
-        f.tw = (gap - 1) + (sft ? (__brev(c) >> (32 - sft)) : 0u);
-    } else {
-        // gaps 256 .. N/2 (s = 8 .. logn - 1): row gap 2^(s-8); the low bits of the global index select the twiddle
-        const u32 sft = 8 + step, lg = step;
-        const u32 col = b & (tm.ccount - 1), pr = b >> tm.lc;
-        const u32 blk = pr >> lg, j = pr & ((1u << lg) - 1);
-        const u32 r0 = (blk << (lg + 1)) | j;
-        f.l = (r0 << tm.lc) + col; f.h = f.l + (tm.ccount << lg);
-        const u32 c = (j << 8) | (tm.base + col);          // (global index of the low partner) mod 2^s
-        f.tw = ((1u << sft) - 1) + (__brev(c) >> (32 - sft));
+// index, in the limb's reference-order table, of the twiddle of the butterfly whose LOW partner sits in slot sl and whose partners
+// differ in slot bit b (hp_ntt_generic.hip's indexing, as the launches see it):
+//   forward, column tiles       stage s = 11 - b, row gap 2^(b - lc):   (1 << (s - 1)) + (row block)                 ntt.cpp:155-169
+//   forward, contiguous tiles   stage s = logn - b, gap 2^b:            (1 << (s - 1)) + (global block)
+//   inverse, contiguous tiles   gap 2^b:   level b, entry bitrev_b(i mod 2^b)                                       ntt.cpp:178-213
+//   inverse, column tiles       gap 2^(8 + b - lc): level 8 + b - lc, entry bitrev(global index of the low partner mod the gap)
+template <bool INVERSE, bool COLS> HP_DEV u32 tw_index(u32 logn, const TileMap<COLS> &tm, u32 b, u32 sl) {
+    if (!INVERSE && COLS) return (1u << (10u - b)) + (sl >> (b + 1));
+    if (!INVERSE) return (1u << (logn - b - 1)) + ((tm.base + sl) >> (b + 1));
+    if (!COLS) return ((1u << b) - 1u) + (b ? (__brev(sl & ((1u << b) - 1u)) >> (32 - b)) : 0u);
+    const u32 step = b - tm.lc, sft = 8 + step;
+    const u32 c = (((sl >> tm.lc) & ((1u << step) - 1u)) << 8) | (tm.base + (sl & (tm.ccount - 1u)));
+    return ((1u << sft) - 1u) + (__brev(c) >> (32 - sft));
+}
+
+// stage j of a round pairs the registers that differ in bit rb of their index (forward: the round's bits from the top, inverse:
+// from the bottom); its twiddles: one per value of the round's bits above (forward) / below (inverse) rb, per group
+template <bool INVERSE, int K> constexpr int stage_bit(int j) { return INVERSE ? j : K - 1 - j; }
+template <bool INVERSE, int K> constexpr int tw_slot(int e_lo, int j) {
+    const int rb = stage_bit<INVERSE, K>(j), r = e_lo & ((1 << K) - 1), g = e_lo >> K;
+    return g * ((1 << K) - 1) + ((1 << j) - 1) + (INVERSE ? (r & ((1 << rb) - 1)) : (r >> (rb + 1)));
+}
+
+template <bool INVERSE, bool COLS, int K>
+HP_DEV void round_twiddles(u64x2 (&tw)[7], gptr_tw table, u32 logn, const TileMap<COLS> &tm, u32 p) {
+#pragma unroll
+    for (int g = 0; g < (8 >> K); ++g)
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int t = 0; t < (1 << j); ++t) {
+                const int rb = stage_bit<INVERSE, K>(j);
+                const int e_lo = (g << K) | (INVERSE ? t : (t << (rb + 1)));   // a representative: bit rb clear, the other bits free
+                tw[g * ((1 << K) - 1) + ((1 << j) - 1) + t] = ld_tw(table, tw_index<INVERSE, COLS>(logn, tm, p + rb, slot_of<K>(threadIdx.x, p, e_lo)));
+            }
+}
+
+template <bool INVERSE, int K>
+HP_DEV void round_stages(u64 (&x)[8], const u64x2 (&tw)[7], u64 two_q, u32 n0, u32 n1) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int rb = stage_bit<INVERSE, K>(j);
+#pragma unroll
+        for (int d = 0; d < 4; d += 2) {   // the stage's four pairs, two at a time (pair d: the 2-bit number d with a zero inserted at bit rb)
+            const int a = ((d >> rb) << (rb + 1)) | (d & ((1 << rb) - 1)), b = (((d + 1) >> rb) << (rb + 1)) | ((d + 1) & ((1 << rb) - 1));
+            const u64x2 wa = tw[tw_slot<INVERSE, K>(a, j)], wb = tw[tw_slot<INVERSE, K>(b, j)];
+            hp_butterfly2_nq(x[a], x[a | (1 << rb)], x[b], x[b | (1 << rb)], wa.x, wa.y, wb.x, wb.y, two_q, n0, n1);
+        }
     }
-    return f;
 }
 
 // DROP (forward only): the drop-last-prime step around the transform, as the tiled k_ntt_fwd_drop has it -- the first launch reads
 // the strict last-limb coefficients and applies Barrett + centring [+ * t] while loading (rescaling.cpp:54-69, mod_switch.cpp:52-69:
 // k_drop_rem's arithmetic), the second finishes with out = ((x - NTT(rem)) * inv) [* (q_last mod t)] [+ addend] while storing
 // (rescaling.cpp:72-74, mod_switch.cpp:72-76, ckks/arith.cpp:70-71: k_drop_fin's arithmetic); the rows between the launches are scratch
-template <bool INVERSE, bool COLS, bool FIRST, bool DROP>
-HP_DEV void ntt_split_body(const HpNttJob &job, const HpDropArgs *da) {
-    __shared__ __attribute__((aligned(16))) u64 buf[SPLIT_TILE];
-    constexpr int PER = SPLIT_TILE / SPLIT_THREADS, BPT = PER / 2;   // coefficients and butterflies per thread and stage
+//
+// Rounds KA @ pA, KB @ pB, KC @ pC in the order they run (KC = 0: two rounds).  Coefficients are loaded straight into the first
+// round's registers when its slots lie in runs of >= 16 in memory (pA >= 4), otherwise in the linear order (slot = tid + 256 e) and
+// through LDS; the same at the end.
+template <bool INVERSE, bool COLS, bool FIRST, bool DROP, int KA, int KB, int KC>
+HP_DEV void ntt_split_rounds(const HpNttJob &job, const HpDropArgs *da, u64 *buf, u32 pA, u32 pB, u32 pC) {
+    constexpr int PER = SPLIT_TILE / SPLIT_THREADS;
+    static_assert(PER == 8, "eight coefficients per thread");
+    constexpr int KL = KC ? KC : KB;     // the last round
+    const u32 pL = KC ? pC : pB;
     const u32 logn = job.logn, n = 1u << logn, tiles = n / SPLIT_TILE;
-    const u32 w = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const u32 w = blockIdx.x / tiles, tile = blockIdx.x % tiles, tid = threadIdx.x;
     HpItem it;
     if (!hp_decode_item(job, w, it)) return;
     const HpLimb m = job.limbs[it.limb];
+    const u32 n0 = (u32)m.neg_q, n1 = (u32)(m.neg_q >> 32);
     const gptr_tw table = (gptr_tw)(INVERSE ? m.inv_ref : m.fwd_ref);
     const TileMap<COLS> tm(logn, tile);
     const u64 *in = FIRST ? it.src : it.dst;   // the second launch works on what the first one left in the destination row
-    const u32 steps = COLS ? logn - 8 : 8;
+    const bool lin_in = pA < 4, lin_out = pL < 4;
     // everything a thread needs from memory before its first butterfly is issued at once: its coefficients, the twiddles of the
-    // first stage and (inverse, last launch) the psi^-i N^-1 pairs of its outputs
+    // first round and (inverse, last launch) the psi^-i N^-1 pairs of its outputs
     u64 x[PER];
 #pragma unroll
-    for (int e = 0; e < PER; ++e) x[e] = in[tm.global(threadIdx.x + e * SPLIT_THREADS)];
+    for (int e = 0; e < PER; ++e) x[e] = in[tm.global(lin_in ? tid + (u32)e * SPLIT_THREADS : slot_of<KA>(tid, pA, e))];
+    u64x2 tw[7];
+    round_twiddles<INVERSE, COLS, KA>(tw, table, logn, tm, pA);
+    u64x2 sc[PER];
+    if (INVERSE && COLS) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e)
+            sc[e] = ld_tw(table, n + tm.global(lin_out ? tid + (u32)e * SPLIT_THREADS : slot_of<KL>(tid, pL, e)));   // ntt.cpp:214-222
+    }
     if (DROP && FIRST) {
         const u32 k = it.limb;
         const u64 bump = m.q - da->dc.r[k];
@@ -125,45 +165,43 @@ HP_DEV void ntt_split_body(const HpNttJob &job, const HpDropArgs *da) {
             x[e] = v;
         }
     }
-    Bfly cur[BPT];
-    u64x2 tw[BPT];
+    if (lin_in) {
 #pragma unroll
-    for (int t = 0; t < BPT; ++t) {
-        cur[t] = bfly_of<INVERSE, COLS>(logn, tm, 0, threadIdx.x + t * SPLIT_THREADS);
-        tw[t] = ld_tw(table, cur[t].tw);
-    }
-    u64x2 sc[PER];
-    if (INVERSE && COLS) {
-#pragma unroll
-        for (int e = 0; e < PER; ++e) sc[e] = ld_tw(table, n + tm.global(threadIdx.x + e * SPLIT_THREADS));   // ntt.cpp:214-222
-    }
-#pragma unroll
-    for (int e = 0; e < PER; ++e) buf[threadIdx.x + e * SPLIT_THREADS] = x[e];
-    lds_barrier();
-    for (u32 step = 0; step < steps; ++step) {
-        // the next stage's twiddles go out before this stage's arithmetic: their L2 latency hides behind it and the barrier
-        Bfly nxt[BPT];
-        u64x2 ntw[BPT];
-        const bool more = step + 1 < steps;
-#pragma unroll
-        for (int t = 0; t < BPT; ++t) {
-            nxt[t] = bfly_of<INVERSE, COLS>(logn, tm, more ? step + 1 : step, threadIdx.x + t * SPLIT_THREADS);
-            ntw[t] = ld_tw(table, nxt[t].tw);
-        }
-#pragma unroll
-        for (int t = 0; t < BPT; ++t) {
-            u64 lo = buf[cur[t].l], hi = buf[cur[t].h];
-            hp_butterfly(lo, hi, tw[t].x, tw[t].y, m.q, m.two_q);
-            buf[cur[t].l] = lo; buf[cur[t].h] = hi;
-        }
+        for (int e = 0; e < PER; ++e) buf[swz(tid + (u32)e * SPLIT_THREADS)] = x[e];
         lds_barrier();
 #pragma unroll
-        for (int t = 0; t < BPT; ++t) { cur[t] = nxt[t]; tw[t] = ntw[t]; }
+        for (int e = 0; e < PER; ++e) x[e] = buf[swz(slot_of<KA>(tid, pA, e))];
+    }
+    round_stages<INVERSE, KA>(x, tw, m.two_q, n0, n1);
+    // the next round's twiddles go out before the exchange: their L2 latency hides behind it and the barrier.  A thread writes the
+    // slots it read (nobody else's), so one barrier per exchange is enough.
+    round_twiddles<INVERSE, COLS, KB>(tw, table, logn, tm, pB);
+#pragma unroll
+    for (int e = 0; e < PER; ++e) buf[swz(slot_of<KA>(tid, pA, e))] = x[e];
+    lds_barrier();
+#pragma unroll
+    for (int e = 0; e < PER; ++e) x[e] = buf[swz(slot_of<KB>(tid, pB, e))];
+    round_stages<INVERSE, KB>(x, tw, m.two_q, n0, n1);
+    if constexpr (KC != 0) {
+        round_twiddles<INVERSE, COLS, KC>(tw, table, logn, tm, pC);
+#pragma unroll
+        for (int e = 0; e < PER; ++e) buf[swz(slot_of<KB>(tid, pB, e))] = x[e];
+        lds_barrier();
+#pragma unroll
+        for (int e = 0; e < PER; ++e) x[e] = buf[swz(slot_of<KC>(tid, pC, e))];
+        round_stages<INVERSE, KC>(x, tw, m.two_q, n0, n1);
+    }
+    if (lin_out) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) buf[swz(slot_of<KL>(tid, pL, e))] = x[e];
+        lds_barrier();
+#pragma unroll
+        for (int e = 0; e < PER; ++e) x[e] = buf[swz(tid + (u32)e * SPLIT_THREADS)];
     }
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
-        const u32 i = threadIdx.x + e * SPLIT_THREADS, g = tm.global(i);
-        u64 v = buf[i];
+        const u32 g = tm.global(lin_out ? tid + (u32)e * SPLIT_THREADS : slot_of<KL>(tid, pL, e));
+        u64 v = x[e];
         if (!INVERSE && !COLS) v = hp_shift_fold(v, m.q, m.k, m.fix);                         // ntt.cpp:171-175 after the last stage
         if (DROP && !FIRST) {
             const u32 k = it.limb, p2 = it.poly;
@@ -182,6 +220,27 @@ HP_DEV void ntt_split_body(const HpNttJob &job, const HpDropArgs *da) {
             if (job.strict) v = hp_strict(v, m.q);
         }
         it.dst[g] = v;
+    }
+}
+
+// The rounds of each launch.  Contiguous tiles: the eight stages of gaps 128 .. 1 = slot bits 7 .. 0 (forward: 3 + 3 + 2 from the
+// top; inverse: 3 + 3 + 2 from the bottom).  Column tiles: the logn - 8 stages of slot bits 10 .. lc (lc = 19 - logn): the round
+// of bits 8 .. 10 -- whose slots are the linear order -- first (forward) / last (inverse), the remaining logn - 11 .. bits as one
+// or two more rounds.
+template <bool INVERSE, bool COLS, bool FIRST, bool DROP>
+HP_DEV void ntt_split_body(const HpNttJob &job, const HpDropArgs *da) {
+    __shared__ __attribute__((aligned(16))) u64 buf[SPLIT_TILE];   // (one buffer: every case of the switch below would otherwise bring its own)
+    if constexpr (!COLS) {
+        if (INVERSE) ntt_split_rounds<INVERSE, COLS, FIRST, DROP, 3, 3, 2>(job, da, buf, 0, 3, 6);
+        else ntt_split_rounds<INVERSE, COLS, FIRST, DROP, 3, 3, 2>(job, da, buf, 5, 2, 0);
+    } else {
+        switch (job.logn) {   // (uniform: one case per launch)
+        case 12: if (INVERSE) ntt_split_rounds<INVERSE, COLS, FIRST, DROP, 1, 3, 0>(job, da, buf, 7, 8, 0); else ntt_split_rounds<INVERSE, COLS, FIRST, DROP, 3, 1, 0>(job, da, buf, 8, 7, 0); break;
+        case 13: if (INVERSE) ntt_split_rounds<INVERSE, COLS, FIRST, DROP, 2, 3, 0>(job, da, buf, 6, 8, 0); else ntt_split_rounds<INVERSE, COLS, FIRST, DROP, 3, 2, 0>(job, da, buf, 8, 6, 0); break;
+        case 14: if (INVERSE) ntt_split_rounds<INVERSE, COLS, FIRST, DROP, 3, 3, 0>(job, da, buf, 5, 8, 0); else ntt_split_rounds<INVERSE, COLS, FIRST, DROP, 3, 3, 0>(job, da, buf, 8, 5, 0); break;
+        case 15: if (INVERSE) ntt_split_rounds<INVERSE, COLS, FIRST, DROP, 1, 3, 3>(job, da, buf, 4, 5, 8); else ntt_split_rounds<INVERSE, COLS, FIRST, DROP, 3, 3, 1>(job, da, buf, 8, 5, 4); break;
+        default: if (INVERSE) ntt_split_rounds<INVERSE, COLS, FIRST, DROP, 2, 3, 3>(job, da, buf, 3, 5, 8); else ntt_split_rounds<INVERSE, COLS, FIRST, DROP, 3, 3, 2>(job, da, buf, 8, 5, 3); break;
+        }
     }
 }
 
