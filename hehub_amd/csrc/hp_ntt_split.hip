@@ -130,8 +130,8 @@ HP_DEV void ntt_split_rounds(const HpNttJob &job, const HpDropArgs *da, u64 *buf
     static_assert(PER == 8, "eight coefficients per thread");
     constexpr int KL = KC ? KC : KB;     // the last round
     const u32 pL = KC ? pC : pB;
-    const u32 logn = job.logn, n = 1u << logn, tiles = n / SPLIT_TILE;
-    const u32 w = blockIdx.x / tiles, tile = blockIdx.x % tiles, tid = threadIdx.x;
+    const u32 logn = job.logn, n = 1u << logn;
+    const u32 w = blockIdx.x >> (logn - 11), tile = blockIdx.x & ((n / SPLIT_TILE) - 1u), tid = threadIdx.x;   // N / 2048 tiles per limb
     HpItem it;
     if (!hp_decode_item(job, w, it)) return;
     const HpLimb m = job.limbs[it.limb];
