@@ -179,9 +179,13 @@ template <class Ct, class Quad, bool BGV> struct Program {
                 level[x] = L;
                 break;
             }
-            case 11: {   // plaintext operations (ckks/arith.cpp:22-53: the plaintext is transformed inside)
-                if constexpr (BGV) break;
-                else {
+            case 11: {   // plaintext operations (ckks/arith.cpp:22-53: the plaintext is transformed inside; bgv/arith.cpp:17-57: lifted first)
+                if constexpr (BGV) {
+                    bgv::BgvPt pt(random_poly(n, std::vector<u64>{65537}, PolyRepForm::coeff));
+                    const size_t which = pick(3);
+                    put(z, which == 0 ? bgv::add_plain(pool[x], pt) : which == 1 ? bgv::sub_plain(pool[x], pt) : bgv::mult_plain(pool[x], pt),
+                        level[x]);
+                } else {
                     ckks::CkksPt pt(random_poly(n, moduli_at(level[x]), PolyRepForm::coeff));
                     pt.scaling_factor = SC;
                     const size_t which = pick(3);

@@ -49,6 +49,7 @@ SIGNATURES = {
     "hp_dev_load_host_rows": (INT, [P, szt, szt, P, P]),
     "hp_dev_gather_rows": (INT, [P, szt, szt, P, P]),
     "hp_dev_scatter_rows": (INT, [P, szt, szt, P, P]),
+    "hp_dev_poly_fold_rows": (INT, [P, szt, szt, P, szt, szt, P, P, P]),
     "hp_ctx_set_force_generic": (INT, [P, INT]),
     "hp_ctx_set_parity_level": (INT, [P, INT]),
     "hp_ctx_get_parity_level": (INT, [P]),

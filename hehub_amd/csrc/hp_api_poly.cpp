@@ -178,6 +178,42 @@ int hp_dev_poly_sub(hp_ctx *ctx, size_t n, size_t L, const uint64_t *m, size_t b
 int hp_dev_poly_mul(hp_ctx *ctx, size_t n, size_t L, const uint64_t *m, size_t batch, const uint64_t *a,
                     const uint64_t *b, uint64_t *out) { return dev_binary(ctx, HP_MUL, n, L, m, batch, a, b, out); }
 
+// a chain of += / -= on polynomials (rns.cpp:58-118) as one pass per 32 terms: the words of the single calls in their order
+int hp_dev_poly_fold_rows(hp_ctx *ctx, size_t n, size_t L, const uint64_t *moduli, size_t polys, size_t terms, const uint8_t *negate,
+                          const uint64_t *const *d_rows, uint64_t *d_out) {
+    HP_ENTER(ctx);
+    HP_REQUIRE(ctx, moduli, negate, d_rows, d_out);
+    HP_ALIGNED(ctx, d_out);
+    if (n == 0 || (n & (n - 1))) return fail(ctx, HP_EUNSUPPORTED, HP_LOGN_MSG);
+    if (terms < 1) return fail(ctx, HP_EINVAL, "a chain has at least one term");
+    if (polys == 0) return HP_OK;
+    for (size_t i = 0; i < polys * terms; i++)
+        if (!d_rows[i] || ((uintptr_t)d_rows[i] & 15u)) return fail(ctx, HP_EINVAL, "device rows: NULL or misaligned row");
+    const Plan *plan;
+    int rc = get_plan(ctx, 0, moduli, L, false, &plan);
+    if (rc) return rc;
+    ProfScope ps(ctx, "elem");
+    const size_t words = L * n;
+    for (size_t p0 = 0; p0 < polys; p0++) {   // (a chain is long and the polynomials are few: one polynomial's segment per launch keeps the argument block small)
+        // segments of at most 32 terms; from the second on, term 0 is the running sum itself (in place: a thread reads what it overwrites)
+        size_t done = 0;
+        while (done < terms) {
+            HpFoldRows fr;
+            memset(&fr, 0, sizeof(fr));
+            size_t cnt = 0;
+            if (done) fr.p[cnt++] = d_out + p0 * words;
+            while (done < terms && cnt < HP_FOLD_TERMS_MAX) {
+                if (done && negate[done]) fr.neg |= 1u << cnt;
+                fr.p[cnt++] = d_rows[p0 * terms + done];
+                done++;
+            }
+            if ((rc = chk(ctx, hp_launch_poly_fold(plan->d_limbs, (u32)L, (u32)n, 1, (u32)cnt, fr, d_out + p0 * words, ctx->stream), "poly_fold")))
+                return rc;
+        }
+    }
+    return HP_OK;
+}
+
 int hp_dev_poly_scalar_mul(hp_ctx *ctx, size_t n, size_t L, const uint64_t *moduli, size_t batch,
                            const uint64_t *rns_scalar, const uint64_t *a, uint64_t *out) {
     HP_ENTER(ctx);

@@ -86,6 +86,59 @@ hipError_t hp_launch_poly_binary(int op, const HpLimb *limbs, u32 L, u32 n, u32 
     return hipGetLastError();
 }
 
+// ---- a chain of += / -= in one pass: rns.cpp:58-118 term after term ----------------------------------------------------
+// out[p] = ((x_0 op_1 x_1) op_2 x_2) ... of polynomial p's `terms` operand rows (anywhere; addresses as kernel arguments), op_j = -= where
+// bit j of neg is set: the words of the single calls in their order (each step is the lazy add / sub of rns.cpp), the intermediate
+// sums never cross HBM.  The accumulate of a diagonal loop (src/circuits/linear_algebra.h:117-121) is such a chain.
+__global__ void __launch_bounds__(ELEM_THREADS) k_poly_fold(const HpLimb *__restrict__ limbs, u32 L, u32 n, u32 chunks, u32 terms,
+                                                           HpFoldRows rows, u64 *__restrict__ out) {
+    const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;   // row = p * L + k
+    const u32 p = row / L, k = row % L;
+    const u64 two_q = limbs[k].two_q;
+    const size_t off = (size_t)k * n;
+    const u64 *const *src = rows.p + (size_t)p * terms;
+    u64 *dst = out + (size_t)row * n;
+    const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
+    if ((chunk + 1) * ELEM_CHUNK <= n) {   // a full chunk: four 16-byte loads of a term in flight per thread
+        constexpr int IT = ELEM_CHUNK / (ELEM_THREADS * 2);
+        const size_t o = off + (size_t)chunk * ELEM_CHUNK + threadIdx.x * 2;
+        U2 acc[IT];
+#pragma unroll
+        for (int t = 0; t < IT; ++t) acc[t] = ld_nt(src[0] + o + (size_t)t * ELEM_THREADS * 2);
+        for (u32 j = 1; j < terms; ++j) {
+            const u64 *x = src[j] + o;
+            U2 v[IT];
+#pragma unroll
+            for (int t = 0; t < IT; ++t) v[t] = ld_nt(x + (size_t)t * ELEM_THREADS * 2);
+            if ((rows.neg >> j) & 1u) {
+#pragma unroll
+                for (int t = 0; t < IT; ++t) { acc[t].x = hp_sub_lazy(acc[t].x, v[t].x, two_q); acc[t].y = hp_sub_lazy(acc[t].y, v[t].y, two_q); }
+            } else {
+#pragma unroll
+                for (int t = 0; t < IT; ++t) { acc[t].x = hp_add_lazy(acc[t].x, v[t].x, two_q); acc[t].y = hp_add_lazy(acc[t].y, v[t].y, two_q); }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < IT; ++t) st_nt(dst + (o - off) + (size_t)t * ELEM_THREADS * 2, acc[t]);
+        return;
+    }
+    for (u32 i = chunk * ELEM_CHUNK + threadIdx.x; i < end; i += ELEM_THREADS) {
+        u64 acc = src[0][off + i];
+        for (u32 j = 1; j < terms; ++j) {
+            const u64 v = src[j][off + i];
+            acc = ((rows.neg >> j) & 1u) ? hp_sub_lazy(acc, v, two_q) : hp_add_lazy(acc, v, two_q);
+        }
+        dst[i] = acc;
+    }
+}
+
+hipError_t hp_launch_poly_fold(const HpLimb *limbs, u32 L, u32 n, u32 polys, u32 terms, const HpFoldRows &rows, u64 *out, hipStream_t stream) {
+    u32 chunks; dim3 grid;
+    elem_grid(n, polys * L, chunks, grid);
+    k_poly_fold<<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, n, chunks, terms, rows, out);
+    return hipGetLastError();
+}
+
 // ---- unary: rns.cpp:142-171 (scalar multiply), mod_arith.h:65-72 (strict) --------
 template <int STRICT>
 __global__ void __launch_bounds__(ELEM_THREADS) k_poly_unary(const HpLimb *__restrict__ limbs, HpScalars sc, u32 L,

@@ -115,6 +115,14 @@ hipError_t hp_launch_vec(int op, const HpVecConsts &c, size_t n, const u64 *a, c
 hipError_t hp_launch_tensor(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32 n, u32 P, const u64 *ct1,
                             const u64 *ct2, u64 *quad, hipStream_t stream);
 // the same with the operands by address: polynomials ct1[0], ct1[1], ct2[0], ct2[1] (u64[L][N] each) of pair p at rows.p[p][0..3]
+// a chain of lazy sums / differences per polynomial: rows.p[poly * terms + j] = term j of polynomial poly (u64[L][n]), bit j of neg: subtracted
+#define HP_FOLD_ROWS_MAX 64
+#define HP_FOLD_TERMS_MAX 32
+struct HpFoldRows {
+    const u64 *p[HP_FOLD_ROWS_MAX];
+    u32 neg;
+};
+hipError_t hp_launch_poly_fold(const HpLimb *limbs, u32 L, u32 n, u32 polys, u32 terms, const HpFoldRows &rows, u64 *out, hipStream_t stream);
 #define HP_TENSOR_ROWS_MAX 64
 struct HpTensorRows {
     const u64 *p[HP_TENSOR_ROWS_MAX][4];

@@ -235,6 +235,18 @@ class Engine:
     def poly_add(self, moduli, a, b, out=None):
         return self._binary(self.lib.hp_dev_poly_add, moduli, a, b, out)
 
+    def poly_fold_rows(self, moduli, chains, negate, out=None):
+        """chains[p] = the term polynomials (device tensors [L][n], anywhere) of polynomial p; out[p] = ((x0 op1 x1) op2 x2) ... with
+        op_j = -= where negate[j] (include/hehub_amd.h: hp_dev_poly_fold_rows): the words of the chain of += / -= calls"""
+        polys, terms = len(chains), len(chains[0])
+        L, n = chains[0][0].shape
+        if out is None:
+            out = self.empty((polys, L, n))
+        ptrs = (capi.P * (polys * terms))(*[t.data_ptr() for c in chains for t in c])
+        neg = (C.c_uint8 * terms)(*[1 if x else 0 for x in negate])
+        self._chk(self.lib.hp_dev_poly_fold_rows(self.h, n, L, _u64arr(moduli), polys, terms, neg, ptrs, self._ptr(out)))
+        return out
+
     def poly_sub(self, moduli, a, b, out=None):
         return self._binary(self.lib.hp_dev_poly_sub, moduli, a, b, out)
 

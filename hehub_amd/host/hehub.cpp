@@ -542,7 +542,7 @@ struct Dst {
 // 256 independent ckks::mult + rescale_inplace so runs as three batch-256 launches groups, 8 interleaved chains as batch-8 ones.
 // Results are word for word those of the eager calls.  What differs: a failure INSIDE the engine (a HIP error, a modulus the
 // transforms reject) surfaces when the queue runs, not at the call that recorded it.
-enum class OpKind { MultLow, Relin, KeySwitch, Drop, AddSub, Copy, PolyMul, Transform };
+enum class OpKind { MultLow, Relin, KeySwitch, Drop, AddSub, Copy, PolyMul, Transform, PolyAddSub, BaseConv };
 struct PendingOp {
     OpKind kind = OpKind::MultLow;
     size_t logn = 0, L = 0, L0 = 0, step = 0;
@@ -1062,6 +1062,17 @@ void run_group(const std::vector<PendingOp *> &g) {
         check(hp_dev_poly_mul(cur(), n, L, o.mod.data(), B, da.p, db.p, big->p));
         break;
     }
+    case OpKind::PolyAddSub: {   // += / -= of two polynomials (rns.cpp:59-98): the plaintext sums of add_plain / sub_plain, the halves of a sum taken apart
+        Src da = group_rows(g, 0, 1, n), db = group_rows(g, 1, 1, n);
+        if (o.sub) check(hp_dev_poly_sub(cur(), n, L, o.mod.data(), B, da.p, db.p, big->p));
+        else check(hp_dev_poly_add(cur(), n, L, o.mod.data(), B, da.p, db.p, big->p));
+        break;
+    }
+    case OpKind::BaseConv: {   // rns_base_transform, one modulus (t) -> many (rns_transform.cpp:113 + :11-37): the plaintext lift of the bgv plain operations
+        Src din = group_rows(g, 0, 1, n);
+        check(hp_dev_rns_base_from_single(cur(), n, o.t, L, o.mod.data(), B, din.p, big->p));
+        break;
+    }
     case OpKind::AddSub: {
         Src da = group_rows(g, 0, 2, n), db = group_rows(g, 2, 2, n);
         if (o.sub) check(hp_dev_poly_sub(cur(), n, L, o.mod.data(), 2 * B, da.p, db.p, big->p));
@@ -1150,6 +1161,70 @@ std::vector<PendingOp *> run_fused_mults(const std::vector<std::unique_ptr<Pendi
     return rest;
 }
 
+
+// A chain of sums: add / sub calls each of which takes the previous one's result as its FIRST operand, that result held by nobody
+// else (`acc = add(acc, term)` in a loop: src/circuits/linear_algebra.h:117-121, examples/ckks_example.cpp), the other operands
+// ready.  The chain runs as one pass over its terms (hp_dev_poly_fold_rows: each step the lazy sum / difference of the single call, in
+// the calls' order -- the same words), the intermediate sums never exist.  Returns the calls of the group that head no such chain.
+std::vector<PendingOp *> run_sum_chains(const std::vector<std::unique_ptr<PendingOp>> &ops, const std::vector<PendingOp *> &g_all) {
+    std::vector<PendingOp *> rest;
+    if (g_all.empty() || g_all[0]->kind != OpKind::AddSub) return g_all;
+    const size_t n = (size_t)1 << g_all[0]->logn, L = g_all[0]->L, w = L * n;
+    auto next_of = [&](const PendingOp &t) -> PendingOp * {
+        if ((size_t)t.out.use_count() != 1 + 2) return nullptr;   // the producer's handle + the consumer's two operand entries, nothing else
+        for (auto &o : ops) {
+            if (o->done || o->kind != OpKind::AddSub || o->in.size() != 4 || o.get() == &t) continue;
+            if (o->in[0].first != t.out || o->in[0].second != 0 || o->in[1].first != t.out || o->in[1].second != w) continue;
+            if (o->logn != t.logn || o->L != t.L || o->in_limbs != t.in_limbs || o->mod != t.mod) return nullptr;
+            if (o->in[2].first->op || o->in[3].first->op) return nullptr;   // its other operand has not been computed yet
+            return o.get();
+        }
+        return nullptr;
+    };
+    for (PendingOp *m : g_all) {
+        std::vector<PendingOp *> chain{m};
+        if (m->in_limbs == L)
+            while (PendingOp *c = next_of(*chain.back())) chain.push_back(c);
+        if (chain.size() < 2) {
+            rest.push_back(m);
+            continue;
+        }
+        const size_t terms = chain.size() + 1;
+        std::vector<const u64 *> rows(2 * terms);
+        std::vector<unsigned char> neg(terms, 0);
+        for (size_t h = 0; h < 2; h++) {
+            rows[h * terms] = words_of(m->in[h].first) + m->in[h].second;
+            track_read(*m->in[h].first);
+            for (size_t j = 0; j < chain.size(); j++) {
+                const auto &r = chain[j]->in[2 + h];
+                rows[h * terms + 1 + j] = words_of(r.first) + r.second;
+                track_read(*r.first);
+                neg[1 + j] = chain[j]->sub ? 1 : 0;
+            }
+        }
+        BlockRef big = alloc_block(2 * w);
+        track_write(*big);
+        check(hp_dev_poly_fold_rows(cur(), n, L, m->mod.data(), 2, terms, neg.data(), rows.data(), big->p));
+        for (size_t j = 0; j < chain.size(); j++) {
+            PendingOp *o = chain[j];
+            if (j + 1 == chain.size()) {
+                o->out->p = big->p;
+                o->out->parent = big;
+                o->out->op = nullptr;
+            } else {   // never materialised, and nobody can ask: see above
+                o->out->op = nullptr;
+                o->out->failed = true;
+            }
+            o->done = true;
+        }
+        for (PendingOp *o : chain) release_operands(*o);
+        g_stats.deferred_groups++;
+        g_stats.deferred_calls += chain.size();
+        g_stats.deferred_chain_sums += chain.size();
+    }
+    return rest;
+}
+
 } // namespace
 
 // nothing is recorded any more: no block is waiting to be read by a recorded call
@@ -1181,6 +1256,7 @@ void flush_all() {
             // against 0.126 ms per call -- the hops cost more than independent small groups could win.)
             OpScope scope({}, 0);
             g = run_fused_mults(ops, g);
+            g = run_sum_chains(ops, g);
             if (!g.empty()) run_group(g);
         }
     } catch (...) {
@@ -1318,6 +1394,10 @@ size_t check_addsub(const RnsIntVec &self, const RnsIntVec &b) {
 }
 
 enum class Bin { add, sub, mul };
+#ifndef HEHUB_AMD_BIND_REFERENCE
+std::unique_ptr<amd::PendingOp> new_op(amd::OpKind kind, size_t logn, size_t L, const std::vector<u64> &mod,
+                                       std::initializer_list<const RnsIntVec *> operands, size_t in_limbs, size_t out_words);
+#endif
 
 void dev_binary(Bin op, size_t n, size_t L, const u64 *m, size_t batch, const u64 *a, const u64 *b, u64 *out) {
     auto *ctx = amd::cur();
@@ -1330,6 +1410,17 @@ void dev_binary(Bin op, size_t n, size_t L, const u64 *m, size_t batch, const u6
 void run_inplace(Bin op, RnsIntVec &self, const RnsIntVec &b, size_t L) {
     const size_t n = self.dimension();
     if (L == 0 || n == 0) return;
+#ifndef HEHUB_AMD_BIND_REFERENCE
+    if (op != Bin::mul && n >= 2 && amd::deferred()) {   // recorded: self becomes the placeholder of the sum (the plaintext sums of a loop run as one batch)
+        OpScope scope({}, 0);
+        size_t lg = 0;
+        while (((size_t)1 << lg) < n) lg++;
+        auto rec = new_op(amd::OpKind::PolyAddSub, lg, L, self.modulus_vec(), {&self, &b}, L, L * n);
+        rec->sub = op == Bin::sub;
+        Access::bind_block(self, amd::record(std::move(rec)), 0);
+        return;
+    }
+#endif
     OpScope scope({Access::home(self), Access::home(b)});
     Src sb = Access::in(b, L);
 #ifndef HEHUB_AMD_BIND_REFERENCE
@@ -1895,6 +1986,19 @@ RnsPolynomial rns_base_transform(RnsPolynomial in, const std::vector<u64> &new_m
     if (in.rep_form == PolyRepForm::value)
         throw std::logic_error("Trying to perform RNS base transformation on NTT values.");
     const size_t n = in.dimension(), L = in.component_count();
+    // recorded in deferred mode: the plaintext lifts of a loop of bgv::add_plain / sub_plain / mult_plain (bgv/arith.cpp:17-57) run as
+    // one batch.  (one -> many only: many -> one is decrypt's, whose caller looks at the words next, and its preconditions -- odd,
+    // pairwise coprime moduli -- are reported by the call itself)
+    if (amd::deferred() && n >= 2 && L == 1 && !new_moduli.empty() && in.modulus_at(0) >= 2) {
+        OpScope scope({}, 0);
+        size_t lg = 0;
+        while (((size_t)1 << lg) < n) lg++;
+        RnsPolynomial out = result_poly(n, new_moduli.size(), new_moduli, PolyRepForm::coeff);
+        auto rec = new_op(amd::OpKind::BaseConv, lg, new_moduli.size(), new_moduli, {&in}, 1, new_moduli.size() * n);
+        rec->t = in.modulus_at(0);
+        Access::bind_block(out, amd::record(std::move(rec)), 0);
+        return out;
+    }
     OpScope op({Access::home(in)});
     if (L == 1) {
         RnsPolynomial out = result_poly(n, new_moduli.size(), new_moduli, PolyRepForm::coeff);

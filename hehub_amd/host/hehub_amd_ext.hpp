@@ -46,6 +46,7 @@ struct TransferStats {
     unsigned long long deferred_calls = 0, deferred_groups = 0, deferred_fused = 0;
     // ... and the groups of rotations / conjugations that ran with a key per ciphertext (hp_dev_ckks_rotate_many)
     unsigned long long deferred_many_key_groups = 0;
+    unsigned long long deferred_chain_sums = 0;   // ... += / -= chains of add / sub calls that ran as ONE pass (hp_dev_poly_fold_rows): calls folded
 };
 TransferStats transfer_stats();
 
@@ -56,11 +57,13 @@ int lanes();
 void set_lanes(int n);
 /// Deferred mode (own-mirror build; default off, HEHUB_AMD_DEFER=1 in the environment turns it on): the scheme-level calls of hehub's
 /// interface -- mult_low_level, relinearize, mult, rotate, conjugate, rescale_inplace, mod_switch_inplace, add / sub of ciphertexts,
-/// polynomial products (mult_plain) and copies of results that are still pending --
+/// polynomial products (mult_plain), += / -= and in-place transforms of polynomials, rns_base_transform from one modulus (the plaintext
+/// lift of bgv::add_plain / sub_plain / mult_plain) and copies of results that are still pending --
 /// are RECORDED with all their argument checks made and their result objects returned; they run when somebody needs words (a look at
 /// a result, a call that cannot be recorded, synchronize(), 1024 recorded calls), grouped: recorded calls with one signature whose
 /// operands are ready run as ONE batched engine call (rotations and conjugations group across keys and steps: the engine takes a key
-/// per ciphertext).  An unchanged loop over independent ciphertexts thereby gets the batch rate
+/// per ciphertext; a chain `acc = add(acc, term)` whose intermediate sums nobody else holds runs as one pass over its terms).
+/// An unchanged loop over independent ciphertexts thereby gets the batch rate
 /// (hehub.cpp "deferred execution").  Results are word for word those of the eager calls; a failure inside the engine surfaces when
 /// the queue runs instead of at the call.  set_deferred(false) runs what is pending.
 void set_deferred(bool on);

@@ -186,6 +186,13 @@ int hp_dev_poly_add(hp_ctx *ctx, size_t n, size_t L, const uint64_t *moduli, siz
                     const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out);
 int hp_dev_poly_sub(hp_ctx *ctx, size_t n, size_t L, const uint64_t *moduli, size_t batch,
                     const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out);
+/* A chain of operator+= / operator-= (rns.cpp:58-87 / :89-118 applied term after term, e.g. the accumulate of the diagonal loop in
+ * src/circuits/linear_algebra.h:117-121) folded into one pass: d_out[p] = ((x_0 op_1 x_1) op_2 x_2) ... op_{terms-1} x_{terms-1} with
+ * x_j = d_rows[p * terms + j] (u64[L][N] each, anywhere on the device, 16-byte aligned; d_rows itself is a HOST array) and op_j = -=
+ * where negate[j] != 0 (negate[0] is ignored).  Each step is the lazy sum / difference of the single call, in the calls' order: the
+ * words of the chain of single calls; the intermediate sums never cross HBM.  d_out u64[polys][L][N] may be one of the rows' x_0. */
+int hp_dev_poly_fold_rows(hp_ctx *ctx, size_t n, size_t L, const uint64_t *moduli, size_t polys, size_t terms,
+                          const uint8_t *negate, const uint64_t *const *d_rows, uint64_t *d_out);
 int hp_dev_poly_mul(hp_ctx *ctx, size_t n, size_t L, const uint64_t *moduli, size_t batch,
                     const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out);
 /* per-limb scalars (operator*=(vector<u64>)); pass the same value L times for operator*=(u64) */

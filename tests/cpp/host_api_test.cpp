@@ -751,6 +751,14 @@ static void test_deferred() {
         e_sum = ckks::add(e_sum, p);
     }
     ckks::CkksCt e_cj = ckks::sub(ckks::conjugate(f.a[1], f.key), f.a[1]);
+    auto mixed_chain = [&] {   // sums and differences in one chain
+        ckks::CkksCt x = f.b[0];
+        x = ckks::add(x, f.b[1]);
+        x = ckks::sub(x, f.b[2]);
+        x = ckks::add(x, f.b[3]);
+        return x;
+    };
+    ckks::CkksCt e_mix = mixed_chain();
     amd::synchronize();
 
     amd::set_deferred(true);
@@ -774,6 +782,7 @@ static void test_deferred() {
         d_sum = ckks::add(d_sum, p);
     }
     ckks::CkksCt d_cj = ckks::sub(ckks::conjugate(f.a[1], f.key), f.a[1]);
+    ckks::CkksCt d_mix = mixed_chain();
     // plaintext products (ckks::mult_plain = two operator* calls, ckks/arith.cpp:47-53) are recorded too: the diagonal loop of
     // src/circuits/linear_algebra.h:109-133 (rotate, mult_plain, add) never runs the queue by itself
     ckks::CkksPt d_pt;
@@ -810,7 +819,9 @@ static void test_deferred() {
         REQUIRE(same_words(d_out[i], e_out[i]));
         REQUIRE(same_words(d_chain[i], e_chain[i]));
     }
-    REQUIRE(same_words(d_sum, e_sum) && same_words(d_cj, e_cj));
+    REQUIRE(same_words(d_sum, e_sum) && same_words(d_cj, e_cj) && same_words(d_mix, e_mix));
+    // the accumulate chain (`sum = add(sum, p)`: src/circuits/linear_algebra.h:117-121) and the mixed one each ran as ONE pass over their terms
+    REQUIRE(st1.deferred_chain_sums - st0.deferred_chain_sums == (B - 1) + 3);
     REQUIRE(same_words(d_copy, e_sum) && same_words(d_copy2, e_out[0]) && d_copy2.scaling_factor == e_out[0].scaling_factor);
     amd::set_deferred(false);
     for (size_t i = 0; i < B; i++) {
@@ -885,6 +896,50 @@ static void test_deferred() {
     auto eb = bgv::relinearize(bgv::mult_low_level(ba, bb), f.key);
     bgv::mod_switch_inplace(eb);
     REQUIRE(same_words(db, eb) && db.plain_modulus == 65537);
+    // bgv plain operations (bgv/arith.cpp:17-57: the plaintext is lifted into the ciphertext's moduli, transformed and combined): the
+    // lift (rns_base_transform, one modulus -> many) and += / -= of polynomials are recorded too -- a loop of them never runs the queue
+    {
+        std::vector<bgv::BgvPt> pts;
+        for (size_t i = 0; i < 4; i++) {
+            bgv::BgvPt p(f.N, 1, std::vector<u64>{65537});
+            for (auto &w : p[0]) w = rnd() % 65537;
+            p.rep_form = PolyRepForm::coeff;
+            pts.push_back(std::move(p));
+        }
+        for (auto &p : pts) amd::prefetch(p);
+        auto plain_loop = [&](std::vector<bgv::BgvCt> &out) {
+            for (size_t i = 0; i < 4; i++) {
+                out.push_back(bgv::add_plain(ba, pts[i]));
+                out.push_back(bgv::sub_plain(bb, pts[i]));
+                out.push_back(bgv::mult_plain(out[3 * i], pts[i]));   // (reads a recorded sum)
+            }
+        };
+        std::vector<bgv::BgvCt> e, d;
+        plain_loop(e);
+        RnsPolynomial es = f.a[4][0];
+        es += f.b[4][0];
+        es -= f.a[4][1];
+        es += es;
+        amd::synchronize();
+        amd::set_deferred(true);
+        const auto q0 = amd::transfer_stats();
+        plain_loop(d);
+        RnsPolynomial ds = f.a[4][0];
+        ds += f.b[4][0];
+        ds -= f.a[4][1];
+        ds += ds;   // (both operands the same recorded sum)
+        REQUIRE(amd::transfer_stats().deferred_calls == q0.deferred_calls);   // recorded, nothing ran
+        REQUIRE_THROWS_AS(bgv::add_plain(ba, bgv::BgvPt(f.N, 1, std::vector<u64>{257})), std::invalid_argument);   // checked at the call
+        RnsPolynomial shorter(f.N, f.L - 1, f.q);
+        REQUIRE_THROWS_AS(ds += shorter, std::invalid_argument);
+        REQUIRE(ds == es);
+        const auto q1 = amd::transfer_stats();
+        // 12 lifts as one batch, 12 transforms as one, the sums / differences / products in a few groups
+        REQUIRE(q1.deferred_calls - q0.deferred_calls >= 12 + 12 + 8 + 8 + 3);
+        REQUIRE(q1.deferred_groups - q0.deferred_groups <= 16);
+        for (size_t i = 0; i < d.size(); i++) REQUIRE((same_words(d[i], e[i]) && d[i].plain_modulus == 65537));
+        amd::set_deferred(false);
+    }
     amd::set_deferred(was);
 }
 

@@ -115,6 +115,36 @@ def test_dev_batch_ops(eng, orc, logn, moduli, B):
     assert eq(eng.to_host(eng.poly_reduce_strict_(moduli, da.clone())), exp(lambda i: orc.poly_reduce_strict(moduli, a[i])))
 
 
+# a chain of += / -= as one pass (hp_dev_poly_fold_rows): the words of the single calls applied in order (rns.cpp:58-118), for chains
+# shorter and longer than one launch's 32 terms, at ring degrees below and above one workgroup's chunk
+@pytest.mark.parametrize("logn,moduli,terms", [(1, [P.P40[0]], 2), (4, P.P40[:2], 5), (10, [P.P50[0], P.P40[1]], 33), (12, P.P40[:3], 16),
+                                               (13, P.P40[:2] + [P.P50[1]], 70), (12, P.P40[:1], 1)])
+def test_dev_poly_fold_rows(eng, orc, logn, moduli, terms):
+    n, L = 1 << logn, len(moduli)
+    rng = SplitMix(logn * 97 + terms)
+    two_q = [2 * m for m in moduli]
+    polys = 2
+    x = rng.poly((polys, terms, L, n), two_q)
+    negate = [0] + [int(w) & 1 for w in rng.words(terms - 1, 0)] if terms > 1 else [1]
+    # the terms lie scattered: views of a bigger tensor in another order
+    pool = eng.to_device(np.ascontiguousarray(x.transpose(1, 0, 2, 3)))      # [terms][polys][L][n]
+    chains = [[pool[j][p] for j in range(terms)] for p in range(polys)]
+    got = eng.to_host(eng.poly_fold_rows(moduli, chains, negate))
+    for p in range(polys):
+        acc = x[p][0]
+        for j in range(1, terms):
+            acc = orc.poly_sub(moduli, acc, x[p][j]) if negate[j] else orc.poly_add(moduli, acc, x[p][j])
+        assert eq(got[p], acc)
+    # in place: the result over the first term
+    out = eng.poly_fold_rows(moduli, chains, negate, out=None)
+    first = [c[0].clone() for c in chains]
+    packed = eng.empty((polys, L, n))
+    for p in range(polys):
+        packed[p].copy_(first[p])
+    eng.poly_fold_rows(moduli, [[packed[p]] + chains[p][1:] for p in range(polys)], negate, out=packed)
+    assert eq(eng.to_host(packed), eng.to_host(out))
+
+
 SCHEME_CASES = [
     (3, [1099510054913, 1073479681, 1072496641, 1099507695617], 4),     # tests/ckks_t.cpp shape {40,30,30}+40, N=8
     (7, [P.P40[0], P.P40[1], P.P50[0]], 3),
