@@ -384,9 +384,9 @@ hipError_t hp_launch_vec(int op, const HpVecConsts &c, size_t n, const u64 *a, c
 // pipelines read them where they lie, hp_dev_*_mult_*_rows); the addresses travel as kernel arguments
 template <bool ROWS>
 __global__ void __launch_bounds__(ELEM_THREADS) k_tensor(const HpLimb *__restrict__ limbs, u32 L, u32 k_first, u32 kc,
-                                                        u32 n, u32 chunks, const u64 *__restrict__ ct1,
+                                                        u32 n, u32 chunks, u32 cw, const u64 *__restrict__ ct1,
                                                         const u64 *__restrict__ ct2, HpTensorRows rows, u64 *__restrict__ quad) {
-    const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;   // row = p*kc + (k - k_first)
+    const u32 row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;   // row = p*kc + (k - k_first); cw = words per workgroup
     const u32 p = row / kc, k = k_first + row % kc;
     const HpLimb m = limbs[k];
     const size_t poly = (size_t)L * n;
@@ -395,9 +395,9 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_tensor(const HpLimb *__restric
     const u64 *b0 = ROWS ? rows.p[p][2] + (size_t)k * n : ct2 + (size_t)p * 2 * poly + (size_t)k * n;
     const u64 *b1 = ROWS ? rows.p[p][3] + (size_t)k * n : b0 + poly;
     u64 *d0 = quad + (size_t)p * 3 * poly + (size_t)k * n, *d1 = d0 + poly, *d2 = d1 + poly;
-    const u32 end = min(n, (chunk + 1) * ELEM_CHUNK);
+    const u32 end = min(n, (chunk + 1) * cw);
     // (issuing the loads of several steps together, which gains 5-9 % in k_poly_binary, measured +-0 here: 0.830 vs 0.827 ms)
-    for (u32 i = chunk * ELEM_CHUNK + threadIdx.x * 2; i < end; i += ELEM_THREADS * 2) {
+    for (u32 i = chunk * cw + threadIdx.x * 2; i < end; i += ELEM_THREADS * 2) {
         if (i + 1 < end) {
             U2 va0 = ld_nt(a0 + i), va1 = ld_nt(a1 + i);
             U2 vb0 = ld_nt(b0 + i), vb1 = ld_nt(b1 + i);
@@ -420,12 +420,22 @@ __global__ void __launch_bounds__(ELEM_THREADS) k_tensor(const HpLimb *__restric
     }
 }
 
+// a workgroup covers 2048 words of a limb in four dependent load -> multiply -> store steps per thread; a launch of a few limbs (one
+// ciphertext through hehub's one-call-per-ciphertext interface: 160 workgroups at C3) is then four memory latencies long with a
+// third of the CUs idle -- such a launch gets 512 words per workgroup (one step per thread)
+static inline void tensor_grid(u32 n, u32 rows, u32 &chunks, u32 &cw, dim3 &grid) {
+    cw = ELEM_CHUNK;
+    if ((size_t)rows * ((n + ELEM_CHUNK - 1) / ELEM_CHUNK) < 1024 && n >= ELEM_THREADS * 2) cw = ELEM_THREADS * 2;
+    chunks = (n + cw - 1) / cw;
+    grid = dim3(chunks * rows, 1, 1);
+}
+
 hipError_t hp_launch_tensor(const HpLimb *limbs, u32 L, u32 k_first, u32 kc, u32 n, u32 P, const u64 *ct1,
                             const u64 *ct2, u64 *quad, hipStream_t stream) {
     if (kc == 0) return hipSuccess;
-    u32 chunks; dim3 grid;
-    elem_grid(n, P * kc, chunks, grid);
-    k_tensor<false><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, kc, n, chunks, ct1, ct2, HpTensorRows{}, quad);
+    u32 chunks, cw; dim3 grid;
+    tensor_grid(n, P * kc, chunks, cw, grid);
+    k_tensor<false><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, kc, n, chunks, cw, ct1, ct2, HpTensorRows{}, quad);
     return hipGetLastError();
 }
 
@@ -433,9 +443,9 @@ hipError_t hp_launch_tensor_rows(const HpLimb *limbs, u32 L, u32 k_first, u32 kc
                                  hipStream_t stream) {
     if (kc == 0 || P == 0) return hipSuccess;
     if (P > HP_TENSOR_ROWS_MAX) return hipErrorInvalidValue;
-    u32 chunks; dim3 grid;
-    elem_grid(n, P * kc, chunks, grid);
-    k_tensor<true><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, kc, n, chunks, nullptr, nullptr, rows, quad);
+    u32 chunks, cw; dim3 grid;
+    tensor_grid(n, P * kc, chunks, cw, grid);
+    k_tensor<true><<<grid, ELEM_THREADS, 0, stream>>>(limbs, L, k_first, kc, n, chunks, cw, nullptr, nullptr, rows, quad);
     return hipGetLastError();
 }
 

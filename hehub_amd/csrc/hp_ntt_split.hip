@@ -153,6 +153,22 @@ HP_DEV void ntt_split_rounds(const HpNttJob &job, const HpDropArgs *da, u64 *buf
         for (int e = 0; e < PER; ++e)
             sc[e] = ld_tw(table, n + tm.global(lin_out ? tid + (u32)e * SPLIT_THREADS : slot_of<KL>(tid, pL, e)));   // ntt.cpp:214-222
     }
+    // (drop, second launch) what the epilogue combines the transform with -- the limb's own coefficients and the optional addend -- is
+    // asked for now as well: loaded in the store loop, their latency sat exposed at the end of a launch that is all latency
+    u64 xs_pre[PER], add_pre[PER];
+    bool with_addend = false;
+    if (DROP && !FIRST) {
+        const u32 k = it.limb, p2 = it.poly;
+        const u64 *xs = da->x + ((size_t)p2 * da->L + k) * n;
+        with_addend = da->addend && ((da->add_mask >> (p2 & 1)) & 1u);
+        const u64 *ad = with_addend ? da->addend + ((size_t)(p2 >> 1) * da->add_ct_stride + (size_t)(p2 & 1) * da->add_poly_stride + k) * n : xs;
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const u32 g = tm.global(lin_out ? tid + (u32)e * SPLIT_THREADS : slot_of<KL>(tid, pL, e));
+            xs_pre[e] = xs[g];
+            add_pre[e] = ad[g];
+        }
+    }
     if (DROP && FIRST) {
         const u32 k = it.limb;
         const u64 bump = m.q - da->dc.r[k];
@@ -205,12 +221,10 @@ HP_DEV void ntt_split_rounds(const HpNttJob &job, const HpDropArgs *da, u64 *buf
         if (!INVERSE && !COLS) v = hp_shift_fold(v, m.q, m.k, m.fix);                         // ntt.cpp:171-175 after the last stage
         if (DROP && !FIRST) {
             const u32 k = it.limb, p2 = it.poly;
-            const u64 *xs = da->x + ((size_t)p2 * da->L + k) * n;
-            v = hp_sub_lazy(xs[g], v, m.two_q);
+            v = hp_sub_lazy(xs_pre[e], v, m.two_q);
             v = hp_harvey_lazy(v, da->dc.inv[k], da->dc.inv_h[k], m.q);
             if (da->dc.bgv) v = hp_harvey_lazy(v, da->dc.qlt[k], da->dc.qlt_h[k], m.q);
-            if (da->addend && ((da->add_mask >> (p2 & 1)) & 1u))
-                v = hp_add_lazy(v, da->addend[((size_t)(p2 >> 1) * da->add_ct_stride + (size_t)(p2 & 1) * da->add_poly_stride + k) * n + g], m.two_q);
+            if (with_addend) v = hp_add_lazy(v, add_pre[e], m.two_q);
             da->out[((size_t)p2 * da->out_stride + k) * n + g] = v;
             continue;
         }
