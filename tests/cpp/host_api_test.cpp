@@ -940,6 +940,24 @@ static void test_deferred() {
         for (size_t i = 0; i < d.size(); i++) REQUIRE((same_words(d[i], e[i]) && d[i].plain_modulus == 65537));
         amd::set_deferred(false);
     }
+    // a chain of sums and differences longer than one launch's 32 terms (examples/ckks_example.cpp accumulates 10 000)
+    {
+        auto long_chain = [&] {
+            ckks::CkksCt x = f.b[0];
+            for (size_t i = 0; i < 40; i++) x = (i % 3 == 2) ? ckks::sub(x, f.b[i % B]) : ckks::add(x, f.b[(i + 1) % B]);
+            return x;
+        };
+        amd::set_deferred(false);
+        ckks::CkksCt e_long = long_chain();
+        amd::synchronize();
+        amd::set_deferred(true);
+        const auto q0 = amd::transfer_stats();
+        ckks::CkksCt d_long = long_chain();
+        REQUIRE(amd::transfer_stats().deferred_calls == q0.deferred_calls);
+        REQUIRE(same_words(d_long, e_long));
+        REQUIRE(amd::transfer_stats().deferred_chain_sums - q0.deferred_chain_sums == 40);
+        amd::set_deferred(false);
+    }
     amd::set_deferred(was);
 }
 

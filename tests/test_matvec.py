@@ -73,7 +73,7 @@ def test_matvec_rotations_under_different_keys_run_batched():
     """width 16: 30 rotations of one vector under 30 keys.  Recorded, they run as one launch sequence with a key per ciphertext
     (hp_dev_ckks_rotate_many_rows), the plaintext transforms as one batch: at N = 8192, L = 6 0.7 against 2.7 ms per product vector for
     the eager single calls, at the C3 shape (N = 32768, L = 10, where the split-limb transforms already make a single call fast)
-    2.1 against 2.9 ms -- hehub on the host CPU: 1234 ms (profiles/r05l_matvec.txt).  Loose bounds: shared boxes."""
+    2.1 against 2.4 ms -- hehub on the host CPU: 1262 ms (profiles/r05t_matvec.txt).  Loose bounds: shared boxes."""
     got, ms, text = run(binary(), (13, 6, 16, "short"), reps=4)
     assert got["eager"] == got["deferred"] == got["batched-form"], text
     assert ms["deferred"] < 0.6 * ms["eager"], (ms, text)
