@@ -37,6 +37,10 @@ One process per GPU; ciphertext batches are sharded across ranks with no data-pa
                         object_api.matvec: the diagonal loop of hehub's matrix_vector_mul_short (linear_algebra.h:104-136) at the C3
                         shape, width 16 (30 rotations of one vector under 30 keys): eager / deferred / batched form, hehub's digest,
                         hehub itself on this host's CPU beside it (examples/diag_matvec, oracle/_ref/ref_matvec_cpu)
+                        object_api.reference_benchmark: hehub's OWN benchmark (bench/benchmarks.cpp:21-37: ckks::rotate, one ciphertext
+                        per call, N = 2^12 .. 2^15 with create_params' modulus chains) on synthetic words: ms per rotation with a look
+                        after every call / back to back / recorded, hehub's digests, hehub itself on this host's CPU beside it
+                        (examples/rotate_bench, oracle/_ref/ref_rotbench_cpu)
   cpu_baseline          the compiled reference (or the C restatement) on ONE core of this host; cpu_baseline_node: the
                         same as P independent processes (P = what affinity mask and CPU quota allow, stated)
   step                  (pipelines) a pass after the timed region with HIP events around EVERY launch: per kernel family launches,

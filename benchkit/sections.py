@@ -344,6 +344,61 @@ def object_api_section(run: Run):
         ent["verified"] = ent["verified"] and ent["matvec"]["verified"]
     except Exception as e:   # noqa: BLE001
         ent["matvec"] = {"error": repr(e)[:300], "verified": None}
+    try:
+        ent["reference_benchmark"] = reference_benchmark_entry(root)
+        ent["verified"] = ent["verified"] and ent["reference_benchmark"]["verified"]
+    except Exception as e:   # noqa: BLE001
+        ent["reference_benchmark"] = {"error": repr(e)[:300], "verified": None}
+    return ent
+
+
+def reference_benchmark_entry(root: str):
+    """hehub's OWN benchmark (bench/benchmarks.cpp:21-37): ckks::rotate(ct, rot_key, 1), one ciphertext per call, at its four parameter
+    sets (N = 2^12 .. 2^15 with the modulus chains of ckks::create_params(N, scaling_bits): 2 x 36 .. 15 x 55 bits) -- the loop on synthetic
+    words through hehub's object API (examples/rotate_bench as a child process, default lanes): ms per rotation with a look at every result
+    before the next call (hehub's synchronous semantics) and back to back, recorded (HEHUB_AMD_DEFER=1) as a second run; every digest must be
+    hehub's own (tests/golden/rotate_bench.json, generated from hehub on the CPU).  `cpu_reference_ms`: the prebuilt
+    oracle/_ref/ref_rotbench_cpu (hehub itself, one core) on this host, when it travelled."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import time
+
+    from hehub_amd.build import build_example
+
+    sys.path.insert(0, os.path.join(root, "tests", "golden"))
+    from make_rotate_bench import LOGNS, REF, run
+
+    with open(os.path.join(root, "tests", "golden", "rotate_bench.json")) as f:
+        want = {int(k): v for k, v in json.load(f)["digests"].items()}
+    t0 = time.perf_counter()
+    binary = build_example("rotate_bench")
+    ent = {"program": "examples/rotate_bench 100", "unit": "ms per rotation", "what": "bench/benchmarks.cpp:21-37 on synthetic words, one ciphertext per call",
+           "by_N": {}}
+    ok = True
+    eager, _ = run(binary, 100)
+    deferred, _ = run(binary, 100, 0, {"HEHUB_AMD_DEFER": "1"})
+    cpu = {}
+    if os.path.exists(REF):
+        cpu, _ = run(REF, 2)
+    for lg in LOGNS:
+        row = {"hehub_digest": want[lg]}
+        if lg in eager:
+            row.update({"look_after_every_call": eager[lg][1], "back_to_back": eager[lg][2]})
+        if lg in deferred:
+            row["recorded_back_to_back"] = deferred[lg][2]
+        row["digests_equal"] = lg in eager and lg in deferred and eager[lg][0] == want[lg] and deferred[lg][0] == want[lg]
+        ok = ok and row["digests_equal"]
+        if lg in cpu:
+            row["cpu_reference_ms"] = cpu[lg][1]
+            row["cpu_reference_digest_equal"] = cpu[lg][0] == want[lg]
+            ok = ok and row["cpu_reference_digest_equal"]
+            if lg in eager:
+                row["speedup_vs_cpu_reference"] = cpu[lg][1] / eager[lg][1]
+        ent["by_N"][str(1 << lg)] = row
+    ent["wall_s"] = round(time.perf_counter() - t0, 1)
+    ent["verified"] = ok
     return ent
 
 

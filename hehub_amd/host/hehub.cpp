@@ -66,10 +66,11 @@ struct Lane {
     hp_ctx *ctx = nullptr;
     unsigned long long ticket = 0;            // number of the lane's current / most recent call
     unsigned long long seen[MAX_LANES] = {};  // seen[l]: this lane is ordered behind lane l's calls up to that ticket
+    bool busy = false;                        // something may still be running on it (cleared by a synchronous copy / a sync on the lane)
 };
 struct LaneSet {
     Lane v[MAX_LANES];
-    int count = 1, cur = 0, rr = 0, depth = 0;
+    int count = 1, cur = 0, rr = 0, depth = 0, last = 0;
     bool level_a = false;
 };
 namespace {
@@ -117,8 +118,10 @@ void synchronize() {
     (void)engine();
     flush_all();
     LaneSet &S = lane_set();
-    for (int l = 0; l < MAX_LANES; l++)
+    for (int l = 0; l < MAX_LANES; l++) {
         if (S.v[l].ctx && hp_sync(S.v[l].ctx) != HP_OK) throw std::runtime_error(std::string("hehub_amd: ") + hp_last_error(S.v[l].ctx));
+        S.v[l].busy = false;
+    }
 }
 void set_lanes(int n) {
 #ifdef HEHUB_AMD_BIND_REFERENCE
@@ -174,6 +177,7 @@ TransferStats g_stats;
 
 void check(int rc) {
     g_stats.engine_calls++;
+    lane_set().v[lane_set().cur].busy = true;
     if (rc == HP_OK) return;
     std::string msg = hp_last_error(cur());   // the calling thread's own last failure (hp_ctx.cpp)
     (void)hp_sync(cur());   // operands may have been enqueued for upload from the caller's memory (limb_copy_h2d): let them finish
@@ -321,8 +325,14 @@ struct OpScope {
             for (int l = 0; l < S.count; l++)
                 if (b.wr[l] && b.wr[l] == S.v[l].ticket) { lane = l; break; }
         }
-        if (lane < 0) lane = S.rr = (S.rr + 1) % S.count;
-        S.cur = lane;
+        if (lane < 0) {
+            // nothing in flight anywhere (a caller that looks at every result before its next call, like hehub's own benchmark loop):
+            // stay on the lane used last -- its workspace is the one in the Infinity Cache, and there is nothing to overlap with
+            bool any_busy = false;
+            for (int l = 0; l < S.count; l++) any_busy = any_busy || S.v[l].busy;
+            lane = any_busy ? (S.rr = (S.rr + 1) % S.count) : (S.last < S.count ? S.last : 0);
+        }
+        S.cur = S.last = lane;
         (void)cur();
         S.v[lane].ticket++;
     }
@@ -332,11 +342,13 @@ struct OpScope {
 
 void h2d(u64 *dst, const u64 *src, size_t words) {
     check(hp_memcpy_h2d(cur(), dst, src, words * sizeof(u64)));
+    lane_set().v[lane_set().cur].busy = false;   // (synchronous on its lane)
     g_stats.h2d_bytes += words * 8;
     g_stats.h2d_copies++;
 }
 void d2h(u64 *dst, const u64 *src, size_t words) {
     check(hp_memcpy_d2h(cur(), dst, src, words * sizeof(u64)));
+    lane_set().v[lane_set().cur].busy = false;   // (synchronous on its lane)
     g_stats.d2h_bytes += words * 8;
     g_stats.d2h_copies++;
 }

@@ -67,8 +67,9 @@ def test_resident_chain_matches_hehub_and_crosses_pcie_once(shape):
             assert run(REF_AMD, shape, env)["digest"] == own["digest"], env
     if shape[0] == 15:
         # C3 shape, one ciphertext at a time through hehub's API: device latency, not PCIe (was 10.8 ms per operation
-        # with staged operands; hp_dev_* at batch 1 is ~0.35-0.4 ms)
-        assert own["mult+add"] < 1.0 and own["rotate"] < 1.0, own
+        # with staged operands; hp_dev_* at batch 1 is ~0.12 ms).  The 23 timed mult + add iterations also carry the first use of
+        # three of the four lanes (a stream, a workspace: ~7 ms each, once per process): ~0.14 + 21 / 23 ms
+        assert own["mult+add"] < 2.5 and own["rotate"] < 1.0, own
 
 
 @pytest.mark.gpu
