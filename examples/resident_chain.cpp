@@ -118,11 +118,12 @@ int main(int argc, char **argv) {
     }
 #ifndef CHAIN_REFERENCE_HEADERS
     const auto st = amd::transfer_stats();
-    // read back: the two results (2 (L-1) + 2 L limbs) + the two probed polynomials that were replaced afterwards (ct_sum[1]
-    // before the rescale, the first ct_rot[1]: L limbs each); the third probe is half of the final ct_rot and is not fetched twice
-    const double in_mib = (double)(2 * 2 * L + 2 * (2 * L * (L + 1))) * n * 8 / 1048576.0, out_mib = (double)(2 * (L - 1) + 2 * L + 2 * L) * n * 8 / 1048576.0;
+    // read back: a look at ONE limb downloads that limb, a second limb the whole polynomial -- the four polynomials of the two results
+    // (their first limb, then all: 2 (1 + L-1) + 2 (1 + L) limbs; a polynomial of one limb once) + the first limbs of the two probed polynomials that were replaced
+    // afterwards (ct_sum[1] before the rescale, the first ct_rot[1]); the third probe is the first limb of the final ct_rot[1]
+    const double in_mib = (double)(2 * 2 * L + 2 * (2 * L * (L + 1))) * n * 8 / 1048576.0, out_mib = (double)(2 * ((L - 1 == 1) ? 1 : L) + 2 * (1 + L) + 2) * n * 8 / 1048576.0;
     std::printf("pcie to_device %.2f MiB in %llu copies (operands + keys once = %.2f MiB)\n", st.h2d_bytes / 1048576.0, st.h2d_copies, in_mib);
-    std::printf("pcie to_host %.2f MiB in %llu copies (the two results + two probed polynomials = %.2f MiB)\n", st.d2h_bytes / 1048576.0, st.d2h_copies, out_mib);
+    std::printf("pcie to_host %.2f MiB in %llu copies (the two results + the probed first limbs = %.2f MiB)\n", st.d2h_bytes / 1048576.0, st.d2h_copies, out_mib);
     std::printf("engine_calls %llu\n", st.engine_calls);
 #endif
     return 0;

@@ -719,6 +719,31 @@ struct Access {
         }
         v.host_ok_ = true;
     }
+    // limb k alone: a caller that looks at one word of a result (`ct[1][0][0]`) pays the PCIe time of one limb, not of the polynomial
+    static void sync_host_limb(const RnsIntVec &v, size_t k) {
+        if (v.host_ok_) return;
+        if (k >= v.count_ || v.count_ > 64) { sync_host(v); return; }
+        if (v.mask_stamp_ != stamp(v)) { v.limb_mask_ = 0; v.mask_stamp_ = v.stamp_; }
+        const size_t n = v.dimension();
+        if (v.limbs_.size() != v.count_) v.limbs_.resize(v.count_);
+        if ((v.limb_mask_ >> k) & 1ull && v.limbs_[k].size() == n) return;
+        // a second limb is asked for: the caller is walking through the vector -- the rest comes down as ONE copy
+        if (v.limb_mask_ != 0) { sync_host(v); return; }
+        {
+            v.limbs_[k].resize(n);
+            LaneSet &S = lane_set();
+            if (v.blk_->op) flush_all();
+            const DevBlock &root = v.blk_->parent ? *v.blk_->parent : *v.blk_;
+            int lane = 0;
+            for (int l = 1; l < MAX_LANES; l++)
+                if (root.wr[l] > root.wr[lane]) lane = l;
+            OpScope op({}, S.depth ? S.cur : lane);
+            track_read(*v.blk_);
+            d2h(v.limbs_[k].data(), words_of(v.blk_) + v.off_ + k * n, n);   // (synchronous)
+            v.limb_mask_ |= 1ull << k;
+        }
+        if (v.limb_mask_ == (v.count_ == 64 ? ~0ull : ((1ull << v.count_) - 1ull))) v.host_ok_ = true;   // every limb has come down by now
+    }
     static void host_written(RnsIntVec &v) {
         sync_host(v);
         if (v.dev_ok_) g_stats.device_copies_invalidated++;   // a non-const access: the next engine call uploads the vector again
@@ -1359,6 +1384,10 @@ std::vector<RnsIntVec::ComponentData> &RnsIntVec::host_rw() {
 const std::vector<RnsIntVec::ComponentData> &RnsIntVec::host_ro() const {
     Access::sync_host(*this);
     return limbs_;
+}
+const RnsIntVec::ComponentData &RnsIntVec::host_ro_limb(int k) const {
+    Access::sync_host_limb(*this, (size_t)k);
+    return limbs_[k];
 }
 bool RnsIntVec::operator==(const RnsIntVec &o) const {
     return logn_ == o.logn_ && count_ == o.count_ && q_ == o.q_ && host_ro() == o.host_ro();

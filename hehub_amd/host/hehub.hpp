@@ -81,10 +81,11 @@ public:
     // limbs (host words: these synchronise with the device copy, see above).  A reference obtained here shows the vector's
     // words as of that moment: after the next engine call on the vector, ask again.
     ComponentData &operator[](int k) { return host_rw()[k]; }
-    const ComponentData &operator[](int k) const { return host_ro()[k]; }
+    const ComponentData &operator[](int k) const { return host_ro_limb(k); }
     /// read-only words of limb k / of all limbs WITHOUT giving up the device copy, also on a non-const vector (`ct[0].view(k)[i]`):
     /// what a caller that only looks at a result should use -- operator[] on a non-const vector must assume a write
-    const ComponentData &view(int k) const { return host_ro()[k]; }
+    /// (a look at ONE limb of a device-resident vector downloads that limb, not the vector)
+    const ComponentData &view(int k) const { return host_ro_limb(k); }
     const std::vector<ComponentData> &view() const { return host_ro(); }
     std::vector<ComponentData> &components() { return host_rw(); }
     const std::vector<ComponentData> &components() const { return host_ro(); }
@@ -105,6 +106,7 @@ private:
     friend struct amd::Access;
     std::vector<ComponentData> &host_rw();               // current host words, writable: the device copy becomes stale
     const std::vector<ComponentData> &host_ro() const;   // current host words, read-only: both copies stay current
+    const ComponentData &host_ro_limb(int k) const;      // ... of limb k alone (the other limbs' host words may stay stale until asked for)
     size_t logn_ = 0, count_ = 0;
     std::vector<u64> q_;
     mutable std::vector<ComponentData> limbs_;       // host copy, count_ limbs when host_ok_
@@ -112,6 +114,7 @@ private:
     mutable size_t off_ = 0;
     mutable bool host_ok_ = true, dev_ok_ = false;
     mutable unsigned long long stamp_ = 0;           // changes whenever the words may have changed (key cache, hehub.cpp)
+    mutable unsigned long long limb_mask_ = 0, mask_stamp_ = 0;   // while !host_ok_: limbs downloaded one by one since the words last changed (valid for stamp_ == mask_stamp_)
 };
 
 class RnsPolynomial : public RnsIntVec {
