@@ -70,7 +70,7 @@ struct Lane {
 };
 struct LaneSet {
     Lane v[MAX_LANES];
-    int count = 1, cur = 0, rr = 0, depth = 0, last = 0;
+    int count = 1, cur = 0, rr = 0, depth = 0, last = -1;   // last: the lane of the most recent call (-1: none yet)
     bool level_a = false;
 };
 namespace {
@@ -330,7 +330,7 @@ struct OpScope {
             // stay on the lane used last -- its workspace is the one in the Infinity Cache, and there is nothing to overlap with
             bool any_busy = false;
             for (int l = 0; l < S.count; l++) any_busy = any_busy || S.v[l].busy;
-            lane = any_busy ? (S.rr = (S.rr + 1) % S.count) : (S.last < S.count ? S.last : 0);
+            lane = any_busy || S.last < 0 ? (S.rr = (S.rr + 1) % S.count) : (S.last < S.count ? S.last : 0);
         }
         S.cur = S.last = lane;
         (void)cur();
