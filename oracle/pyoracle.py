@@ -34,7 +34,7 @@ def build(ref: bool = True) -> None:
         if os.path.exists(os.path.join(HERE, "..", "hehub_amd", "lib", "libhehub_amd.so")):
             # hehub's own test-suite / benchmark program and our end-to-end program over the binding (GPU box only)
             subprocess.run(["make", "-s", "-j8", "-C", HERE, "ref_tests", "ref_e2e", "ref_bench", "ref_chain", "ref_indep", "ref_randprog_amd", "ref_matvec"], check=True)
-        subprocess.run(["make", "-s", "-C", HERE, "ref_randprog"], check=True)   # hehub alone: needs no engine library
+        subprocess.run(["make", "-s", "-C", HERE, "ref_randprog", "ref_rotbench"], check=True)   # hehub alone: need no engine library
 
 
 def have_ref() -> bool:
