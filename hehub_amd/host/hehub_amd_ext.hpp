@@ -53,6 +53,9 @@ TransferStats transfer_stats();
 /// Lanes: independent single-ciphertext calls are spread over this many streams of the engine and overlap on the device; a call
 /// waits, on the device, for exactly the calls that produced its operands.  Default 4 (HEHUB_AMD_LANES), at most 8; 1 = everything on
 /// one stream.  The binding build (hehub's own host-memory objects) always has one.  set_lanes() drains the device first.
+/// A caller that looks at every result before its next call leaves nothing in flight: while every lane is known idle (after a look
+/// or synchronize()) the layer stays on the lane it used last -- that lane's workspace is the one in the Infinity Cache -- and
+/// spreads calls over the lanes only while something is running.  A look at ONE limb (`ct[1][0][i]`, `view(k)`) downloads that limb.
 int lanes();
 void set_lanes(int n);
 /// Deferred mode (own-mirror build; default off, HEHUB_AMD_DEFER=1 in the environment turns it on): the scheme-level calls of hehub's
