@@ -15,7 +15,9 @@ A "step" is one pass of the hot path over one batch of synthetic ciphertexts tha
   bgv  (BASELINE config 5 shape): bgv mult + relinearize + mod_switch, N = 8192, L = 6
 
 One process per GPU; ciphertext batches are sharded across ranks with no data-path collective
-(SURVEY.md section 8e), so per-GPU work is fixed: weak scaling.  Rank 0 prints ONE JSON line:
+(SURVEY.md section 8e), so per-GPU work is fixed: weak scaling.  Rank 0 prints, as its LAST stdout line, ONE compact JSON line
+(< 8 KB: the contract fields, `roofline`, `cpu_baseline`, `summary` = one number per section); the detailed sections named below go
+to `#section <name> <json>` lines before it and to bench_sections.json (benchkit/line.py; `tools/benchline.py` merges them back):
 
   value / ms_per_step   whole-job throughput of the timed region (barrier + synchronize on both sides, max over ranks)
   roofline              dominant kernel (digit-spread k_ntt_fwd launch), HIP events recorded by the library on its stream
@@ -55,7 +57,6 @@ only here, only after the timed region, as the checker and as the CPU baseline.
 from __future__ import annotations
 
 import argparse
-import json
 import os
 import sys
 import time
@@ -321,6 +322,7 @@ def extra_sections(run, res, wl, value, lib, cpu_budget):
                                                                                                   if isinstance(v, dict)]
     checks.append(res.get("object_api", {}))
     bad = any(s.get("verified") is False for s in checks) or not copy["engine_copy_verified"]
+    res["all_sections_verified"] = not bad
     return bad
 
 
@@ -476,7 +478,9 @@ def main() -> int:
                                                                  res["cpu_baseline"].get("value"))
                 except Exception as e:
                     res["cpu_baseline_node"] = {"error": repr(e)}
-        print(json.dumps(res))
+        from benchkit.line import emit
+
+        emit(res, sys.stdout)   # the sections (`#section <name> <json>` lines + bench_sections.json), then the compact contract line LAST
     hd.finalize()
     run.eng.close()
     if failed:

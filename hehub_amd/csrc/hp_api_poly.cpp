@@ -144,7 +144,7 @@ static int dev_ntt_residues(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *
         return fail(ctx, HP_EUNSUPPORTED, "residue transforms need a ring degree of 2^11 .. 2^15 and every modulus below 2^50 (and the tiled kernels enabled)");
     HpNttJob j = batch_job(plan, logn, L, batch, d_x, d_x, L, L, inverse, inverse);
     j.limbs_a = plan->d_limbs_a;
-    ctx->sh->a_used = true;   // (the range guard of the level-A kernels: hp_ctx.cpp range_check)
+    mark_level_a(ctx);   // (the range guard of the level-A kernels: hp_ctx.cpp range_check)
     return run_ntt(ctx, j);
 }
 int hp_dev_ntt_residues(hp_ctx *ctx, size_t logn, size_t L, const uint64_t *moduli, size_t batch, uint64_t *d_x) {
@@ -192,8 +192,19 @@ int hp_dev_poly_fold_rows(hp_ctx *ctx, size_t n, size_t L, const uint64_t *modul
     const Plan *plan;
     int rc = get_plan(ctx, 0, moduli, L, false, &plan);
     if (rc) return rc;
-    ProfScope ps(ctx, "elem");
     const size_t words = L * n;
+    // the running sum is accumulated in place in d_out, polynomial by polynomial, 32 terms per launch: an output row may be its own
+    // polynomial's first term (x_0 += ...), nothing else -- a row read by a later launch would have been overwritten by then
+    for (size_t p0 = 0; p0 < polys; p0++) {
+        const u64 *o = d_out + p0 * words;
+        for (size_t i = 0; i < polys * terms; i++) {
+            const u64 *r = d_rows[i];
+            if (r + words <= o || o + words <= r) continue;
+            if (r == o && i == p0 * terms) continue;
+            return fail(ctx, HP_EINVAL, "poly_fold_rows: an output row overlaps an input row other than its own first term");
+        }
+    }
+    ProfScope ps(ctx, "elem");
     for (size_t p0 = 0; p0 < polys; p0++) {   // (a chain is long and the polynomials are few: one polynomial's segment per launch keeps the argument block small)
         // segments of at most 32 terms; from the second on, term 0 is the running sum itself (in place: a thread reads what it overwrites)
         size_t done = 0;

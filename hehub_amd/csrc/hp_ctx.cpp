@@ -174,12 +174,16 @@ int ensure_plan_a(hp_ctx *ctx, const Plan *plan, bool *ok) {
 
 int range_check(hp_ctx *ctx) {
     Shared *sh = ctx->sh;
-    if (!sh->a_used || !sh->range_flag) return HP_OK;
-    sh->a_used = false;
+    if (!ctx->a_pending || !sh->range_flag) return HP_OK;
+    ctx->a_pending = false;     // (THIS context's stream has just been synchronised; the other members keep their own pending state)
     u32 flag = 0;
     HIP_TRY(ctx, hipMemcpy(&flag, sh->range_flag, sizeof(u32), hipMemcpyDeviceToHost));
-    if (!flag) return HP_OK;
-    HIP_TRY(ctx, hipMemset(sh->range_flag, 0, sizeof(u32)));
+    if (flag) {
+        HIP_TRY(ctx, hipMemset(sh->range_flag, 0, sizeof(u32)));
+        sh->range_trips++;
+    }
+    if (ctx->trips_seen == sh->range_trips) return HP_OK;
+    ctx->trips_seen = sh->range_trips;
     return fail(ctx, HP_ERANGE, "parity level A: an input word was not a lazy word of its limb (>= 2 q): the results of the calls since the "
                                 "last synchronisation are not the residues of hehub's words (level B takes any u64)");
 }
@@ -351,7 +355,10 @@ static int make_ctx(int device, hpi::Shared *sh, hp_ctx **out) {
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (hipSetDevice(device) != hipSuccess) return HP_EHIP;
     hp_ctx *c = new (std::nothrow) hp_ctx(sh);
-    if (!c) return HP_ENOMEM;
+    if (!c) {
+        if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+        return HP_ENOMEM;
+    }
     c->device = device;
     const hipError_t es = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (prev >= 0 && prev != device) (void)hipSetDevice(prev);   // the caller's current device is not ours to change
@@ -583,10 +590,16 @@ int hp_host_register(hp_ctx *ctx, void *hptr, size_t bytes) {
         (void)hipGetLastError();
         // a range that lies inside pages an earlier registration already covers (two heap blocks on one page, a block that was
         // registered as part of a larger one) is as DMA-able as it gets: that is a success, anything else is not
-        void *d0 = nullptr, *d1 = nullptr;
-        if (e == hipErrorHostMemoryAlreadyRegistered && bytes > 0 && hipHostGetDevicePointer(&d0, hptr, 0) == hipSuccess &&
-            hipHostGetDevicePointer(&d1, (char *)hptr + bytes - 1, 0) == hipSuccess)
-            return HP_OK;
+        // (EVERY page of the range is asked for: two registrations at its ends with unregistered pages between them are not a cover)
+        if (e == hipErrorHostMemoryAlreadyRegistered && bytes > 0) {
+            bool covered = true;
+            const uintptr_t first = (uintptr_t)hptr, last = first + bytes - 1;
+            void *d = nullptr;
+            for (uintptr_t a = first; covered && a <= last; a = (a | (uintptr_t)4095) + 1)
+                covered = hipHostGetDevicePointer(&d, (void *)a, 0) == hipSuccess;
+            covered = covered && hipHostGetDevicePointer(&d, (void *)last, 0) == hipSuccess;
+            if (covered) return HP_OK;
+        }
         (void)hipGetLastError();
         return fail(ctx, HP_EHIP, std::string("hipHostRegister: ") + hipGetErrorString(e));
     }

@@ -62,10 +62,12 @@ struct Shared {
     std::map<std::pair<size_t, size_t>, u32 *> perms;                 // (logn, step mod N/2) -> gather map
     std::map<std::pair<std::vector<u64>, u64>, HpCrtConsts *> crt;    // (old moduli, new modulus) -> CRT-branch constants
     std::map<std::pair<std::vector<u64>, std::pair<size_t, size_t>>, HpHksConsts *> hks;   // (extended moduli, (k, alpha))
-    // level A range guard (hp_ntt_a.hip: RangeAcc): one sticky device word for the family, looked at by the synchronising entry
-    // points after a call has run at level A
+    // level A range guard (hp_ntt_a.hip: RangeAcc): one sticky device word for the family.  Every member keeps its OWN "a level-A call
+    // of mine has not been checked yet" state (hp_ctx::a_pending) and reads the word after a synchronisation of its OWN stream; a
+    // non-zero word is counted here (`range_trips`) and cleared, and every member that had level-A work pending when a trip was
+    // counted reports HP_ERANGE once -- whichever lane synchronises first (range_check, hp_ctx.cpp).
     u32 *range_flag = nullptr;
-    bool a_used = false;
+    unsigned long range_trips = 0;
 };
 } // namespace hpi
 
@@ -85,6 +87,8 @@ struct hp_ctx {
     // hehub's (default); 1 = A, canonical residues through the FP64 transforms of hp_ntt_a.hip where the chain allows
     int parity_level = 0;
     bool cur_a = false;           // set for the duration of one entry point (under the context lock): this call runs at level A
+    bool a_pending = false;       // a level-A call has been enqueued on THIS context since its last range_check
+    unsigned long trips_seen = 0; // the family's range_trips when a_pending was set / last reported
     // the family's caches (hpi::Shared)
     std::map<std::pair<u64, size_t>, hpi::DevTables> &tables;
     std::map<std::pair<u64, size_t>, hpi::DevTables> &tables_a;
@@ -190,8 +194,17 @@ int get_tables(hp_ctx *ctx, u64 q, size_t logn, DevTables &out);
 int get_plan(hp_ctx *ctx, size_t logn, const uint64_t *moduli, size_t count, bool with_ntt, const Plan **out);
 // level-A records of a plan (built once); *ok = false when the chain / ring degree has no level-A kernels (the call then runs at B)
 int ensure_plan_a(hp_ctx *ctx, const Plan *plan, bool *ok);
-// after a host synchronisation: HP_ERANGE (and the flag cleared) when a level-A kernel of the family saw a word outside its range
+// after a host synchronisation of ctx's stream: HP_ERANGE when a level-A kernel of the family saw a word outside its range while
+// this context had level-A work that had not been checked (per context: a lane that synchronises first does not use up the report
+// of a lane whose kernels are still running)
 int range_check(hp_ctx *ctx);
+// a level-A call is being enqueued on ctx: its next synchronising entry point looks at the family's range word
+inline void mark_level_a(hp_ctx *c) {
+    if (!c->a_pending) {
+        c->a_pending = true;
+        c->trips_seen = c->sh->range_trips;   // (trips counted before this context had anything at stake are not its concern)
+    }
+}
 // first thing a scheme-level entry point does after get_plan: decides whether THIS call runs at level A
 struct LevelScope {
     hp_ctx *ctx;
@@ -204,7 +217,7 @@ struct LevelScope {
             bool ok = false;
             rc = ensure_plan_a(c, plan, &ok);
             c->cur_a = (rc == 0) && ok;
-            if (c->cur_a) c->sh->a_used = true;
+            if (c->cur_a) mark_level_a(c);
         }
     }
     ~LevelScope() { ctx->cur_a = false; }

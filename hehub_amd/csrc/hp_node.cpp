@@ -117,7 +117,7 @@ struct Worker {
     std::mutex mu;
     std::condition_variable cv;
     std::function<int()> task;
-    bool has_task = false, done = false, quit = false;
+    bool has_task = false, done = false, quit = false, started = false;   // started: the placement fields above are final
     int rc = HP_OK;
     std::string msg;   // the failing call's message, taken on the worker thread itself (its thread-local slot is the right one)
 };
@@ -144,15 +144,23 @@ namespace {
 
 void worker_loop(Worker *w, int device) {
     // the rank's thread runs on the socket of its GPU (HP_NODE_NO_AFFINITY: leave it where the scheduler puts it)
+    int numa = -1, bound = 0;
     if (!getenv("HP_NODE_NO_AFFINITY")) {
         std::string cpus;
-        w->numa_node = device_numa(device, &cpus);
+        numa = device_numa(device, &cpus);
         cpu_set_t set;
-        if (w->numa_node >= 0 && !cpus.empty()) {
+        if (numa >= 0 && !cpus.empty()) {
             const int n = parse_cpulist(cpus, &set);
-            if (n > 0 && pthread_setaffinity_np(pthread_self(), sizeof(set), &set) == 0) w->cpus_bound = n;
+            if (n > 0 && pthread_setaffinity_np(pthread_self(), sizeof(set), &set) == 0) bound = n;
         }
     }
+    {   // hp_node_create waits for this: hp_node_placement never reads a half-written record
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->numa_node = numa;
+        w->cpus_bound = bound;
+        w->started = true;
+    }
+    w->cv.notify_all();
     for (;;) {
         std::function<int()> task;
         {
@@ -287,6 +295,10 @@ int hp_node_create(const int *devices, size_t count, hp_node **out) {
         node->workers.emplace_back(new Worker());
         Worker *w = node->workers.back().get();
         w->th = std::thread(worker_loop, w, devices[r]);
+    }
+    for (auto &w : node->workers) {   // every rank's thread is where it will stay (and says where) before the node is handed out
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->cv.wait(lk, [&] { return w->started; });
     }
     *out = node;
     return HP_OK;

@@ -129,9 +129,14 @@ void set_lanes(int n) {
 #else
     synchronize();   // (a lane that goes out of use must not owe anybody anything)
     LaneSet &S = lane_set();
+    // everything every lane has enqueued is done: every lane has "seen" every other one up to now, so the read / write records that
+    // blocks still carry from before (also of lanes that go out of use) never make anybody wait again
+    for (int a = 0; a < MAX_LANES; a++)
+        for (int b = 0; b < MAX_LANES; b++) S.v[a].seen[b] = S.v[b].ticket;
     S.count = std::max(1, std::min(MAX_LANES, n));
     S.cur = 0;
     S.rr = 0;
+    S.last = -1;
 #endif
 }
 
@@ -163,6 +168,7 @@ struct DevBlock {
     u64 *p = nullptr;
     size_t words = 0;
     unsigned long long rd[MAX_LANES] = {}, wr[MAX_LANES] = {};
+    int last_wr = 0;   // the lane of the most recent write (tickets are per-lane counters: they do not say which lane wrote LAST)
     // deferred mode (see "deferred execution" below): the result of a call that has been recorded but not run is a PLACEHOLDER
     // (p == NULL, op = the recorded call); when the call runs, the placeholder becomes a view of the block its batch filled
     std::shared_ptr<DevBlock> parent;
@@ -248,6 +254,7 @@ void track_write(DevBlock &b0) {
     for (int l = 0; l < MAX_LANES; l++)
         if (l != S.cur && std::max(b.wr[l], b.rd[l]) > me.seen[l]) order_after(l);
     b.wr[S.cur] = me.ticket;
+    b.last_wr = S.cur;
 }
 // after a host synchronisation of the current lane that followed track_write: every earlier user of the block has finished
 void settled(DevBlock &b) {
@@ -707,12 +714,9 @@ struct Access {
         {
             // the download runs on the lane that wrote the words last (no event needed there), behind the block's other writers
             LaneSet &S = lane_set();
-            int lane = 0;
             if (v.blk_->op) flush_all();
             const DevBlock &root = v.blk_->parent ? *v.blk_->parent : *v.blk_;
-            lane = 0;
-            for (int l = 1; l < MAX_LANES; l++)
-                if (root.wr[l] > root.wr[lane]) lane = l;
+            const int lane = root.last_wr < S.count ? root.last_wr : 0;
             OpScope op({}, S.depth ? S.cur : lane);
             track_read(*v.blk_);
             d2h_limbs(v.limbs_, words_of(v.blk_) + v.off_, v.count_, n);   // (synchronous)
@@ -734,9 +738,7 @@ struct Access {
             LaneSet &S = lane_set();
             if (v.blk_->op) flush_all();
             const DevBlock &root = v.blk_->parent ? *v.blk_->parent : *v.blk_;
-            int lane = 0;
-            for (int l = 1; l < MAX_LANES; l++)
-                if (root.wr[l] > root.wr[lane]) lane = l;
+            const int lane = root.last_wr < S.count ? root.last_wr : 0;
             OpScope op({}, S.depth ? S.cur : lane);
             track_read(*v.blk_);
             d2h(v.limbs_[k].data(), words_of(v.blk_) + v.off_ + k * n, n);   // (synchronous)

@@ -190,7 +190,8 @@ int hp_dev_poly_sub(hp_ctx *ctx, size_t n, size_t L, const uint64_t *moduli, siz
  * src/circuits/linear_algebra.h:117-121) folded into one pass: d_out[p] = ((x_0 op_1 x_1) op_2 x_2) ... op_{terms-1} x_{terms-1} with
  * x_j = d_rows[p * terms + j] (u64[L][N] each, anywhere on the device, 16-byte aligned; d_rows itself is a HOST array) and op_j = -=
  * where negate[j] != 0 (negate[0] is ignored).  Each step is the lazy sum / difference of the single call, in the calls' order: the
- * words of the chain of single calls; the intermediate sums never cross HBM.  d_out u64[polys][L][N] may be one of the rows' x_0. */
+ * words of the chain of single calls; the intermediate sums never cross HBM.  d_out u64[polys][L][N]: row p may be polynomial p's own
+ * x_0 (the chain then runs in place); an output row that overlaps any other input row is refused (HP_EINVAL). */
 int hp_dev_poly_fold_rows(hp_ctx *ctx, size_t n, size_t L, const uint64_t *moduli, size_t polys, size_t terms,
                           const uint8_t *negate, const uint64_t *const *d_rows, uint64_t *d_out);
 int hp_dev_poly_mul(hp_ctx *ctx, size_t n, size_t L, const uint64_t *moduli, size_t batch,

@@ -24,6 +24,8 @@ os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1048576")   # MiB
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
     config.addinivalue_line("markers", "slow: takes more than a few seconds on CPU")
+    config.addinivalue_line("markers", "perf: compares measured rates / times with thresholds or with each other (needs an MI355X); NOT part of "
+                                       "the correctness tiers: deselected unless the -m expression names perf (`-m perf`)")
 
 
 @pytest.fixture(scope="session")
@@ -45,5 +47,14 @@ def ref():
 
 
 def pytest_collection_modifyitems(config, items):
-    # "slow" is informational only; everything not marked gpu runs on CPU
-    pass
+    # "slow" is informational only; everything not marked gpu runs on CPU.
+    # "perf" tests hold wall-clock thresholds and ratios: a noisy box must not turn a parity-green tier red (and, with -x, hide every later
+    # test), so they run only when asked for by name: `pytest -m perf`.
+    if "perf" in (config.getoption("-m") or ""):
+        return
+    keep, drop = [], []
+    for it in items:
+        (drop if it.get_closest_marker("perf") else keep).append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep

@@ -3,6 +3,8 @@ the P of cpu_baseline_node must respect the cgroup CPU quota, not only the affin
 import os
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -94,3 +96,42 @@ def test_rank_placement_on_the_gpus_numa_node():
     finally:
         os.environ.pop("HP_BENCH_NO_AFFINITY", None)
         os.sched_setaffinity(0, before)
+
+
+def test_contract_line_is_compact_and_strict(tmp_path, monkeypatch):
+    """benchkit/line.py on round 5's 34.5 KB line (the one the driver could not read): the LAST stdout line is the contract, < 8 KB,
+    strict JSON; the sections travel as `#section` lines and in the side file; collect() puts them back together."""
+    import io
+    import json
+
+    from benchkit import line as L
+
+    with open(os.path.join(ROOT, "profiles", "r05y_bench_default.json")) as f:
+        res = json.load(f)
+    res["level_a"]["poison"] = float("nan")            # a non-finite float anywhere must come out as null, never as NaN
+    res["pipeline_roofline"]["inf"] = float("inf")
+    monkeypatch.chdir(tmp_path)
+    buf = io.StringIO()
+    text = L.emit(res, buf)
+    lines = buf.getvalue().splitlines()
+    assert lines[-1] == text and len(text.encode()) < L.LINE_LIMIT < 8193 and text.startswith("{")
+    assert len([l for l in lines if l.startswith("{")]) == 1 and all(l.startswith(L.PREFIX) for l in lines[:-1])
+    line = L.strict_loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "pipeline_roofline", "cpu_baseline_node", "cpu_model", "parity_level", "verified", "summary"):
+        assert k in line, k
+    assert line["pipeline_roofline"]["inf"] is None and line["vs_baseline"] is None
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
+    assert abs(line["value"] - res["value"]) < 1e-5 * res["value"]
+    sm = line["summary"]
+    assert sm["ntt_fwd_per_s"] == pytest.approx(res["ntt"]["steady_state"]["forward"]["per_s"], rel=1e-5) and sm["c2_fwd_frac"] == pytest.approx(res["c2"]["forward"]["roofline"]["frac"], rel=1e-5) and sm["level_a_per_s"] > 3.5e4 and sm["object_api_batched_per_s"] > 2e4
+    got, full = L.collect(buf.getvalue())
+    assert got == line and full["level_a"]["poison"] is None and set(line["sections"]["names"]) <= set(full)
+    assert full["ntt"]["by_N"]["4096"]["forward"]["per_s"] == pytest.approx(res["ntt"]["by_N"]["4096"]["forward"]["per_s"], rel=1e-6)
+    with open(tmp_path / "bench_sections.json") as f:
+        side = L.strict_loads(f.read())
+    assert side["c2"] == full["c2"]
+    with pytest.raises(ValueError):
+        L.strict_loads('{"a": NaN}')
+    with pytest.raises(ValueError):     # a line over the limit is refused by the reader the tests use
+        L.collect("x\n{" + '"a": "' + "y" * 9000 + '"}')

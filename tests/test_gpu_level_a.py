@@ -452,3 +452,44 @@ def test_range_guard_flags_words_that_are_not_lazy(enga):
         eng.sync()
     finally:
         eng.set_parity_level("A")
+
+
+@pytest.mark.gpu
+def test_range_guard_is_kept_per_lane(enga):
+    """the sticky range word belongs to the family, but `a level-A call of mine has not been checked` is kept per context:
+    a lane that synchronises first must not use up the report of a lane whose bad call it did not wait for -- every lane that had
+    level-A work pending when the word tripped reports HP_ERANGE once, a lane without such work reports nothing."""
+    from hehub_amd import capi
+    from hehub_amd.engine import HpError
+
+    root = enga
+    logn, mext = 12, [P.P50[1]] + P.P40[:3] + [P.P50[0]]
+    n, L = 1 << logn, len(mext) - 1
+    q = mext[:L]
+    rng = SplitMix(777)
+    good = rng.poly((2, 2, L, n), q)
+    bad = good.copy()
+    bad[1, 1, 1, 5] = U(2 * q[1] + (1 << 33))
+    lane1, lane2 = root.fork(), root.fork()
+    for lane in (lane1, lane2):
+        lane.set_parity_level("A")
+    try:
+        root.sync(); lane1.sync(); lane2.sync()
+        d_good, d_bad, d_good2 = root.to_device(good), root.to_device(bad), root.to_device(good)
+        root.torch.cuda.synchronize()
+        root.ckks_rescale(q, d_good)          # level-A work on the root lane, in range
+        out_bad = lane1.ckks_rescale(q, d_bad)   # the bad call runs on lane 1
+        root.torch.cuda.synchronize()         # (everything has run: whoever looks first sees the word set)
+        with pytest.raises(HpError) as e:     # the root had level-A work pending when the word tripped: it reports (conservative) ...
+            root.sync()
+        assert e.value.code == capi.HP_ERANGE
+        with pytest.raises(HpError) as e:     # ... and that did NOT use up lane 1's own report (round 5: lane 1 returned HP_OK here)
+            lane1.sync()
+        assert e.value.code == capi.HP_ERANGE
+        lane2.sync()                          # a lane without level-A work pending reports nothing
+        root.sync(); lane1.sync()             # reported once each, then clear
+        lane2.ckks_rescale(q, d_good2)        # work that starts after the trip was counted is not blamed for it
+        lane2.sync()
+        del out_bad
+    finally:
+        lane1.close(); lane2.close()

@@ -7,6 +7,7 @@ mode: the rotations under different keys run as ONE hp_dev_ckks_rotate_many sequ
 amd::rotate(cts, keys, steps)."""
 import json
 import os
+import re
 import sys
 
 import pytest
@@ -71,19 +72,12 @@ def test_matvec_modes_agree_at_parity_level_a():
 @pytest.mark.gpu
 def test_matvec_rotations_under_different_keys_run_batched():
     """width 16: 30 rotations of one vector under 30 keys.  Recorded, they run as one launch sequence with a key per ciphertext
-    (hp_dev_ckks_rotate_many_rows), the plaintext transforms as one batch: at N = 8192, L = 6 0.7 against 2.7 ms per product vector for
-    the eager single calls, at the C3 shape (N = 32768, L = 10, where the split-limb transforms already make a single call fast)
-    2.1 against 2.4 ms -- hehub on the host CPU: 1262 ms (profiles/r05t_matvec.txt).  Loose bounds: shared boxes."""
-    def timed(case, ok):   # (a timing on a shared box: a miss is measured again once before it counts)
-        for attempt in range(2):
-            got, ms, text = run(binary(), case, reps=4)
-            assert got["eager"] == got["deferred"] == got["batched-form"], text
-            if ok(ms):
-                break
-        assert ok(ms), (ms, text)
-        return got, text
-
-    timed((13, 6, 16, "short"), lambda ms: ms["deferred"] < 0.6 * ms["eager"])                     # typically 0.25
-    # (C3: typically 0.78 - 0.88 and 0.85 - 0.92 of the eager time; the bound only says "not slower than the single calls")
-    got, text = timed(CASES[6], lambda ms: ms["deferred"] < 1.05 * ms["eager"] and ms["batched-form"] < 1.1 * ms["eager"])
+    (hp_dev_ckks_rotate_many_rows), the plaintext transforms as one batch; every mode prints hehub's digest, and the layer's own counters
+    say the rotations ran grouped across keys.  (The times -- 0.7 against 2.7 ms per product vector at N = 8192, 2.1 against 2.4 at the
+    C3 shape, hehub on the host CPU 1262 ms -- are held in tests/test_perf.py.)"""
+    for case in ((13, 6, 16, "short"), CASES[6]):
+        got, ms, text = run(binary(), case, reps=2)
+        assert got["eager"] == got["deferred"] == got["batched-form"], text
+        m = re.search(r"many_key_groups (\d+)", text)
+        assert m and int(m.group(1)) >= 1, text
     assert got["eager"] == GOLDEN[key(CASES[6])], text

@@ -45,6 +45,9 @@ def run(binary, args, env=None):
         m = re.match(r"chains .* ([\d.]+) ms per step on 1 lane, ([\d.]+) ms on (\d+) lanes", line)
         if m:
             f["chain_ms"] = (float(m.group(1)), float(m.group(2)), int(m.group(3)))
+        m = re.match(r"deferred: (\d+) recorded calls ran as (\d+) batched engine calls \((\d+) ", line)
+        if m:
+            f["recorded"], f["groups"], f["fused"] = int(m.group(1)), int(m.group(2)), int(m.group(3))
     return f
 
 
@@ -103,7 +106,7 @@ def test_c3_unchanged_loop_in_deferred_mode():
     eager = run(build_example(), [15, 10, 64, "serial", 3])
     lazy = run(build_example(), [15, 10, 64, "serial", 3], {"HEHUB_AMD_DEFER": "1"})
     assert lazy["serial"] == eager["serial"] and lazy["serial-chain"] == eager["serial-chain"]
-    assert lazy["serial_per_s"] > 12000 and lazy["serial_per_s"] > 1.25 * eager["serial_per_s"], (lazy, eager)   # (typically 22 k against 12.5 k)
+    assert lazy["fused"] >= 64, lazy     # (the rates: tests/test_perf.py)
 
 
 @pytest.mark.gpu
@@ -112,6 +115,4 @@ def test_c3_batched_form_reaches_the_engine_rate():
     MI355X at B = 256, 24 k at the B = 64 used here; the bounds are loose: shared boxes), the loop of single calls is latency-bound
     (3 k on one lane, 6 k over the default four), and lanes make independent chains overlap"""
     r = run(build_example(), [15, 10, 64, "all", 3, 8, 8, 4])
-    assert r["serial"] == r["batch"] and r["chains"] == r["chains-lanes"], r
-    assert r["batch_per_s"] > 15000 and r["batch_per_s"] > 1.3 * r["serial_per_s"], r     # (the single calls: 12.5 k since the split transforms in register rounds)
-    assert r["chain_ms"][1] < 1.1 * r["chain_ms"][0], r   # (typically 0.7: loose, shared boxes)
+    assert r["serial"] == r["batch"] and r["chains"] == r["chains-lanes"], r     # (the rates: tests/test_perf.py)

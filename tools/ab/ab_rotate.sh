@@ -5,7 +5,7 @@ REPS=$1; shift
 for i in $(seq $REPS); do
   for v in "$@"; do
     if [ "$v" = main ]; then unset HEHUB_AMD_LIB; else export HEHUB_AMD_LIB=$R/hehub_amd/lib_variants/libhehub_amd_$v.so; fi
-    rot=$(python $R/bench.py --workload rotate --steps 10 --warmup 3 --roofline-only 2>/dev/null | python3 -c "import sys,json; print(round(json.loads(sys.stdin.read())['value']))")
+    rot=$(python $R/bench.py --workload rotate --steps 10 --warmup 3 --roofline-only 2>/dev/null | python $R/tools/benchline.py | python3 -c "import sys,json; print(round(json.loads(sys.stdin.read())['value']))")
     echo "$v rot=$rot $(python $R/tools/bench_families.py 2>/dev/null) $(FAM=1 python $R/tools/bench_families.py --workload bgv 2>/dev/null | sed 's/\([a-z_]*\)=/bgv_\1=/g')"
   done
 done | python3 -c "

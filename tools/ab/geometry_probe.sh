@@ -8,7 +8,7 @@ cd $R
 for lvl in B A; do
   for shape in "15 256" "14 512" "13 1024"; do
     set -- $shape
-    python bench.py --workload ckks --logn $1 --batch $2 --parity-level $lvl --no-cpu-baseline --no-verify --steps 10 --warmup 2 2>/dev/null | python -c "
+    python bench.py --workload ckks --logn $1 --batch $2 --parity-level $lvl --no-cpu-baseline --no-verify --steps 10 --warmup 2 2>/dev/null | python $R/tools/benchline.py | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = d['roofline']
 print('level $lvl N=%6d batch %4d: spread launch %.3f ms, frac %.3f, %.0f hom-mult/s (x N/32768: %.0f), step %.3f ms' % (1 << $1, $2, r['avg_launch_ms'], r['frac'], d['value'], d['value'] * (1 << $1) / 32768, d['ms_per_step']))"

@@ -11,5 +11,5 @@ for i in $(seq 60); do
   sleep 1
 done | awk '{print}' | grep -v "(9[0-9]Mhz)\|(1[0-9][0-9]Mhz)" | head -20
 wait $BP
-python3 -c "import json; r=json.load(open('/tmp/probe_bench.json')); print('ntt15 steady: frac', round(r['roofline']['frac'],4), 'avg_launch_ms', round(r['roofline']['avg_launch_ms'],4))"
+python3 -c "import json; r=json.loads(open('/tmp/probe_bench.json').read().strip().splitlines()[-1]); print('ntt15 steady: frac', round(r['roofline']['frac'],4), 'avg_launch_ms', round(r['roofline']['avg_launch_ms'],4))"
 echo "idle:"; rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Power" | tr -s ' ' | tr '\n' ';'; echo

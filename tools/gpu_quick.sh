@@ -7,8 +7,10 @@ python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py tests/test_gp
 tail -3 gpurun_out/${TAG}_pytest.txt
 python bench.py --steps 10 --warmup 2 --cpu-seconds 2 --cpu-procs 0 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 python - <<PY
-import json
-r=json.load(open('gpurun_out/${TAG}_bench.json'))
+import json, sys
+sys.path.insert(0, '.')
+from benchkit.line import collect
+r=collect(open('gpurun_out/${TAG}_bench.json').read())[1]
 print('hom-mult/s', round(r['value']), 'verified', r.get('verified'), 'spread ms', round(r['roofline']['avg_launch_ms'],3), 'frac', round(r['roofline']['frac'],3))
 for n,e in r['ntt']['by_N'].items():
     print(n, 'fwd', round(e['forward']['frac_of_hbm_peak'],3), 'inv', round(e['inverse']['frac_of_hbm_peak'],3), e.get('verified'))

@@ -41,7 +41,7 @@ tools/prof_object_api.sh ${TAG} > gpurun_out/${TAG}_objapi.txt 2>&1
 for s in "15 10 256 all 3 8 8 6" "13 6 512 all 3 8 8 6"; do for d in 0 1; do echo "== HEHUB_AMD_DEFER=$d independent_mults $s"; HEHUB_AMD_DEFER=$d examples/independent_mults $s; done; done > gpurun_out/${TAG}_independent_mults.txt 2>&1
 tools/prof_matvec.sh ${TAG} > /dev/null 2>&1      # hehub's circuit-level caller: the diagonal loop of matrix_vector_mul_short, every mode + CPU
 tools/by_n_levels.sh > gpurun_out/${TAG}_by_n_levels.txt 2>&1
-for lv in B A; do python bench.py --workload ckks-hks --parity-level $lv --no-cpu-baseline 2>/dev/null | python -c "
+for lv in B A; do python bench.py --workload ckks-hks --parity-level $lv --no-cpu-baseline 2>/dev/null | python $R/tools/benchline.py | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('ckks-hks level $lv', round(d['value']), 'hom-mult/s', round(d['ms_per_step'], 3), 'ms per step')"; done > gpurun_out/${TAG}_hks_levels.txt 2>&1
 python tools/bench_latency.py > gpurun_out/${TAG}_latency.txt 2>&1
