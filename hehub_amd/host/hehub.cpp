@@ -547,7 +547,9 @@ struct Dst {
     explicit Dst(size_t words) : blk(alloc_block(words)), p(blk->p) { track_write(*blk); }
 };
 
-// ---- deferred execution (own-mirror build, opt-in: amd::set_deferred / HEHUB_AMD_DEFER=1) --------------------------------------------
+// ---- deferred execution (own-mirror build; ON by default since round 6, amd::set_deferred(false) / HEHUB_AMD_DEFER=0 turn it off) ----
+// (The binding build cannot defer anything: hehub's own objects are host memory the caller may dereference the moment a call returns,
+// with no accessor in between -- every call there ends with the download of its result.)
 // hehub's interface is one ciphertext per call and its callers loop over INDEPENDENT ciphertexts (src/circuits/linear_algebra.h:
 // 109-133, bench/benchmarks.cpp:24-35); at batch 1 a C3 call is a chain of ~12 dependent launches of 40 us that fill 10 .. 100 of
 // 256 CUs, and the GPU runs at most 2 - 3 such chains side by side (lanes: x 2.3).  In deferred mode the scheme-level calls
@@ -596,6 +598,7 @@ OpQueue &op_queue() {
     static OpQueue &q = *[] {
         OpQueue *x = new OpQueue;
 #ifndef HEHUB_AMD_BIND_REFERENCE
+        x->on = true;   // (the default since round 6: an unchanged loop of single calls gets the batch rate; HEHUB_AMD_DEFER=0 is the escape)
         if (const char *e = std::getenv("HEHUB_AMD_DEFER")) x->on = std::atoi(e) != 0;
 #endif
         return x;

@@ -58,7 +58,8 @@ TransferStats transfer_stats();
 /// spreads calls over the lanes only while something is running.  A look at ONE limb (`ct[1][0][i]`, `view(k)`) downloads that limb.
 int lanes();
 void set_lanes(int n);
-/// Deferred mode (own-mirror build; default off, HEHUB_AMD_DEFER=1 in the environment turns it on): the scheme-level calls of hehub's
+/// Deferred mode (own-mirror build; ON by default since round 6 -- HEHUB_AMD_DEFER=0 in the environment or set_deferred(false) give
+/// the call-by-call behaviour back; the binding build over hehub's own host-memory objects never defers): the scheme-level calls of hehub's
 /// interface -- mult_low_level, relinearize, mult, rotate, conjugate, rescale_inplace, mod_switch_inplace, add / sub of ciphertexts,
 /// polynomial products (mult_plain), += / -= and in-place transforms of polynomials, rns_base_transform from one modulus (the plaintext
 /// lift of bgv::add_plain / sub_plain / mult_plain) and copies of results that are still pending --

@@ -30,8 +30,13 @@ def test_host_layer_compiles_and_links():
 
 
 @pytest.mark.gpu
-def test_host_layer_runs_reference_unit_tests():
-    out = subprocess.run([build_binary()], capture_output=True, text=True, timeout=600)
+@pytest.mark.parametrize("env", [{}, {"HEHUB_AMD_DEFER": "0"}, {"HEHUB_AMD_DEFER": "0", "HEHUB_AMD_LANES": "1"}],
+                         ids=["default-recorded", "call-by-call", "call-by-call-one-lane"])
+def test_host_layer_runs_reference_unit_tests(env):
+    """hehub's unit tests for this path over the mirror, in the layer's default mode (calls recorded and run grouped, since round 6) and
+    call by call"""
+    base = {k: v for k, v in os.environ.items() if k not in ("HEHUB_AMD_DEFER", "HEHUB_AMD_LANES")}
+    out = subprocess.run([build_binary()], capture_output=True, text=True, timeout=600, env=dict(base, **env))
     print(out.stdout[-3000:], out.stderr[-2000:])
     assert out.returncode == 0 and "All tests passed" in out.stdout
 

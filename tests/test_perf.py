@@ -126,3 +126,14 @@ def test_matvec_recorded_rotations_do_not_lose():
 
     timed((13, 6, 16, "short"), lambda ms: ms["deferred"] < 0.6 * ms["eager"])                     # typically 0.25
     timed(CASES[6], lambda ms: ms["deferred"] < 1.05 * ms["eager"] and ms["batched-form"] < 1.1 * ms["eager"])   # typically 0.8 - 0.9
+
+
+def test_resident_chain_latency():
+    """C3 shape, one ciphertext at a time through hehub's API, call by call: device latency, not PCIe (was 10.8 ms per operation with staged
+    operands; hp_dev_* at batch 1 is ~0.12 ms).  The 23 timed mult + add iterations also carry the first use of three of the four lanes
+    (a stream, a workspace: ~7 ms each, once per process): ~0.14 + 21 / 23 ms"""
+    need_gpu()
+    from test_host_residency import build_chain, run
+
+    own = run(build_chain(), (15, 10, 24), {"HEHUB_AMD_DEFER": "0"})
+    assert own["mult+add"] < 2.5 and own["rotate"] < 1.0, own

@@ -18,8 +18,9 @@ with open(os.path.join(ROOT, "tests", "golden", "random_program.json")) as f:
     GOLDEN = json.load(f)["digests"]
 
 REF_AMD = os.path.join(ROOT, "oracle", "_ref", "ref_randprog_amd")
-MODES = {"1 lane": {"HEHUB_AMD_LANES": "1"}, "8 lanes": {"HEHUB_AMD_LANES": "8"}, "deferred": {"HEHUB_AMD_DEFER": "1"},
-         "deferred, 8 lanes": {"HEHUB_AMD_DEFER": "1", "HEHUB_AMD_LANES": "8"}}
+MODES = {"1 lane": {"HEHUB_AMD_LANES": "1", "HEHUB_AMD_DEFER": "0"}, "8 lanes": {"HEHUB_AMD_LANES": "8", "HEHUB_AMD_DEFER": "0"},
+         "deferred": {"HEHUB_AMD_DEFER": "1"}, "deferred, 8 lanes": {"HEHUB_AMD_DEFER": "1", "HEHUB_AMD_LANES": "8"},
+         "default": {}}     # (the layer's default since round 6: recorded, four lanes)
 
 
 def binary():
@@ -44,8 +45,10 @@ def test_random_program_prints_hehubs_digest_in_every_mode(case):
         assert got == want, (mode, case, got, want, text)
     if os.path.exists(REF_AMD) and case[0] <= 12:   # hehub's own objects over the binding: every call crosses PCIe, small rings only
         assert digest(REF_AMD, case)[0] == want, ("binding", case)
-    text = digest(binary(), case, MODES["deferred"])[1]
-    assert "deferred 1" in text and "deferred_calls 0" not in text      # the calls really were recorded
+    for mode in ("deferred", "default"):
+        text = digest(binary(), case, MODES[mode])[1]
+        assert "deferred 1" in text and "deferred_calls 0" not in text      # the calls really were recorded
+    assert "deferred 0" in digest(binary(), case, MODES["1 lane"])[1]
 
 
 @pytest.mark.gpu

@@ -37,12 +37,13 @@ def test_example_builds():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{}, {"HEHUB_AMD_LANES": "1"}, {"HEHUB_AMD_DEFER": "1"}, {"HP_SPLIT_MAX_ITEMS": "0"}],
-                         ids=["lanes", "one-lane", "deferred", "tiled-transforms-only"])
+@pytest.mark.parametrize("env", [{"HEHUB_AMD_DEFER": "0"}, {"HEHUB_AMD_LANES": "1", "HEHUB_AMD_DEFER": "0"}, {"HEHUB_AMD_DEFER": "1"}, {},
+                                 {"HP_SPLIT_MAX_ITEMS": "0", "HEHUB_AMD_DEFER": "0"}],
+                         ids=["lanes", "one-lane", "deferred", "default", "tiled-transforms-only"])
 def test_rotate_bench_prints_hehubs_digests(env):
     rows, text = run(binary(), 3, 0, env)
     assert set(rows) == set(LOGNS), text
     for logn in LOGNS:
         assert rows[logn][0] == GOLDEN[logn], (logn, env, rows[logn], GOLDEN[logn], text)
-    if env.get("HEHUB_AMD_DEFER"):
+    if env.get("HEHUB_AMD_DEFER", "1") == "1":     # (nothing in the environment: recorded, the default)
         assert "deferred 1" in text and "deferred_calls 0" not in text, text

@@ -12,8 +12,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 from make_random_program import REF, digest  # noqa: E402
 from hehub_amd.build import build_example  # noqa: E402
 
-MODES = {"1 lane": {"HEHUB_AMD_LANES": "1"}, "8 lanes": {"HEHUB_AMD_LANES": "8"}, "deferred": {"HEHUB_AMD_DEFER": "1"},
-         "deferred, 8 lanes": {"HEHUB_AMD_DEFER": "1", "HEHUB_AMD_LANES": "8"}, "3 lanes": {"HEHUB_AMD_LANES": "3"}}
+MODES = {"1 lane": {"HEHUB_AMD_LANES": "1", "HEHUB_AMD_DEFER": "0"}, "8 lanes": {"HEHUB_AMD_LANES": "8", "HEHUB_AMD_DEFER": "0"},
+         "deferred": {"HEHUB_AMD_DEFER": "1"}, "deferred, 8 lanes": {"HEHUB_AMD_DEFER": "1", "HEHUB_AMD_LANES": "8"},
+         "3 lanes": {"HEHUB_AMD_LANES": "3", "HEHUB_AMD_DEFER": "0"}, "default": {}}
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 assert os.path.exists(REF), "oracle/_ref/ref_randprog_cpu is built where /root/reference is (make -C oracle ref_randprog)"
