@@ -215,6 +215,11 @@ int main(int argc, char **argv) {
         if (st.deferred_calls)
             std::printf("deferred: %llu recorded calls ran as %llu batched engine calls (%llu mult + rescale_inplace triples as the one-call pipeline)\n",
                         st.deferred_calls, st.deferred_groups, st.deferred_fused);
+#ifndef CHAIN_REFERENCE_HEADERS
+        std::printf("devices %d engine calls per device rank:", amd::devices());   // (HEHUB_AMD_DEVICES: the layer spreads independent ciphertexts over them)
+        for (int r = 0; r < amd::devices(); r++) std::printf(" %llu", st.calls_by_device[r]);
+        std::printf("; copies between ranks %llu (%.1f MiB)\n", st.peer_copies, st.peer_bytes / 1048576.0);
+#endif
     }
 #endif
     return 0;

@@ -270,6 +270,9 @@ template <class Ct, class Quad, bool BGV> static int run_program(size_t logn, si
     const auto st = amd::transfer_stats();
     std::printf("layer: lanes %d deferred %d engine_calls %llu lane_waits %llu deferred_calls %llu deferred_groups %llu deferred_fused %llu\n", amd::lanes(),
                 (int)amd::deferred(), st.engine_calls, st.lane_waits, st.deferred_calls, st.deferred_groups, st.deferred_fused);
+    std::printf("devices %d engine calls per device rank:", amd::devices());
+    for (int r = 0; r < amd::devices(); r++) std::printf(" %llu", st.calls_by_device[r]);
+    std::printf("; copies between ranks %llu (%.1f MiB)\n", st.peer_copies, st.peer_bytes / 1048576.0);
 #endif
     return 0;
 }

@@ -45,6 +45,8 @@ SIGNATURES = {
     "hp_host_unregister": (INT, [P, P]),
     "hp_memcpy_h2d_async": (INT, [P, P, P, szt]),
     "hp_memcpy_d2h_async": (INT, [P, P, P, szt]),
+    "hp_memcpy_peer_async": (INT, [P, P, P, P, szt]),
+    "hp_ctx_device": (INT, [P]),
     "hp_dev_store_host_rows": (INT, [P, szt, szt, P, P]),
     "hp_dev_load_host_rows": (INT, [P, szt, szt, P, P]),
     "hp_dev_gather_rows": (INT, [P, szt, szt, P, P]),

@@ -618,6 +618,34 @@ int hp_memcpy_h2d_async(hp_ctx *ctx, void *dst, const void *src, size_t bytes) {
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     return HP_OK;
 }
+int hp_ctx_device(hp_ctx *ctx) { return ctx ? ctx->device : HP_EINVAL; }
+int hp_memcpy_peer_async(hp_ctx *dst_ctx, void *dst, hp_ctx *src_ctx, const void *src, size_t bytes) {
+    if (!src_ctx) return HP_EINVAL;
+    const int src_dev = src_ctx->device;   // (set once when the context is made)
+    HP_ENTER(dst_ctx);
+    HP_REQUIRE(dst_ctx, dst, src);
+    if (bytes == 0) return HP_OK;
+    if (src_dev == dst_ctx->device) {
+        HIP_TRY(dst_ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, dst_ctx->stream));
+        return HP_OK;
+    }
+    // direct access for the pair, once (both directions are asked for by whoever copies that way first); a refusal is not an error:
+    // hipMemcpyPeerAsync then goes through the runtime's staging
+    static std::mutex pair_mu;
+    static std::map<std::pair<int, int>, bool> asked;
+    {
+        std::lock_guard<std::mutex> lk(pair_mu);
+        bool &done = asked[{dst_ctx->device, src_dev}];
+        if (!done) {
+            done = true;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, dst_ctx->device, src_dev) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(src_dev, 0);
+            (void)hipGetLastError();
+        }
+    }
+    HIP_TRY(dst_ctx, hipMemcpyPeerAsync(dst, dst_ctx->device, src, src_dev, bytes, dst_ctx->stream));
+    return HP_OK;
+}
 int hp_memcpy_d2h_async(hp_ctx *ctx, void *dst, const void *src, size_t bytes) {
     HP_ENTER(ctx);
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -61,17 +61,35 @@ namespace amd {
 //   * uploads and downloads are synchronous on their lane, so they leave no debt behind.
 // One lane (HEHUB_AMD_LANES=1) is the round-4 behaviour: everything on one stream.  The binding build always has one lane: hehub's
 // objects are host memory, every call ends with the download of its result.
-constexpr int MAX_LANES = 8;
+//
+// DEVICES (round 6).  hehub has no devices; its callers hold many independent ciphertexts (src/circuits/linear_algebra.h:
+// 109-133, examples/ckks_example.cpp:10-27), and those "shard naturally across the 8 GPUs" of a node.  With amd::set_devices /
+// HEHUB_AMD_DEVICES the layer keeps one engine family (root context + lanes) PER DEVICE RANK; a lane is then a SLOT = (rank, lane).
+//   * a device block belongs to the rank it was allocated on; the block pool is kept per rank;
+//   * a call runs where its operands live (the rank of its first device-resident operand), a call on host-only operands goes to the
+//     next rank round robin and uploads them THERE -- independent ciphertexts spread over the devices, a dependent chain stays put;
+//   * recorded calls carry their rank in the signature: a group is one rank's, groups of different ranks overlap;
+//   * the batched forms cut a batch into contiguous slices, one per rank (batch / ranks each, no collective);
+//   * keys and tables are replicated per rank on first use (the key cache is keyed by rank);
+//   * an operand that lives on another rank than the call is copied over (hp_memcpy_peer_async: one xGMI link) and, when it is a
+//     vector, stays there -- counted in TransferStats::peer_copies.  Ranks may share a GPU (HEHUB_AMD_DEVICES=0,0: the one-GPU tests).
+constexpr int MAX_LANES = 8;                       // lanes per device rank
+constexpr int MAX_DEVS = 8;                        // device ranks
+constexpr int MAX_SLOTS = MAX_LANES * MAX_DEVS;    // slot = rank * MAX_LANES + lane
+inline int rank_of(int slot) { return slot / MAX_LANES; }
 struct Lane {
     hp_ctx *ctx = nullptr;
     unsigned long long ticket = 0;            // number of the lane's current / most recent call
-    unsigned long long seen[MAX_LANES] = {};  // seen[l]: this lane is ordered behind lane l's calls up to that ticket
+    unsigned long long seen[MAX_SLOTS] = {};  // seen[l]: this lane is ordered behind slot l's calls up to that ticket
     bool busy = false;                        // something may still be running on it (cleared by a synchronous copy / a sync on the lane)
 };
 struct LaneSet {
-    Lane v[MAX_LANES];
-    int count = 1, cur = 0, rr = 0, depth = 0, last = -1;   // last: the lane of the most recent call (-1: none yet)
+    Lane v[MAX_SLOTS];
+    int count = 1;                            // lanes per rank in use
+    int ndev = 1, devs[MAX_DEVS] = {};        // device ranks in use and the HIP device of each
+    int cur = 0, rr[MAX_DEVS] = {}, rr_dev = -1, depth = 0, last = -1;   // cur / last: slots; last: the slot of the most recent call (-1: none yet)
     bool level_a = false;
+    bool active(int slot) const { return rank_of(slot) < ndev && slot % MAX_LANES < count; }
 };
 namespace {
 LaneSet &lane_set() {
@@ -86,7 +104,30 @@ hp_ctx *engine() {
     std::call_once(once, [&S] {
         int dev = 0;
         if (const char *e = std::getenv("HEHUB_AMD_DEVICE")) dev = std::atoi(e);
-        if (hp_ctx_create(dev, &S.v[0].ctx) != HP_OK) S.v[0].ctx = nullptr;
+        S.devs[0] = dev;
+#ifndef HEHUB_AMD_BIND_REFERENCE
+        // HEHUB_AMD_DEVICES=<n>: HIP devices 0 .. n-1; HEHUB_AMD_DEVICES=<a>,<b>,...: those devices, one rank each (a device may
+        // appear more than once: ranks then share it)
+        if (const char *e = std::getenv("HEHUB_AMD_DEVICES")) {
+            std::vector<int> list;
+            if (std::strchr(e, ',')) {
+                for (const char *p = e; *p;) {
+                    char *end = nullptr;
+                    const long d = std::strtol(p, &end, 10);
+                    if (end == p) break;
+                    list.push_back((int)d);
+                    p = *end == ',' ? end + 1 : end;
+                }
+            } else {
+                for (int d = 0; d < std::atoi(e); d++) list.push_back(d);
+            }
+            if (!list.empty()) {
+                S.ndev = (int)std::min(list.size(), (size_t)MAX_DEVS);
+                for (int r = 0; r < S.ndev; r++) S.devs[r] = list[r];
+            }
+        }
+#endif
+        if (hp_ctx_create(S.devs[0], &S.v[0].ctx) != HP_OK) S.v[0].ctx = nullptr;
 #ifndef HEHUB_AMD_BIND_REFERENCE
         S.count = 4;
         if (const char *e = std::getenv("HEHUB_AMD_LANES")) S.count = std::max(1, std::min(MAX_LANES, std::atoi(e)));
@@ -103,10 +144,34 @@ static hp_ctx *cur() {
     LaneSet &S = lane_set();
     Lane &L = S.v[S.cur];
     if (!L.ctx) {
-        if (hp_ctx_fork(root, &L.ctx) != HP_OK) throw std::runtime_error(std::string("hehub_amd: ") + hp_last_error(root));
-        (void)hp_ctx_set_parity_level(L.ctx, S.level_a ? HP_PARITY_A : HP_PARITY_B);
+        const int rank = rank_of(S.cur);
+        Lane &R = S.v[rank * MAX_LANES];   // the rank's root context: its own engine family (tables, plans) on its own device
+        if (!R.ctx) {
+            if (hp_ctx_create(S.devs[rank], &R.ctx) != HP_OK) {
+                R.ctx = nullptr;
+                throw std::runtime_error("hehub_amd: no engine on HIP device " + std::to_string(S.devs[rank]) + " (rank " + std::to_string(rank) + " of HEHUB_AMD_DEVICES)");
+            }
+            (void)hp_ctx_set_parity_level(R.ctx, S.level_a ? HP_PARITY_A : HP_PARITY_B);
+        }
+        if (!L.ctx) {
+            if (hp_ctx_fork(R.ctx, &L.ctx) != HP_OK) throw std::runtime_error(std::string("hehub_amd: ") + hp_last_error(R.ctx));
+            (void)hp_ctx_set_parity_level(L.ctx, S.level_a ? HP_PARITY_A : HP_PARITY_B);
+        }
+        (void)root;
     }
     return L.ctx;
+}
+static int cur_rank() { return rank_of(lane_set().cur); }
+// the root context of a device rank (made on first use)
+static hp_ctx *rank_ctx(int rank) {
+    LaneSet &S = lane_set();
+    if (!S.v[rank * MAX_LANES].ctx) {
+        const int saved = S.cur;
+        S.cur = rank * MAX_LANES;
+        (void)cur();
+        S.cur = saved;
+    }
+    return S.v[rank * MAX_LANES].ctx;
 }
 
 int lanes() {
@@ -118,10 +183,17 @@ void synchronize() {
     (void)engine();
     flush_all();
     LaneSet &S = lane_set();
-    for (int l = 0; l < MAX_LANES; l++) {
+    for (int l = 0; l < MAX_SLOTS; l++) {
         if (S.v[l].ctx && hp_sync(S.v[l].ctx) != HP_OK) throw std::runtime_error(std::string("hehub_amd: ") + hp_last_error(S.v[l].ctx));
         S.v[l].busy = false;
     }
+}
+// everything every slot has enqueued is done: every slot has "seen" every other one up to now, so the read / write records that blocks
+// still carry from before (also of lanes / ranks that go out of use) never make anybody wait again
+[[maybe_unused]] static void all_seen() {
+    LaneSet &S = lane_set();
+    for (int a = 0; a < MAX_SLOTS; a++)
+        for (int b = 0; b < MAX_SLOTS; b++) S.v[a].seen[b] = S.v[b].ticket;
 }
 void set_lanes(int n) {
 #ifdef HEHUB_AMD_BIND_REFERENCE
@@ -129,15 +201,41 @@ void set_lanes(int n) {
 #else
     synchronize();   // (a lane that goes out of use must not owe anybody anything)
     LaneSet &S = lane_set();
-    // everything every lane has enqueued is done: every lane has "seen" every other one up to now, so the read / write records that
-    // blocks still carry from before (also of lanes that go out of use) never make anybody wait again
-    for (int a = 0; a < MAX_LANES; a++)
-        for (int b = 0; b < MAX_LANES; b++) S.v[a].seen[b] = S.v[b].ticket;
+    all_seen();
     S.count = std::max(1, std::min(MAX_LANES, n));
     S.cur = 0;
-    S.rr = 0;
+    for (int r = 0; r < MAX_DEVS; r++) S.rr[r] = 0;
     S.last = -1;
 #endif
+}
+int devices() {
+    (void)engine();
+    return lane_set().ndev;
+}
+void set_devices(const std::vector<int> &hip_devices) {
+#ifdef HEHUB_AMD_BIND_REFERENCE
+    (void)hip_devices;   // (hehub's own objects are host memory: one device, every call ends with a download)
+#else
+    if (hip_devices.empty() || hip_devices.size() > (size_t)MAX_DEVS) throw std::invalid_argument("hehub_amd: between 1 and 8 device ranks");
+    synchronize();
+    LaneSet &S = lane_set();
+    // a rank that has been used keeps its device: blocks, keys and tables made there stay valid (a rank that goes out of use keeps its
+    // contexts; what lives there moves over when a call needs it)
+    for (size_t r = 0; r < hip_devices.size(); r++)
+        if (S.v[r * MAX_LANES].ctx && S.devs[r] != hip_devices[r])
+            throw std::logic_error("hehub_amd: device rank " + std::to_string(r) + " is already in use on another HIP device");
+    all_seen();
+    S.ndev = (int)hip_devices.size();
+    for (int r = 0; r < S.ndev; r++) S.devs[r] = hip_devices[r];
+    S.cur = 0;
+    S.rr_dev = -1;
+    S.last = -1;
+#endif
+}
+void set_devices(int n) {
+    std::vector<int> list;
+    for (int d = 0; d < n; d++) list.push_back(d);
+    set_devices(list);
 }
 
 // parity level of the process-wide engine (include/hehub_amd.h: hp_ctx_set_parity_level): false = B, hehub's raw lazy words (default);
@@ -146,7 +244,7 @@ void set_parity_level_a(bool on) {
     (void)engine();
     flush_all();   // (recorded calls run at the level that was set when they were recorded)
     LaneSet &S = lane_set();
-    for (int l = 0; l < MAX_LANES; l++)
+    for (int l = 0; l < MAX_SLOTS; l++)
         if (S.v[l].ctx && hp_ctx_set_parity_level(S.v[l].ctx, on ? HP_PARITY_A : HP_PARITY_B) != HP_OK)
             throw std::runtime_error(hp_last_error(S.v[l].ctx));
     S.level_a = on;
@@ -167,8 +265,9 @@ struct PendingOp;
 struct DevBlock {
     u64 *p = nullptr;
     size_t words = 0;
-    unsigned long long rd[MAX_LANES] = {}, wr[MAX_LANES] = {};
-    int last_wr = 0;   // the lane of the most recent write (tickets are per-lane counters: they do not say which lane wrote LAST)
+    int rank = 0;      // the device rank the words live on (a placeholder: the rank its recorded call will run on)
+    unsigned long long rd[MAX_SLOTS] = {}, wr[MAX_SLOTS] = {};
+    int last_wr = 0;   // the slot of the most recent write (tickets are per-lane counters: they do not say which lane wrote LAST)
     // deferred mode (see "deferred execution" below): the result of a call that has been recorded but not run is a PLACEHOLDER
     // (p == NULL, op = the recorded call); when the call runs, the placeholder becomes a view of the block its batch filled
     std::shared_ptr<DevBlock> parent;
@@ -183,6 +282,7 @@ TransferStats g_stats;
 
 void check(int rc) {
     g_stats.engine_calls++;
+    g_stats.calls_by_device[rank_of(lane_set().cur)]++;
     lane_set().v[lane_set().cur].busy = true;
     if (rc == HP_OK) return;
     std::string msg = hp_last_error(cur());   // the calling thread's own last failure (hp_ctx.cpp)
@@ -199,9 +299,10 @@ struct Report {
     ~Report() {
         if (std::getenv("HEHUB_AMD_VERBOSE"))
             std::fprintf(stderr, "hehub_amd: %llu engine calls (%s); PCIe: %llu copies / %.1f MiB to the device, %llu copies / %.1f MiB back; "
-                                 "%llu host blocks registered for DMA; %llu waits between lanes\n",
+                                 "%llu host blocks registered for DMA; %llu waits between lanes; %d device rank(s), %llu copies / %.1f MiB between them\n",
                          g_stats.engine_calls, hp_version(), g_stats.h2d_copies, g_stats.h2d_bytes / 1048576.0, g_stats.d2h_copies,
-                         g_stats.d2h_bytes / 1048576.0, g_stats.host_blocks_registered, g_stats.lane_waits);
+                         g_stats.d2h_bytes / 1048576.0, g_stats.host_blocks_registered, g_stats.lane_waits, lane_set().ndev, g_stats.peer_copies,
+                         g_stats.peer_bytes / 1048576.0);
     }
 } g_report;
 
@@ -209,7 +310,7 @@ struct Report {
 // process exit, when the HIP runtime may already be gone (crash or hang at exit).  Pooled blocks go back with the process.
 struct Pool {
     std::mutex mu;
-    std::map<size_t, std::vector<DevBlock *>> free;
+    std::map<std::pair<int, size_t>, std::vector<DevBlock *>> free;   // (rank, words)
     size_t free_bytes = 0;
     size_t cap_bytes = (size_t)8 << 30;   // beyond this a returned block goes back to the device (HEHUB_AMD_POOL_MIB)
 };
@@ -239,47 +340,51 @@ using BlockRef = std::shared_ptr<DevBlock>;
 // the current call reads / writes the block: wait for whoever it depends on, leave the call's ticket
 void track_read(DevBlock &b0) {
     LaneSet &S = lane_set();
-    if (S.count == 1) return;
+    if (S.count == 1 && S.ndev == 1) return;
     DevBlock &b = b0.parent ? *b0.parent : b0;
     Lane &me = S.v[S.cur];
-    for (int l = 0; l < MAX_LANES; l++)
+    for (int l = 0; l < MAX_SLOTS; l++)
         if (l != S.cur && b.wr[l] > me.seen[l]) order_after(l);
     b.rd[S.cur] = me.ticket;
 }
 void track_write(DevBlock &b0) {
     LaneSet &S = lane_set();
-    if (S.count == 1) return;
     DevBlock &b = b0.parent ? *b0.parent : b0;
+    b.last_wr = S.cur;
+    if (S.count == 1 && S.ndev == 1) return;
     Lane &me = S.v[S.cur];
-    for (int l = 0; l < MAX_LANES; l++)
+    for (int l = 0; l < MAX_SLOTS; l++)
         if (l != S.cur && std::max(b.wr[l], b.rd[l]) > me.seen[l]) order_after(l);
     b.wr[S.cur] = me.ticket;
-    b.last_wr = S.cur;
 }
+// the device rank a block's words live on
+int home_rank(const DevBlock &b) { return b.parent ? b.parent->rank : b.rank; }
 // after a host synchronisation of the current lane that followed track_write: every earlier user of the block has finished
 void settled(DevBlock &b) {
     if (b.parent) return;
-    for (int l = 0; l < MAX_LANES; l++) b.rd[l] = b.wr[l] = 0;
+    for (int l = 0; l < MAX_SLOTS; l++) b.rd[l] = b.wr[l] = 0;
 }
 
 BlockRef alloc_block(size_t words) {
     if (words == 0) words = 2;
     Pool &P = pool();
     DevBlock *blk = nullptr;
+    const int rank = cur_rank();   // (a block is made on the device of the call that asks for it)
     {
         std::lock_guard<std::mutex> lk(P.mu);
         // a pooled block whose previous users are all on the current lane (or have been waited for): taking one that another lane
         // still reads or writes would make this call wait for that lane -- a dependency the program does not have.  (Each lane
         // so ends up recycling its own working set; a block nobody can take yet stays pooled.)
-        auto it = P.free.find(words);
+        auto it = P.free.find({rank, words});
         if (it != P.free.end()) {
             LaneSet &S = lane_set();
             const Lane &me = S.v[S.cur];
             auto &list = it->second;
+            const bool one = S.count == 1 && S.ndev == 1;
             for (size_t i = list.size(); i-- > 0;) {
                 bool clean = true;
-                for (int l = 0; l < MAX_LANES && clean; l++)
-                    clean = l == S.cur || S.count == 1 || std::max(list[i]->wr[l], list[i]->rd[l]) <= me.seen[l];
+                for (int l = 0; l < MAX_SLOTS && clean; l++)
+                    clean = l == S.cur || one || std::max(list[i]->wr[l], list[i]->rd[l]) <= me.seen[l];
                 if (!clean) continue;
                 blk = list[i];
                 list.erase(list.begin() + i);
@@ -294,6 +399,7 @@ BlockRef alloc_block(size_t words) {
         blk = new DevBlock;
         blk->p = (u64 *)d;
         blk->words = words;
+        blk->rank = rank;
     }
     return BlockRef(blk, [](DevBlock *b) {
         Pool &Q = pool();
@@ -302,15 +408,15 @@ BlockRef alloc_block(size_t words) {
             std::lock_guard<std::mutex> lk(Q.mu);
             keep = Q.free_bytes + b->words * 8 <= Q.cap_bytes;
             if (keep) {
-                Q.free[b->words].push_back(b);   // (with its record: the next owner waits for this one's readers and writers)
+                Q.free[{b->rank, b->words}].push_back(b);   // (with its record: the next owner waits for this one's readers and writers)
                 Q.free_bytes += b->words * 8;
             }
         }
         if (!keep) {
             LaneSet &S = lane_set();
-            for (int l = 0; l < MAX_LANES; l++)
+            for (int l = 0; l < MAX_SLOTS; l++)
                 if (S.v[l].ctx) (void)hp_sync(S.v[l].ctx);
-            (void)hp_dev_free(S.v[0].ctx, b->p);
+            (void)hp_dev_free(S.v[b->rank * MAX_LANES].ctx, b->p);
             delete b;
         }
     });
@@ -319,32 +425,64 @@ BlockRef alloc_block(size_t words) {
 // One call of the public interface: picks the lane (see "lanes" above) and opens a new ticket on it.  Calls nest (ckks::add ->
 // add -> operator+=): the outermost scope decides.
 struct OpScope {
-    explicit OpScope(std::initializer_list<const BlockRef *> operands, int force_lane = -1) {
+    // force_lane / force_rank >= 0: the call runs on that lane / device rank whatever its operands say (batches and the queue: lane 0 of
+    // the rank that holds their operands).  A FORCED scope switches slots also when it is nested inside another call (the queue may run
+    // in the middle of a call on another rank; a download runs on the device that holds the words) and switches back when it ends.
+    explicit OpScope(std::initializer_list<const BlockRef *> operands, int force_lane = -1, int force_rank = -1) {
         (void)engine();
         LaneSet &S = lane_set();
-        if (S.depth++ > 0) return;
-        int lane = force_lane;
-        if (S.count == 1) lane = 0;
-        for (const BlockRef *r : operands) {
-            if (lane >= 0) break;
-            if (!r || !*r) continue;
-            const DevBlock &b = (*r)->parent ? *(*r)->parent : **r;
-            for (int l = 0; l < S.count; l++)
-                if (b.wr[l] && b.wr[l] == S.v[l].ticket) { lane = l; break; }
+        saved_ = S.cur;
+        const bool forced = force_lane >= 0 || force_rank >= 0;
+        if (S.depth++ > 0 && !forced) return;
+        const bool nested = S.depth > 1;
+        int slot = -1;
+        const bool one = S.count == 1 && S.ndev == 1;
+        if (one) slot = 0;
+        // the lane whose most recent call produced one of the operands: a dependent chain stays on one stream
+        if (slot < 0 && !forced)
+            for (const BlockRef *r : operands) {
+                if (slot >= 0) break;
+                if (!r || !*r) continue;
+                const DevBlock &b = (*r)->parent ? *(*r)->parent : **r;
+                for (int l = 0; l < MAX_SLOTS; l++)
+                    if (S.active(l) && b.wr[l] && b.wr[l] == S.v[l].ticket) { slot = l; break; }
+            }
+        if (slot < 0) {
+            // the device: where the first device-resident operand lives; host-only operands go to the next rank round robin
+            int rank = force_rank;
+            if (rank < 0 && nested) rank = rank_of(S.cur);   // (a forced lane inside another call: that call's rank)
+            for (const BlockRef *r : operands) {
+                if (rank >= 0) break;
+                if (!r || !*r) continue;
+                const int h = home_rank(**r);
+                if (h < S.ndev) rank = h;
+            }
+            if (rank < 0) rank = S.ndev == 1 ? 0 : (S.rr_dev = (S.rr_dev + 1) % S.ndev);
+            int lane = force_lane;
+            if (lane < 0 && S.count == 1) lane = 0;
+            if (lane < 0) {
+                // nothing in flight on the rank (a caller that looks at every result before its next call, like hehub's own benchmark
+                // loop): stay on the lane used last -- its workspace is the one in the Infinity Cache, and there is nothing to overlap with
+                bool any_busy = false;
+                for (int l = 0; l < S.count; l++) any_busy = any_busy || S.v[rank * MAX_LANES + l].busy;
+                const bool stay = !any_busy && S.last >= 0 && rank_of(S.last) == rank;
+                lane = stay ? (S.last % MAX_LANES < S.count ? S.last % MAX_LANES : 0) : (S.rr[rank] = (S.rr[rank] + 1) % S.count);
+            }
+            slot = rank * MAX_LANES + lane;
         }
-        if (lane < 0) {
-            // nothing in flight anywhere (a caller that looks at every result before its next call, like hehub's own benchmark loop):
-            // stay on the lane used last -- its workspace is the one in the Infinity Cache, and there is nothing to overlap with
-            bool any_busy = false;
-            for (int l = 0; l < S.count; l++) any_busy = any_busy || S.v[l].busy;
-            lane = any_busy || S.last < 0 ? (S.rr = (S.rr + 1) % S.count) : (S.last < S.count ? S.last : 0);
-        }
-        S.cur = S.last = lane;
+        S.cur = slot;
+        if (!nested) S.last = slot;
         (void)cur();
-        S.v[lane].ticket++;
+        S.v[slot].ticket++;
     }
-    ~OpScope() { lane_set().depth--; }
+    ~OpScope() {
+        LaneSet &S = lane_set();
+        if (--S.depth > 0) S.cur = saved_;   // (a forced scope inside another call: that call goes on where it was)
+    }
     OpScope(const OpScope &) = delete;
+
+private:
+    int saved_ = 0;
 };
 
 void h2d(u64 *dst, const u64 *src, size_t words) {
@@ -567,6 +705,7 @@ enum class OpKind { MultLow, Relin, KeySwitch, Drop, AddSub, Copy, PolyMul, Tran
 struct PendingOp {
     OpKind kind = OpKind::MultLow;
     size_t logn = 0, L = 0, L0 = 0, step = 0;
+    int rank = 0;           // the device rank the call runs on: where its first device-resident operand lived when it was recorded
     std::vector<u64> mod;   // q_0 .. q_{L-1} (MultLow, Drop, AddSub) or the extended chain (Relin, KeySwitch)
     BlockRef key;           // the assembled key block (Relin, KeySwitch)
     bool conj = false, bgv = false, sub = false;
@@ -579,7 +718,7 @@ struct PendingOp {
     // the rotations of one vector under the keys of a rotation key set, src/circuits/linear_algebra.h:123-130, are one launch sequence)
     bool same_signature(const PendingOp &o) const {
         const bool ks = kind == OpKind::KeySwitch;
-        return kind == o.kind && logn == o.logn && L == o.L && L0 == o.L0 && (ks || (step == o.step && conj == o.conj && key == o.key)) &&
+        return kind == o.kind && rank == o.rank && logn == o.logn && L == o.L && L0 == o.L0 && (ks || (step == o.step && conj == o.conj && key == o.key)) &&
                bgv == o.bgv && sub == o.sub && t == o.t && in_limbs == o.in_limbs && in.size() == o.in.size() && mod == o.mod;
     }
     bool ready() const {
@@ -614,6 +753,34 @@ u64 *words_of(const BlockRef &b) {
     if (!b->p) throw std::runtime_error("hehub_amd: this object is the result of a deferred call that failed when the queue ran");
     return b->p;
 }
+// `words` words at [off, ..) of a block, enqueued for copying from the device rank that holds them into `dst` on the CURRENT rank
+// (ordered behind the block's writers; the block records the read)
+void peer_fetch(u64 *dst, const BlockRef &b, size_t off, size_t words) {
+    const u64 *src = words_of(b) + off;
+    track_read(*b);
+    check(hp_memcpy_peer_async(cur(), dst, rank_ctx(home_rank(*b)), src, words * sizeof(u64)));
+    g_stats.peer_copies++;
+    g_stats.peer_bytes += words * 8;
+}
+// the words [off, off + words) of a block for an engine call on the CURRENT rank: where they are when they live on this rank, otherwise
+// a copy made here for this call (a recorded operand has no vector to re-home; Access::in moves a vector for good)
+Src here(const BlockRef &b, size_t off, size_t words) {
+    u64 *p = words_of(b);
+    if (home_rank(*b) == cur_rank()) {
+        track_read(*b);
+        return Src{p + off, b};
+    }
+    BlockRef tmp = alloc_block(words);
+    track_write(*tmp);
+    peer_fetch(tmp->p, b, off, words);
+    return Src{tmp->p, tmp};
+}
+// a key block assembled for another rank than the call's is a bug of this file, not of the caller (keys are cached per rank)
+const u64 *key_here(const BlockRef &key) {
+    if (home_rank(*key) != cur_rank()) throw std::logic_error("hehub_amd: key block of another device rank (internal error)");
+    track_read(*key);
+    return key->p;
+}
 
 #ifndef HEHUB_AMD_BIND_REFERENCE
 // ---- own mirror: the vector carries its device copy -----------------------------------------------------------
@@ -632,7 +799,8 @@ struct Access {
         if (v.dev_ok_ && v.blk_->op) flush_all();   // a placeholder: the recorded calls run now
         if (!v.dev_ok_) {
             if (v.blk_ && (v.blk_->pending_reads || (v.blk_->parent && v.blk_->parent->pending_reads))) flush_all();   // (a recorded call still wants the words this upload replaces)
-            if (!v.blk_ || v.off_ + v.count_ * n > v.blk_->words) {   // (a view keeps its place: sibling views are disjoint)
+            // (a view keeps its place: sibling views are disjoint -- unless that place is on another device than this call)
+            if (!v.blk_ || v.off_ + v.count_ * n > v.blk_->words || home_rank(*v.blk_) != cur_rank()) {
                 v.blk_ = alloc_block(v.count_ * n);
                 v.off_ = 0;
             }
@@ -643,8 +811,19 @@ struct Access {
             v.dev_ok_ = true;
         }
         (void)limbs;
+        if (home_rank(*v.blk_) != cur_rank()) move_here(v);
         track_read(*v.blk_);
         return Src{words_of(v.blk_) + v.off_, v.blk_};
+    }
+    // the vector's device words live on another rank than the current call: they are copied over (one peer copy, ordered behind their
+    // writers) and the vector lives HERE from now on -- same words, another place: invisible to the caller
+    static void move_here(const RnsIntVec &v) {
+        const size_t w = v.count_ * v.dimension();
+        BlockRef nb = alloc_block(w);
+        track_write(*nb);
+        peer_fetch(nb->p, v.blk_, v.off_, w);
+        v.blk_ = nb;
+        v.off_ = 0;
     }
     // deferred mode: where the vector's device words are or WILL be (a placeholder is not resolved); host words are uploaded now
     static std::pair<BlockRef, size_t> ref(const RnsIntVec &v) {
@@ -694,7 +873,7 @@ struct Access {
         return v.stamp_;
     }
     static bool adjacent(const RnsIntVec &a, const RnsIntVec &b, size_t limbs) {
-        return a.dev_ok_ && b.dev_ok_ && a.blk_ == b.blk_ && b.off_ == a.off_ + limbs * a.dimension();
+        return a.dev_ok_ && b.dev_ok_ && a.blk_ == b.blk_ && b.off_ == a.off_ + limbs * a.dimension() && home_rank(*a.blk_) == cur_rank();
     }
     // give the device copy up when the host copy is current too (the block returns to the pool once its last user is gone)
     static void drop_device_copy(const RnsIntVec &v) {
@@ -719,8 +898,9 @@ struct Access {
             LaneSet &S = lane_set();
             if (v.blk_->op) flush_all();
             const DevBlock &root = v.blk_->parent ? *v.blk_->parent : *v.blk_;
-            const int lane = root.last_wr < S.count ? root.last_wr : 0;
-            OpScope op({}, S.depth ? S.cur : lane);
+            (void)S;
+            const int slot = S.active(root.last_wr) && rank_of(root.last_wr) == root.rank ? root.last_wr : root.rank * MAX_LANES;
+            OpScope op({}, slot % MAX_LANES, rank_of(slot));   // (on the device that holds the words, whatever call this look is part of)
             track_read(*v.blk_);
             d2h_limbs(v.limbs_, words_of(v.blk_) + v.off_, v.count_, n);   // (synchronous)
         }
@@ -741,8 +921,9 @@ struct Access {
             LaneSet &S = lane_set();
             if (v.blk_->op) flush_all();
             const DevBlock &root = v.blk_->parent ? *v.blk_->parent : *v.blk_;
-            const int lane = root.last_wr < S.count ? root.last_wr : 0;
-            OpScope op({}, S.depth ? S.cur : lane);
+            (void)S;
+            const int slot = S.active(root.last_wr) && rank_of(root.last_wr) == root.rank ? root.last_wr : root.rank * MAX_LANES;
+            OpScope op({}, slot % MAX_LANES, rank_of(slot));
             track_read(*v.blk_);
             d2h(v.limbs_[k].data(), words_of(v.blk_) + v.off_ + k * n, n);   // (synchronous)
             v.limb_mask_ |= 1ull << k;
@@ -764,6 +945,7 @@ struct Access {
             if (o.blk_->op && deferred() && (w & 1) == 0) {   // a copy of a result that is still a placeholder is recorded like the call that makes it
                 std::unique_ptr<PendingOp> rec(new PendingOp);
                 rec->kind = OpKind::Copy; rec->logn = o.logn_; rec->L = o.count_; rec->in_limbs = o.count_; rec->out_words = w;
+                rec->rank = home_rank(*o.blk_);
                 rec->in.push_back({o.blk_, o.off_});
                 dst.blk_ = record(std::move(rec));
                 dst.dev_ok_ = true;
@@ -773,9 +955,13 @@ struct Access {
             if (o.blk_->op) flush_all();   // (a copy of a placeholder: the recorded calls run now)
             OpScope op({&o.blk_});
             dst.blk_ = alloc_block(w);
-            track_read(*o.blk_);
             track_write(*dst.blk_);
-            check(hp_dev_copy(cur(), w, words_of(o.blk_) + o.off_, dst.blk_->p));
+            if (home_rank(*o.blk_) == cur_rank()) {
+                track_read(*o.blk_);
+                check(hp_dev_copy(cur(), w, words_of(o.blk_) + o.off_, dst.blk_->p));
+            } else {
+                peer_fetch(dst.blk_->p, o.blk_, o.off_, w);   // (the source's rank went out of use: the copy is made on a rank that is)
+            }
             dst.dev_ok_ = true;
             dst.host_ok_ = false;
         } else {
@@ -792,7 +978,8 @@ struct Access {
         bool packed = true;
         for (size_t r = 0; r < polys.size() && packed; r++) {
             const RnsIntVec &v = *polys[r];
-            packed = v.dev_ok_ && !v.blk_->op && v.blk_->p && f.blk_->p && v.blk_->p + v.off_ == f.blk_->p + f.off_ + r * w && v.count_ == limbs;
+            packed = v.dev_ok_ && !v.blk_->op && v.blk_->p && f.blk_->p && v.blk_->p + v.off_ == f.blk_->p + f.off_ + r * w && v.count_ == limbs &&
+                     home_rank(*v.blk_) == cur_rank();
         }
         if (packed) {   // (polynomials that are views of one block, directly or through the placeholders a deferred batch resolved)
             for (const RnsIntVec *v : polys) track_read(*v->blk_);
@@ -1011,14 +1198,15 @@ Src group_rows(const std::vector<PendingOp *> &g, size_t first, size_t count, si
     const u64 *base = words_of(g[0]->in[first].first) + g[0]->in[first].second;
     bool packed = true;
     std::vector<const u64 *> rows;
+    std::vector<BlockRef> holds;   // (copies of operands that live on another rank: alive until the gather has been enqueued)
     rows.reserve(g.size() * count);
     for (size_t b = 0; b < g.size(); b++)
         for (size_t c = 0; c < count; c++) {
             const auto &r = g[b]->in[first + c];
-            const u64 *p = words_of(r.first) + r.second;
-            track_read(*r.first);
-            packed = packed && p == base + (b * count + c) * w;
-            rows.push_back(p);
+            Src s = here(r.first, r.second, w);
+            if (s.hold != r.first) holds.push_back(s.hold);
+            packed = packed && s.p == base + (b * count + c) * w && holds.empty();
+            rows.push_back(s.p);
         }
     if (packed) return Src{base, nullptr};   // (the calls of the group hold their operand blocks until the group has been enqueued)
     BlockRef tmp = alloc_block(rows.size() * w);
@@ -1040,28 +1228,29 @@ void run_group(const std::vector<PendingOp *> &g) {
     }
     case OpKind::Relin: {
         Src dq = group_rows(g, 0, 3, n);
-        track_read(*o.key);
-        if (o.bgv) check(hp_dev_bgv_relinearize(cur(), o.logn, L, o.mod.data(), 1 /* bgv.h:32 */, B, dq.p, o.key->p, big->p));
-        else check(hp_dev_ckks_relinearize_at(cur(), o.logn, L, o.L0, o.mod.data(), B, dq.p, o.key->p, big->p));
+        const u64 *key = key_here(o.key);
+        if (o.bgv) check(hp_dev_bgv_relinearize(cur(), o.logn, L, o.mod.data(), 1 /* bgv.h:32 */, B, dq.p, key, big->p));
+        else check(hp_dev_ckks_relinearize_at(cur(), o.logn, L, o.L0, o.mod.data(), B, dq.p, key, big->p));
         break;
     }
     case OpKind::KeySwitch: {
         bool one_key = true;
         for (PendingOp *c : g) {
-            track_read(*c->key);
+            (void)key_here(c->key);
             one_key = one_key && c->key == o.key && c->step == o.step && c->conj == o.conj;
         }
         if (!one_key) {   // every ciphertext with its own key and step; the operands are read where they are (often ONE vector)
             std::vector<const u64 *> keys, polys;
             std::vector<size_t> steps;
             std::vector<unsigned char> conj;
+            std::vector<Src> holds;
             for (PendingOp *c : g) {
                 keys.push_back(c->key->p);
                 steps.push_back(c->step);
                 conj.push_back(c->conj ? 1 : 0);
                 for (size_t h = 0; h < 2; h++) {
-                    polys.push_back(words_of(c->in[h].first) + c->in[h].second);
-                    track_read(*c->in[h].first);
+                    holds.push_back(here(c->in[h].first, c->in[h].second, L * n));
+                    polys.push_back(holds.back().p);
                 }
             }
             check(hp_dev_ckks_rotate_many_rows(cur(), o.logn, L, o.L0, o.mod.data(), B, steps.data(), conj.data(), polys.data(), keys.data(), big->p));
@@ -1069,8 +1258,8 @@ void run_group(const std::vector<PendingOp *> &g) {
             break;
         }
         Src dc = group_rows(g, 0, 2, n);
-        if (o.conj) check(hp_dev_ckks_conjugate_at(cur(), o.logn, L, o.L0, o.mod.data(), B, dc.p, o.key->p, big->p));
-        else check(hp_dev_ckks_rotate_at(cur(), o.logn, L, o.L0, o.mod.data(), B, o.step, dc.p, o.key->p, big->p));
+        if (o.conj) check(hp_dev_ckks_conjugate_at(cur(), o.logn, L, o.L0, o.mod.data(), B, dc.p, key_here(o.key), big->p));
+        else check(hp_dev_ckks_rotate_at(cur(), o.logn, L, o.L0, o.mod.data(), B, o.step, dc.p, key_here(o.key), big->p));
         break;
     }
     case OpKind::Drop: {
@@ -1081,18 +1270,20 @@ void run_group(const std::vector<PendingOp *> &g) {
     }
     case OpKind::Copy: {   // a deep copy of a result that has not been computed yet (`ct_sum = ct_prod`): the gather IS the copy
         std::vector<const u64 *> rows;
+        std::vector<Src> holds;
         for (PendingOp *c : g) {
-            rows.push_back(words_of(c->in[0].first) + c->in[0].second);
-            track_read(*c->in[0].first);
+            holds.push_back(here(c->in[0].first, c->in[0].second, o.in_limbs * n));
+            rows.push_back(holds.back().p);
         }
         check(hp_dev_gather_rows(cur(), rows.size(), o.in_limbs * n, rows.data(), big->p));
         break;
     }
     case OpKind::Transform: {   // NTT / INTT of a polynomial in place (ntt.h:41-92): the plaintext transforms inside add / sub / mult_plain (ckks/arith.cpp:25,41,49)
         std::vector<const u64 *> rows;   // (the operands' blocks may have other holders: the batch is transformed in its own block)
+        std::vector<Src> holds;
         for (PendingOp *c : g) {
-            rows.push_back(words_of(c->in[0].first) + c->in[0].second);
-            track_read(*c->in[0].first);
+            holds.push_back(here(c->in[0].first, c->in[0].second, o.in_limbs * n));
+            rows.push_back(holds.back().p);
         }
         check(hp_dev_gather_rows(cur(), rows.size(), o.in_limbs * n, rows.data(), big->p));
         if (o.conj) check(hp_dev_intt(cur(), o.logn, L, o.mod.data(), B, big->p, o.sub ? 1 : 0));
@@ -1158,7 +1349,7 @@ std::vector<PendingOp *> run_fused_mults(const std::vector<std::unique_ptr<Pendi
     for (PendingOp *m : g_all) {
         PendingOp *r = consumer_of(m->out, OpKind::Relin, 3);
         PendingOp *d = (r && r->L == L && (!r->bgv || r->L0 == L)) ? consumer_of(r->out, OpKind::Drop, 2) : nullptr;
-        const bool ok = d && d->L == L && d->bgv == r->bgv && (relin.empty() || (r->same_signature(*relin[0]) && d->same_signature(*drop[0])));
+        const bool ok = d && d->L == L && d->bgv == r->bgv && r->rank == m->rank && d->rank == m->rank && (relin.empty() || (r->same_signature(*relin[0]) && d->same_signature(*drop[0])));
         if (!ok) {
             rest.push_back(m);
             continue;
@@ -1174,15 +1365,16 @@ std::vector<PendingOp *> run_fused_mults(const std::vector<std::unique_ptr<Pendi
     track_write(*big);
     // the operands are read where they lie (the tensor product takes their addresses): no gather of the 4 L limbs per pair
     std::vector<const u64 *> polys;
+    std::vector<Src> holds;
     polys.reserve(4 * B);
     for (PendingOp *m : g)
         for (size_t h = 0; h < 4; h++) {
-            polys.push_back(words_of(m->in[h].first) + m->in[h].second);
-            track_read(*m->in[h].first);
+            holds.push_back(here(m->in[h].first, m->in[h].second, w));
+            polys.push_back(holds.back().p);
         }
-    track_read(*r0.key);
-    if (r0.bgv) check(hp_dev_bgv_mult_relin_modswitch_rows(cur(), r0.logn, L, r0.mod.data(), d0.t, B, polys.data(), r0.key->p, big->p));
-    else check(hp_dev_ckks_mult_relin_rescale_rows(cur(), r0.logn, L, r0.L0, r0.mod.data(), B, polys.data(), r0.key->p, big->p));
+    const u64 *key = key_here(r0.key);
+    if (r0.bgv) check(hp_dev_bgv_mult_relin_modswitch_rows(cur(), r0.logn, L, r0.mod.data(), d0.t, B, polys.data(), key, big->p));
+    else check(hp_dev_ckks_mult_relin_rescale_rows(cur(), r0.logn, L, r0.L0, r0.mod.data(), B, polys.data(), key, big->p));
     for (size_t b = 0; b < B; b++) {
         DevBlock &ph = *drop[b]->out;
         ph.p = big->p + b * d0.out_words;
@@ -1217,7 +1409,7 @@ std::vector<PendingOp *> run_sum_chains(const std::vector<std::unique_ptr<Pendin
         for (auto &o : ops) {
             if (o->done || o->kind != OpKind::AddSub || o->in.size() != 4 || o.get() == &t) continue;
             if (o->in[0].first != t.out || o->in[0].second != 0 || o->in[1].first != t.out || o->in[1].second != w) continue;
-            if (o->logn != t.logn || o->L != t.L || o->in_limbs != t.in_limbs || o->mod != t.mod) return nullptr;
+            if (o->rank != t.rank || o->logn != t.logn || o->L != t.L || o->in_limbs != t.in_limbs || o->mod != t.mod) return nullptr;
             if (o->in[2].first->op || o->in[3].first->op) return nullptr;   // its other operand has not been computed yet
             return o.get();
         }
@@ -1234,13 +1426,14 @@ std::vector<PendingOp *> run_sum_chains(const std::vector<std::unique_ptr<Pendin
         const size_t terms = chain.size() + 1;
         std::vector<const u64 *> rows(2 * terms);
         std::vector<unsigned char> neg(terms, 0);
+        std::vector<Src> holds;
         for (size_t h = 0; h < 2; h++) {
-            rows[h * terms] = words_of(m->in[h].first) + m->in[h].second;
-            track_read(*m->in[h].first);
+            holds.push_back(here(m->in[h].first, m->in[h].second, w));
+            rows[h * terms] = holds.back().p;
             for (size_t j = 0; j < chain.size(); j++) {
                 const auto &r = chain[j]->in[2 + h];
-                rows[h * terms + 1 + j] = words_of(r.first) + r.second;
-                track_read(*r.first);
+                holds.push_back(here(r.first, r.second, w));
+                rows[h * terms + 1 + j] = holds.back().p;
                 neg[1 + j] = chain[j]->sub ? 1 : 0;
             }
         }
@@ -1296,7 +1489,7 @@ void flush_all() {
             // everything the queue runs goes to lane 0: a batch fills the GPU by itself and only one lane grows a batch-sized workspace.
             // (Groups of one or two calls spread over the lanes like eager calls were measured: a dependent chain of rotations 0.163
             // against 0.126 ms per call -- the hops cost more than independent small groups could win.)
-            OpScope scope({}, 0);
+            OpScope scope({}, 0, g[0]->rank);   // (lane 0 of the rank the group was recorded for)
             g = run_fused_mults(ops, g);
             g = run_sum_chains(ops, g);
             if (!g.empty()) run_group(g);
@@ -1317,6 +1510,7 @@ BlockRef record(std::unique_ptr<PendingOp> op) {
     OpQueue &Q = op_queue();
     BlockRef ph(new DevBlock, [](DevBlock *b) { delete b; });
     ph->words = op->out_words;
+    ph->rank = op->rank;
     ph->op = op.get();
     op->out = ph;
     for (auto &r : op->in) {   // (views of a batch block share its words: counted on the view and on the block that owns them)
@@ -1458,7 +1652,7 @@ void run_inplace(Bin op, RnsIntVec &self, const RnsIntVec &b, size_t L) {
     if (L == 0 || n == 0) return;
 #ifndef HEHUB_AMD_BIND_REFERENCE
     if (op != Bin::mul && n >= 2 && amd::deferred()) {   // recorded: self becomes the placeholder of the sum (the plaintext sums of a loop run as one batch)
-        OpScope scope({}, 0);
+        OpScope scope({Access::home(self), Access::home(b)}, 0);
         size_t lg = 0;
         while (((size_t)1 << lg) < n) lg++;
         auto rec = new_op(amd::OpKind::PolyAddSub, lg, L, self.modulus_vec(), {&self, &b}, L, L * n);
@@ -1560,7 +1754,7 @@ public:
             assemble(own_->p, rgsw, L, n);
             return;
         }
-        std::vector<u64> sig{(u64)L, (u64)n};
+        std::vector<u64> sig{(u64)L, (u64)n, (u64)amd::cur_rank()};   // (a key is assembled once per device rank that uses it)
         for (size_t j = 0; j < L; j++)
             for (size_t h = 0; h < 2; h++) {
 #ifndef HEHUB_AMD_BIND_REFERENCE
@@ -1618,6 +1812,7 @@ std::unique_ptr<amd::PendingOp> new_op(amd::OpKind kind, size_t logn, size_t L, 
                                        std::initializer_list<const RnsIntVec *> operands, size_t in_limbs, size_t out_words) {
     std::unique_ptr<amd::PendingOp> op(new amd::PendingOp);
     op->kind = kind; op->logn = logn; op->L = L; op->L0 = L; op->mod = mod; op->in_limbs = in_limbs; op->out_words = out_words;
+    op->rank = amd::rank_of(amd::lane_set().cur);   // (the recording scope chose the rank from the operands: RecordScope)
     for (const RnsIntVec *v : operands) op->in.push_back(Access::ref(*v));
     return op;
 }
@@ -1648,7 +1843,7 @@ RlweCt relinearize_common(const std::array<RnsPolynomial, 3> &quad, const RlweKs
     if (bgv && L0 != L) throw std::invalid_argument("Inconsistent RGSW ciphertext.");   // no higher-level keys for the BGV quirk path
 #ifndef HEHUB_AMD_BIND_REFERENCE
     if (amd::deferred()) {
-        OpScope scope({}, 0);
+        OpScope scope({Access::home(quad[0]), Access::home(quad[1]), Access::home(quad[2])}, 0);
         DevKey dk(key, L0, n);
         auto rec = new_op(amd::OpKind::Relin, quad[2].log_dimension(), L, mext, {&quad[0], &quad[1], &quad[2]}, L, 2 * L * n);
         rec->L0 = L0; rec->bgv = bgv; rec->key = dk.block();
@@ -1682,7 +1877,7 @@ template <class Quad, class Ct> Quad mult_low_level_common(const Ct &ct1, const 
     if (m1 != m2) throw std::invalid_argument("Operands' moduli mismatch.");
 #ifndef HEHUB_AMD_BIND_REFERENCE
     if (amd::deferred()) {
-        OpScope scope({}, 0);
+        OpScope scope({Access::home(ct1[0]), Access::home(ct1[1]), Access::home(ct2[0]), Access::home(ct2[1])}, 0);
         auto rec = new_op(amd::OpKind::MultLow, ct1[0].log_dimension(), L, m1, {&ct1[0], &ct1[1], &ct2[0], &ct2[1]}, L, 3 * L * n);
         Quad quad;
         for (int h = 0; h < 3; h++) quad[h] = result_poly(n, L, m1, PolyRepForm::value);
@@ -1718,7 +1913,7 @@ void drop_last_prime(RlweCt &ct, bool bgv, u64 t) {
     const size_t n = ct[0].dimension(), L = ct[0].component_count(), logn = ct[0].log_dimension();
 #ifndef HEHUB_AMD_BIND_REFERENCE
     if (amd::deferred()) {
-        OpScope scope({}, 0);
+        OpScope scope({Access::home(ct[0]), Access::home(ct[1])}, 0);
         auto rec = new_op(amd::OpKind::Drop, logn, L, ct[0].modulus_vec(), {&ct[0], &ct[1]}, L, 2 * (L - 1) * n);
         rec->bgv = bgv; rec->t = t;
         const amd::BlockRef ph = amd::record(std::move(rec));
@@ -1783,7 +1978,7 @@ RnsIntVec operator*(const RnsIntVec &a, const RnsIntVec &b) {
     if (components == 0 || n == 0) return result;
 #ifndef HEHUB_AMD_BIND_REFERENCE
     if (amd::deferred() && n >= 2) {
-        OpScope scope({}, 0);
+        OpScope scope({Access::home(a), Access::home(b)}, 0);
         size_t lg = 0;
         while (((size_t)1 << lg) < n) lg++;
         auto rec = new_op(amd::OpKind::PolyMul, lg, components, moduli, {&a, &b}, components, components * n);
@@ -1906,7 +2101,7 @@ void intt_negacyclic_inplace_lazy(const size_t logn, const u64 q, u64 v[]) {
 static void poly_transform(RnsPolynomial &p, bool inverse, bool strict) {
     const size_t n = p.dimension(), L = p.component_count();
     if (L && n >= 2 && amd::deferred()) {   // recorded: the transforms of a loop's plaintexts run as one batch (conj = inverse, sub = strict)
-        OpScope scope({}, 0);
+        OpScope scope({Access::home(p)}, 0);
         auto rec = new_op(amd::OpKind::Transform, p.log_dimension(), L, p.modulus_vec(), {&p}, L, L * n);
         rec->conj = inverse; rec->sub = strict;
         Access::bind_block(p, amd::record(std::move(rec)), 0);
@@ -1962,7 +2157,7 @@ static RlweCt addsub(const RlweCt &a, const RlweCt &b, bool sub) {
     const bool same = L[0] == L[1] && L[0] > 0 && a[1].dimension() == n && a[0].modulus_vec() == a[1].modulus_vec() &&
                       b[0].component_count() == L[0] && b[1].component_count() == L[0];
     if (same && amd::deferred()) {
-        OpScope scope({}, 0);
+        OpScope scope({Access::home(a[0]), Access::home(a[1]), Access::home(b[0]), Access::home(b[1])}, 0);
         size_t lg = 0;
         while (((size_t)1 << lg) < n) lg++;
         auto rec = new_op(amd::OpKind::AddSub, lg, L[0], a[0].modulus_vec(), {&a[0], &a[1], &b[0], &b[1]}, L[0], 2 * L[0] * n);
@@ -2036,7 +2231,7 @@ RnsPolynomial rns_base_transform(RnsPolynomial in, const std::vector<u64> &new_m
     // one batch.  (one -> many only: many -> one is decrypt's, whose caller looks at the words next, and its preconditions -- odd,
     // pairwise coprime moduli -- are reported by the call itself)
     if (amd::deferred() && n >= 2 && L == 1 && !new_moduli.empty() && in.modulus_at(0) >= 2) {
-        OpScope scope({}, 0);
+        OpScope scope({Access::home(in)}, 0);
         size_t lg = 0;
         while (((size_t)1 << lg) < n) lg++;
         RnsPolynomial out = result_poly(n, new_moduli.size(), new_moduli, PolyRepForm::coeff);
@@ -2155,7 +2350,7 @@ static CkksCt key_switched(const CkksCt &ct, const RlweKsk &key, bool conj, size
     if (ct[0].dimension() != n || ct[0].component_count() != L) throw std::invalid_argument("Ill-formed ciphertext.");
 #ifndef HEHUB_AMD_BIND_REFERENCE
     if (amd::deferred()) {
-        OpScope scope({}, 0);
+        OpScope scope({Access::home(ct[0]), Access::home(ct[1])}, 0);
         DevKey dk(key, L0, n);
         auto rec = new_op(amd::OpKind::KeySwitch, logn, L, mext, {&ct[0], &ct[1]}, L, 2 * L * n);
         rec->L0 = L0; rec->conj = conj; rec->step = conj ? 0 : step; rec->key = dk.block();
@@ -2285,16 +2480,38 @@ template <class Ct> std::vector<const RnsIntVec *> halves(const std::vector<Ct> 
     for (const Ct &ct : cts) { v.push_back(&ct[0]); v.push_back(&ct[1]); }
     return v;
 }
-// result ciphertexts as views of u64[B][2][L][N]
-template <class Ct> std::vector<Ct> result_batch(size_t B, size_t n, size_t L, const std::vector<u64> &q, const Dst &d) {
+// B result ciphertexts of the given shape, no words yet
+template <class Ct> std::vector<Ct> result_shells(size_t B, size_t n, size_t L, const std::vector<u64> &q) {
     std::vector<Ct> out;
     out.reserve(B);
-    std::vector<RnsIntVec *> polys;
     for (size_t i = 0; i < B; i++)
         out.emplace_back(RlweCt{result_poly(n, L, q, PolyRepForm::value), result_poly(n, L, q, PolyRepForm::value)});
-    for (Ct &ct : out) { polys.push_back(&ct[0]); polys.push_back(&ct[1]); }
-    Access::bind_many(polys, d, L);
     return out;
+}
+// ... elements [lo, hi) become views of u64[hi - lo][2][L][N], the block one rank's engine call filled
+template <class Ct> void bind_slice(std::vector<Ct> &out, size_t lo, size_t hi, const Dst &d, size_t L) {
+    std::vector<RnsIntVec *> polys;
+    for (size_t i = lo; i < hi; i++) { polys.push_back(&out[i][0]); polys.push_back(&out[i][1]); }
+    Access::bind_many(polys, d, L);
+}
+template <class Ct> std::vector<const RnsIntVec *> halves(const std::vector<Ct> &cts, size_t lo, size_t hi) {
+    std::vector<const RnsIntVec *> v;
+    v.reserve(2 * (hi - lo));
+    for (size_t i = lo; i < hi; i++) { v.push_back(&cts[i][0]); v.push_back(&cts[i][1]); }
+    return v;
+}
+// A batch is cut into contiguous slices, one per device rank (batch / ranks each; with one rank: the whole batch), and
+// f(lo, hi) runs for each slice inside a scope on lane 0 of its rank: a batch fills a GPU by itself, and only one lane per rank
+// grows a batch-sized workspace.  The slices' engine calls are enqueued one after the other and run side by side on their devices.
+template <class F> void for_slices(size_t B, F &&f) {
+    (void)engine();
+    const int nd = lane_set().ndev;
+    for (int r = 0; r < nd; r++) {
+        const size_t lo = B * (size_t)r / (size_t)nd, hi = B * (size_t)(r + 1) / (size_t)nd;
+        if (lo == hi) continue;
+        OpScope op({}, 0, r);
+        f(lo, hi);
+    }
 }
 void same_size(size_t a, size_t b) {
     if (a != b) throw std::invalid_argument("hehub_amd: the two batches have different sizes.");
@@ -2326,21 +2543,25 @@ std::vector<Ct> mult_batch(const std::vector<Ct> &a, const std::vector<Ct> &b, c
     const size_t L0 = check_ext_prod(result_poly(n, L, q, PolyRepForm::value), key, mext);
     if (bgv && L0 != L) throw std::invalid_argument("Inconsistent RGSW ciphertext.");
     if (drop && L == 1) throw std::invalid_argument("Unable to drop the only one prime.");
-    OpScope op({}, 0);   // (batches run on lane 0: a batch fills the GPU by itself, and only one lane grows a batch-sized workspace)
-    DevKey dk(key, L0, n);
-    Src d1 = Access::batch_in(halves(a), L), d2 = Access::batch_in(halves(b), L);
     const size_t Lout = drop ? L - 1 : L;
-    Dst dout(B * 2 * Lout * n);
-    if (drop) {
-        if (bgv) check(hp_dev_bgv_mult_relin_modswitch(cur(), logn, L, mext.data(), t, B, d1.p, d2.p, dk.p(), dout.p));
-        else check(hp_dev_ckks_mult_relin_rescale_at(cur(), logn, L, L0, mext.data(), B, d1.p, d2.p, dk.p(), dout.p));
-    } else {
-        Dst dq(B * 3 * L * n);
-        check(hp_dev_mult_low_level(cur(), logn, L, q.data(), B, d1.p, d2.p, dq.p));
-        if (bgv) check(hp_dev_bgv_relinearize(cur(), logn, L, mext.data(), 1 /* bgv.h:32 */, B, dq.p, dk.p(), dout.p));
-        else check(hp_dev_ckks_relinearize_at(cur(), logn, L, L0, mext.data(), B, dq.p, dk.p(), dout.p));
-    }
-    return result_batch<Ct>(B, n, Lout, q, dout);
+    std::vector<Ct> out = result_shells<Ct>(B, n, Lout, q);
+    for_slices(B, [&](size_t lo, size_t hi) {
+        const size_t S = hi - lo;
+        DevKey dk(key, L0, n);   // (the key on this slice's device: assembled there on first use, cached per rank)
+        Src d1 = Access::batch_in(halves(a, lo, hi), L), d2 = Access::batch_in(halves(b, lo, hi), L);
+        Dst dout(S * 2 * Lout * n);
+        if (drop) {
+            if (bgv) check(hp_dev_bgv_mult_relin_modswitch(cur(), logn, L, mext.data(), t, S, d1.p, d2.p, dk.p(), dout.p));
+            else check(hp_dev_ckks_mult_relin_rescale_at(cur(), logn, L, L0, mext.data(), S, d1.p, d2.p, dk.p(), dout.p));
+        } else {
+            Dst dq(S * 3 * L * n);
+            check(hp_dev_mult_low_level(cur(), logn, L, q.data(), S, d1.p, d2.p, dq.p));
+            if (bgv) check(hp_dev_bgv_relinearize(cur(), logn, L, mext.data(), 1 /* bgv.h:32 */, S, dq.p, dk.p(), dout.p));
+            else check(hp_dev_ckks_relinearize_at(cur(), logn, L, L0, mext.data(), S, dq.p, dk.p(), dout.p));
+        }
+        bind_slice(out, lo, hi, dout, Lout);
+    });
+    return out;
 }
 
 // rescale_inplace / mod_switch_inplace by one prime on a batch of one shape
@@ -2348,21 +2569,23 @@ template <class Ct> void drop_batch(std::vector<Ct> &cts, bool bgv, u64 t, size_
     const size_t B = cts.size();
     size_t logn = 0;
     while (((size_t)1 << logn) < n) logn++;
-    OpScope op({}, 0);
-    Src din = Access::batch_in(halves(cts), L);
-    Dst dout(B * 2 * (L - 1) * n);
-    if (bgv) check(hp_dev_bgv_mod_switch(cur(), logn, L, q.data(), t, B, din.p, dout.p));
-    else check(hp_dev_ckks_rescale(cur(), logn, L, q.data(), B, din.p, dout.p));
+    for_slices(B, [&](size_t lo, size_t hi) {
+        const size_t S = hi - lo;
+        Src din = Access::batch_in(halves(cts, lo, hi), L);
+        Dst dout(S * 2 * (L - 1) * n);
+        if (bgv) check(hp_dev_bgv_mod_switch(cur(), logn, L, q.data(), t, S, din.p, dout.p));
+        else check(hp_dev_ckks_rescale(cur(), logn, L, q.data(), S, din.p, dout.p));
 #ifdef HEHUB_AMD_BIND_REFERENCE
-    limb_copies_wait();   // (remove_components hands limb blocks back to hehub's pool: their uploads must have happened, see drop_last_prime)
+        limb_copies_wait();   // (remove_components hands limb blocks back to hehub's pool: their uploads must have happened, see drop_last_prime)
 #endif
-    std::vector<RnsIntVec *> polys;
-    for (Ct &ct : cts)
-        for (int h = 0; h < 2; h++) {
-            ct[h].remove_components();
-            polys.push_back(&ct[h]);
-        }
-    Access::bind_many(polys, dout, L - 1);
+        std::vector<RnsIntVec *> polys;
+        for (size_t i = lo; i < hi; i++)
+            for (int h = 0; h < 2; h++) {
+                cts[i][h].remove_components();
+                polys.push_back(&cts[i][h]);
+            }
+        Access::bind_many(polys, dout, L - 1);
+    });
 }
 
 std::vector<ckks::CkksCt> ckks_mult(const std::vector<ckks::CkksCt> &a, const std::vector<ckks::CkksCt> &b, const RlweKsk &key, bool rescale) {
@@ -2424,13 +2647,15 @@ std::vector<ckks::CkksCt> ckks_key_switched(const std::vector<ckks::CkksCt> &cts
     std::vector<u64> mext;
     const size_t L0 = check_ext_prod(cts[0][1], key, mext);
     const size_t logn = cts[0][1].log_dimension(), B = cts.size();
-    OpScope op({}, 0);
-    DevKey dk(key, L0, n);
-    Src din = Access::batch_in(halves(cts), L);
-    Dst dout(B * 2 * L * n);
-    if (conj) check(hp_dev_ckks_conjugate_at(cur(), logn, L, L0, mext.data(), B, din.p, dk.p(), dout.p));
-    else check(hp_dev_ckks_rotate_at(cur(), logn, L, L0, mext.data(), B, step, din.p, dk.p(), dout.p));
-    out = result_batch<ckks::CkksCt>(B, n, L, q, dout);
+    out = result_shells<ckks::CkksCt>(B, n, L, q);
+    for_slices(B, [&](size_t lo, size_t hi) {
+        DevKey dk(key, L0, n);
+        Src din = Access::batch_in(halves(cts, lo, hi), L);
+        Dst dout((hi - lo) * 2 * L * n);
+        if (conj) check(hp_dev_ckks_conjugate_at(cur(), logn, L, L0, mext.data(), hi - lo, din.p, dk.p(), dout.p));
+        else check(hp_dev_ckks_rotate_at(cur(), logn, L, L0, mext.data(), hi - lo, step, din.p, dk.p(), dout.p));
+        bind_slice(out, lo, hi, dout, L);
+    });
     for (size_t i = 0; i < B; i++) out[i].scaling_factor = cts[i].scaling_factor;
     return out;
 }
@@ -2470,28 +2695,40 @@ std::vector<ckks::CkksCt> ckks_rotate_many(const std::vector<const ckks::CkksCt 
     for (size_t i = 1; i < B; i++)
         if (check_ext_prod((*cts[i])[1], *keys[i], mext_i) != L0 || mext_i != mext) throw std::invalid_argument("Inconsistent RGSW ciphertext.");
     const size_t logn = (*cts[0])[1].log_dimension();
-    OpScope op({}, 0);
-    std::vector<DevKey> dks;
-    dks.reserve(B);
-    std::vector<const u64 *> kp;
-    for (size_t i = 0; i < B; i++) {   // (a key that appears several times is assembled once: the key cache, or the earlier element)
-        size_t same = i;
-        for (size_t j = 0; j < i && same == i; j++)
-            if (keys[j] == keys[i]) same = j;
-        if (same < i) { kp.push_back(kp[same]); continue; }
-        dks.emplace_back(*keys[i], L0, n);
-        kp.push_back(dks.back().p());
-    }
-    std::vector<const u64 *> polys;   // the operands are read where they are: the same object may appear many times
-    std::vector<Src> holds;
-    for (const ckks::CkksCt *ct : cts)
-        for (int h = 0; h < 2; h++) {
-            holds.push_back(Access::in((*ct)[h], L));
-            polys.push_back(holds.back().p);
+    out = result_shells<ckks::CkksCt>(B, n, L, q);
+    // ONE ciphertext under many keys (src/circuits/linear_algebra.h:123-130) is one operand: it stays on its device, the batch is not cut
+    // (a slice elsewhere would drag the vector and every key of the slice over).  Different ciphertexts: contiguous slices, one per rank.
+    bool one_ct = true;
+    for (size_t i = 1; i < B; i++) one_ct = one_ct && cts[i] == cts[0];
+    auto run = [&](size_t lo, size_t hi) {
+        std::vector<DevKey> dks;
+        dks.reserve(hi - lo);
+        std::vector<const u64 *> kp;
+        for (size_t i = lo; i < hi; i++) {   // (a key that appears several times is assembled once: the key cache, or the earlier element)
+            size_t same = i;
+            for (size_t j = lo; j < i && same == i; j++)
+                if (keys[j] == keys[i]) same = j;
+            if (same < i) { kp.push_back(kp[same - lo]); continue; }
+            dks.emplace_back(*keys[i], L0, n);
+            kp.push_back(dks.back().p());
         }
-    Dst dout(B * 2 * L * n);
-    check(hp_dev_ckks_rotate_many_rows(cur(), logn, L, L0, mext.data(), B, steps.data(), nullptr, polys.data(), kp.data(), dout.p));
-    out = result_batch<ckks::CkksCt>(B, n, L, q, dout);
+        std::vector<const u64 *> polys;   // the operands are read where they are: the same object may appear many times
+        std::vector<Src> holds;
+        for (size_t i = lo; i < hi; i++)
+            for (int h = 0; h < 2; h++) {
+                holds.push_back(Access::in((*cts[i])[h], L));
+                polys.push_back(holds.back().p);
+            }
+        Dst dout((hi - lo) * 2 * L * n);
+        check(hp_dev_ckks_rotate_many_rows(cur(), logn, L, L0, mext.data(), hi - lo, steps.data() + lo, nullptr, polys.data(), kp.data(), dout.p));
+        bind_slice(out, lo, hi, dout, L);
+    };
+    if (one_ct) {
+        OpScope op({Access::home((*cts[0])[0]), Access::home((*cts[0])[1])}, 0);
+        run(0, B);
+    } else {
+        for_slices(B, run);
+    }
     for (size_t i = 0; i < B; i++) out[i].scaling_factor = cts[i]->scaling_factor;
     return out;
 }
@@ -2515,11 +2752,13 @@ std::vector<ckks::CkksCt> ckks_addsub(const std::vector<ckks::CkksCt> &a, const 
         return out;
     }
     const size_t B = a.size();
-    OpScope op({}, 0);
-    Src da = Access::batch_in(halves(a), L), db = Access::batch_in(halves(b), L);
-    Dst dout(B * 2 * L * n);
-    dev_binary(sub ? Bin::sub : Bin::add, n, L, q.data(), 2 * B, da.p, db.p, dout.p);
-    out = result_batch<ckks::CkksCt>(B, n, L, q, dout);
+    out = result_shells<ckks::CkksCt>(B, n, L, q);
+    for_slices(B, [&](size_t lo, size_t hi) {
+        Src da = Access::batch_in(halves(a, lo, hi), L), db = Access::batch_in(halves(b, lo, hi), L);
+        Dst dout((hi - lo) * 2 * L * n);
+        dev_binary(sub ? Bin::sub : Bin::add, n, L, q.data(), 2 * (hi - lo), da.p, db.p, dout.p);
+        bind_slice(out, lo, hi, dout, L);
+    });
     for (size_t i = 0; i < B; i++) {
         out[i].scaling_factor = a[i].scaling_factor;
         for (int h = 0; h < 2; h++) out[i][h].rep_form = a[i][h].rep_form;

@@ -47,6 +47,9 @@ struct TransferStats {
     // ... and the groups of rotations / conjugations that ran with a key per ciphertext (hp_dev_ckks_rotate_many)
     unsigned long long deferred_many_key_groups = 0;
     unsigned long long deferred_chain_sums = 0;   // ... += / -= chains of add / sub calls that ran as ONE pass (hp_dev_poly_fold_rows): calls folded
+    // devices: engine calls per device rank, and the copies between ranks an operand on the wrong device cost (hp_memcpy_peer_async)
+    unsigned long long calls_by_device[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long peer_copies = 0, peer_bytes = 0;
 };
 TransferStats transfer_stats();
 
@@ -58,6 +61,20 @@ TransferStats transfer_stats();
 /// spreads calls over the lanes only while something is running.  A look at ONE limb (`ct[1][0][i]`, `view(k)`) downloads that limb.
 int lanes();
 void set_lanes(int n);
+/// Devices (own-mirror build): the GPUs of the node the layer spreads hehub's calls over.  hehub has no devices; its callers
+/// hold many INDEPENDENT ciphertexts (src/circuits/linear_algebra.h:109-133, examples/ckks_example.cpp:10-27).  With n device ranks
+///   * a call runs on the device where its first device-resident operand lives; a call on host-only operands goes to the next rank
+///     round robin and uploads them there -- independent ciphertexts spread over the GPUs, a dependent chain stays on its GPU;
+///   * recorded calls are grouped per rank; the groups of different ranks run side by side;
+///   * the batched forms below cut a batch into contiguous slices, one per rank (batch / n each, no collective);
+///   * keys and tables are replicated per rank on first use; an operand found on another rank is copied over one xGMI link
+///     (TransferStats::peer_copies).
+/// Results are word for word those of one device.  Default: one rank on HIP device HEHUB_AMD_DEVICE (0); HEHUB_AMD_DEVICES=<n> = devices
+/// 0 .. n-1, HEHUB_AMD_DEVICES=<a>,<b>,.. = those devices (a device may repeat: ranks then share it -- how the one-GPU tests run this).
+/// set_devices() drains the layer first; a rank that has been used keeps its device.  At most 8 ranks.
+int devices();
+void set_devices(int n);
+void set_devices(const std::vector<int> &hip_devices);
 /// Deferred mode (own-mirror build; ON by default since round 6 -- HEHUB_AMD_DEFER=0 in the environment or set_deferred(false) give
 /// the call-by-call behaviour back; the binding build over hehub's own host-memory objects never defers): the scheme-level calls of hehub's
 /// interface -- mult_low_level, relinearize, mult, rotate, conjugate, rescale_inplace, mod_switch_inplace, add / sub of ciphertexts,

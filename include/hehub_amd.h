@@ -129,6 +129,12 @@ int hp_host_register(hp_ctx *ctx, void *hptr, size_t bytes);
 int hp_host_unregister(hp_ctx *ctx, void *hptr);
 int hp_memcpy_h2d_async(hp_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int hp_memcpy_d2h_async(hp_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+/* Device memory of one context -> device memory of another (the two may sit on different GPUs of the node, on one GPU, or be the same
+ * context): enqueued on DST's stream.  Order it behind the producer with hp_ctx_wait_for(dst_ctx, src_ctx) first.  Between two GPUs the
+ * copy crosses one xGMI link (peer access is enabled for the pair on first use; without it the runtime stages the copy).  hehub has no
+ * devices; the host layer uses this when an operand lives on another GPU than the call (hehub_amd/host: "devices"). */
+int hp_memcpy_peer_async(hp_ctx *dst_ctx, void *d_dst, hp_ctx *src_ctx, const void *d_src, size_t bytes);
+int hp_ctx_device(hp_ctx *ctx);   /* the HIP device ordinal the context was created on (HP_EINVAL < 0 for NULL) */
 /* A polynomial whose limbs are SEPARATE registered host blocks (rns.h:15-156: one SmartArray per limb) <-> its contiguous device rows
  * u64[rows][words], by ONE kernel that reads / writes the host blocks over PCIe: 47-49 GB/s either way on an MI355X against
  * 11-17 GB/s for one DMA command per 256 KiB block (tools/ubench/ubench_pcie.hip, profiles/archive/r04_ubench_pcie.txt).  Every h_rows[r] must be

@@ -80,8 +80,10 @@ def test_bench_line_reports_an_initialised_rccl_communicator():
                           "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, (out.stdout[-2000:], out.stderr[-3000:])
-    # RCCL's version banner (printed on fd 1 when the communicator is created) must not reach the bench's stdout
-    assert [l for l in out.stdout.splitlines() if l.strip()] == lines, out.stdout[-2000:]
+    # RCCL's version banner (printed on fd 1 when the communicator is created) must not reach the bench's stdout: nothing but the
+    # `#section` lines and, LAST, the contract line
+    nonempty = [l for l in out.stdout.splitlines() if l.strip()]
+    assert nonempty[-1] == lines[0] and all(l.startswith("#section ") for l in nonempty[:-1]), out.stdout[-2000:]
     r = json.loads(lines[0])
     assert r["rccl_ranks"] == 1 and r["rccl"]["initialised"] is True and r["rccl"]["backend"] == "nccl" and r["verified"] is True
 
