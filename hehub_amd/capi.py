@@ -105,6 +105,8 @@ SIGNATURES = {
     "hp_node_placement": (INT, [P, szt, P, P]),
     "hp_device_numa": (INT, [INT, P, P, szt]),
     "hp_node_peer_matrix": (INT, [P, P]),
+    "hp_node_set_transport": (INT, [P, INT]),
+    "hp_node_get_transport": (INT, [P]),
     "hp_node_slice": (INT, [P, szt, szt, C.POINTER(szt), C.POINTER(szt)]),
     "hp_node_sync": (INT, [P]),
     "hp_node_replicate": (INT, [P, P, szt, P]),

@@ -26,10 +26,54 @@
 #include <memory>
 #include <thread>
 
+#include <dlfcn.h>
 #include <pthread.h>
 #include <sched.h>
 
+#include <rccl/rccl.h>   // types and prototypes only: the library itself is loaded on demand (hp_node_set_transport), never linked
+
 using namespace hpi;
+
+// ---- RCCL, loaded on demand ---------------------------------------------------------------------------------------------------------
+// north star: "RCCL all-gather over xGMI ... for the key-switch accumulation".  The limb-sharded plan below can run its exchanges as
+// RCCL collectives (HP_TRANSPORT_RCCL) instead of direct peer writes; the engine library does not link librccl -- a process that never
+// asks for the collective never loads it.
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string why;   // when lib == nullptr: what went wrong
+};
+Rccl &rccl() {
+    static Rccl &r = *[] {
+        Rccl *x = new Rccl;
+        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            x->lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (x->lib) break;
+        }
+        if (!x->lib) {
+            const char *e = dlerror();
+            x->why = std::string("librccl.so could not be loaded: ") + (e ? e : "?");
+            return x;
+        }
+        x->CommInitAll = (decltype(x->CommInitAll))dlsym(x->lib, "ncclCommInitAll");
+        x->CommDestroy = (decltype(x->CommDestroy))dlsym(x->lib, "ncclCommDestroy");
+        x->AllGather = (decltype(x->AllGather))dlsym(x->lib, "ncclAllGather");
+        x->Broadcast = (decltype(x->Broadcast))dlsym(x->lib, "ncclBroadcast");
+        x->GetErrorString = (decltype(x->GetErrorString))dlsym(x->lib, "ncclGetErrorString");
+        if (!x->CommInitAll || !x->CommDestroy || !x->AllGather || !x->Broadcast || !x->GetErrorString) {
+            x->why = "librccl.so lacks one of ncclCommInitAll / ncclCommDestroy / ncclAllGather / ncclBroadcast / ncclGetErrorString";
+            x->lib = nullptr;
+        }
+        return x;
+    }();
+    return r;
+}
+} // namespace
 
 namespace {
 
@@ -138,6 +182,9 @@ struct hp_node {
     std::vector<Staging> staging;
     std::mutex mu;        // one node-level call at a time
     std::string err;
+    // how the limb-sharded plans made from now on exchange their limbs (hp_node_set_transport)
+    int transport = HP_TRANSPORT_PEER;
+    std::vector<ncclComm_t> comms;   // HP_TRANSPORT_RCCL: one communicator rank per node rank (ncclCommInitAll over the node's devices)
 };
 
 namespace {
@@ -317,8 +364,38 @@ void hp_node_destroy(hp_node *node) {
     for (size_t r = 0; r < node->staging.size(); r++)
         for (int s = 0; s < 3; s++)
             if (node->staging[r].d[s]) (void)hp_dev_free(node->ctx[r], node->staging[r].d[s]);
+    for (ncclComm_t c : node->comms)
+        if (c) (void)rccl().CommDestroy(c);
     for (hp_ctx *c : node->ctx) hp_ctx_destroy(c);
     delete node;
+}
+
+int hp_node_get_transport(const hp_node *node) { return node ? node->transport : HP_EINVAL; }
+int hp_node_set_transport(hp_node *node, int transport) {
+    if (!node) return HP_EINVAL;
+    std::lock_guard<std::mutex> lk(node->mu);
+    if (transport != HP_TRANSPORT_PEER && transport != HP_TRANSPORT_PACKED && transport != HP_TRANSPORT_RCCL)
+        return node_fail(node, HP_EINVAL, "transport: HP_TRANSPORT_PEER, HP_TRANSPORT_PACKED or HP_TRANSPORT_RCCL");
+    if (transport == HP_TRANSPORT_RCCL && node->comms.empty()) {
+        Rccl &R = rccl();
+        if (!R.lib) return node_fail(node, HP_EUNSUPPORTED, R.why);
+        // one communicator rank per node rank; RCCL refuses two ranks of one communicator on one device, so ranks that share a GPU
+        // (the one-GPU tests) cannot use it -- HP_TRANSPORT_PACKED moves the same packed buffers by plain copies there
+        for (size_t a = 0; a < node->devices.size(); a++)
+            for (size_t b = a + 1; b < node->devices.size(); b++)
+                if (node->devices[a] == node->devices[b])
+                    return node_fail(node, HP_EUNSUPPORTED, "HP_TRANSPORT_RCCL needs every rank on its own device (ranks " + std::to_string(a) + " and " +
+                                                                std::to_string(b) + " share one); HP_TRANSPORT_PACKED exchanges the same buffers by copies");
+        int prev = -1;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        std::vector<ncclComm_t> comms(node->devices.size(), nullptr);
+        const ncclResult_t e = R.CommInitAll(comms.data(), (int)node->devices.size(), node->devices.data());
+        if (prev >= 0) (void)hipSetDevice(prev);
+        if (e != ncclSuccess) return node_fail(node, HP_EHIP, std::string("ncclCommInitAll: ") + R.GetErrorString(e));
+        node->comms = comms;
+    }
+    node->transport = transport;
+    return HP_OK;
 }
 
 size_t hp_node_size(const hp_node *node) { return node ? node->ctx.size() : 0; }
@@ -490,8 +567,13 @@ struct hp_node_sharded {
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // coef sent, c_p sent, c_q sent, result sent
         // page-locked host staging per exchange, allocated only for a rank that has a peer it cannot write directly
         uint64_t *hstage[4] = {nullptr, nullptr, nullptr, nullptr};
+        // HP_TRANSPORT_PACKED / _RCCL: the two all-gather shaped exchanges (0: coefficient limbs, 3: result limbs) go through a packed
+        // send buffer u64[rows][pad][N] (pad = the largest number of limbs any rank owns) and a receive buffer u64[W][rows][pad][N]
+        uint64_t *pack[2] = {nullptr, nullptr}, *gath[2] = {nullptr, nullptr};
     };
     std::vector<Rank> rk;
+    int transport = HP_TRANSPORT_PEER;   // the node's transport when the plan was made
+    size_t pad[2] = {0, 0};              // padded limbs per rank of exchange 0 / 3
 };
 
 namespace {
@@ -573,7 +655,7 @@ void free_plan(hp_node_sharded *p) {
     for (size_t r = 0; r < p->rk.size(); r++) {
         hp_ctx *c = p->node->ctx[r];
         auto &R = p->rk[r];
-        for (uint64_t *b : {R.ct1, R.ct2, R.quad, R.coef, R.ks, R.c_p, R.relin, R.c_q, R.out})
+        for (uint64_t *b : {R.ct1, R.ct2, R.quad, R.coef, R.ks, R.c_p, R.relin, R.c_q, R.out, R.pack[0], R.pack[1], R.gath[0], R.gath[1]})
             if (b) (void)hp_dev_free(c, b);
         for (uint64_t *h : R.hstage)
             if (h) (void)hp_host_free(c, h);
@@ -631,44 +713,84 @@ int sharded_run(hp_node_sharded *p, const uint64_t *h_ct1, const uint64_t *h_ct2
         // stage 1: tensor product and strict coefficients of the owned digits              ckks/arith.cpp:55-62, rgsw.cpp:103-105
         if (!rc) step(hp_dev_mult_low_level_range(c, logn, L, mext, B, a0, a1, ct1, ct2, R.quad));
         if (!rc) step(hp_dev_ks_coef_range(c, logn, L, mext, B, a0, a1, d2, 3 * L, R.coef));
-        // exchange 1: owned coefficient limbs into every peer's coef buffer
-        if (!rc) step(send_block(p, r, 0, s, R.coef, [&](size_t d) { return p->rk[d].coef; }, everyone));
-        if (!rc) step(chk_local(c, hipEventRecord(R.ev[0], s), "event"));
-        node->barrier->wait();
-        if (all_ok())
-            for (size_t d = 0; d < W && !rc; d++)
-                if (d != r) step(recv_block(p, r, 0, s, d, R.coef));
+        // One exchange in lockstep.  `mine`: this rank's buffer of the exchanged object (its own part is there already; the others'
+        // parts arrive there); `buf_of(d)`: rank d's buffer of it; e = 0 / 3: every rank contributes its owned limbs (all-gather
+        // shaped), e = 1 / 2: `root` has the whole object (broadcast shaped); receive: this rank needs the others' parts.
+        //   HP_TRANSPORT_PEER    the sender writes its part straight into every receiver's buffer (staged through page-locked host
+        //                        memory where a pair has no peer access), ordered by the sender's event
+        //   HP_TRANSPORT_RCCL    ncclAllGather of the packed, padded parts / ncclBroadcast from the root on the ranks' streams
+        //   HP_TRANSPORT_PACKED  the packed parts moved by plain device copies: the collective's data movement without RCCL
+        //                        (ranks that share a GPU cannot form a communicator)
+        auto exchange = [&](size_t e, bool i_send, uint64_t *mine, const std::function<uint64_t *(size_t)> &buf_of, bool receive, size_t root) {
+            const bool gather = e == 0 || e == 3;
+            const size_t gi = e == 3 ? 1 : 0, pad = p->pad[gi];
+            const Block own = block_of(p, e, r);
+            if (p->transport == HP_TRANSPORT_PEER) {
+                if (!rc && i_send)
+                    step(send_block(p, r, e, s, mine, buf_of, gather && !(e == 3 && !d_out) ? std::function<bool(size_t)>(everyone)
+                                                                                             : std::function<bool(size_t)>([&](size_t d) { return gather ? d == 0 : true; })));
+                if (!rc) step(chk_local(c, hipEventRecord(R.ev[e], s), "event"));
+                node->barrier->wait();
+                if (all_ok() && !rc && receive) {
+                    if (gather) {
+                        for (size_t d = 0; d < W && !rc; d++)
+                            if (d != r) step(recv_block(p, r, e, s, d, mine));
+                    } else if (r != root) {
+                        step(recv_block(p, r, e, s, root, mine));
+                    }
+                }
+                return;
+            }
+            // packed transports: own limbs [lo, hi) of every row -> pack[rows][pad][N]
+            if (!rc && gather && i_send && !own.empty())
+                step(chk_local(c, hipMemcpy2DAsync(R.pack[gi], pad * own.n * 8, (const char *)mine + own.lo * own.n * 8, own.pitch(), own.width(), own.rows,
+                                                   hipMemcpyDeviceToDevice, s), "pack owned limbs"));
+            if (!rc) step(chk_local(c, hipEventRecord(R.ev[e], s), "event"));
+            node->barrier->wait();
+            if (!all_ok() || rc) return;     // (every rank sees the same verdict here: all of them make the collective call, or none)
+            const size_t rows = gather ? (e == 0 ? B : 2 * B) : 1, part = rows * pad * n;   // words of one rank's packed part
+            if (p->transport == HP_TRANSPORT_RCCL) {
+                Rccl &X = rccl();
+                const ncclResult_t er = gather ? X.AllGather(R.pack[gi], R.gath[gi], part, ncclUint64, node->comms[r], s)
+                                               : X.Broadcast(mine, mine, 2 * B * n, ncclUint64, (int)root, node->comms[r], s);
+                if (er != ncclSuccess) step(fail_local(c, HP_EHIP, std::string(gather ? "ncclAllGather: " : "ncclBroadcast: ") + X.GetErrorString(er)));
+            } else if (receive) {
+                for (size_t d = 0; d < W && !rc; d++) {
+                    if (d == r || (gather ? block_of(p, e, d).empty() : d != root)) continue;
+                    step(chk_local(c, hipStreamWaitEvent(s, p->rk[d].ev[e], 0), "wait for a peer's exchange"));
+                    if (rc) break;
+                    if (gather)
+                        step(chk_local(c, hipMemcpyPeerAsync(R.gath[gi] + d * part, node->devices[r], p->rk[d].pack[gi], node->devices[d], part * 8, s),
+                                       "copy of a peer's packed limbs"));
+                    else
+                        step(chk_local(c, hipMemcpyPeerAsync(mine, node->devices[r], buf_of(d), node->devices[d], 2 * B * n * 8, s), "copy of the root's limb"));
+                }
+            }
+            // the others' limbs out of gath[W][rows][pad][N] into their places in `mine`
+            if (!rc && gather && receive)
+                for (size_t d = 0; d < W && !rc; d++) {
+                    const Block b = block_of(p, e, d);
+                    if (d == r || b.empty()) continue;
+                    step(chk_local(c, hipMemcpy2DAsync((char *)mine + b.lo * b.n * 8, b.pitch(), R.gath[gi] + d * part, pad * b.n * 8, b.width(), b.rows,
+                                                       hipMemcpyDeviceToDevice, s), "unpack a peer's limbs"));
+                }
+        };
+        // exchange 1: owned coefficient limbs into every peer's coef buffer (the all-gather of the key-switch digits)
+        exchange(0, true, R.coef, [&](size_t d) { return p->rk[d].coef; }, true, 0);
         // stage 2: digits + inner product for the owned output moduli; the owner of p prepares the coefficients of its limb
         if (!rc && all_ok()) step(hp_dev_ks_inner_range_strict(c, logn, L, mext, B, k0, k1, R.coef, d2, 3 * L, d_key[r], R.ks));
-        if (!rc && all_ok() && r == own_p) {
-            step(hp_dev_drop_coeffs(c, logn, L + 1, mext, inner_t, 2 * B, R.ks, R.c_p));
-            if (!rc) step(send_block(p, r, 1, s, R.c_p, [&](size_t d) { return p->rk[d].c_p; }, everyone));
-        }
-        if (!rc) step(chk_local(c, hipEventRecord(R.ev[1], s), "event"));
-        node->barrier->wait();
-        if (all_ok() && !rc && r != own_p) step(recv_block(p, r, 1, s, own_p, R.c_p));
+        if (!rc && all_ok() && r == own_p) step(hp_dev_drop_coeffs(c, logn, L + 1, mext, inner_t, 2 * B, R.ks, R.c_p));
+        exchange(1, r == own_p && all_ok(), R.c_p, [&](size_t d) { return p->rk[d].c_p; }, true, own_p);
         // stage 3: drop p on the owned limbs (+= d0, d1); the owner of q_{L-1} prepares that limb's coefficients
         if (!rc && all_ok())
             step(hp_dev_drop_apply_range_strict(c, logn, L + 1, mext, inner_t, 2 * B, a0, a1, R.ks, R.c_p, R.quad, L, 3 * L, 3, R.relin));
-        if (!rc && all_ok() && r == own_q) {
-            step(hp_dev_drop_coeffs(c, logn, L, mext, p->t, 2 * B, R.relin, R.c_q));
-            if (!rc) step(send_block(p, r, 2, s, R.c_q, [&](size_t d) { return p->rk[d].c_q; }, everyone));
-        }
-        if (!rc) step(chk_local(c, hipEventRecord(R.ev[2], s), "event"));
-        node->barrier->wait();
-        if (all_ok() && !rc && r != own_q) step(recv_block(p, r, 2, s, own_q, R.c_q));
+        if (!rc && all_ok() && r == own_q) step(hp_dev_drop_coeffs(c, logn, L, mext, p->t, 2 * B, R.relin, R.c_q));
+        exchange(2, r == own_q && all_ok(), R.c_q, [&](size_t d) { return p->rk[d].c_q; }, true, own_q);
         // stage 4: drop q_{L-1} on the owned limbs; result limbs go to rank 0 (and to the caller's per-rank buffers)
         uint64_t *out = d_out ? d_out[r] : R.out;
         if (!rc && all_ok()) step(hp_dev_drop_apply_range_strict(c, logn, L, mext, p->t, 2 * B, b0, b1, R.relin, R.c_q, nullptr, 0, 0, 0, out));
-        if (!rc && all_ok()) {
-            if (d_out) step(send_block(p, r, 3, s, out, [&](size_t d) { return d_out[d]; }, everyone));   // every rank ends up with the whole result
-            else if (r != 0) step(send_block(p, r, 3, s, out, [&](size_t d) { return p->rk[d].out; }, [](size_t d) { return d == 0; }));
-        }
-        if (!rc) step(chk_local(c, hipEventRecord(R.ev[3], s), "event"));
-        node->barrier->wait();
-        if (all_ok() && !rc && (d_out || r == 0))
-            for (size_t d = 0; d < W && !rc; d++)
-                if (d != r) step(recv_block(p, r, 3, s, d, out));
+        exchange(3, all_ok() && (d_out || r != 0 || p->transport != HP_TRANSPORT_PEER), out,
+                 [&](size_t d) { return d_out ? d_out[d] : p->rk[d].out; }, d_out || r == 0, 0);
         if (!rc && all_ok() && !d_out && r == 0) step(hp_memcpy_d2h(c, h_out, R.out, B * 2 * (L - 1) * n * 8));
         // the call returns with every stream drained: the next call may overwrite peers' buffers at once
         step(hp_sync(c));
@@ -700,14 +822,23 @@ int hp_node_sharded_create(hp_node *node, size_t logn, size_t L, const uint64_t 
     p->own.resize(W);
     for (size_t r = 0; r < W; r++) slice_of(L + 1, W, r, &p->own[r].first, &p->own[r].second);
     p->rk.resize(W);
+    p->transport = node->transport;
+    if (p->transport != HP_TRANSPORT_PEER)
+        for (size_t r = 0; r < W; r++) {
+            const Block b0 = block_of(p, 0, r), b3 = block_of(p, 3, r);
+            p->pad[0] = std::max(p->pad[0], b0.empty() ? (size_t)0 : b0.hi - b0.lo);
+            p->pad[1] = std::max(p->pad[1], b3.empty() ? (size_t)0 : b3.hi - b3.lo);
+        }
     int rc = run_all(node, [&](size_t r) {
         hp_ctx *c = node->ctx[r];
         auto &R = p->rk[r];
+        const size_t pk0 = batch * p->pad[0] * n, pk3 = 2 * batch * p->pad[1] * n;   // (zero words: never allocated)
         struct { uint64_t **ptr; size_t words; } bufs[] = {
             {&R.ct1, batch * 2 * L * n}, {&R.ct2, batch * 2 * L * n}, {&R.quad, batch * 3 * L * n}, {&R.coef, batch * L * n},
             {&R.ks, batch * 2 * (L + 1) * n}, {&R.c_p, 2 * batch * n}, {&R.relin, batch * 2 * L * n}, {&R.c_q, 2 * batch * n},
-            {&R.out, batch * 2 * (L - 1) * n}};
+            {&R.out, batch * 2 * (L - 1) * n}, {&R.pack[0], pk0}, {&R.gath[0], W * pk0}, {&R.pack[1], pk3}, {&R.gath[1], W * pk3}};
         for (auto &b : bufs) {
+            if (b.words == 0) continue;
             int rc2 = hp_dev_alloc(c, b.words * 8, (void **)b.ptr);
             if (rc2) return rc2;
         }

@@ -49,6 +49,17 @@ class Node:
         """"B" (default) or "A" on every rank's context (include/hehub_amd.h: hp_ctx_set_parity_level)"""
         self._chk(self.lib.hp_node_set_parity_level(self.h, {"B": 0, "A": 1}[level.upper()]))
 
+    TRANSPORTS = {"peer": 0, "rccl": 1, "packed": 2}   # include/hehub_amd.h: HP_TRANSPORT_*
+
+    def set_transport(self, name: str):
+        """how the limb-sharded plans made from now on exchange their limbs: "peer" (direct peer writes, default), "rccl" (ncclAllGather /
+        ncclBroadcast through a communicator over the node's devices: every rank on its own device), "packed" (the collective's packed
+        buffers moved by plain copies)"""
+        self._chk(self.lib.hp_node_set_transport(self.h, self.TRANSPORTS[name]))
+
+    def transport(self) -> str:
+        return {v: k for k, v in self.TRANSPORTS.items()}[self.lib.hp_node_get_transport(self.h)]
+
     def peer_matrix(self) -> np.ndarray:
         """[a][b] = 1 when rank a writes rank b's device memory directly (hp_node_peer_matrix)"""
         m = (C.c_int * (self.world * self.world))()

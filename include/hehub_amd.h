@@ -395,6 +395,21 @@ int hp_node_dev_bgv_mult_relin_modswitch(hp_node *node, size_t logn, size_t L, c
  * (hp_node_peer_matrix) go through the owner's page-locked staging buffer instead.  With L+1 moduli over W ranks the
  * speed-up is bounded by (L+1) / ceil((L+1)/W): 11 moduli over 8 GPUs -> 5.5 x.  plain_modulus 0: CKKS pipeline. */
 typedef struct hp_node_sharded hp_node_sharded;
+/* How the plans made FROM NOW ON exchange their limbs (the four exchanges of one multiplication: the all-gather of the key-switch
+ * coefficient limbs, the broadcasts of the two dropped limbs' coefficients, the all-gather of the result limbs):
+ *   HP_TRANSPORT_PEER    (default) direct peer writes, one xGMI link per shard, ordered by HIP events (staged through page-locked host
+ *                        memory for a pair without peer access)
+ *   HP_TRANSPORT_RCCL    the collective the north star names: ncclAllGather of the packed, padded per-rank parts and ncclBroadcast from
+ *                        the owner, on the ranks' streams.  librccl.so is loaded when this is first asked for (the engine does not link
+ *                        it); one communicator rank per node rank (ncclCommInitAll over the node's devices), so every rank needs its
+ *                        own device -- HP_EUNSUPPORTED otherwise, or when the library cannot be loaded
+ *   HP_TRANSPORT_PACKED  the same packed send / receive buffers as _RCCL, moved by plain device copies (ranks that share a GPU cannot
+ *                        form a communicator: this is how the one-GPU tests cover the packing)
+ * Every sum over the digits for an output modulus is formed on ONE rank in hehub's order (rgsw.cpp:98-153) whatever the transport:
+ * the words are identical under all three (tests/test_gpu_node.py). */
+enum { HP_TRANSPORT_PEER = 0, HP_TRANSPORT_RCCL = 1, HP_TRANSPORT_PACKED = 2 };
+int hp_node_set_transport(hp_node *node, int transport);
+int hp_node_get_transport(const hp_node *node);
 int hp_node_sharded_create(hp_node *node, size_t logn, size_t L, const uint64_t *moduli_ext, uint64_t plain_modulus, size_t batch,
                            hp_node_sharded **out);
 void hp_node_sharded_destroy(hp_node_sharded *plan);

@@ -99,12 +99,12 @@ def test_random_program_over_device_ranks_at_level_a():
 def test_matvec_and_rotate_bench_over_two_ranks():
     """hehub's circuit-level caller (one vector under 30 keys: ONE operand -- the rotations stay on its device) and hehub's own benchmark
     loop (dependent on nothing: consecutive rotations of the same ciphertext stay where it lives)"""
-    from make_matvec import run as run_matvec
+    from make_matvec import CASES, run as run_matvec
     from make_rotate_bench import LOGNS, run as run_rot
     from test_matvec import GOLDEN as MV, binary as mv_binary, key
     from test_rotate_bench import GOLDEN as RB, binary as rb_binary
 
-    case = (13, 6, 16, "short")
+    case = CASES[2]     # N = 8192, L = 6, width 20: 38 rotations of one vector under 38 keys
     got, _, text = run_matvec(mv_binary(), case, {"HEHUB_AMD_DEVICES": "0,0"}, reps=2)
     assert got["eager"] == got["deferred"] == got["batched-form"] == MV[key(case)], text
     rows, text = run_rot(rb_binary(), 3, 0, {"HEHUB_AMD_DEVICES": "0,0"})

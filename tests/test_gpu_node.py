@@ -293,3 +293,54 @@ def test_failing_rank_is_the_one_reported():
         node.free_replicas(dk)
     finally:
         node.close()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_limb_sharded_transports_give_the_same_words(orc, world):
+    """the collective the north star names, inside the C node layer.  hp_node_set_transport: direct peer writes
+    (default), RCCL (ncclAllGather of the packed coefficient-digit parts / of the result limbs, ncclBroadcast of the dropped limbs'
+    coefficients; librccl.so loaded on demand) and the same packed buffers moved by copies.  Every sum over the digits for an output
+    modulus is formed on one rank in hehub's order (rgsw.cpp:98-153), so the words are hehub's under every transport.  RCCL needs one
+    device per rank: on this one-GPU box it runs with ONE rank (the calls, the packing and the unpacking of a one-rank communicator) and
+    must refuse ranks that share the GPU with HP_EUNSUPPORTED; the packed transport covers the multi-rank packing."""
+    from hehub_amd import capi
+    from hehub_amd.engine import HpError
+    from hehub_amd.node import ShardedPlan
+
+    import torch
+
+    node = make_node(world)
+    try:
+        logn, mext, B = 12, [P.P50[1]] + P.P40[:4] + [P.P50[0]], 3
+        n, L = 1 << logn, len(mext) - 1
+        assert node.transport() == "peer"
+        shared = world > 1 and torch.cuda.device_count() < world
+        names = ["peer", "packed"] + ([] if shared else ["rccl"])
+        if shared:
+            with pytest.raises(HpError) as e:
+                node.set_transport("rccl")
+            assert e.value.code == capi.HP_EUNSUPPORTED and "own device" in e.value.msg and node.transport() == "peer"
+        for t in (0, P.C5_T):
+            ct1, ct2, key = case(logn, mext, B, 9100 + world)
+            dk = node.replicate(key)
+            want = np.stack([orc.bgv_mult(mext, t, ct1[i], ct2[i], key) if t else orc.ckks_mult(mext, ct1[i], ct2[i], key) for i in range(B)])
+            for name in names:
+                node.set_transport(name)
+                assert node.transport() == name
+                plan = ShardedPlan(node, logn, mext, B, plain_modulus=t)
+                for rep in range(2):   # (the plan's buffers are reused)
+                    out = plan.mult(ct1, ct2, dk)
+                    assert np.array_equal(out, want), (world, t, name, rep)
+                # operands replicated on the ranks, the whole result left on EVERY rank (the all-gather of the result limbs)
+                tdev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to("cuda:0")
+                r1 = [tdev(ct1) for _ in range(world)]; r2 = [tdev(ct2) for _ in range(world)]
+                ro = [torch.full((B, 2, L - 1, n), -1, dtype=torch.int64, device="cuda:0") for _ in range(world)]
+                torch.cuda.synchronize()
+                plan.mult_dev(r1, r2, dk, ro)
+                for r in range(world):
+                    assert np.array_equal(ro[r].cpu().numpy().view(np.uint64), want), (world, t, name, r)
+                plan.close()
+            node.free_replicas(dk)
+        node.set_transport("peer")
+    finally:
+        node.close()

@@ -13,6 +13,9 @@
 #   5 node_batch.txt      examples/node_batch on N real devices (the C node layer: host-resident and device-resident batches)
 #   6 rccl_allgather.txt  RCCL all_gather bandwidth, 2^20 .. 2^28 bytes per rank (the exchange size of the limb-sharded digits is
 #                         batch x L x N x 8 / ranks bytes per rank)
+#   7 objapi_scale.txt    hehub's OBJECT API over 1 / 2 / 4 / 8 device ranks (HEHUB_AMD_DEVICES; examples/independent_mults at the C3 shape,
+#                         B = 256 per device): the unchanged loop of single calls, the batched form, independent chains -- rates and digests
+#   8 node_transports.txt the limb-sharded plan of the C node layer under its three transports (peer writes / RCCL / packed copies)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
 VIS=$(python -c "import torch; print(torch.cuda.device_count())")
@@ -88,4 +91,18 @@ else
   python tools/rccl_probe.py > $OUT/rccl_allgather.txt 2>&1
 fi
 tail -12 $OUT/rccl_allgather.txt
+
+# 7 ---- hehub's object API over device ranks ------------------------------------------------------------------------------------------
+: > $OUT/objapi_scale.txt
+for n in $SIZES; do
+  if [ $TEST_RANKS -gt 1 ]; then DEVS=$(python -c "print(','.join(['0'] * $n) + (',' if $n == 1 else ''))"); B=$((32 * n)); else DEVS=$n; B=$((256 * n)); fi
+  echo "== HEHUB_AMD_DEVICES=$DEVS examples/independent_mults 15 10 $B all 3 8 $((8 * n)) 6" >> $OUT/objapi_scale.txt
+  HEHUB_AMD_DEVICES=$DEVS examples/independent_mults 15 10 $B all 3 8 $((8 * n)) 6 >> $OUT/objapi_scale.txt 2>&1
+done
+grep -E "^==|^serial [0-9]|^batch [0-9]|^chains [0-9]|^devices|digest" $OUT/objapi_scale.txt | grep -v "chain digest" | head -60
+
+# 8 ---- the C node layer's limb-sharded plan under its three transports ---------------------------------------------------------------
+if [ $TEST_RANKS -gt 1 ]; then python tools/node_transports.py $TEST_RANKS 4 1 > $OUT/node_transports.txt 2>&1; python tools/node_transports.py 1 4 >> $OUT/node_transports.txt 2>&1
+else python tools/node_transports.py $G 8 > $OUT/node_transports.txt 2>&1; fi
+cat $OUT/node_transports.txt
 ls -la $OUT
