@@ -311,7 +311,7 @@ def object_api_section(run: Run):
     ent["digests"] = dg
     ent["digests_equal"] = bool(dg) and dg.get("serial") == dg.get("batch") and dg.get("serial-chain") == dg.get("batch-chain") and \
         dg.get("chains") == dg.get("chains-lanes")
-    # (2) the same program, unchanged, with NOTHING in the environment: the layer's default (calls are recorded and run as batches, hehub.cpp)
+    # (2) the same program, unchanged, with NOTHING in the environment: the layer's default (calls are recorded and run as batches, hehub_amd/host/deferred_*.cpp)
     t0 = time.perf_counter()
     env0 = {k: v for k, v in os.environ.items() if k != "HEHUB_AMD_DEFER"}
     out2 = subprocess.run([build_example("independent_mults")] + [str(a) for a in shape + ["all", 3, 1, 8, 6]], capture_output=True,

@@ -65,16 +65,19 @@ if __name__ == "__main__":
 
 
 HOST_LIB = os.path.join(LIBDIR, "libhehub_amd_host.so")
+# the hehub-compatible host layer (hehub_amd/host/layer.hpp has the map); binding.cpp is empty in this (own-mirror) build
+HOST_SOURCES = ["engine_lanes.cpp", "block_pool.cpp", "residency.cpp", "binding.cpp", "deferred_record.cpp", "deferred_run.cpp",
+                "scheme_calls.cpp", "batched_forms.cpp"]
 
 
 def build_host(force: bool = False, verbose: bool = False) -> str:
     """The hehub-compatible C++ host layer (hehub_amd/host) over the C ABI; plain g++, no HIP needed."""
     build_lib(force=False, verbose=verbose)
-    src = os.path.join(HERE, "host", "hehub.cpp")
-    deps = [src, os.path.join(HERE, "host", "hehub.hpp"), os.path.join(HERE, "host", "hehub_amd_ext.hpp"),
-            os.path.join(os.path.dirname(HERE), "include", "hehub_amd.h")]
+    hdir = os.path.join(HERE, "host")
+    srcs = [os.path.join(hdir, f) for f in HOST_SOURCES]
+    deps = srcs + [os.path.join(hdir, f) for f in os.listdir(hdir) if f.endswith(".hpp")] + [os.path.join(os.path.dirname(HERE), "include", "hehub_amd.h")]
     if force or _stale(HOST_LIB, deps):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", src, "-o", HOST_LIB, f"-L{LIBDIR}", "-lhehub_amd",
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall"] + srcs + ["-o", HOST_LIB, f"-L{LIBDIR}", "-lhehub_amd",
                "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

@@ -47,8 +47,8 @@ using u128 = unsigned __int128;
 // (device to device when the device copy is current), a move leaves the source empty (allocator.h:113-155).  Like hehub
 // itself (process-global unsynchronised caches and pools) the layer is for ONE thread at a time.
 namespace amd {
-struct DevBlock;   // a pooled device allocation (hehub.cpp)
-struct Access;     // the binding's view of a vector's two copies (hehub.cpp)
+struct DevBlock;   // a pooled device allocation (layer.hpp, block_pool.cpp)
+struct Access;     // the layer's view of a vector's two copies (residency.hpp)
 } // namespace amd
 
 class RnsIntVec {
@@ -113,7 +113,7 @@ private:
     mutable std::shared_ptr<amd::DevBlock> blk_;     // device copy: limb k at block + off_ + k * N words
     mutable size_t off_ = 0;
     mutable bool host_ok_ = true, dev_ok_ = false;
-    mutable unsigned long long stamp_ = 0;           // changes whenever the words may have changed (key cache, hehub.cpp)
+    mutable unsigned long long stamp_ = 0;           // changes whenever the words may have changed (key cache, scheme_calls.cpp)
     mutable unsigned long long limb_mask_ = 0, mask_stamp_ = 0;   // while !host_ok_: limbs downloaded one by one since the words last changed (valid for stamp_ == mask_stamp_)
 };
 

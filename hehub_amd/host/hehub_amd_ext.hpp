@@ -7,7 +7,7 @@
 //     a batch whose members do not all have one shape simply runs as that loop of single calls).  hehub's callers loop over
 //     independent ciphertexts (src/circuits/linear_algebra.h:109-133, bench/benchmarks.cpp:24-35); one C3 ciphertext fills
 //     10 .. 100 of the 256 CUs, a batch of 256 fills the GPU: 29.6 k instead of 4.3 k hom-mult/s;
-//   * lanes: how many independent single calls may overlap on the device (own-mirror build; see hehub.cpp "lanes").
+//   * lanes: how many independent single calls may overlap on the device (own-mirror build; see layer.hpp "lanes").
 //
 // Include it after hehub_amd/host/hehub.hpp (which does so itself) or, in a build against hehub's OWN headers over the binding
 // (-DHEHUB_AMD_BIND_REFERENCE), after "fhe/ckks/ckks.h", "fhe/bgv/bgv.h" and "fhe/primitives/keys.h".
@@ -85,7 +85,7 @@ void set_devices(const std::vector<int> &hip_devices);
 /// operands are ready run as ONE batched engine call (rotations and conjugations group across keys and steps: the engine takes a key
 /// per ciphertext; a chain `acc = add(acc, term)` whose intermediate sums nobody else holds runs as one pass over its terms).
 /// An unchanged loop over independent ciphertexts thereby gets the batch rate
-/// (hehub.cpp "deferred execution").  Results are word for word those of the eager calls; a failure inside the engine surfaces when
+/// (layer.hpp "deferred execution", deferred_record.cpp / deferred_run.cpp).  Results are word for word those of the eager calls; a failure inside the engine surfaces when
 /// the queue runs instead of at the call.  set_deferred(false) runs what is pending.
 void set_deferred(bool on);
 bool deferred();

@@ -2,7 +2,7 @@
 //
 // Built only where hehub's tree exists (the `ref_e2e` make target next to the checker): hehub's own parameter
 // generation, sampling, encoding, key generation and decryption, with the hot path (NTT/INTT, coefficient-wise
-// products, key switch, rescale / mod switch, rotation) taken over by hehub_amd/host/hehub.cpp
+// products, key switch, rescale / mod switch, rotation) taken over by hehub_amd/host/*.cpp
 // (-DHEHUB_AMD_BIND_REFERENCE).  Linked without the binding (ref_e2e_cpu) the same program runs on hehub alone.
 //
 //   C3 shape  CKKS N=32768, moduli {50,40x9} bits + 50-bit special prime, scale 2^40:

@@ -48,7 +48,7 @@ REF_TESTS = os.path.join(ROOT, "oracle", "_ref", "ref_tests_amd")
 @pytest.mark.skipif(not os.path.exists(REF_TESTS), reason="oracle/_ref/ref_tests_amd is only built where the reference tree exists (make -C oracle ref_tests)")
 def test_reference_test_suite_over_the_binding():
     """hehub's own Catch2 suite (tests/*.cpp, 481 assertions), linked with hehub's own sampling / encoding /
-    key generation and with hehub_amd/host/hehub.cpp (-DHEHUB_AMD_BIND_REFERENCE) in place of hehub's hot-path
+    key generation and with hehub_amd/host/*.cpp (-DHEHUB_AMD_BIND_REFERENCE) in place of hehub's hot-path
     definitions.  The binary is prebuilt by oracle/Makefile; nothing is read from the reference tree here."""
     env = dict(os.environ, HEHUB_AMD_VERBOSE="1")
     out = subprocess.run([REF_TESTS], capture_output=True, text=True, timeout=900, env=env)

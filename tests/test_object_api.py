@@ -81,7 +81,7 @@ def test_every_mode_prints_hehubs_words(shape):
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(12, 4, 6), (13, 6, 9)])
 def test_deferred_mode_prints_the_same_words(shape):
-    """the layer's default: the scheme-level calls are recorded and run as batches (hehub.cpp "deferred execution") -- every mode of the
+    """the layer's default: the scheme-level calls are recorded and run as batches (hehub_amd/host/deferred_record.cpp, deferred_run.cpp) -- every mode of the
     program must print what the call-by-call run (HEHUB_AMD_DEFER=0) prints, with and without the variable in the environment"""
     args = list(shape) + ["all", 2, 8, 3, 2]
     eager = run(build_example(), args, EAGER)
