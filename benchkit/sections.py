@@ -345,6 +345,13 @@ def object_api_section(run: Run):
                              "digest_equal": bool(dg2) and dg2.get("serial") == dg.get("serial"),
                              "what": "for i: ckks::mult(a[i], b[i], key); ckks::rescale_inplace(.), B = 256, as hehub's callers write it"}
     ent["verified"] = ent["digests_equal"] and de["digests_equal_eager"]
+    # (3) the same program over DEVICE RANKS (HEHUB_AMD_DEVICES: the layer places every call on a device itself): every GPU this process
+    # can see, or -- on a one-GPU box -- two ranks sharing GPU 0 (the code path, not a scaling number; the entry says which)
+    try:
+        ent["devices"] = devices_entry(run, root, shape, dg)
+        ent["verified"] = ent["verified"] and ent["devices"]["verified"]
+    except Exception as e:   # noqa: BLE001
+        ent["devices"] = {"error": repr(e)[:300], "verified": None}
     try:
         ent["matvec"] = matvec_entry(root)
         ent["verified"] = ent["verified"] and ent["matvec"]["verified"]
@@ -355,6 +362,53 @@ def object_api_section(run: Run):
         ent["verified"] = ent["verified"] and ent["reference_benchmark"]["verified"]
     except Exception as e:   # noqa: BLE001
         ent["reference_benchmark"] = {"error": repr(e)[:300], "verified": None}
+    return ent
+
+
+def devices_entry(run: Run, root: str, shape, want):
+    """hehub's object API over device ranks: examples/independent_mults with HEHUB_AMD_DEVICES and nothing else in the environment --
+    the unchanged loop of single calls (recorded, grouped per rank), the batched form (contiguous slices per rank), chains; digests must be
+    the one-device digests `want`; the layer's own counters say how many engine calls each rank made and how many operands had to move"""
+    import os
+    import re
+    import subprocess
+    import time
+
+    from hehub_amd.build import build_example
+
+    visible = run.torch.cuda.device_count()
+    shared = visible < 2
+    ranks = 2 if shared else min(visible, 8)
+    devs = ",".join(["0"] * ranks) if shared else str(ranks)
+    B = shape[2] if shared else shape[2] * ranks      # (shared: the one GPU's batch; real devices: the per-GPU batch on each)
+    args = [str(a) for a in [shape[0], shape[1], B, "all", 3, 1, 8 * ranks, 6]]
+    env = {k: v for k, v in os.environ.items() if k not in ("HEHUB_AMD_DEFER", "HEHUB_AMD_LANES")}
+    t0 = time.perf_counter()
+    out = subprocess.run([build_example("independent_mults")] + args, capture_output=True, text=True, timeout=900, cwd=root,
+                         env=dict(env, HEHUB_AMD_DEVICES=devs))
+    ent = {"program": "HEHUB_AMD_DEVICES=" + devs + " examples/independent_mults " + " ".join(args), "ranks": ranks, "ranks_share_one_gpu": shared,
+           "B": B, "wall_s": round(time.perf_counter() - t0, 1), "unit": "hom-mult/s"}
+    if out.returncode != 0:
+        ent.update(error=(out.stdout[-300:] + out.stderr[-300:]), verified=False)
+        return ent
+    dg = {m.group(1): m.group(2) for m in re.finditer(r"^([\w-]+) digest (\w+)", out.stdout, re.M)}
+    m = re.search(r"^serial ([\d.]+) ms per hom-mult \((\d+) hom-mult/s\)", out.stdout, re.M)
+    if m:
+        ent["unchanged_loop_per_s"] = float(m.group(2))
+    m = re.search(r"^batch ([\d.]+) ms per hom-mult \((\d+) hom-mult/s\)", out.stdout, re.M)
+    if m:
+        ent["batched_call_per_s"] = float(m.group(2))
+    m = re.search(r"devices (\d+) engine calls per device rank:((?: \d+)+); copies between ranks (\d+) \(([\d.]+) MiB\)", out.stdout)
+    if m:
+        ent["engine_calls_by_rank"] = [int(x) for x in m.group(2).split()]
+        ent["copies_between_ranks"] = int(m.group(3))
+        ent["MiB_between_ranks"] = float(m.group(4))
+    # (the digests depend on the batch: only a run at the one-device batch can be compared with the one-device digests)
+    ent["digests_equal_one_device"] = (all(dg.get(k) == want.get(k) for k in ("serial", "batch", "serial-chain", "batch-chain")) if B == shape[2] else None)
+    ent["modes_agree"] = bool(dg) and dg.get("serial") == dg.get("batch") and dg.get("serial-chain") == dg.get("batch-chain")
+    ent["verified"] = ent["modes_agree"] and ent["digests_equal_one_device"] is not False and \
+        all(c > 0 for c in ent.get("engine_calls_by_rank", [0]))
+    ent["summary"] = {"ranks": ranks, "shared_gpu": shared, "unchanged_loop_per_s": ent.get("unchanged_loop_per_s"), "batched_per_s": ent.get("batched_call_per_s")}
     return ent
 
 

@@ -82,7 +82,12 @@ hp_ctx *rank_ctx(int rank) {
     if (!S.v[rank * MAX_LANES].ctx) {
         const int saved = S.cur;
         S.cur = rank * MAX_LANES;
-        (void)cur();
+        try {
+            (void)cur();
+        } catch (...) {
+            S.cur = saved;
+            throw;
+        }
         S.cur = saved;
     }
     return S.v[rank * MAX_LANES].ctx;

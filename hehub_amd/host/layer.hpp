@@ -183,8 +183,14 @@ struct OpScope {
             slot = rank * MAX_LANES + lane;
         }
         S.cur = slot;
+        try {
+            (void)cur();   // (makes the slot's context on first use: may throw -- no engine on that device)
+        } catch (...) {
+            S.cur = saved_;
+            S.depth--;
+            throw;
+        }
         if (!nested) S.last = slot;
-        (void)cur();
         S.v[slot].ticket++;
     }
     ~OpScope() {

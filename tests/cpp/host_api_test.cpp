@@ -730,6 +730,78 @@ static void test_lanes() {
     amd::set_lanes(before);
 }
 
+// device ranks (hehub_amd_ext.hpp: set_devices; here the ranks share the GPU): the program of test_lanes with the calls spread over 1 / 2 /
+// 3 ranks -- independent chains land on different ranks, the fan-in reads what several ranks produced (operands move over), a batched
+// call is cut into per-rank slices -- returns the words of one rank, call by call and recorded; a rank whose device does not exist fails
+// the calls that are routed there with hehub-style exceptions and leaves the layer usable
+static void test_devices() {
+    const int before = amd::devices();
+    if (before != 1) return;   // (the process was started with HEHUB_AMD_DEVICES: its ranks keep their devices; this test sets its own)
+    BatchFixture f;
+    const bool was = amd::deferred();
+    std::vector<std::vector<ckks::CkksCt>> res;
+    for (int mode = 0; mode < 2; mode++)
+        for (int ranks : {1, 2, 3}) {
+            amd::set_deferred(mode == 1);
+            amd::set_devices(std::vector<int>((size_t)ranks, 0));
+            REQUIRE(amd::devices() == ranks);
+            const auto s0 = amd::transfer_stats();
+            // (fresh copies of the inputs made on the HOST side of the fixture: every configuration uploads its own operands)
+            std::vector<ckks::CkksCt> x;
+            for (auto &ct : f.a) {
+                ckks::CkksCt c(ct);
+                for (int h = 0; h < 2; h++) (void)c[h][0][0];   // a writable look: the copy's words are host words again
+                x.push_back(std::move(c));
+            }
+            for (int it = 0; it < 2; it++)
+                for (size_t c = 0; c < x.size(); c++) x[c] = ckks::rotate(ckks::mult(x[c], f.b[c], f.key), f.key, c + 1);
+            ckks::CkksCt acc = ckks::mult(x[0], x[1], f.key);
+            for (size_t c = 2; c < x.size(); c++) acc = ckks::mult(acc, x[c], f.key);
+            x.push_back(acc);
+            auto rot = amd::rotate(x, f.key, 2);          // a batch: contiguous slices, one per rank
+            x.insert(x.end(), rot.begin(), rot.end());
+            auto sq = amd::mult_rescale(x, x, f.key);
+            x.insert(x.end(), sq.begin(), sq.end());
+            amd::synchronize();
+            const auto s1 = amd::transfer_stats();
+            for (int r = 0; r < ranks; r++) REQUIRE(s1.calls_by_device[r] > s0.calls_by_device[r]);   // every rank worked
+            if (ranks > 1) REQUIRE(s1.peer_copies > s0.peer_copies);                                     // the fan-in moved operands
+            res.push_back(std::move(x));
+        }
+    for (size_t v = 1; v < res.size(); v++) {
+        REQUIRE(res[v].size() == res[0].size());
+        for (size_t i = 0; i < res[0].size(); i++) REQUIRE(same_words(res[0][i], res[v][i]));
+    }
+    res.clear();
+    // a device that does not exist: the call routed to that rank throws, the others work, and the layer recovers
+    REQUIRE_THROWS_AS(amd::set_devices(std::vector<int>{}), std::invalid_argument);
+    REQUIRE_THROWS_AS(amd::set_devices(std::vector<int>(9, 0)), std::invalid_argument);
+    amd::set_deferred(false);
+    amd::set_devices(std::vector<int>{0, 0, 0, 4242});
+    int thrown = 0, fine = 0;
+    for (int i = 0; i < 8; i++) {
+        ckks::CkksCt c(f.a[0]);
+        for (int h = 0; h < 2; h++) (void)c[h][0][0];
+        try {
+            auto r = ckks::rotate(c, f.key, 1);
+            (void)r[0].view(0)[0];
+            fine++;
+        } catch (const std::runtime_error &) {
+            thrown++;
+        }
+    }
+    REQUIRE(thrown == 2);   // round robin over four ranks: every fourth host-only call went to the rank without a device
+    REQUIRE(fine == 6);
+    REQUIRE_THROWS_AS(amd::set_devices(2), std::logic_error);   // (rank 1 was made on HIP device 0: asking for device 1 there now is refused)
+    REQUIRE(amd::devices() == 4);
+    amd::set_devices(std::vector<int>{0, 0});
+    ckks::CkksCt again = ckks::rotate(f.a[0], f.key, 1);
+    amd::set_devices(1);
+    ckks::CkksCt again2 = ckks::rotate(f.a[0], f.key, 1);
+    REQUIRE(same_words(again, again2));
+    amd::set_deferred(was);
+}
+
 // deferred mode: the same calls recorded and run as batches -- the words, the argument checks and the object state of the eager calls
 static void test_deferred() {
     BatchFixture f;
@@ -967,7 +1039,7 @@ int main() {
         {"ntt", test_ntt}, {"rns_polynomial", test_rns_polynomial}, {"ckks_rescaling", test_ckks_rescaling},
         {"scheme_level_vs_oracle", test_scheme_level_vs_oracle}, {"plain_ops_and_decrypt_core", test_plain_ops_and_decrypt_core},
         {"ragged_operands", test_ragged_operands}, {"device_residency", test_device_residency}, {"parity_level_a", test_parity_level_a},
-        {"batched_forms", test_batched_forms}, {"lanes", test_lanes}, {"deferred", test_deferred}};
+        {"batched_forms", test_batched_forms}, {"lanes", test_lanes}, {"devices", test_devices}, {"deferred", test_deferred}};
     for (auto &t : tests) {
         try {
             t.fn();

@@ -130,6 +130,10 @@ def test_default_line_carries_both_halves_of_the_metric(tmp_path):
     assert api["verified"] is True and api["digests_equal"] is True and api["deferred"]["digests_equal_eager"] is True
     assert api["deferred"]["fused_triples"] >= 256 and api["unchanged_loop"]["fused_triples"] >= 256 and "numa_node" in full["placement"]
     assert api["unchanged_loop"]["environment"] == "none" and api["unchanged_loop"]["digest_equal"] is True
+    dv = api["devices"]     # the same program over device ranks (here: two ranks sharing the GPU): the one-device digests, every rank worked
+    assert dv["verified"] is True and dv["ranks"] >= 2 and len(dv["engine_calls_by_rank"]) == dv["ranks"] and min(dv["engine_calls_by_rank"]) > 0
+    assert dv["ranks_share_one_gpu"] is False or dv["digests_equal_one_device"] is True
+    assert sm["object_api_devices"]["ranks"] == dv["ranks"]
     mv = api["matvec"]      # the diagonal loop of matrix_vector_mul_short: every mode prints hehub's digest
     assert mv["verified"] is True and set(mv["digests"]) == {"eager", "deferred", "batched-form"}
     assert mv.get("cpu_reference_digest_equal", True) is True
