@@ -15,9 +15,9 @@ cd $R; mkdir -p gpurun_out
     echo "== ... HEHUB_AMD_KEY_CACHE=4 HEHUB_AMD_CT_CACHE=64"; HEHUB_AMD_KEY_CACHE=4 HEHUB_AMD_CT_CACHE=64 oracle/_ref/ref_bench_amd 2>&1 | grep -E "CKKS rotation|ns/op|ms/op|hehub_amd"
   fi
   [ -x oracle/_ref/ref_rotbench_cpu ] && { echo "== the benchmark's loop on synthetic words, hehub alone (one core): oracle/_ref/ref_rotbench_cpu 5"; oracle/_ref/ref_rotbench_cpu 5; }
-  echo "== own mirror, one lane: HEHUB_AMD_LANES=1 examples/rotate_bench 200"; HEHUB_AMD_LANES=1 examples/rotate_bench 200
-  echo "== own mirror, default lanes: examples/rotate_bench 200"; examples/rotate_bench 200
+  echo "== own mirror, one lane: HEHUB_AMD_LANES=1 examples/rotate_bench 200"; HEHUB_AMD_DEFER=0 HEHUB_AMD_LANES=1 examples/rotate_bench 200
+  echo "== own mirror, default lanes: examples/rotate_bench 200"; HEHUB_AMD_DEFER=0 examples/rotate_bench 200
   echo "== own mirror, recorded: HEHUB_AMD_DEFER=1 examples/rotate_bench 200"; HEHUB_AMD_DEFER=1 examples/rotate_bench 200
-  echo "== own mirror, parity level A: HP_PARITY_LEVEL=A examples/rotate_bench 200"; HP_PARITY_LEVEL=A examples/rotate_bench 200
+  echo "== own mirror, parity level A: HP_PARITY_LEVEL=A examples/rotate_bench 200"; HEHUB_AMD_DEFER=0 HP_PARITY_LEVEL=A examples/rotate_bench 200
 } > gpurun_out/${TAG}_ref_benchmark.txt 2>&1
 cat gpurun_out/${TAG}_ref_benchmark.txt

@@ -9,7 +9,7 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_W
            "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS" \
            "FETCH_SIZE" "WRITE_SIZE TCC_HIT TCC_MISS"; do
   i=$((i+1))
-  HEHUB_AMD_LANES=1 rocprofv3 --pmc $SET --kernel-trace -d $R/gpurun_out/pmcs_${TAG}_$i -o p -- $R/examples/independent_mults 15 10 8 serial 2 > $R/gpurun_out/pmcs_${TAG}_$i.log 2>&1
+  HEHUB_AMD_DEFER=0 HEHUB_AMD_LANES=1 rocprofv3 --pmc $SET --kernel-trace -d $R/gpurun_out/pmcs_${TAG}_$i -o p -- $R/examples/independent_mults 15 10 8 serial 2 > $R/gpurun_out/pmcs_${TAG}_$i.log 2>&1
 done
 python $R/tools/rocpd_summary.py $R/gpurun_out/pmcs_${TAG}_*/p_results.db > $R/gpurun_out/${TAG}_split_pmc_summary.txt 2>&1
 rm -rf $R/gpurun_out/pmcs_${TAG}_[0-9]*
