@@ -149,7 +149,7 @@ struct OpScope {
         const bool nested = S.depth > 1;
         int slot = -1;
         const bool one = S.count == 1 && S.ndev == 1;
-        if (one) slot = 0;
+        if (one && force_rank <= 0) slot = 0;   // (a forced rank > 0 with one rank in use: a look at words left on a rank that went out of use)
         // the lane whose most recent call produced one of the operands: a dependent chain stays on one stream
         if (slot < 0 && !forced)
             for (const BlockRef *r : operands) {
