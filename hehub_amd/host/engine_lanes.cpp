@@ -54,7 +54,7 @@ hp_ctx *engine() {
 
 // the context of the lane the current call runs on
 hp_ctx *cur() {
-    hp_ctx *root = engine();
+    (void)engine();
     LaneSet &S = lane_set();
     Lane &L = S.v[S.cur];
     if (!L.ctx) {
@@ -67,11 +67,10 @@ hp_ctx *cur() {
             }
             (void)hp_ctx_set_parity_level(R.ctx, S.level_a ? HP_PARITY_A : HP_PARITY_B);
         }
-        if (!L.ctx) {
+        if (!L.ctx) {   // (a lane of the rank: a fork of its root -- own stream and scratch, the family's tables)
             if (hp_ctx_fork(R.ctx, &L.ctx) != HP_OK) throw std::runtime_error(std::string("hehub_amd: ") + hp_last_error(R.ctx));
             (void)hp_ctx_set_parity_level(L.ctx, S.level_a ? HP_PARITY_A : HP_PARITY_B);
         }
-        (void)root;
     }
     return L.ctx;
 }

@@ -114,7 +114,6 @@ struct Access {
             LaneSet &S = lane_set();
             if (v.blk_->op) flush_all();
             const DevBlock &root = v.blk_->parent ? *v.blk_->parent : *v.blk_;
-            (void)S;
             const int slot = S.active(root.last_wr) && rank_of(root.last_wr) == root.rank ? root.last_wr : root.rank * MAX_LANES;
             OpScope op({}, slot % MAX_LANES, rank_of(slot));   // (on the device that holds the words, whatever call this look is part of)
             track_read(*v.blk_);
@@ -137,7 +136,6 @@ struct Access {
             LaneSet &S = lane_set();
             if (v.blk_->op) flush_all();
             const DevBlock &root = v.blk_->parent ? *v.blk_->parent : *v.blk_;
-            (void)S;
             const int slot = S.active(root.last_wr) && rank_of(root.last_wr) == root.rank ? root.last_wr : root.rank * MAX_LANES;
             OpScope op({}, slot % MAX_LANES, rank_of(slot));
             track_read(*v.blk_);
