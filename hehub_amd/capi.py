@@ -58,6 +58,7 @@ SIGNATURES = {
     "hp_ntt_negacyclic_inplace_lazy": (INT, [P, szt, u64, P]),
     "hp_intt_negacyclic_inplace_lazy": (INT, [P, szt, u64, P]),
     "hp_cache_ntt_factors_strict": (INT, [P, szt, P, szt]),
+    "hp_check_chain": (INT, [P, szt, P, szt, INT]),
     "hp_batched_barrett_lazy": (INT, [P, u64, szt, P]),
     "hp_batched_barrett": (INT, [P, u64, szt, P]),
     "hp_batched_reduce_strict": (INT, [P, u64, szt, P]),

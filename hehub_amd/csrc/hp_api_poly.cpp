@@ -73,6 +73,18 @@ int hp_cache_ntt_factors_strict(hp_ctx *ctx, size_t logn, const uint64_t *moduli
     }
     return HP_OK;
 }
+int hp_check_chain(hp_ctx *ctx, size_t logn, const uint64_t *moduli, size_t count, int montgomery) {
+    HP_ENTER(ctx);
+    HP_REQUIRE(ctx, moduli);
+    if (logn && !logn_ok(logn)) return fail(ctx, HP_EUNSUPPORTED, HP_LOGN_MSG);
+    const Plan *plan;
+    int rc = get_plan(ctx, logn, moduli, count, logn != 0, &plan);
+    if (rc) return rc;
+    if (montgomery)
+        for (auto &c : plan->consts)
+            if ((c.q & 1) == 0) return fail(ctx, HP_EINVAL, "Montgomery reduction needs an odd modulus");
+    return HP_OK;
+}
 int hp_batched_barrett_lazy(hp_ctx *ctx, uint64_t q, size_t n, uint64_t *v) {
     HP_ENTER(ctx);
     return host_vec(ctx, HP_V_BARRETT_LAZY, q, n, v, nullptr, v, 1);

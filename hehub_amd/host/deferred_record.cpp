@@ -56,7 +56,30 @@ const u64 *key_here(const BlockRef &key) {
 }
 
 // record a call: returns the placeholder of its result words
+// What the engine would refuse when the call RUNS is refused when it is RECORDED: hehub throws at the call (ntt.cpp:26-29,43-47 for a
+// modulus the transforms cannot use), and so does the call-by-call mode (check() on the engine call's status).  hp_check_chain builds
+// what the first call on the chain builds anyway (tables, constants -- on the rank the call is recorded for); a chain that has been
+// accepted once on a rank is remembered, so a recorded call costs one set lookup.
+static void validate(const PendingOp &op) {
+    if (op.kind == OpKind::Copy || op.mod.empty()) return;   // (a copy of pending words: no arithmetic, no chain)
+    bool ntt = false, mont = false;
+    switch (op.kind) {
+    case OpKind::Relin: case OpKind::KeySwitch: case OpKind::Drop: case OpKind::Transform: ntt = true; break;
+    case OpKind::MultLow: case OpKind::PolyMul: mont = true; break;
+    default: break;
+    }
+    if (op.kind == OpKind::KeySwitch && !op.conj && op.step >= ((size_t)1 << 17)) throw std::invalid_argument("rotation step out of range");
+    if (op.kind == OpKind::Drop && op.bgv && op.t == 0) throw std::invalid_argument("plain modulus must be positive");
+    typedef std::tuple<int, int, size_t, std::vector<u64>> Key;
+    static std::set<Key> &accepted = *new std::set<Key>;   // (never destroyed, like the pool)
+    Key key(op.rank, (ntt ? 2 : 0) | (mont ? 1 : 0), ntt ? op.logn : 0, op.mod);
+    if (accepted.count(key)) return;
+    check(hp_check_chain(cur(), ntt ? op.logn : 0, op.mod.data(), op.mod.size(), mont ? 1 : 0));
+    accepted.insert(std::move(key));
+}
+
 BlockRef record(std::unique_ptr<PendingOp> op) {
+    validate(*op);   // (throws what the call-by-call mode throws, before anything about the call has been written down)
     OpQueue &Q = op_queue();
     BlockRef ph(new DevBlock, [](DevBlock *b) { delete b; });
     ph->words = op->out_words;

@@ -50,6 +50,8 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
+#include <tuple>
 #include <string>
 #include <unordered_map>
 

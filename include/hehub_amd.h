@@ -157,6 +157,13 @@ int hp_ntt_negacyclic_inplace_lazy(hp_ctx *ctx, size_t log_dimension, uint64_t m
 int hp_intt_negacyclic_inplace_lazy(hp_ctx *ctx, size_t log_dimension, uint64_t modulus, uint64_t *values);
 /* ntt.h:102  void cache_ntt_factors_strict(u64 log_dimension, const std::vector<u64>&) */
 int hp_cache_ntt_factors_strict(hp_ctx *ctx, size_t log_dimension, const uint64_t *moduli, size_t count);
+/* Would the engine accept this modulus chain?  Builds (and keeps) exactly what the first real call on the chain builds -- per-limb
+ * constants, and for log_dimension != 0 the twiddle tables of every modulus at that ring degree -- and returns what that call would:
+ * HP_EINVAL for a modulus the transforms reject (2N does not divide q - 1, more than 59 bits: ntt.cpp:26-29,43-47), for moduli that are
+ * not pairwise coprime, for an even modulus when `montgomery` is set (the products of rns.cpp:120-140 need -q^-1 mod 2^64,
+ * mod_arith.cpp:49-52); HP_EUNSUPPORTED for a ring degree outside 2 .. 2^16.  log_dimension == 0: no transforms on the chain.
+ * The host layer calls this when it RECORDS a call instead of running it, so that the exception comes at the call, as hehub's does. */
+int hp_check_chain(hp_ctx *ctx, size_t log_dimension, const uint64_t *moduli, size_t count, int montgomery);
 /* mod_arith.h:16   batched_barrett_lazy(modulus, vec_len, vec) */
 int hp_batched_barrett_lazy(hp_ctx *ctx, uint64_t modulus, size_t vec_len, uint64_t *vec);
 /* mod_arith.h:18   batched_barrett */

@@ -968,6 +968,33 @@ static void test_deferred() {
     auto eb = bgv::relinearize(bgv::mult_low_level(ba, bb), f.key);
     bgv::mod_switch_inplace(eb);
     REQUIRE(same_words(db, eb) && db.plain_modulus == 65537);
+    // what the ENGINE refuses is refused when the call is recorded, not when the queue runs (round 6: hp_check_chain at record time): a
+    // modulus the transforms cannot use (ntt.cpp:26-29: 2N does not divide q - 1) throws std::invalid_argument at the call in both modes,
+    // nothing is recorded, the object is unchanged and the queue keeps working
+    for (int mode = 0; mode < 2; mode++) {
+        amd::set_deferred(mode == 1);
+        const std::vector<u64> bad{1099510054913ull, 1234567890111111111ull};   // the second: 60.1 bits, 2N does not divide q - 1
+        RnsPolynomial p(f.N, 2, bad);
+        for (size_t k = 0; k < 2; k++)
+            for (auto &w : p[(int)k]) w = rnd() % bad[k];
+        const RnsPolynomial before(p);
+        const auto s0 = amd::transfer_stats();
+        REQUIRE_THROWS_AS(ntt_negacyclic_inplace_lazy(p), std::invalid_argument);
+        REQUIRE(p.rep_form == PolyRepForm::coeff);
+        REQUIRE(p == before);
+        ckks::CkksCt badct(RlweCt{p, p});
+        for (int h = 0; h < 2; h++) badct[h].rep_form = PolyRepForm::value;
+        REQUIRE_THROWS_AS(ckks::rescale_inplace(badct), std::invalid_argument);
+        REQUIRE(badct[0].component_count() == 2);                       // (the drop did not happen)
+        const std::vector<u64> even{1099510054913ull, 1099510054912ull};   // Montgomery products need an odd modulus
+        RnsPolynomial e1(f.N, 2, even), e2(f.N, 2, even);
+        e1.rep_form = e2.rep_form = PolyRepForm::value;
+        REQUIRE_THROWS_AS((void)(e1 * e2), std::invalid_argument);
+        REQUIRE(amd::transfer_stats().deferred_calls == s0.deferred_calls);
+        auto fine = ckks::rotate(f.a[0], f.key, 1);                     // ... and the layer goes on
+        (void)fine[0].view(0)[0];
+    }
+    amd::set_deferred(false);
     // bgv plain operations (bgv/arith.cpp:17-57: the plaintext is lifted into the ciphertext's moduli, transformed and combined): the
     // lift (rns_base_transform, one modulus -> many) and += / -= of polynomials are recorded too -- a loop of them never runs the queue
     {
