@@ -85,8 +85,10 @@ void set_devices(const std::vector<int> &hip_devices);
 /// operands are ready run as ONE batched engine call (rotations and conjugations group across keys and steps: the engine takes a key
 /// per ciphertext; a chain `acc = add(acc, term)` whose intermediate sums nobody else holds runs as one pass over its terms).
 /// An unchanged loop over independent ciphertexts thereby gets the batch rate
-/// (layer.hpp "deferred execution", deferred_record.cpp / deferred_run.cpp).  Results are word for word those of the eager calls; a failure inside the engine surfaces when
-/// the queue runs instead of at the call.  set_deferred(false) runs what is pending.
+/// (layer.hpp "deferred execution", deferred_record.cpp / deferred_run.cpp).  Results are word for word those of the eager calls, and so
+/// are the exceptions: what the engine would refuse (a modulus the transforms cannot use, an even modulus in a product, a rotation step out
+/// of range) is refused by the recording call (hp_check_chain), like every argument check of hehub's; only a failure of the DEVICE (a HIP
+/// error, out of memory) surfaces when the queue runs.  set_deferred(false) runs what is pending.
 void set_deferred(bool on);
 bool deferred();
 /// Upload a vector's host words now (own-mirror build; both copies stay current).  hehub's objects are created on the host; the layer

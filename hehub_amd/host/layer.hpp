@@ -249,8 +249,9 @@ struct Dst {
 // the recorded calls: calls with the same signature (operation, ring degree, moduli, key, step, ...) whose operands are ready run as
 // ONE batched engine call (operands gathered by one kernel unless they already lie packed, results views of one block).  A loop of
 // 256 independent ckks::mult + rescale_inplace so runs as three batch-256 launches groups, 8 interleaved chains as batch-8 ones.
-// Results are word for word those of the eager calls.  What differs: a failure INSIDE the engine (a HIP error, a modulus the
-// transforms reject) surfaces when the queue runs, not at the call that recorded it.
+// Results are word for word those of the eager calls, exceptions included: record() asks the engine whether it accepts the call's modulus
+// chain (hp_check_chain) before anything is written down, so a modulus the transforms reject throws at the call.  What differs: a failure
+// of the DEVICE (a HIP error, out of memory) surfaces when the queue runs, not at the call that recorded it.
 enum class OpKind { MultLow, Relin, KeySwitch, Drop, AddSub, Copy, PolyMul, Transform, PolyAddSub, BaseConv };
 struct PendingOp {
     OpKind kind = OpKind::MultLow;
