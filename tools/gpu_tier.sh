@@ -1,5 +1,5 @@
 #!/bin/bash
-# the full GPU tier (no -x: every failure is listed), then the default bench command as the driver runs it: tools/r06_tier.sh <tag>
+# the full GPU tier (no -x: every failure is listed), then the default bench command as the driver runs it: tools/gpu_tier.sh <tag>
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-r06}
 cd $R; mkdir -p gpurun_out
