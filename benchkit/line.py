@@ -5,7 +5,9 @@ record of it was `parsed: null`.  So the last line is the contract (a few KB, bo
 every detailed section goes
 
   * to `bench_sections.json` in the working directory (`HP_BENCH_SECTIONS=<path>` moves it, `HP_BENCH_SECTIONS=` = no file), and
-  * to stdout BEFORE the contract line, one line per section, `#section <name> <json>` -- never starting with `{`.
+  * to stdout BEFORE the contract line, one line per section, `#section <name> <json>` -- never starting with `{`; a BRIEF copy (floats to 5
+    significant digits, long explanatory strings cut, objects nested deeper than three levels left to the side file) so that everything
+    bench.py prints stays near 20 KB.
 
 `collect(stdout)` puts the two back together (tests, tools).  No NaN / Infinity anywhere: non-finite floats become null.
 """
@@ -34,6 +36,25 @@ def finite(x, digits=7):
         return {str(k): finite(v, digits) for k, v in x.items()}
     if isinstance(x, (list, tuple)):
         return [finite(v, digits) for v in x]
+    return x
+
+
+DEEPER = "(in the side file)"
+
+
+def brief(x, digits=5, maxlen=96, depth=0, maxdepth=3):
+    """the stdout copy of a section: floats to `digits` significant digits, long explanatory strings cut, objects nested deeper than
+    `maxdepth` replaced by a pointer (the side file has everything whole)"""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}") if math.isfinite(x) else None
+    if isinstance(x, str):
+        return x if len(x) <= maxlen else x[:maxlen - 3] + "..."
+    if isinstance(x, dict):
+        if depth >= maxdepth:
+            return DEEPER
+        return {str(k): brief(v, digits, maxlen, depth + 1, maxdepth) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [brief(v, digits, maxlen, depth, maxdepth) for v in x]
     return x
 
 
@@ -120,6 +141,9 @@ def section_names(res):
     return [k for k in res if k not in CONTRACT and k not in ("rccl",)]
 
 
+STDOUT_LIMIT = 24576   # everything bench.py prints (sections + contract line), asserted by the tests
+
+
 def emit(res, out):
     """print the sections, write the side file, print the contract line LAST; returns the line's text"""
     path = os.environ.get("HP_BENCH_SECTIONS", "bench_sections.json")
@@ -134,8 +158,10 @@ def emit(res, out):
             wrote = path
         except OSError as e:    # a read-only working directory must not void the number: the stdout lines still carry the sections
             wrote = f"not written: {e!r}"[:120]
+    # stdout carries a BRIEF copy of every section (5 significant digits, explanatory strings cut): everything bench.py prints stays well
+    # inside 32 KiB, so a reader that keeps only the tail of the output still has whole lines; the side file has every digit and word
     for k in names:
-        print(PREFIX + k + " " + json.dumps(full[k], allow_nan=False, separators=(",", ":")), file=out)
+        print(PREFIX + k + " " + json.dumps(brief(res[k]), allow_nan=False, separators=(",", ":")), file=out)
     line = contract_line(res, wrote)
     text = json.dumps(line, allow_nan=False)
     if len(text.encode()) >= LINE_LIMIT:     # never again a line the driver cannot read: drop the optional parts, loudly

@@ -11,14 +11,16 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from benchkit.line import LINE_LIMIT, collect, strict_loads   # noqa: E402
+from benchkit.line import LINE_LIMIT, STDOUT_LIMIT, brief, collect, strict_loads   # noqa: E402
 
 REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data", "config", "roofline", "cpu_baseline"}
 
 
 def run_bench(flags, timeout=900, env=None, cwd=None):
-    """bench.py as the driver runs it; returns (the last stdout line parsed ALONE and strictly, contract + sections merged, process)"""
+    """bench.py as the driver runs it; returns (the last stdout line parsed ALONE and strictly, contract + sections merged, process).
+    The sections come from the side file when the run wrote one into `cwd` (every digit, every level), else from the brief copies on
+    stdout."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + flags, capture_output=True, text=True, timeout=timeout,
                          env=env, cwd=cwd)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
@@ -29,6 +31,14 @@ def run_bench(flags, timeout=900, env=None, cwd=None):
     line = strict_loads(last)                                                         # ... strict JSON: no NaN / Infinity
     got, full = collect(out.stdout)
     assert got == line
+    assert len(out.stdout.encode()) < STDOUT_LIMIT, len(out.stdout)                   # ... and everything printed stays small
+    side_path = os.path.join(cwd, "bench_sections.json") if cwd else None
+    if side_path and os.path.exists(side_path) and line.get("sections", {}).get("file") == "bench_sections.json":
+        with open(side_path) as f:
+            side = strict_loads(f.read())
+        for name in line["sections"]["names"]:     # the stdout lines are the brief copies of what the side file holds
+            assert json.dumps(brief(side[name]), sort_keys=True) == json.dumps(brief(full[name]), sort_keys=True), name
+        full = dict(line, **{k: side[k] for k in line["sections"]["names"]})
     return line, full, out
 
 
@@ -67,12 +77,8 @@ def test_default_line_carries_both_halves_of_the_metric(tmp_path):
                            timeout=1800, cwd=str(tmp_path))
     assert REQUIRED <= set(r) and r["metric"] == "ckks_hom_mult_per_s" and r["config"]["batch_per_gpu"] == 256
     assert r["verified"] is True and r["verify"]["outputs_compared_per_gpu"] == 256 and r["verify"]["checker"] in ("reference", "port")
-    # the side file holds what the stdout lines hold
-    with open(tmp_path / "bench_sections.json") as f:
-        side = strict_loads(f.read())
-    assert r["sections"]["file"] == "bench_sections.json" and set(r["sections"]["names"]) <= set(side)
-    for name in r["sections"]["names"]:
-        assert json.dumps(side[name], sort_keys=True) == json.dumps(full[name], sort_keys=True), name
+    # (run_bench compared the brief stdout copies with the side file and handed back the side file's sections)
+    assert r["sections"]["file"] == "bench_sections.json" and os.path.exists(tmp_path / "bench_sections.json")
     sm = r["summary"]
     assert {"ntt_fwd_per_s", "ntt_inv_per_s", "ntt_fwd_frac", "c2_fwd_per_s", "c2_fwd_frac", "c2_inv_frac", "bgv_per_s", "level_a_per_s",
             "object_api_single_per_s", "object_api_batched_per_s", "object_api_unchanged_loop_per_s", "step_traffic_bytes_per_op",

@@ -11,6 +11,8 @@ import json, sys
 sys.path.insert(0, '.')
 from benchkit.line import collect
 r=collect(open('gpurun_out/${TAG}_bench.json').read())[1]
+import os
+if os.path.exists('bench_sections.json'): r.update({k: v for k, v in json.load(open('bench_sections.json')).items() if k in r})   # every level of the sections
 print('hom-mult/s', round(r['value']), 'verified', r.get('verified'), 'spread ms', round(r['roofline']['avg_launch_ms'],3), 'frac', round(r['roofline']['frac'],3))
 for n,e in r['ntt']['by_N'].items():
     print(n, 'fwd', round(e['forward']['frac_of_hbm_peak'],3), 'inv', round(e['inverse']['frac_of_hbm_peak'],3), e.get('verified'))
