@@ -161,7 +161,7 @@ def emit(res, out):
     # stdout carries a BRIEF copy of every section (5 significant digits, explanatory strings cut): everything bench.py prints stays well
     # inside 32 KiB, so a reader that keeps only the tail of the output still has whole lines; the side file has every digit and word
     for k in names:
-        print(PREFIX + k + " " + json.dumps(brief(res[k]), allow_nan=False, separators=(",", ":")), file=out)
+        print(PREFIX + k + " " + json.dumps(brief(full[k]), allow_nan=False, separators=(",", ":")), file=out)   # (brief OF the side file's values)
     line = contract_line(res, wrote)
     text = json.dumps(line, allow_nan=False)
     if len(text.encode()) >= LINE_LIMIT:     # never again a line the driver cannot read: drop the optional parts, loudly

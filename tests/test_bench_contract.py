@@ -37,7 +37,7 @@ def run_bench(flags, timeout=900, env=None, cwd=None):
         with open(side_path) as f:
             side = strict_loads(f.read())
         for name in line["sections"]["names"]:     # the stdout lines are the brief copies of what the side file holds
-            assert json.dumps(brief(side[name]), sort_keys=True) == json.dumps(brief(full[name]), sort_keys=True), name
+            assert json.dumps(brief(side[name]), sort_keys=True) == json.dumps(full[name], sort_keys=True), name
         full = dict(line, **{k: side[k] for k in line["sections"]["names"]})
     return line, full, out
 

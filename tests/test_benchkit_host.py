@@ -135,7 +135,7 @@ def test_contract_line_is_compact_and_strict(tmp_path, monkeypatch):
         side = L.strict_loads(f.read())
     assert side["ntt"]["by_N"]["4096"]["forward"]["per_s"] == pytest.approx(res["ntt"]["by_N"]["4096"]["forward"]["per_s"], rel=1e-8)
     for name in line["sections"]["names"]:
-        assert L.brief(side[name]) == L.brief(full[name]), name
+        assert L.brief(side[name]) == full[name], name
     with pytest.raises(ValueError):
         L.strict_loads('{"a": NaN}')
     with pytest.raises(ValueError):     # a line over the limit is refused by the reader the tests use
