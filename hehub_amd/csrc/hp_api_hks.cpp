@@ -163,6 +163,23 @@ static int hks_front(hp_ctx *ctx, const Plan *plan, const HpHksConsts *hc, size_
     return HP_OK;
 }
 
+// Parity level A for the drops that end a hybrid key switch (round 6; DESIGN section 7 item 1 of round 5): the FP64 drop kernels of
+// hp_ntt_a.hip take them as they are -- their compile-time flavours 1 / 2 / 5 (no addend / addend on both polynomials / on polynomial 0)
+// for ModDown, flavour 6 (two drops in one transform) for ModDown merged with the rescale.  What differs from hehub's drops is only
+// that the transform's input rows already ARE the per-limb remainders: no centring, which the kernels do against a threshold -- a
+// threshold out of reach (2^62) switches it off.  Constants travel as pairs of doubles (v, RN(v / q)) like every level-A constant.
+static bool a_drop_shape(const u64 *addend, u32 add_mask) { return !addend || add_mask == 0 || add_mask == 3u || add_mask == 1u; }
+static void a_pair(u64 v, u64 q, u64 *bits, u64 *bits_h) {
+    *bits = hp::f64_bits((double)v);
+    *bits_h = hp::f64_bits((double)v / (double)q);
+}
+static void a_raw_rows(HpDropArgs &da) {
+    da.raw_input = 0;
+    da.dc.bgv = 0;
+    da.dc.q_last = hp::f64_bits(0.0);
+    da.dc.half_q_last = hp::f64_bits(4611686018427387904.0);   // 2^62: no word is ever "above half"
+}
+
 static int hks_switch(hp_ctx *ctx, const Plan *plan, const HpHksConsts *hc, size_t logn, size_t L, size_t k, size_t alpha, size_t P,
                       const u64 *pt, size_t pt_pstride, const u64 *key, const u64 *addend, size_t add_poly_stride,
                       size_t add_ct_stride, u32 add_mask, const uint64_t *mext, u64 *out, Carver &cv) {
@@ -180,6 +197,12 @@ static int hks_switch(hp_ctx *ctx, const Plan *plan, const HpHksConsts *hc, size
         da.x = ks; da.L = (u32)E; da.addend = addend; da.add_poly_stride = (u32)add_poly_stride; da.add_ct_stride = (u32)add_ct_stride;
         da.add_mask = addend ? add_mask : 0u; da.out = out; da.out_stride = (u32)L;
         ProfScope ps(ctx, "ntt_drop");
+        if (ctx->cur_a && a_drop_shape(addend, add_mask)) {   // out = canonical residues of (ks - NTT(rem)) P^-1 [+ addend]
+            fj.limbs_a = plan->d_limbs_a;
+            a_raw_rows(da);
+            for (size_t i = 0; i < L; i++) a_pair(da.dc.inv[i], mext[i], &da.dc.inv[i], &da.dc.inv_h[i]);
+            return chk(ctx, hp_launch_ntt_a_drop(fj, da, ctx->stream), "hks fused ModDown (level A)");
+        }
         return chk(ctx, hp_launch_ntt_fast_drop(fj, da, ctx->stream), "hks fused ModDown");
     }
     if ((rc = run_ntt(ctx, batch_job(plan, logn, L, 2 * P, rem, rem, L, L, 0, 0)))) return rc;
@@ -303,7 +326,15 @@ extern "C" int hp_dev_ckks_mult_relin_rescale_hks(hp_ctx *ctx, size_t logn, size
             da.x = ks + (L - 1) * n; da.L = (u32)E; da.addend = quad + (L - 1) * n; da.add_poly_stride = (u32)L;
             da.add_ct_stride = (u32)(3 * L); da.add_mask = 3u; da.out = r_last; da.out_stride = 1;
             ProfScope ps(ctx, "ntt_drop");
-            if ((rc = chk(ctx, hp_launch_ntt_fast_drop(fj, da, ctx->stream), "hks ModDown of the last limb"))) return rc;
+            if (ctx->cur_a) {
+                fj.limbs_a = plan->d_limbs_a + (L - 1);
+                a_raw_rows(da);
+                a_pair(da.dc.inv[0], moduli_ext[L - 1], &da.dc.inv[0], &da.dc.inv_h[0]);
+                rc = chk(ctx, hp_launch_ntt_a_drop(fj, da, ctx->stream), "hks ModDown of the last limb (level A)");
+            } else {
+                rc = chk(ctx, hp_launch_ntt_fast_drop(fj, da, ctx->stream), "hks ModDown of the last limb");
+            }
+            if (rc) return rc;
         }
         {
             HpNttJob lj = batch_job(plan, logn, 1, P2, r_last, c_last, 1, 1, 1, 1);
@@ -334,6 +365,24 @@ extern "C" int hp_dev_ckks_mult_relin_rescale_hks(hp_ctx *ctx, size_t logn, size
         da.x = ks; da.L = (u32)E; da.addend = quad; da.add_poly_stride = (u32)L; da.add_ct_stride = (u32)(3 * L); da.add_mask = 3u;
         da.out = out; da.out_stride = (u32)(L - 1);
         ProfScope ps(ctx, "ntt_drop");
+        if (ctx->cur_a && in_loads) {
+            // the two-drops flavour of hp_ntt_a.hip (DropPre2A has the algebra): z = ((A x + a) - NTT(m c1 + c2)) B with x = ks, a = quad,
+            // c1 = the remainders (as they are), c2 = the centred coefficients of the relinearised last limb, A = m = P^-1, B = q_last^-1 --
+            // by linearity the level-B line above: ((ks - NTT(rem + P centre(c))) P^-1 + quad) q_last^-1
+            fj.limbs_a = plan->d_limbs_a;
+            a_raw_rows(da);
+            da.fin_on = 0;
+            da.q2_last = hp::f64_bits((double)q_last);
+            da.half_q2_last = hp::f64_bits((double)(q_last / 2));
+            for (size_t i = 0; i + 1 < L; i++) {
+                const u64 q = moduli_ext[i], A = da.dc.inv[i], B = da.fin[i];
+                a_pair(A, q, &da.dc.inv[i], &da.dc.inv_h[i]);
+                a_pair(A, q, &da.dc.t[i], &da.dc.t_h[i]);
+                a_pair(1 % q, q, &da.comb_mul[i], &da.comb_mul_h[i]);
+                a_pair(B, q, &da.dc.qlt[i], &da.dc.qlt_h[i]);
+            }
+            return chk(ctx, hp_launch_ntt_a_drop(fj, da, ctx->stream), "hks fused ModDown + rescale (level A)");
+        }
         return chk(ctx, hp_launch_ntt_fast_drop(fj, da, ctx->stream), "hks fused ModDown + rescale");
     }
     if ((rc = hks_switch(ctx, plan, hc, logn, L, k, alpha, batch, quad + 2 * L * n, 3 * L, key, quad, L, 3 * L, 3, moduli_ext, lin, cv)))
