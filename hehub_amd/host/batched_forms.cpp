@@ -44,29 +44,54 @@ template <class Ct> std::vector<Ct> result_shells(size_t B, size_t n, size_t L, 
         out.emplace_back(RlweCt{result_poly(n, L, q, PolyRepForm::value), result_poly(n, L, q, PolyRepForm::value)});
     return out;
 }
-// ... elements [lo, hi) become views of u64[hi - lo][2][L][N], the block one rank's engine call filled
-template <class Ct> void bind_slice(std::vector<Ct> &out, size_t lo, size_t hi, const Dst &d, size_t L) {
+// the elements of a batch that one device rank runs (ascending)
+typedef std::vector<size_t> Part;
+// ... the elements of `part` become views of u64[part.size()][2][L][N], the block one rank's engine call filled
+template <class Ct> void bind_part(std::vector<Ct> &out, const Part &part, const Dst &d, size_t L) {
     std::vector<RnsIntVec *> polys;
-    for (size_t i = lo; i < hi; i++) { polys.push_back(&out[i][0]); polys.push_back(&out[i][1]); }
+    for (size_t i : part) { polys.push_back(&out[i][0]); polys.push_back(&out[i][1]); }
     Access::bind_many(polys, d, L);
 }
-template <class Ct> std::vector<const RnsIntVec *> halves(const std::vector<Ct> &cts, size_t lo, size_t hi) {
+template <class Ct> std::vector<const RnsIntVec *> halves(const std::vector<Ct> &cts, const Part &part) {
     std::vector<const RnsIntVec *> v;
-    v.reserve(2 * (hi - lo));
-    for (size_t i = lo; i < hi; i++) { v.push_back(&cts[i][0]); v.push_back(&cts[i][1]); }
+    v.reserve(2 * part.size());
+    for (size_t i : part) { v.push_back(&cts[i][0]); v.push_back(&cts[i][1]); }
     return v;
 }
-// A batch is cut into contiguous slices, one per device rank (batch / ranks each; with one rank: the whole batch), and
-// f(lo, hi) runs for each slice inside a scope on lane 0 of its rank: a batch fills a GPU by itself, and only one lane per rank
-// grows a batch-sized workspace.  The slices' engine calls are enqueued one after the other and run side by side on their devices.
-template <class F> void for_slices(size_t B, F &&f) {
+// the device rank element i's ciphertext lives on (-1: only on the host so far)
+template <class Ct> int home_of(const Ct &ct) {
+    for (int h = 0; h < 2; h++)
+        if (const BlockRef *r = Access::home(ct[h]))
+            if (*r) return home_rank(**r);
+    return -1;
+}
+// A batch is cut into parts, one per device rank (no collective; with one rank: the whole batch), and f(part) runs for each
+// inside a scope on lane 0 of its rank: a batch fills a GPU by itself, and only one lane per rank grows a batch-sized workspace.  An
+// element whose operand already lives on a rank stays THERE (nothing crosses between ranks: a batched call after a loop of single calls,
+// or on the results of an earlier batched call, finds its operands where they are); the elements that live only on the host fill the
+// ranks up to an even share, contiguously (a batch of host objects: batch / ranks each, the contiguous slices of SURVEY.md 8e).  The
+// parts' engine calls are enqueued one after the other and run side by side on their devices.
+template <class Home, class F> void for_parts(size_t B, Home &&home, F &&f) {
     (void)engine();
-    const int nd = lane_set().ndev;
-    for (int r = 0; r < nd; r++) {
-        const size_t lo = B * (size_t)r / (size_t)nd, hi = B * (size_t)(r + 1) / (size_t)nd;
-        if (lo == hi) continue;
-        OpScope op({}, 0, r);
-        f(lo, hi);
+    const size_t nd = (size_t)lane_set().ndev;
+    std::vector<Part> part(nd);
+    Part homeless;
+    for (size_t i = 0; i < B; i++) {
+        const int h = nd == 1 ? 0 : home(i);
+        if (h >= 0 && (size_t)h < nd) part[(size_t)h].push_back(i);
+        else homeless.push_back(i);
+    }
+    const size_t share = (B + nd - 1) / nd;
+    size_t r = 0;
+    for (size_t i : homeless) {
+        while (r + 1 < nd && part[r].size() >= share) r++;
+        part[r].push_back(i);
+    }
+    for (size_t k = 0; k < nd; k++) {
+        if (part[k].empty()) continue;
+        std::sort(part[k].begin(), part[k].end());
+        OpScope op({}, 0, (int)k);
+        f(part[k]);
     }
 }
 void same_size(size_t a, size_t b) {
@@ -101,10 +126,10 @@ std::vector<Ct> mult_batch(const std::vector<Ct> &a, const std::vector<Ct> &b, c
     if (drop && L == 1) throw std::invalid_argument("Unable to drop the only one prime.");
     const size_t Lout = drop ? L - 1 : L;
     std::vector<Ct> out = result_shells<Ct>(B, n, Lout, q);
-    for_slices(B, [&](size_t lo, size_t hi) {
-        const size_t S = hi - lo;
-        DevKey dk(key, L0, n);   // (the key on this slice's device: assembled there on first use, cached per rank)
-        Src d1 = Access::batch_in(halves(a, lo, hi), L), d2 = Access::batch_in(halves(b, lo, hi), L);
+    for_parts(B, [&](size_t i) { const int h = home_of(a[i]); return h >= 0 ? h : home_of(b[i]); }, [&](const Part &part) {
+        const size_t S = part.size();
+        DevKey dk(key, L0, n);   // (the key on this part's device: assembled there on first use, cached per rank)
+        Src d1 = Access::batch_in(halves(a, part), L), d2 = Access::batch_in(halves(b, part), L);
         Dst dout(S * 2 * Lout * n);
         if (drop) {
             if (bgv) check(hp_dev_bgv_mult_relin_modswitch(cur(), logn, L, mext.data(), t, S, d1.p, d2.p, dk.p(), dout.p));
@@ -115,7 +140,7 @@ std::vector<Ct> mult_batch(const std::vector<Ct> &a, const std::vector<Ct> &b, c
             if (bgv) check(hp_dev_bgv_relinearize(cur(), logn, L, mext.data(), 1 /* bgv.h:32 */, S, dq.p, dk.p(), dout.p));
             else check(hp_dev_ckks_relinearize_at(cur(), logn, L, L0, mext.data(), S, dq.p, dk.p(), dout.p));
         }
-        bind_slice(out, lo, hi, dout, Lout);
+        bind_part(out, part, dout, Lout);
     });
     return out;
 }
@@ -125,9 +150,9 @@ template <class Ct> void drop_batch(std::vector<Ct> &cts, bool bgv, u64 t, size_
     const size_t B = cts.size();
     size_t logn = 0;
     while (((size_t)1 << logn) < n) logn++;
-    for_slices(B, [&](size_t lo, size_t hi) {
-        const size_t S = hi - lo;
-        Src din = Access::batch_in(halves(cts, lo, hi), L);
+    for_parts(B, [&](size_t i) { return home_of(cts[i]); }, [&](const Part &part) {
+        const size_t S = part.size();
+        Src din = Access::batch_in(halves(cts, part), L);
         Dst dout(S * 2 * (L - 1) * n);
         if (bgv) check(hp_dev_bgv_mod_switch(cur(), logn, L, q.data(), t, S, din.p, dout.p));
         else check(hp_dev_ckks_rescale(cur(), logn, L, q.data(), S, din.p, dout.p));
@@ -135,7 +160,7 @@ template <class Ct> void drop_batch(std::vector<Ct> &cts, bool bgv, u64 t, size_
         limb_copies_wait();   // (remove_components hands limb blocks back to hehub's pool: their uploads must have happened, see drop_last_prime)
 #endif
         std::vector<RnsIntVec *> polys;
-        for (size_t i = lo; i < hi; i++)
+        for (size_t i : part)
             for (int h = 0; h < 2; h++) {
                 cts[i][h].remove_components();
                 polys.push_back(&cts[i][h]);
@@ -204,13 +229,13 @@ std::vector<ckks::CkksCt> ckks_key_switched(const std::vector<ckks::CkksCt> &cts
     const size_t L0 = check_ext_prod(cts[0][1], key, mext);
     const size_t logn = cts[0][1].log_dimension(), B = cts.size();
     out = result_shells<ckks::CkksCt>(B, n, L, q);
-    for_slices(B, [&](size_t lo, size_t hi) {
+    for_parts(B, [&](size_t i) { return home_of(cts[i]); }, [&](const Part &part) {
         DevKey dk(key, L0, n);
-        Src din = Access::batch_in(halves(cts, lo, hi), L);
-        Dst dout((hi - lo) * 2 * L * n);
-        if (conj) check(hp_dev_ckks_conjugate_at(cur(), logn, L, L0, mext.data(), hi - lo, din.p, dk.p(), dout.p));
-        else check(hp_dev_ckks_rotate_at(cur(), logn, L, L0, mext.data(), hi - lo, step, din.p, dk.p(), dout.p));
-        bind_slice(out, lo, hi, dout, L);
+        Src din = Access::batch_in(halves(cts, part), L);
+        Dst dout(part.size() * 2 * L * n);
+        if (conj) check(hp_dev_ckks_conjugate_at(cur(), logn, L, L0, mext.data(), part.size(), din.p, dk.p(), dout.p));
+        else check(hp_dev_ckks_rotate_at(cur(), logn, L, L0, mext.data(), part.size(), step, din.p, dk.p(), dout.p));
+        bind_part(out, part, dout, L);
     });
     for (size_t i = 0; i < B; i++) out[i].scaling_factor = cts[i].scaling_factor;
     return out;
@@ -253,37 +278,42 @@ std::vector<ckks::CkksCt> ckks_rotate_many(const std::vector<const ckks::CkksCt 
     const size_t logn = (*cts[0])[1].log_dimension();
     out = result_shells<ckks::CkksCt>(B, n, L, q);
     // ONE ciphertext under many keys (src/circuits/linear_algebra.h:123-130) is one operand: it stays on its device, the batch is not cut
-    // (a slice elsewhere would drag the vector and every key of the slice over).  Different ciphertexts: contiguous slices, one per rank.
+    // (a part elsewhere would drag the vector and every key of the part over).  Different ciphertexts: a part per rank (for_parts).
     bool one_ct = true;
     for (size_t i = 1; i < B; i++) one_ct = one_ct && cts[i] == cts[0];
-    auto run = [&](size_t lo, size_t hi) {
+    auto run = [&](const Part &part) {
         std::vector<DevKey> dks;
-        dks.reserve(hi - lo);
+        dks.reserve(part.size());
         std::vector<const u64 *> kp;
-        for (size_t i = lo; i < hi; i++) {   // (a key that appears several times is assembled once: the key cache, or the earlier element)
-            size_t same = i;
-            for (size_t j = lo; j < i && same == i; j++)
-                if (keys[j] == keys[i]) same = j;
-            if (same < i) { kp.push_back(kp[same - lo]); continue; }
+        std::vector<size_t> st;
+        for (size_t a = 0; a < part.size(); a++) {   // (a key that appears several times is assembled once: the key cache, or the earlier element)
+            const size_t i = part[a];
+            st.push_back(steps[i]);
+            size_t same = a;
+            for (size_t b = 0; b < a && same == a; b++)
+                if (keys[part[b]] == keys[i]) same = b;
+            if (same < a) { kp.push_back(kp[same]); continue; }
             dks.emplace_back(*keys[i], L0, n);
             kp.push_back(dks.back().p());
         }
         std::vector<const u64 *> polys;   // the operands are read where they are: the same object may appear many times
         std::vector<Src> holds;
-        for (size_t i = lo; i < hi; i++)
+        for (size_t i : part)
             for (int h = 0; h < 2; h++) {
                 holds.push_back(Access::in((*cts[i])[h], L));
                 polys.push_back(holds.back().p);
             }
-        Dst dout((hi - lo) * 2 * L * n);
-        check(hp_dev_ckks_rotate_many_rows(cur(), logn, L, L0, mext.data(), hi - lo, steps.data() + lo, nullptr, polys.data(), kp.data(), dout.p));
-        bind_slice(out, lo, hi, dout, L);
+        Dst dout(part.size() * 2 * L * n);
+        check(hp_dev_ckks_rotate_many_rows(cur(), logn, L, L0, mext.data(), part.size(), st.data(), nullptr, polys.data(), kp.data(), dout.p));
+        bind_part(out, part, dout, L);
     };
     if (one_ct) {
+        Part all(B);
+        for (size_t i = 0; i < B; i++) all[i] = i;
         OpScope op({Access::home((*cts[0])[0]), Access::home((*cts[0])[1])}, 0);
-        run(0, B);
+        run(all);
     } else {
-        for_slices(B, run);
+        for_parts(B, [&](size_t i) { return home_of(*cts[i]); }, run);
     }
     for (size_t i = 0; i < B; i++) out[i].scaling_factor = cts[i]->scaling_factor;
     return out;
@@ -309,11 +339,11 @@ std::vector<ckks::CkksCt> ckks_addsub(const std::vector<ckks::CkksCt> &a, const 
     }
     const size_t B = a.size();
     out = result_shells<ckks::CkksCt>(B, n, L, q);
-    for_slices(B, [&](size_t lo, size_t hi) {
-        Src da = Access::batch_in(halves(a, lo, hi), L), db = Access::batch_in(halves(b, lo, hi), L);
-        Dst dout((hi - lo) * 2 * L * n);
-        dev_binary(sub ? Bin::sub : Bin::add, n, L, q.data(), 2 * (hi - lo), da.p, db.p, dout.p);
-        bind_slice(out, lo, hi, dout, L);
+    for_parts(B, [&](size_t i) { const int h = home_of(a[i]); return h >= 0 ? h : home_of(b[i]); }, [&](const Part &part) {
+        Src da = Access::batch_in(halves(a, part), L), db = Access::batch_in(halves(b, part), L);
+        Dst dout(part.size() * 2 * L * n);
+        dev_binary(sub ? Bin::sub : Bin::add, n, L, q.data(), 2 * part.size(), da.p, db.p, dout.p);
+        bind_part(out, part, dout, L);
     });
     for (size_t i = 0; i < B; i++) {
         out[i].scaling_factor = a[i].scaling_factor;

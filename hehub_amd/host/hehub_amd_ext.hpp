@@ -66,7 +66,8 @@ void set_lanes(int n);
 ///   * a call runs on the device where its first device-resident operand lives; a call on host-only operands goes to the next rank
 ///     round robin and uploads them there -- independent ciphertexts spread over the GPUs, a dependent chain stays on its GPU;
 ///   * recorded calls are grouped per rank; the groups of different ranks run side by side;
-///   * the batched forms below cut a batch into contiguous slices, one per rank (batch / n each, no collective);
+///   * the batched forms below cut a batch into parts, one per rank (no collective): an element stays where its operand lives, host-only
+///     elements fill the ranks up to batch / n each, contiguously;
 ///   * keys and tables are replicated per rank on first use; an operand found on another rank is copied over one xGMI link
 ///     (TransferStats::peer_copies).
 /// Results are word for word those of one device.  Default: one rank on HIP device HEHUB_AMD_DEVICE (0); HEHUB_AMD_DEVICES=<n> = devices

@@ -79,7 +79,8 @@ namespace amd {
 //   * a call runs where its operands live (the rank of its first device-resident operand), a call on host-only operands goes to the
 //     next rank round robin and uploads them THERE -- independent ciphertexts spread over the devices, a dependent chain stays put;
 //   * recorded calls carry their rank in the signature: a group is one rank's, groups of different ranks overlap;
-//   * the batched forms cut a batch into contiguous slices, one per rank (batch / ranks each, no collective);
+//   * the batched forms cut a batch into parts, one per rank (no collective): an element stays on the rank its operand
+//     lives on, elements that live only on the host fill the ranks up to batch / ranks each, contiguously;
 //   * keys and tables are replicated per rank on first use (the key cache is keyed by rank);
 //   * an operand that lives on another rank than the call is copied over (hp_memcpy_peer_async: one xGMI link) and, when it is a
 //     vector, stays there -- counted in TransferStats::peer_copies.  Ranks may share a GPU (HEHUB_AMD_DEVICES=0,0: the one-GPU tests).
