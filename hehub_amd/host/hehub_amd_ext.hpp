@@ -70,6 +70,8 @@ void set_lanes(int n);
 ///     elements fill the ranks up to batch / n each, contiguously;
 ///   * keys and tables are replicated per rank on first use; an operand found on another rank is copied over one xGMI link
 ///     (TransferStats::peer_copies).
+/// A vector has one device copy: an operand SHARED by calls on several ranks is moved, not replicated (give each rank its own copy, or keep
+/// such a workload on one rank); keys are the exception (assembled per rank).
 /// Results are word for word those of one device.  Default: one rank on HIP device HEHUB_AMD_DEVICE (0); HEHUB_AMD_DEVICES=<n> = devices
 /// 0 .. n-1, HEHUB_AMD_DEVICES=<a>,<b>,.. = those devices (a device may repeat: ranks then share it -- how the one-GPU tests run this).
 /// set_devices() drains the layer first; a rank that has been used keeps its device.  At most 8 ranks.

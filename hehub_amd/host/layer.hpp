@@ -84,6 +84,10 @@ namespace amd {
 //   * keys and tables are replicated per rank on first use (the key cache is keyed by rank);
 //   * an operand that lives on another rank than the call is copied over (hp_memcpy_peer_async: one xGMI link) and, when it is a
 //     vector, stays there -- counted in TransferStats::peer_copies.  Ranks may share a GPU (HEHUB_AMD_DEVICES=0,0: the one-GPU tests).
+// Known limit: a vector has ONE device copy.  An operand that several ranks read (a shared plaintext, a common second factor) is moved
+// to the rank of each call that reads it, not replicated: chains that were spread first and then share an operand pass it back and forth
+// (peer_copies shows it).  An operand that is resident BEFORE the chains start draws them all to its rank instead (no copies, no
+// spreading).  Independent ciphertexts with their own operands -- the loops of hehub's callers -- have neither problem.
 constexpr int MAX_LANES = 8;                       // lanes per device rank
 constexpr int MAX_DEVS = 8;                        // device ranks
 constexpr int MAX_SLOTS = MAX_LANES * MAX_DEVS;    // slot = rank * MAX_LANES + lane

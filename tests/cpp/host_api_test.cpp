@@ -746,15 +746,20 @@ static void test_devices() {
             amd::set_devices(std::vector<int>((size_t)ranks, 0));
             REQUIRE(amd::devices() == ranks);
             const auto s0 = amd::transfer_stats();
-            // (fresh copies of the inputs made on the HOST side of the fixture: every configuration uploads its own operands)
-            std::vector<ckks::CkksCt> x;
-            for (auto &ct : f.a) {
-                ckks::CkksCt c(ct);
-                for (int h = 0; h < 2; h++) (void)c[h][0][0];   // a writable look: the copy's words are host words again
-                x.push_back(std::move(c));
-            }
+            // (fresh copies of the inputs made on the HOST side of the fixture: every configuration uploads its own operands -- an operand
+            // that is already resident somewhere draws the calls that read it to its rank)
+            auto host_copies = [](const std::vector<ckks::CkksCt> &src) {
+                std::vector<ckks::CkksCt> v;
+                for (auto &ct : src) {
+                    ckks::CkksCt c(ct);
+                    for (int h = 0; h < 2; h++) (void)c[h][0][0];   // a writable look: the copy's words are host words again
+                    v.push_back(std::move(c));
+                }
+                return v;
+            };
+            std::vector<ckks::CkksCt> x = host_copies(f.a), b = host_copies(f.b);
             for (int it = 0; it < 2; it++)
-                for (size_t c = 0; c < x.size(); c++) x[c] = ckks::rotate(ckks::mult(x[c], f.b[c], f.key), f.key, c + 1);
+                for (size_t c = 0; c < x.size(); c++) x[c] = ckks::rotate(ckks::mult(x[c], b[c], f.key), f.key, c + 1);
             ckks::CkksCt acc = ckks::mult(x[0], x[1], f.key);
             for (size_t c = 2; c < x.size(); c++) acc = ckks::mult(acc, x[c], f.key);
             x.push_back(acc);
