@@ -202,7 +202,14 @@ struct OpScope {
     }
     ~OpScope() {
         LaneSet &S = lane_set();
-        if (--S.depth > 0) S.cur = saved_;   // (a forced scope inside another call: that call goes on where it was)
+        if (--S.depth > 0 && S.cur != saved_) {
+            // a forced scope inside another call, on another slot: that call goes on where it was -- under a NEW ticket.  While the
+            // inner scope ran, its slot may have ordered itself behind the outer call's slot (order_after: "seen up to ticket T", T the
+            // outer call's OPEN ticket); what the outer call enqueues from here on must not pass for seen -- a block it still uses
+            // would look free to the inner slot's next call (found by the random-program fuzz over device ranks: 1 program in 129)
+            S.cur = saved_;
+            S.v[saved_].ticket++;
+        }
     }
     OpScope(const OpScope &) = delete;
 

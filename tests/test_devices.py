@@ -121,3 +121,24 @@ def test_reference_unit_tests_over_device_ranks(env):
     base = {k: v for k, v in os.environ.items() if k not in ("HEHUB_AMD_DEFER", "HEHUB_AMD_LANES")}
     out = subprocess.run([build_binary()], capture_output=True, text=True, timeout=900, env=dict(base, **env))
     assert out.returncode == 0 and "All tests passed" in out.stdout, (out.stdout[-3000:], out.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_recorded_calls_over_ranks_while_another_lane_has_an_open_call():
+    """Regression (round 6, found by tools/fuzz_random_program.py after 129 programs): the queue may run in the MIDDLE of a call on another
+    slot (a look, an in-place operator on a recorded result); its groups switch to lane 0 of their rank and may order themselves behind the
+    outer call's slot -- whose ticket is still open.  What the outer call enqueued afterwards then passed for `seen`, and a block it still
+    used looked free to the other slot: 15 runs of 24 printed another digest (2 ranks, recorded, 4 lanes, level A; 3 of 24 at level B).
+    The outer call now continues under a new ticket (layer.hpp: ~OpScope).  The same seed, many times: one digest, hehub's."""
+    from make_random_program import REF, digest
+    from test_random_program import binary
+
+    case = (12, 4, 12, 1085, 41028, 0)
+    want_b = digest(binary(), case, {"HEHUB_AMD_DEFER": "0", "HEHUB_AMD_LANES": "1"})[0]
+    if os.path.exists(REF):
+        assert digest(REF, case)[0] == want_b           # hehub itself on the CPU
+    want_a = digest(binary(), case, {"HEHUB_AMD_DEFER": "0", "HEHUB_AMD_LANES": "1", "HP_PARITY_LEVEL": "A"})[0]
+    for env, want in (({"HP_PARITY_LEVEL": "A", "HEHUB_AMD_DEVICES": "0,0"}, want_a), ({"HP_PARITY_LEVEL": "A", "HEHUB_AMD_DEVICES": "0,0", "HP_SPLIT_MAX_ITEMS": "0"}, want_a),
+                      ({"HEHUB_AMD_DEVICES": "0,0"}, want_b), ({"HEHUB_AMD_DEVICES": "0,0,0", "HEHUB_AMD_LANES": "8"}, want_b), ({"HEHUB_AMD_LANES": "8"}, want_b)):
+        got = [digest(binary(), case, env)[0] for _ in range(10)]
+        assert got == [want] * 10, (env, got, want)
