@@ -18,7 +18,9 @@ MODES = {"1 lane": {"HEHUB_AMD_LANES": "1", "HEHUB_AMD_DEFER": "0"}, "8 lanes": 
          # device ranks (round 6; the ranks share the GPU of a one-GPU box): calls placed by operand residency / round robin, groups per rank
          "2 ranks": {"HEHUB_AMD_DEVICES": "0,0", "HEHUB_AMD_DEFER": "0"}, "3 ranks, recorded": {"HEHUB_AMD_DEVICES": "0,0,0"},
          "8 ranks, 2 lanes": {"HEHUB_AMD_DEVICES": "0,0,0,0,0,0,0,0", "HEHUB_AMD_LANES": "2", "HEHUB_AMD_DEFER": "0"},
-         "5 ranks, recorded, 1 lane": {"HEHUB_AMD_DEVICES": "0,0,0,0,0", "HEHUB_AMD_LANES": "1"}}
+         "5 ranks, recorded, 1 lane": {"HEHUB_AMD_DEVICES": "0,0,0,0,0", "HEHUB_AMD_LANES": "1"},
+         "2 ranks, recorded, 8 lanes": {"HEHUB_AMD_DEVICES": "0,0", "HEHUB_AMD_LANES": "8"},
+         "8 ranks, recorded": {"HEHUB_AMD_DEVICES": "0,0,0,0,0,0,0,0"}}
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 assert os.path.exists(REF), "oracle/_ref/ref_randprog_cpu is built where /root/reference is (make -C oracle ref_randprog)"
@@ -36,11 +38,11 @@ while time.time() - t0 < seconds:
             if got != want:
                 bad += 1
                 print("MISMATCH", case, mode, got, want, flush=True)
-    a = {mode: digest(binary, case, dict(env, HP_PARITY_LEVEL="A"))[0] for mode, env in list(MODES.items())[:3] + list(MODES.items())[6:8]}
+    a = {mode: digest(binary, case, dict(env, HP_PARITY_LEVEL="A"))[0] for mode, env in list(MODES.items())[:3] + list(MODES.items())[6:8] + list(MODES.items())[10:]}
     if len(set(a.values())) != 1:
         bad += 1
         print("MISMATCH at level A", case, a, flush=True)
     cases += 1
-print(f"{cases} random programs x {len(MODES)} modes at level B against hehub on the CPU, x 5 modes at level A against each other: {bad} mismatches "
+print(f"{cases} random programs x {len(MODES)} modes at level B against hehub on the CPU, x 7 modes at level A against each other: {bad} mismatches "
       f"in {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
